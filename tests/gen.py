@@ -1,0 +1,128 @@
+"""Seeded synthetic inputs: SplitMix64, identical in Python,
+numpy and the C/HIP generators of the product's bench harness.
+
+    x += 0x9E3779B97F4A7C15
+    z = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EB
+    z ^ (z >> 31)
+
+SplitMix64 is counter based: the k-th output (k = 1, 2, ...) is
+mix(seed + k * GOLDEN), which is what the vectorised helpers use.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence
+
+import numpy as np
+
+GOLDEN = 0x9E3779B97F4A7C15
+M64 = (1 << 64) - 1
+
+
+def mix64(x: int) -> int:
+    z = x & M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & M64
+    return z ^ (z >> 31)
+
+
+class SplitMix64:
+    def __init__(self, seed: int):
+        self.x = seed & M64
+
+    def next(self) -> int:
+        self.x = (self.x + GOLDEN) & M64
+        return mix64(self.x)
+
+
+def mix64_np(x: np.ndarray) -> np.ndarray:
+    z = x.astype(np.uint64)
+    with np.errstate(over="ignore"):
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+    return z ^ (z >> np.uint64(31))
+
+
+def stream_np(seed: int, n: int, start: int = 1) -> np.ndarray:
+    """outputs start..start+n-1 of SplitMix64(seed)."""
+    with np.errstate(over="ignore"):
+        k = np.arange(start, start + n, dtype=np.uint64)
+        return mix64_np(np.uint64(seed & M64) + k * np.uint64(GOLDEN))
+
+
+def gen_patterns(n: int, lo: int, hi: int, alphabet: Sequence, seed: int) -> List:
+    """pattern i: L = lo + next() % (hi-lo+1), then L symbols alphabet[next() % len]."""
+    rng = SplitMix64(seed)
+    is_bytes = isinstance(alphabet, (bytes, bytearray))
+    out = []
+    for _ in range(n):
+        L = lo + rng.next() % (hi - lo + 1)
+        syms = [alphabet[rng.next() % len(alphabet)] for _ in range(L)]
+        out.append(bytes(syms) if is_bytes else "".join(syms))
+    return out
+
+
+AZ = bytes(range(97, 123))
+ALL_BYTES = bytes(range(256))
+
+
+def gen_uniform(n: int, alphabet: bytes, seed: int) -> np.ndarray:
+    """(U): iid uniform symbols of `alphabet`, one SplitMix64 output per byte."""
+    a = np.frombuffer(alphabet, dtype=np.uint8)
+    z = stream_np(seed, n)
+    return a[(z % np.uint64(len(a))).astype(np.int64)]
+
+
+def gen_textlike(n: int, seed: int, patterns: Sequence[bytes] = (),
+                 plant_every: int = 1024) -> np.ndarray:
+    """(T): a-z letters, a space with probability 1/6 at every position
+    (geometric word lengths, mean 5), one pattern planted per `plant_every`
+    bytes at a seeded offset inside each block."""
+    z = stream_np(seed, n)
+    letters = (97 + ((z >> np.uint64(8)) % np.uint64(26))).astype(np.uint8)
+    space = (z & np.uint64(0xFF)) < np.uint64(43)  # 43/256 ~ 1/6
+    out = np.where(space, np.uint8(32), letters)
+    if len(patterns):
+        nb = n // plant_every
+        zz = stream_np(seed ^ 0x5EED, 2 * nb)
+        for b in range(nb):
+            p = patterns[int(zz[2 * b] % np.uint64(len(patterns)))]
+            if len(p) >= plant_every:
+                continue
+            o = b * plant_every + int(zz[2 * b + 1] % np.uint64(plant_every - len(p)))
+            out[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    return out
+
+
+def canonical_sha256(matches) -> str:
+    """SHA-256 of the (pattern:u64,start:u64,end:u64) little-endian stream."""
+    import hashlib
+    a = np.asarray(matches, dtype=np.uint64).reshape(-1, 3)
+    return hashlib.sha256(a.astype("<u8").tobytes()).hexdigest()
+
+
+UNI_EXTRA = ["é", "☃", "🤦"]
+AZ_UNI = [chr(c) for c in range(97, 123)] + UNI_EXTRA
+
+
+def gen_unicode_textlike(nchars: int, seed: int, patterns: Sequence[str] = (),
+                         plant_every: int = 512) -> str:
+    """cfg5-shaped str haystack: a-z text with spaces (1/6), ~5 % non-ASCII
+    characters (2-, 3- and 4-byte UTF-8), one pattern planted per block."""
+    rng = SplitMix64(seed)
+    chars = []
+    for _ in range(nchars):
+        z = rng.next()
+        r = z & 0xFF
+        if r < 43:
+            chars.append(" ")
+        elif r < 56:  # 13/256 ~ 5 %
+            chars.append(UNI_EXTRA[(z >> 8) % 3])
+        else:
+            chars.append(chr(97 + (z >> 8) % 26))
+    if len(patterns):
+        for b in range(nchars // plant_every):
+            p = patterns[rng.next() % len(patterns)]
+            o = b * plant_every + rng.next() % (plant_every - len(p))
+            chars[o:o + len(p)] = list(p)
+    return "".join(chars)
