@@ -1,0 +1,306 @@
+"""ctypes binding of the C ABI (include/acx.h -> libacx_hip.so).
+
+This is the thin Python view of the drop-in boundary used by the device-pointer
+workflows (bench.py, the multi-GPU harness, tests).  The reference-shaped
+classes (`AhoCorasick`, `BytesAhoCorasick`) live in the C++ CPython extension
+`ahocorasick_rs_amd.ahocorasick_rs`; both sit on the same shared library.
+
+There is no CPU fallback: if libacx_hip.so is missing this module raises
+ImportError, and without a HIP device every matching call raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import sys
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libacx_hip.so")
+
+OK, EINVAL, EEMPTY, EOVERLAP, ENOMEM, EDEVICE, ETOOBIG = 0, -1, -2, -3, -4, -5, -6
+MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
+IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
+KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
+KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
+
+MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
+
+
+class Info(ctypes.Structure):
+    _fields_ = [("n_patterns", ctypes.c_uint64), ("n_states", ctypes.c_uint64),
+                ("n_classes", ctypes.c_uint32), ("stride", ctypes.c_uint32),
+                ("min_pattern_len", ctypes.c_uint32), ("max_pattern_len", ctypes.c_uint32),
+                ("table_bytes", ctypes.c_uint64), ("lds_hot_rows", ctypes.c_uint32),
+                ("kernel", ctypes.c_int32), ("match_kind", ctypes.c_int32),
+                ("device", ctypes.c_int32), ("filter_q", ctypes.c_uint32)]
+
+
+class Profile(ctypes.Structure):
+    _fields_ = [("scan_ms", ctypes.c_double), ("scan_launches", ctypes.c_uint64),
+                ("post_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
+                ("raw_occurrences", ctypes.c_uint64)]
+
+
+def _preload_hip_runtime() -> None:
+    # One process must hold ONE HIP runtime.  PyTorch wheels bundle their own
+    # libamdhip64 (same SONAME as /opt/rocm's); if torch is importable, let it
+    # load first so that libacx_hip.so binds to the same runtime and device
+    # pointers of torch tensors are valid here.  Opt out with ACX_NO_TORCH=1.
+    if os.environ.get("ACX_NO_TORCH") == "1" or "torch" in sys.modules:
+        return
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
+
+
+_lib: Optional[ctypes.CDLL] = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise ImportError(
+            f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            " (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    _preload_hip_runtime()
+    L = ctypes.CDLL(_SO, mode=ctypes.RTLD_GLOBAL)
+    vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
+    L.acx_version.restype = i32
+    L.acx_last_error.restype = ctypes.c_char_p
+    L.acx_device_count.argtypes = [ctypes.POINTER(i32)]
+    L.acx_set_device.argtypes = [i32]
+    L.acx_build.argtypes = [vp, vp, u64, i32, i32, ctypes.POINTER(vp)]
+    L.acx_free_automaton.argtypes = [vp]
+    L.acx_free_automaton.restype = None
+    L.acx_automaton_info.argtypes = [vp, ctypes.POINTER(Info)]
+    L.acx_set_kernel.argtypes = [vp, i32]
+    L.acx_find.argtypes = [vp, vp, u64, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
+    L.acx_free_matches.argtypes = [vp]
+    L.acx_free_matches.restype = None
+    L.acx_find_batch.argtypes = [vp, vp, vp, u64, i32, i32, ctypes.POINTER(vp),
+                                 ctypes.POINTER(u64), vp]
+    L.acx_find_device.argtypes = [vp, vp, u64, vp, u64, u64, i32, i32, ctypes.POINTER(vp)]
+    L.acx_result_count.argtypes = [vp]
+    L.acx_result_count.restype = u64
+    L.acx_result_device_matches.argtypes = [vp]
+    L.acx_result_device_matches.restype = vp
+    L.acx_result_device_counts.argtypes = [vp]
+    L.acx_result_device_counts.restype = vp
+    L.acx_result_copy.argtypes = [vp, vp]
+    L.acx_result_copy_counts.argtypes = [vp, vp]
+    L.acx_free_result.argtypes = [vp]
+    L.acx_free_result.restype = None
+    L.acx_profile_enable.argtypes = [vp, i32]
+    L.acx_profile_read.argtypes = [vp, ctypes.POINTER(Profile), i32]
+    L.acx_device_alloc.argtypes = [ctypes.POINTER(vp), u64]
+    L.acx_device_free.argtypes = [vp]
+    L.acx_device_upload.argtypes = [vp, vp, u64]
+    L.acx_device_download.argtypes = [vp, vp, u64]
+    L.acx_device_synchronize.argtypes = []
+    L.acx_generate_haystack.argtypes = [vp, vp, u64, i32, u64, u64]
+    _lib = L
+    return L
+
+
+class AcxError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"acx error {code}: {msg}")
+        self.code = code
+        self.msg = msg
+
+
+def _check(rc: int) -> None:
+    if rc != OK:
+        msg = lib().acx_last_error().decode("utf-8", "replace")
+        if rc in (EINVAL, EEMPTY, EOVERLAP, ETOOBIG):
+            e = ValueError(msg)
+            e.code = rc  # type: ignore[attr-defined]
+            raise e
+        if rc == ENOMEM:
+            raise MemoryError(msg)
+        raise AcxError(rc, msg)
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    rc = lib().acx_device_count(ctypes.byref(n))
+    return n.value if rc == OK else 0
+
+
+def set_device(ordinal: int) -> None:
+    _check(lib().acx_set_device(ordinal))
+
+
+def pack(patterns: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
+    off = np.zeros(len(patterns) + 1, dtype=np.uint64)
+    if len(patterns):
+        off[1:] = np.cumsum([len(p) for p in patterns], dtype=np.uint64)
+    blob = np.frombuffer(b"".join(bytes(p) for p in patterns) + b"\0" * 16, dtype=np.uint8).copy()
+    return blob, off
+
+
+class DeviceBuffer:
+    """hipMalloc'ed bytes owned by this object (for hosts without torch)."""
+
+    def __init__(self, nbytes: int):
+        p = ctypes.c_void_p()
+        _check(lib().acx_device_alloc(ctypes.byref(p), nbytes))
+        self.ptr = p.value
+        self.nbytes = nbytes
+
+    def upload(self, arr: np.ndarray) -> "DeviceBuffer":
+        a = np.ascontiguousarray(arr)
+        assert a.nbytes <= self.nbytes
+        _check(lib().acx_device_upload(self.ptr, a.ctypes.data, a.nbytes))
+        return self
+
+    def download(self, nbytes: Optional[int] = None) -> np.ndarray:
+        n = self.nbytes if nbytes is None else nbytes
+        out = np.empty(n, dtype=np.uint8)
+        _check(lib().acx_device_download(out.ctypes.data, self.ptr, n))
+        return out
+
+    def free(self) -> None:
+        if self.ptr:
+            lib().acx_device_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class DeviceResult:
+    """Matches resident in HBM (acx_result_t)."""
+
+    def __init__(self, handle: int, n_hay: int):
+        self._h = handle
+        self.n_hay = n_hay
+
+    @property
+    def count(self) -> int:
+        return int(lib().acx_result_count(self._h))
+
+    @property
+    def device_ptr(self) -> int:
+        return lib().acx_result_device_matches(self._h) or 0
+
+    def matches(self) -> np.ndarray:
+        out = np.empty(self.count, dtype=MATCH_DTYPE)
+        if self.count:
+            _check(lib().acx_result_copy(self._h, out.ctypes.data))
+        return out
+
+    def counts(self) -> np.ndarray:
+        out = np.zeros(self.n_hay, dtype=np.uint64)
+        if self.n_hay:
+            _check(lib().acx_result_copy_counts(self._h, out.ctypes.data))
+        return out
+
+    def free(self) -> None:
+        if self._h:
+            lib().acx_free_result(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+class Automaton:
+    """acx_automaton_t: compiled patterns + device tables."""
+
+    def __init__(self, patterns: Sequence[bytes], match_kind: int = MATCH_STANDARD,
+                 implementation: int = IMPL_AUTO, kernel: Optional[int] = None):
+        blob, off = pack(patterns)
+        h = ctypes.c_void_p()
+        _check(lib().acx_build(blob.ctypes.data, off.ctypes.data, len(patterns), match_kind,
+                               implementation, ctypes.byref(h)))
+        self._h = h.value
+        if kernel is not None:
+            self.set_kernel(kernel)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().acx_free_automaton(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def info(self) -> Info:
+        i = Info()
+        _check(lib().acx_automaton_info(self._h, ctypes.byref(i)))
+        return i
+
+    def set_kernel(self, kernel: int) -> None:
+        _check(lib().acx_set_kernel(self._h, kernel))
+
+    # ---- host-memory entry points
+    def find(self, hay, overlapping: bool = False, codepoints: bool = False) -> np.ndarray:
+        a = np.frombuffer(hay, dtype=np.uint8) if not isinstance(hay, np.ndarray) else hay
+        a = np.ascontiguousarray(a)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        _check(lib().acx_find(self._h, a.ctypes.data if a.size else None, a.size,
+                              int(overlapping), int(codepoints), ctypes.byref(out),
+                              ctypes.byref(n)))
+        res = np.empty(n.value, dtype=MATCH_DTYPE)
+        if n.value:
+            ctypes.memmove(res.ctypes.data, out.value, n.value * 24)
+            lib().acx_free_matches(out.value)
+        return res
+
+    def find_tuples(self, hay, overlapping: bool = False,
+                    codepoints: bool = False) -> List[Tuple[int, int, int]]:
+        return [(int(p), int(s), int(e)) for (p, s, e) in self.find(hay, overlapping, codepoints)]
+
+    def find_batch(self, haystacks: Sequence[bytes], overlapping: bool = False,
+                   codepoints: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        blob, off = pack(haystacks)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        counts = np.zeros(len(haystacks), dtype=np.uint64)
+        _check(lib().acx_find_batch(self._h, blob.ctypes.data, off.ctypes.data, len(haystacks),
+                                    int(overlapping), int(codepoints), ctypes.byref(out),
+                                    ctypes.byref(n), counts.ctypes.data))
+        res = np.empty(n.value, dtype=MATCH_DTYPE)
+        if n.value:
+            ctypes.memmove(res.ctypes.data, out.value, n.value * 24)
+            lib().acx_free_matches(out.value)
+        return res, counts
+
+    # ---- device-resident entry point
+    def find_device(self, d_ptr: int, nbytes: int, *, d_offsets: int = 0, n_hay: int = 0,
+                    uniform_len: int = 0, overlapping: bool = False,
+                    codepoints: bool = False) -> DeviceResult:
+        out = ctypes.c_void_p()
+        _check(lib().acx_find_device(self._h, d_ptr, nbytes, d_offsets or None, n_hay,
+                                     uniform_len, int(overlapping), int(codepoints),
+                                     ctypes.byref(out)))
+        return DeviceResult(out.value, n_hay if (uniform_len or d_offsets) else 0)
+
+    def generate(self, d_ptr: int, nbytes: int, kind: int, seed: int,
+                 stream_offset: int = 0) -> None:
+        _check(lib().acx_generate_haystack(self._h, d_ptr, nbytes, kind, seed, stream_offset))
+
+    # ---- measurement
+    def profile_enable(self, on: bool = True) -> None:
+        _check(lib().acx_profile_enable(self._h, int(on)))
+
+    def profile_read(self, reset: bool = True) -> Profile:
+        p = Profile()
+        _check(lib().acx_profile_read(self._h, ctypes.byref(p), int(reset)))
+        return p

@@ -1,0 +1,636 @@
+// acx_api.cpp -- implementation of the C ABI declared in include/acx.h.
+// Host orchestration of the device pipeline (kernels.hip).  There is no CPU
+// matching path here: without a HIP device every find call fails (ACX_EDEVICE).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/acx.h"
+#include "automaton.hpp"
+#include "kernels.hpp"
+
+using namespace acx;
+
+namespace {
+
+thread_local std::string g_err;
+thread_local int g_device = -1; // -1: use the current HIP device
+
+int fail(int code, const std::string &msg) {
+    g_err = msg;
+    return code;
+}
+int hipfail(hipError_t e, const char *what) {
+    return fail(ACX_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(expr)                                   \
+    do {                                               \
+        hipError_t e__ = (expr);                       \
+        if (e__ != hipSuccess) return hipfail(e__, #expr); \
+    } while (0)
+
+struct Workspace {
+    uint64_t cap = 0; // occurrence capacity
+    uint64_t *keys[2] = {nullptr, nullptr};
+    uint32_t *pids[2] = {nullptr, nullptr};
+    uint64_t *S = nullptr, *E = nullptr, *M = nullptr;
+    uint32_t *flags = nullptr, *idx = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    unsigned long long *counter = nullptr; // device
+    uint64_t *h_pinned = nullptr;          // pinned host scratch (4 x u64)
+    uint64_t *blockcnt = nullptr, *blockpre = nullptr;
+    uint64_t block_cap = 0;
+    uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
+    uint64_t hay_cap = 0;
+    uint64_t *offsets = nullptr;
+    uint64_t offsets_cap = 0;
+};
+
+} // namespace
+
+struct acx_automaton {
+    Automaton host;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DevAutomaton dev{};
+    std::vector<void *> allocs;
+    int kernel = ACX_KERNEL_DFA_WALK;
+    int n_cus = 1;
+    size_t max_lds = 65536;
+    uint64_t table_bytes = 0;
+    std::mutex mu;       // guards the workspace + device pipeline
+    std::mutex stage_mu; // guards the host staging buffers (taken before mu)
+    Workspace ws;
+    bool prof = false;
+    acx_profile_t profile{};
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+struct acx_result {
+    int device = 0;
+    acx_match_t *d_matches = nullptr;
+    uint64_t n = 0;
+    uint64_t *d_counts = nullptr;
+    uint64_t n_hay = 0;
+};
+
+namespace {
+
+template <typename T>
+int upload(acx_automaton *a, const T *src, size_t count, const T **dst) {
+    size_t bytes = std::max<size_t>(count * sizeof(T), 16);
+    bytes = (bytes + 15) / 16 * 16;
+    void *d = nullptr;
+    HIPCHK(hipMalloc(&d, bytes));
+    a->allocs.push_back(d);
+    HIPCHK(hipMemsetAsync(d, 0, bytes, a->stream));
+    if (count) HIPCHK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, a->stream));
+    *dst = (const T *)d;
+    return ACX_OK;
+}
+
+void free_ws(Workspace &w) {
+    for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
+    (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
+    (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
+    (void)hipFree(w.counter); (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
+    (void)hipFree(w.hay); (void)hipFree(w.offsets);
+    if (w.h_pinned) (void)hipHostFree(w.h_pinned);
+    w = Workspace();
+}
+
+int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
+    Workspace &w = a->ws;
+    if (!w.counter) {
+        HIPCHK(hipMalloc((void **)&w.counter, 64));
+        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
+    }
+    if (want <= w.cap) return ACX_OK;
+    uint64_t cap = std::max<uint64_t>(want, 1u << 16);
+    for (int i = 0; i < 2; i++) {
+        (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]);
+        w.keys[i] = nullptr; w.pids[i] = nullptr;
+    }
+    (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
+    (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
+    w.S = w.E = w.M = nullptr; w.flags = w.idx = nullptr; w.temp = nullptr; w.cap = 0;
+    for (int i = 0; i < 2; i++) {
+        HIPCHK(hipMalloc((void **)&w.keys[i], cap * 8));
+        HIPCHK(hipMalloc((void **)&w.pids[i], cap * 4));
+    }
+    HIPCHK(hipMalloc((void **)&w.S, cap * 8));
+    HIPCHK(hipMalloc((void **)&w.E, cap * 8));
+    HIPCHK(hipMalloc((void **)&w.M, cap * 8));
+    HIPCHK(hipMalloc((void **)&w.flags, (cap + 1) * 4));
+    HIPCHK(hipMalloc((void **)&w.idx, (cap + 1) * 4));
+    w.temp_bytes = std::max(sort_temp_bytes(cap), scan_temp_bytes(cap)) + 256;
+    HIPCHK(hipMalloc(&w.temp, w.temp_bytes));
+    w.cap = cap;
+    return ACX_OK;
+}
+
+int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
+    Workspace &w = a->ws;
+    if (nblocks_plus1 <= w.block_cap) {
+        // the scan temp storage may need to cover this size too
+    } else {
+        (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
+        w.blockcnt = w.blockpre = nullptr; w.block_cap = 0;
+        HIPCHK(hipMalloc((void **)&w.blockcnt, nblocks_plus1 * 8));
+        HIPCHK(hipMalloc((void **)&w.blockpre, nblocks_plus1 * 8));
+        w.block_cap = nblocks_plus1;
+    }
+    size_t need = scan_temp_bytes(nblocks_plus1) + 256;
+    if (need > w.temp_bytes) {
+        (void)hipFree(w.temp); w.temp = nullptr;
+        HIPCHK(hipMalloc(&w.temp, need));
+        w.temp_bytes = need;
+    }
+    return ACX_OK;
+}
+
+int bits_for(uint64_t x) { // number of bits needed to represent x
+    int b = 0;
+    while (x) { b++; x >>= 1; }
+    return b;
+}
+
+// The whole device pipeline.  d_hay: device pointer, len bytes.
+int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
+             int overlapping, int codepoints, acx_result **out) {
+    *out = nullptr;
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
+        static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
+        return fail(ACX_EOVERLAP, std::string("match kind ") + names[a->host.match_kind] +
+                                      " does not support overlapping searches");
+    }
+    if (len >= (1ull << 40)) return fail(ACX_ETOOBIG, "haystack stream of 2^40 bytes or more");
+    std::lock_guard<std::mutex> lock(a->mu);
+    HIPCHK(hipSetDevice(a->device));
+    hipStream_t st = a->stream;
+    const bool segmented = G.uniform_len != 0 || G.offsets != nullptr;
+    acx_result *r = new (std::nothrow) acx_result();
+    if (!r) return fail(ACX_ENOMEM, "out of memory");
+    r->device = a->device;
+    r->n_hay = segmented ? G.n_hay : 0;
+    auto bail = [&](int code) { acx_free_result(r); return code; };
+#define HIPCHK_R(expr)                                         \
+    do {                                                       \
+        hipError_t e__ = (expr);                               \
+        if (e__ != hipSuccess) return bail(hipfail(e__, #expr)); \
+    } while (0)
+    if (segmented) {
+        HIPCHK_R(hipMalloc((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8));
+        HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
+    }
+    uint64_t n_raw = 0;
+    const int key_mode = overlapping ? 0 : a->host.match_kind;
+    if (len > 0 && a->host.n_patterns > 0) {
+        int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
+        if (rc) return bail(rc);
+        Workspace &w = a->ws;
+        for (int attempt = 0; attempt < 3; attempt++) {
+            Sink K{w.keys[0], w.pids[0], w.counter, w.cap, key_mode};
+            HIPCHK_R(hipMemsetAsync(w.counter, 0, 8, st));
+            if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
+            hipError_t e = a->kernel == ACX_KERNEL_PREFILTER
+                               ? launch_prefilter(a->dev, G, K, d_hay, len, a->n_cus, st)
+                               : launch_dfa_walk(a->dev, G, K, d_hay, len, a->n_cus, a->max_lds, st);
+            if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
+            if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.counter, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK_R(hipStreamSynchronize(st));
+            if (a->prof) {
+                float ms = 0;
+                HIPCHK_R(hipEventElapsedTime(&ms, a->ev[0], a->ev[1]));
+                a->profile.scan_ms += ms;
+                a->profile.scan_launches++;
+                a->profile.scan_bytes += len;
+            }
+            n_raw = w.h_pinned[0];
+            if (n_raw <= w.cap) break;
+            if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
+            rc = ensure_occ_capacity(a, n_raw + n_raw / 16 + 1024);
+            if (rc) return bail(rc);
+        }
+        if (a->prof) a->profile.raw_occurrences += n_raw;
+    }
+    if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
+    uint64_t n_final = 0;
+    if (n_raw > 0) {
+        Workspace &w = a->ws;
+        if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+        int end_bit = std::min(64, 24 + bits_for(len));
+        HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[0], w.keys[1], w.pids[0],
+                                  w.pids[1], n_raw, end_bit, st));
+        HIPCHK_R(make_spans(a->dev, key_mode, w.keys[1], w.pids[1], w.S, w.E, n_raw, st));
+        if (overlapping) {
+            n_final = n_raw;
+            HIPCHK_R(hipMalloc((void **)&r->d_matches, n_final * sizeof(acx_match_t)));
+            HIPCHK_R(write_matches(w.pids[1], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
+        } else {
+            HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+            HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
+            HIPCHK_R(resolve_greedy(w.S, w.E, w.M, w.flags, n_raw, st));
+            HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned + 1, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
+            HIPCHK_R(hipStreamSynchronize(st));
+            n_final = *(uint32_t *)(w.h_pinned + 1);
+            HIPCHK_R(hipMalloc((void **)&r->d_matches, std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t)));
+            HIPCHK_R(write_matches(w.pids[1], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
+        }
+        r->n = n_final;
+        if (n_final && (codepoints || segmented)) {
+            if (codepoints) {
+                uint64_t nb1 = (len + 1023) / 1024 + 1;
+                int rc = ensure_blocks(a, nb1);
+                if (rc) return bail(rc);
+                HIPCHK_R(count_lead_bytes(d_hay, len, w.blockcnt, st));
+                HIPCHK_R(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
+            }
+            if (segmented)
+                HIPCHK_R(localize(G, d_hay, len, w.blockpre, codepoints, r->d_matches, n_final,
+                                  r->d_counts, st));
+            else
+                HIPCHK_R(to_code_points(d_hay, len, w.blockpre, r->d_matches, n_final, st));
+        }
+        if (a->prof) {
+            HIPCHK_R(hipEventRecord(a->ev[2], st));
+            HIPCHK_R(hipStreamSynchronize(st));
+            float ms = 0;
+            HIPCHK_R(hipEventElapsedTime(&ms, a->ev[1], a->ev[2]));
+            a->profile.post_ms += ms;
+        }
+    }
+    HIPCHK_R(hipStreamSynchronize(st));
+#undef HIPCHK_R
+    *out = r;
+    return ACX_OK;
+}
+
+int stage_host(acx_automaton *a, const uint8_t *hay, uint64_t len, const uint64_t *offsets,
+               uint64_t n_off) {
+    Workspace &w = a->ws;
+    HIPCHK(hipSetDevice(a->device));
+    if (len > w.hay_cap) {
+        (void)hipFree(w.hay); w.hay = nullptr; w.hay_cap = 0;
+        uint64_t cap = std::max<uint64_t>(len + len / 8, 4096);
+        HIPCHK(hipMalloc((void **)&w.hay, cap));
+        w.hay_cap = cap;
+    }
+    if (len) HIPCHK(hipMemcpyAsync(w.hay, hay, len, hipMemcpyHostToDevice, a->stream));
+    if (n_off) {
+        if (n_off > w.offsets_cap) {
+            (void)hipFree(w.offsets); w.offsets = nullptr; w.offsets_cap = 0;
+            HIPCHK(hipMalloc((void **)&w.offsets, n_off * 8));
+            w.offsets_cap = n_off;
+        }
+        HIPCHK(hipMemcpyAsync(w.offsets, offsets, n_off * 8, hipMemcpyHostToDevice, a->stream));
+    }
+    return ACX_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------
+extern "C" {
+
+int acx_version(void) { return ACX_VERSION; }
+const char *acx_last_error(void) { return g_err.c_str(); }
+
+int acx_device_count(int *n) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) { *n = 0; return hipfail(e, "hipGetDeviceCount"); }
+    *n = c;
+    return ACX_OK;
+}
+
+int acx_set_device(int ordinal) {
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) return hipfail(e, "hipGetDeviceCount");
+    if (ordinal < 0 || ordinal >= c) return fail(ACX_EINVAL, "device ordinal out of range");
+    g_device = ordinal;
+    HIPCHK(hipSetDevice(ordinal));
+    return ACX_OK;
+}
+
+int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns, int match_kind,
+              int implementation, acx_automaton_t **out) {
+    if (!out) return fail(ACX_EINVAL, "null output pointer");
+    *out = nullptr;
+    if (n_patterns && (!offsets || (!blob && offsets[n_patterns] != offsets[0])))
+        return fail(ACX_EINVAL, "null pattern buffer");
+    if (implementation < ACX_IMPL_AUTO || implementation > ACX_IMPL_DFA)
+        return fail(ACX_EINVAL, "unknown implementation hint");
+    acx_automaton *a = new (std::nothrow) acx_automaton();
+    if (!a) return fail(ACX_ENOMEM, "out of memory");
+    static const uint64_t zero_off[1] = {0};
+    int code = ACX_OK;
+    std::string err;
+    try {
+        err = compile(blob, n_patterns ? offsets : zero_off, n_patterns, match_kind, a->host, code);
+    } catch (const std::bad_alloc &) {
+        delete a;
+        return fail(ACX_ENOMEM, "out of host memory while compiling the automaton");
+    }
+    if (code != ACX_OK) { delete a; return fail(code, err); }
+
+    // ---- device side.  No device => no matcher (there is no CPU fallback).
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0) {
+        delete a;
+        return fail(ACX_EDEVICE, std::string("no HIP device available: ") +
+                                     (e != hipSuccess ? hipGetErrorString(e) : "device count is 0"));
+    }
+    int dev = g_device;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    a->device = dev;
+    auto destroy = [&](int rc) { acx_free_automaton(a); return rc; };
+#define HIPCHK_A(expr)                                            \
+    do {                                                          \
+        hipError_t e__ = (expr);                                  \
+        if (e__ != hipSuccess) return destroy(hipfail(e__, #expr)); \
+    } while (0)
+    HIPCHK_A(hipSetDevice(dev));
+    {
+        int v = 0;
+        HIPCHK_A(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
+        a->n_cus = std::max(v, 1);
+        int l1 = 0, l2 = 0;
+        (void)hipDeviceGetAttribute(&l1, hipDeviceAttributeMaxSharedMemoryPerBlock, dev);
+        (void)hipDeviceGetAttribute(&l2, hipDeviceAttributeMaxSharedMemoryPerMultiprocessor, dev);
+        a->max_lds = (size_t)std::max(std::max(l1, l2), 65536);
+        if (a->max_lds > 160 * 1024) a->max_lds = 160 * 1024;
+    }
+    HIPCHK_A(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
+    for (auto &ev : a->ev) HIPCHK_A(hipEventCreate(&ev));
+
+    Automaton &H = a->host;
+    DevAutomaton &D = a->dev;
+    D.n_patterns = H.n_patterns; D.n_states = H.n_states; D.stride2 = H.stride2;
+    D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
+    // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile
+    uint32_t hot_rows = dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024);
+    std::vector<uint16_t> hot16(((size_t)hot_rows << H.stride2) + 8, 0xFFFF);
+    for (size_t i = 0; i < ((size_t)hot_rows << H.stride2); i++) {
+        uint32_t en = H.table[i], id = en & ID_MASK;
+        hot16[i] = id < 0x3FFFu ? (uint16_t)(id | ((en >> 30) << 14)) : (uint16_t)0xFFFF;
+    }
+    D.hot_rows = hot_rows;
+    int rc;
+#define UP(vec, field)                                                                   \
+    if ((rc = upload(a, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
+    UP(H.table, table)
+    UP(hot16, hot16)
+    UP(H.own_off, own_off)
+    UP(H.own_pid, own_pid)
+    UP(H.dlink, dlink)
+    UP(H.level_start, level_start)
+    UP(H.plen, plen)
+    UP(H.rank, rank)
+    UP(H.filterA, filterA)
+    UP(H.blob, pat_blob)
+    UP(H.offsets, pat_off)
+#undef UP
+    if ((rc = upload(a, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
+    HIPCHK_A(hipStreamSynchronize(a->stream));
+    a->table_bytes = H.table.size() * 4;
+    // the big host copy of the table is no longer needed
+    std::vector<uint32_t>().swap(H.table);
+    // kernel selection
+    bool prefilter_ok = H.filter_q >= 3 && a->max_lds >= prefilter_lds_bytes();
+    if (implementation == ACX_IMPL_NONCONTIGUOUS_NFA || implementation == ACX_IMPL_CONTIGUOUS_NFA)
+        a->kernel = ACX_KERNEL_DFA_WALK;
+    else
+        a->kernel = prefilter_ok ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
+    if (const char *envk = std::getenv("ACX_KERNEL")) {
+        if (!std::strcmp(envk, "dfa_walk")) a->kernel = ACX_KERNEL_DFA_WALK;
+        else if (!std::strcmp(envk, "prefilter") && H.filter_q >= 1 &&
+                 a->max_lds >= prefilter_lds_bytes())
+            a->kernel = ACX_KERNEL_PREFILTER;
+    }
+#undef HIPCHK_A
+    *out = a;
+    return ACX_OK;
+}
+
+void acx_free_automaton(acx_automaton_t *a) {
+    if (!a) return;
+    (void)hipSetDevice(a->device);
+    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    for (void *p : a->allocs) (void)hipFree(p);
+    free_ws(a->ws);
+    for (auto &ev : a->ev) if (ev) (void)hipEventDestroy(ev);
+    if (a->stream) (void)hipStreamDestroy(a->stream);
+    delete a;
+}
+
+int acx_automaton_info(const acx_automaton_t *a, acx_info_t *out) {
+    if (!a || !out) return fail(ACX_EINVAL, "null argument");
+    std::memset(out, 0, sizeof(*out));
+    out->n_patterns = a->host.n_patterns;
+    out->n_states = a->host.n_states;
+    out->n_classes = a->host.n_classes;
+    out->stride = a->host.stride;
+    out->min_pattern_len = a->host.min_len;
+    out->max_pattern_len = a->host.max_len;
+    out->table_bytes = a->table_bytes;
+    out->lds_hot_rows = std::min(a->dev.hot_rows,
+                                 dfa_walk_hot_rows(a->host.n_states, a->host.stride2, a->max_lds));
+    out->kernel = a->kernel;
+    out->match_kind = a->host.match_kind;
+    out->device = a->device;
+    out->filter_q = a->host.filter_q;
+    return ACX_OK;
+}
+
+int acx_set_kernel(acx_automaton_t *a, int kernel) {
+    if (!a) return fail(ACX_EINVAL, "null automaton");
+    if (kernel == ACX_KERNEL_DFA_WALK) { a->kernel = kernel; return ACX_OK; }
+    if (kernel == ACX_KERNEL_PREFILTER) {
+        if (a->host.filter_q == 0 || a->max_lds < prefilter_lds_bytes())
+            return fail(ACX_EINVAL, "prefilter kernel unavailable for this automaton/device");
+        a->kernel = kernel;
+        return ACX_OK;
+    }
+    if (kernel == ACX_KERNEL_AUTO) {
+        a->kernel = (a->host.filter_q >= 3 && a->max_lds >= prefilter_lds_bytes())
+                        ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
+        return ACX_OK;
+    }
+    return fail(ACX_EINVAL, "unknown kernel");
+}
+
+int acx_find_device(acx_automaton_t *a, const void *d_hay, uint64_t len, const uint64_t *d_offsets,
+                    uint64_t n_hay, uint64_t uniform_len, int overlapping, int codepoints,
+                    acx_result_t **out) {
+    if (!a || !out) return fail(ACX_EINVAL, "null argument");
+    if (len && !d_hay) return fail(ACX_EINVAL, "null haystack");
+    Segments G{nullptr, 1, 0};
+    if (uniform_len) {
+        if (n_hay * uniform_len != len) return fail(ACX_EINVAL, "n_hay * uniform_len != len");
+        G.uniform_len = uniform_len; G.n_hay = n_hay;
+    } else if (d_offsets) {
+        G.offsets = d_offsets; G.n_hay = n_hay;
+    }
+    return run_find(a, (const uint8_t *)d_hay, len, G, overlapping, codepoints, out);
+}
+
+uint64_t acx_result_count(const acx_result_t *r) { return r ? r->n : 0; }
+const acx_match_t *acx_result_device_matches(const acx_result_t *r) { return r ? r->d_matches : nullptr; }
+const uint64_t *acx_result_device_counts(const acx_result_t *r) { return r ? r->d_counts : nullptr; }
+
+int acx_result_copy(const acx_result_t *r, acx_match_t *host_out) {
+    if (!r) return fail(ACX_EINVAL, "null result");
+    if (!r->n) return ACX_OK;
+    HIPCHK(hipSetDevice(r->device));
+    HIPCHK(hipMemcpy(host_out, r->d_matches, r->n * sizeof(acx_match_t), hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts) {
+    if (!r) return fail(ACX_EINVAL, "null result");
+    if (!r->d_counts || !r->n_hay) return ACX_OK;
+    HIPCHK(hipSetDevice(r->device));
+    HIPCHK(hipMemcpy(host_counts, r->d_counts, r->n_hay * 8, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+
+void acx_free_result(acx_result_t *r) {
+    if (!r) return;
+    (void)hipSetDevice(r->device);
+    (void)hipFree(r->d_matches);
+    (void)hipFree(r->d_counts);
+    delete r;
+}
+
+int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
+             acx_match_t **out, uint64_t *n_out) {
+    if (!a || !out || !n_out) return fail(ACX_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0;
+    if (len && !hay) return fail(ACX_EINVAL, "null haystack");
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
+        acx_result_t *dummy = nullptr; // produces the error message, touches no device state
+        return run_find(a, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &dummy);
+    }
+    acx_result_t *r = nullptr;
+    int rc;
+    {
+        // the staging buffer is shared by the host-memory entry points
+        std::lock_guard<std::mutex> lk(a->stage_mu);
+        rc = stage_host(a, hay, len, nullptr, 0);
+        if (rc == ACX_OK)
+            rc = run_find(a, a->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r);
+    }
+    if (rc != ACX_OK) return rc;
+    uint64_t n = acx_result_count(r);
+    if (n) {
+        acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
+        if (!m) { acx_free_result(r); return fail(ACX_ENOMEM, "out of memory"); }
+        rc = acx_result_copy(r, m);
+        if (rc != ACX_OK) { std::free(m); acx_free_result(r); return rc; }
+        *out = m;
+    }
+    *n_out = n;
+    acx_free_result(r);
+    return ACX_OK;
+}
+
+void acx_free_matches(acx_match_t *m) { std::free(m); }
+
+int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offsets, uint64_t n_hay,
+                   int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out,
+                   uint64_t *counts) {
+    if (!a || !out || !n_out || !offsets) return fail(ACX_EINVAL, "null argument");
+    *out = nullptr; *n_out = 0;
+    for (uint64_t i = 0; i < n_hay; i++) {
+        if (offsets[i + 1] < offsets[i]) return fail(ACX_EINVAL, "offsets not monotone");
+        if (counts) counts[i] = 0;
+    }
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
+        acx_result_t *dummy = nullptr;
+        return run_find(a, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &dummy);
+    }
+    if (n_hay == 0) return ACX_OK;
+    uint64_t base = offsets[0], len = offsets[n_hay] - base;
+    std::vector<uint64_t> rel(n_hay + 1);
+    for (uint64_t i = 0; i <= n_hay; i++) rel[i] = offsets[i] - base;
+    acx_result_t *r = nullptr;
+    int rc;
+    {
+        std::lock_guard<std::mutex> lk(a->stage_mu);
+        rc = stage_host(a, hay ? hay + base : nullptr, len, rel.data(), n_hay + 1);
+        if (rc == ACX_OK) {
+            Segments G{a->ws.offsets, n_hay, 0};
+            rc = run_find(a, a->ws.hay, len, G, overlapping, codepoints, &r);
+        }
+    }
+    if (rc != ACX_OK) return rc;
+    uint64_t n = acx_result_count(r);
+    if (n) {
+        acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
+        if (!m) { acx_free_result(r); return fail(ACX_ENOMEM, "out of memory"); }
+        rc = acx_result_copy(r, m);
+        if (rc != ACX_OK) { std::free(m); acx_free_result(r); return rc; }
+        *out = m;
+    }
+    if (counts && rc == ACX_OK) rc = acx_result_copy_counts(r, counts);
+    *n_out = n;
+    acx_free_result(r);
+    return rc;
+}
+
+int acx_profile_enable(acx_automaton_t *a, int on) {
+    if (!a) return fail(ACX_EINVAL, "null automaton");
+    a->prof = on != 0;
+    return ACX_OK;
+}
+
+int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset) {
+    if (!a || !out) return fail(ACX_EINVAL, "null argument");
+    std::lock_guard<std::mutex> lock(a->mu);
+    *out = a->profile;
+    if (reset) a->profile = acx_profile_t{};
+    return ACX_OK;
+}
+
+int acx_device_alloc(void **d_ptr, uint64_t bytes) {
+    if (!d_ptr) return fail(ACX_EINVAL, "null argument");
+    HIPCHK(hipMalloc(d_ptr, bytes ? bytes : 16));
+    return ACX_OK;
+}
+int acx_device_free(void *d_ptr) { HIPCHK(hipFree(d_ptr)); return ACX_OK; }
+int acx_device_upload(void *d_dst, const void *h_src, uint64_t bytes) {
+    if (bytes) HIPCHK(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
+    return ACX_OK;
+}
+int acx_device_download(void *h_dst, const void *d_src, uint64_t bytes) {
+    if (bytes) HIPCHK(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
+    return ACX_OK;
+}
+int acx_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return ACX_OK; }
+
+int acx_generate_haystack(acx_automaton_t *a, void *d_dst, uint64_t len, int kind, uint64_t seed,
+                          uint64_t stream_offset) {
+    if (!a || (!d_dst && len)) return fail(ACX_EINVAL, "null argument");
+    if (kind != 0 && kind != 1) return fail(ACX_EINVAL, "unknown haystack kind");
+    if (kind == 1 && (stream_offset % 1024)) return fail(ACX_EINVAL, "stream_offset must be a multiple of 1024");
+    std::lock_guard<std::mutex> lock(a->mu);
+    HIPCHK(hipSetDevice(a->device));
+    HIPCHK(generate(a->dev, (uint8_t *)d_dst, len, kind, seed, stream_offset, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    return ACX_OK;
+}
+
+} // extern "C"

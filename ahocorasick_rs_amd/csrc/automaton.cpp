@@ -1,0 +1,253 @@
+// automaton.cpp -- see automaton.hpp.  Host compiler: patterns -> BFS-numbered
+// Standard Aho-Corasick DFA + output lists + prefilter bitmaps.
+//
+// Reference behaviour reproduced (semantics only, /root/reference/src/lib.rs):
+//   * empty patterns are an error (204-208, 386-389) -> ACX_EEMPTY
+//   * zero patterns is legal and matches nothing
+//   * duplicate patterns are legal; all copies are reported (overlapping) and
+//     ties resolve to the lowest pattern index
+#include "automaton.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+#include "../../include/acx.h"
+
+namespace acx {
+
+namespace {
+
+// open-addressing map (parent << 8 | byte) -> child, for trie construction
+struct EdgeMap {
+    std::vector<uint64_t> keys;
+    std::vector<uint32_t> vals;
+    uint64_t mask = 0, used = 0;
+    static uint64_t mixh(uint64_t x) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33;
+        x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    }
+    void init(uint64_t cap_pow2) {
+        keys.assign(cap_pow2, ~0ULL);
+        vals.assign(cap_pow2, 0);
+        mask = cap_pow2 - 1; used = 0;
+    }
+    void rehash() {
+        std::vector<uint64_t> ok; ok.swap(keys);
+        std::vector<uint32_t> ov; ov.swap(vals);
+        init((mask + 1) * 2);
+        for (size_t i = 0; i < ok.size(); i++)
+            if (ok[i] != ~0ULL) insert(ok[i], ov[i]);
+    }
+    uint32_t find(uint64_t k) const {
+        uint64_t i = mixh(k) & mask;
+        while (keys[i] != ~0ULL) {
+            if (keys[i] == k) return vals[i];
+            i = (i + 1) & mask;
+        }
+        return NONE;
+    }
+    void insert(uint64_t k, uint32_t v) {
+        if ((used + 1) * 10 > (mask + 1) * 7) rehash();
+        uint64_t i = mixh(k) & mask;
+        while (keys[i] != ~0ULL) i = (i + 1) & mask;
+        keys[i] = k; vals[i] = v; used++;
+    }
+};
+
+} // namespace
+
+std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
+                    int match_kind, Automaton &A, int &code) {
+    code = ACX_OK;
+    if (match_kind < 0 || match_kind > 2) { code = ACX_EINVAL; return "unknown match kind"; }
+    if (n > (1ull << 24)) { code = ACX_ETOOBIG; return "more than 2^24 patterns"; }
+    A = Automaton();
+    A.match_kind = match_kind;
+    A.n_patterns = n;
+    uint64_t total = n ? offsets[n] - offsets[0] : 0;
+    A.plen.resize(n);
+    uint64_t minl = ~0ull, maxl = 0;
+    for (uint64_t i = 0; i < n; i++) {
+        if (offsets[i + 1] < offsets[i]) { code = ACX_EINVAL; return "offsets not monotone"; }
+        uint64_t L = offsets[i + 1] - offsets[i];
+        if (L == 0) { code = ACX_EEMPTY; return "empty pattern"; }
+        if (L > 0x3FFFFFFFull) { code = ACX_ETOOBIG; return "pattern longer than 2^30 bytes"; }
+        A.plen[i] = (uint32_t)L;
+        minl = std::min(minl, L); maxl = std::max(maxl, L);
+    }
+    A.min_len = n ? (uint32_t)minl : 0;
+    A.max_len = (uint32_t)maxl;
+    A.blob.assign(blob + (n ? offsets[0] : 0), blob + (n ? offsets[0] : 0) + total);
+    A.offsets.resize(n + 1);
+    for (uint64_t i = 0; i <= n; i++) A.offsets[i] = n ? offsets[i] - offsets[0] : 0;
+    const uint8_t *pb = A.blob.data();
+
+    // ---- byte classes
+    {
+        bool bound[256] = {false};
+        for (uint64_t i = 0; i < total; i++) {
+            uint8_t b = pb[i];
+            if (b > 0) bound[b - 1] = true;
+            bound[b] = true;
+        }
+        uint32_t c = 0;
+        for (int b = 0; b < 256; b++) {
+            A.classes[b] = (uint8_t)c;
+            if (bound[b] && b != 255) c++;
+        }
+        A.n_classes = (uint32_t)A.classes[255] + 1;
+        A.stride = 1; A.stride2 = 0;
+        while (A.stride < A.n_classes) { A.stride <<= 1; A.stride2++; }
+    }
+
+    // ---- trie in creation order
+    EdgeMap em;
+    {
+        uint64_t cap = 1024;
+        while (cap < total * 2 + 16) cap <<= 1;
+        em.init(cap);
+    }
+    std::vector<uint32_t> e_parent, e_child; // edge list, creation order
+    std::vector<uint8_t> e_byte;
+    e_parent.reserve(total); e_child.reserve(total); e_byte.reserve(total);
+    std::vector<uint32_t> term_node(n);
+    uint32_t n_nodes = 1;
+    for (uint64_t i = 0; i < n; i++) {
+        uint32_t cur = 0;
+        for (uint64_t k = A.offsets[i]; k < A.offsets[i + 1]; k++) {
+            uint64_t key = ((uint64_t)cur << 8) | pb[k];
+            uint32_t nx = em.find(key);
+            if (nx == NONE) {
+                if (n_nodes >= ID_MASK) { code = ACX_ETOOBIG; return "more than 2^30 states"; }
+                nx = n_nodes++;
+                em.insert(key, nx);
+                e_parent.push_back(cur); e_child.push_back(nx); e_byte.push_back(pb[k]);
+            }
+            cur = nx;
+        }
+        term_node[i] = cur;
+    }
+    A.n_states = n_nodes;
+    {
+        unsigned __int128 tb = (unsigned __int128)n_nodes * A.stride * 4;
+        if (tb > ((unsigned __int128)48 << 30)) {
+            code = ACX_ETOOBIG;
+            return "dense DFA would exceed 48 GiB";
+        }
+    }
+    // children CSR by parent (creation ids), children sorted by byte
+    std::vector<uint32_t> c_off(n_nodes + 1, 0);
+    for (uint32_t p : e_parent) c_off[p + 1]++;
+    for (uint32_t i = 0; i < n_nodes; i++) c_off[i + 1] += c_off[i];
+    std::vector<uint32_t> c_edge(e_parent.size());
+    {
+        std::vector<uint32_t> fill(c_off.begin(), c_off.end() - 1);
+        for (uint32_t e = 0; e < e_parent.size(); e++) c_edge[fill[e_parent[e]]++] = e;
+        for (uint32_t p = 0; p < n_nodes; p++)
+            std::sort(c_edge.begin() + c_off[p], c_edge.begin() + c_off[p + 1],
+                      [&](uint32_t a, uint32_t b) { return e_byte[a] < e_byte[b]; });
+    }
+    // ---- BFS numbering
+    std::vector<uint32_t> order(n_nodes), newid(n_nodes);
+    std::vector<uint32_t> depth(n_nodes);
+    {
+        uint32_t qh = 0, qt = 0;
+        order[qt++] = 0; newid[0] = 0; depth[0] = 0;
+        while (qh < qt) {
+            uint32_t u = order[qh];
+            for (uint32_t k = c_off[u]; k < c_off[u + 1]; k++) {
+                uint32_t v = e_child[c_edge[k]];
+                newid[v] = qt; depth[qt] = depth[qh] + 1;
+                order[qt++] = v;
+            }
+            qh++;
+        }
+    }
+    A.level_start.assign((size_t)A.max_len + 2, n_nodes);
+    for (uint32_t s = n_nodes; s-- > 0;) A.level_start[depth[s]] = s;
+    // BFS-id children: first_child (contiguous) + bytes
+    std::vector<uint32_t> first_child(n_nodes + 1);
+    std::vector<uint8_t> in_byte(n_nodes, 0);
+    {
+        uint32_t next = 1;
+        for (uint32_t s = 0; s < n_nodes; s++) {
+            uint32_t u = order[s];
+            first_child[s] = next;
+            for (uint32_t k = c_off[u]; k < c_off[u + 1]; k++) {
+                in_byte[next] = e_byte[c_edge[k]];
+                next++;
+            }
+        }
+        first_child[n_nodes] = next;
+    }
+    // own lists (stable: pattern id order)
+    A.own_off.assign((size_t)n_nodes + 1, 0);
+    for (uint64_t i = 0; i < n; i++) A.own_off[newid[term_node[i]] + 1]++;
+    for (uint32_t s = 0; s < n_nodes; s++) A.own_off[s + 1] += A.own_off[s];
+    A.own_pid.resize(n);
+    {
+        std::vector<uint32_t> fill(A.own_off.begin(), A.own_off.end() - 1);
+        for (uint64_t i = 0; i < n; i++) A.own_pid[fill[newid[term_node[i]]]++] = (uint32_t)i;
+    }
+    // free construction scratch early (large automata)
+    em = EdgeMap(); e_parent = {}; e_child = {}; e_byte = {}; c_off = {}; c_edge = {};
+    order = {}; newid = {}; term_node = {};
+
+    // ---- dense table + fail links, in BFS order
+    const uint32_t S = A.stride;
+    A.table.assign((size_t)n_nodes * S, 0);
+    std::vector<uint32_t> fail(n_nodes, 0);
+    for (uint32_t s = 0; s < n_nodes; s++) {
+        uint32_t *row = A.table.data() + (size_t)s * S;
+        if (s != 0) std::memcpy(row, A.table.data() + (size_t)fail[s] * S, sizeof(uint32_t) * S);
+        for (uint32_t c = first_child[s]; c < first_child[s + 1]; c++) {
+            uint32_t cl = A.classes[in_byte[c]];
+            fail[c] = (s == 0) ? 0 : row[cl]; // delta(fail(s), byte)
+            row[cl] = c;
+        }
+    }
+    // ---- dictionary suffix links and output flags
+    A.dlink.assign(n_nodes, NONE);
+    std::vector<uint32_t> flags(n_nodes, 0);
+    for (uint32_t s = 1; s < n_nodes; s++) {
+        uint32_t f = fail[s];
+        bool f_own = A.own_off[f + 1] > A.own_off[f];
+        A.dlink[s] = f_own ? f : A.dlink[f];
+        bool own = A.own_off[s + 1] > A.own_off[s];
+        if (own) flags[s] |= FLAG_OWN | FLAG_OUT;
+        if (A.dlink[s] != NONE) flags[s] |= FLAG_OUT;
+    }
+    for (size_t i = 0; i < A.table.size(); i++) A.table[i] |= flags[A.table[i]];
+
+    // ---- tie-break rank (len desc, pid asc)
+    {
+        std::vector<uint32_t> idx(n);
+        std::iota(idx.begin(), idx.end(), 0u);
+        std::stable_sort(idx.begin(), idx.end(),
+                         [&](uint32_t a, uint32_t b) { return A.plen[a] > A.plen[b]; });
+        A.rank.resize(n);
+        for (uint32_t r = 0; r < n; r++) A.rank[idx[r]] = r;
+    }
+
+    // ---- q-gram prefilter bitmap (K1b)
+    A.filter_q = 0;
+    if (n > 0) {
+        uint32_t q = std::min<uint32_t>(FILTER_MAX_Q, A.min_len);
+        A.filter_q = q;
+        A.filterA.assign(FILTER_WORDS, 0);
+        uint8_t *bits = reinterpret_cast<uint8_t *>(A.filterA.data());
+        uint64_t set = 0;
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t h = gram_hash(pb + A.offsets[i], q);
+            uint8_t &b = bits[gram_byte(h)];
+            uint8_t bit = (uint8_t)(1u << gram_bit(h));
+            if (!(b & bit)) { b |= bit; set++; }
+        }
+        A.filter_density = (double)set / (double)(1u << FILTER_BITS_LOG2);
+    }
+    return std::string();
+}
+
+} // namespace acx

@@ -1,0 +1,50 @@
+// device_types.hpp -- structs passed by value to the HIP kernels.
+#pragma once
+#include <cstdint>
+
+namespace acx {
+
+// Device-resident automaton (all pointers are device pointers).
+struct DevAutomaton {
+    const uint32_t *table;       // n_states << stride2 entries: id | FLAG_OUT | FLAG_OWN
+    const uint16_t *hot16;       // hot_rows << stride2 entries, compact copy for LDS
+    const uint8_t *classes;      // 256
+    const uint32_t *own_off;     // n_states + 1
+    const uint32_t *own_pid;
+    const uint32_t *dlink;       // n_states
+    const uint32_t *level_start; // max_len + 2
+    const uint32_t *plen;        // n_patterns
+    const uint32_t *rank;        // n_patterns
+    const uint32_t *filterA;     // FILTER_WORDS: q-gram bitmap of the K1b prefilter
+    const uint8_t *pat_blob;     // pattern bytes (generator only)
+    const uint64_t *pat_off;     // n_patterns + 1
+    uint64_t n_patterns;
+    uint32_t n_states;
+    uint32_t stride2;
+    uint32_t min_len, max_len;
+    uint32_t hot_rows;           // rows present in hot16
+    uint32_t filter_q;           // 0 (no patterns) .. 6
+};
+
+// How the byte stream is cut into haystacks.
+struct Segments {
+    const uint64_t *offsets; // device, n_hay + 1 (ragged) or null
+    uint64_t n_hay;          // >= 1
+    uint64_t uniform_len;    // > 0: every haystack has this length
+};
+
+// Raw occurrence sink of the scan kernels.
+//   key_mode 0 (Standard / overlapping): key = end   << 24 | rank(pid)
+//   key_mode 1 (LeftmostFirst):          key = start << 24 | pid
+//   key_mode 2 (LeftmostLongest):        key = start << 24 | rank(pid)
+// Sorting by key ascending therefore yields exactly the order each match kind
+// consumes.
+struct Sink {
+    uint64_t *keys;
+    uint32_t *pids;
+    unsigned long long *counter; // total occurrences (keeps counting past cap)
+    uint64_t cap;
+    int key_mode;
+};
+
+} // namespace acx

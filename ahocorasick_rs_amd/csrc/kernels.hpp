@@ -1,0 +1,70 @@
+// kernels.hpp -- launch wrappers of the HIP kernels in kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstddef>
+#include <cstdint>
+
+#include "../../include/acx.h"
+#include "device_types.hpp"
+
+namespace acx {
+
+// ---- K1: scan kernels (emit every occurrence of every pattern into the sink)
+// K1a: chunked DFA walk, class map + hot rows in LDS.
+hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink &K,
+                           const uint8_t *d_hay, uint64_t len, int n_cus,
+                           size_t max_lds, hipStream_t st);
+// K1b: LDS q-gram prefilter + anchored DFA verification.
+hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
+                            const uint8_t *d_hay, uint64_t len, int n_cus,
+                            hipStream_t st);
+size_t prefilter_lds_bytes(); // dynamic LDS K1b needs (bitmap + class map + queues)
+// rows of the hot16 table K1a can stage for this automaton and LDS size
+uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds);
+
+// ---- post-processing (n = number of raw occurrences)
+size_t sort_temp_bytes(uint64_t n);
+hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
+                            uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
+                            uint64_t n, int end_bit, hipStream_t st);
+// spans from sorted (key,pid): S[i], E[i]
+hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
+                      const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,
+                      hipStream_t st);
+size_t scan_temp_bytes(uint64_t n);
+// running max of E (inclusive) -> M
+hipError_t prefix_max(void *temp, size_t temp_bytes, const uint64_t *E, uint64_t *M,
+                      uint64_t n, hipStream_t st);
+// non-overlapping greedy: flags[i] = 1 iff occurrence i is reported
+hipError_t resolve_greedy(const uint64_t *S, const uint64_t *E, const uint64_t *M,
+                          uint32_t *flags, uint64_t n, hipStream_t st);
+// exclusive prefix sum of flags -> idx (idx[n] = total)
+hipError_t flag_offsets(void *temp, size_t temp_bytes, const uint32_t *flags,
+                        uint32_t *idx, uint64_t n, hipStream_t st);
+// write final matches; flags == nullptr keeps everything (overlapping)
+hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t *E,
+                         const uint32_t *flags, const uint32_t *idx, acx_match_t *out,
+                         uint64_t n, hipStream_t st);
+
+// ---- UTF-8 code-point fix-up (reference: get_byte_to_code_point)
+// lead-byte count of every 1 KiB block -> cnt[nblocks + 1] (last = 0)
+hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt,
+                            hipStream_t st);
+hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uint64_t *out,
+                          uint64_t n, hipStream_t st);
+hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre,
+                          acx_match_t *m, uint64_t n, hipStream_t st);
+
+// ---- batch: make offsets local to each haystack, count matches per haystack.
+// base_cp != nullptr: subtract the code-point index of the haystack start
+// (computed from blockpre) instead of the byte offset.
+hipError_t localize(const Segments &G, const uint8_t *d_hay, uint64_t len,
+                    const uint64_t *blockpre, int codepoints, acx_match_t *m, uint64_t n,
+                    uint64_t *counts, hipStream_t st);
+
+// ---- synthetic haystacks
+hipError_t generate(const DevAutomaton &A, uint8_t *dst, uint64_t len, int kind,
+                    uint64_t seed, uint64_t stream_offset, hipStream_t st);
+
+} // namespace acx

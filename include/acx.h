@@ -1,0 +1,160 @@
+/*
+ * acx.h -- C ABI of the MI355X-native Aho-Corasick matcher (libacx_hip.so).
+ *
+ * This is the drop-in boundary for the ONE hot path this project replaces:
+ * the match loop behind `find_matches_as_indexes` of G-Research/ahocorasick_rs.
+ * Every entry point cites the reference interface it replaces
+ * (paths relative to the reference repository).  Plain pointers and sizes
+ * only; no torch / Python types.  A Rust/PyO3 host would bind these with an
+ * `extern "C"` block; this repository's host shim is the
+ * C++ CPython extension ahocorasick_rs_amd/csrc/pymodule.cpp.
+ *
+ * All functions return ACX_OK (0) or a negative ACX_E* code; the message of
+ * the last failure on the calling thread is available from acx_last_error().
+ * There is NO CPU fallback: without a usable HIP device every matching call
+ * fails with ACX_EDEVICE.
+ */
+#ifndef ACX_H
+#define ACX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACX_VERSION 1
+
+/* status codes */
+#define ACX_OK 0
+#define ACX_EINVAL (-1)      /* bad argument                                  */
+#define ACX_EEMPTY (-2)      /* empty pattern (src/lib.rs:204-208, 386-389)   */
+#define ACX_EOVERLAP (-3)    /* overlapping search on a non-Standard automaton:
+                                the crate's MatchError -> ValueError,
+                                src/lib.rs:36-39, 52-54                        */
+#define ACX_ENOMEM (-4)
+#define ACX_EDEVICE (-5)     /* HIP runtime / no device / kernel failure      */
+#define ACX_ETOOBIG (-6)     /* automaton or haystack exceeds an encoding limit*/
+
+/* enum PyMatchKind, src/lib.rs:92-108 */
+#define ACX_MATCH_STANDARD 0
+#define ACX_MATCH_LEFTMOST_FIRST 1
+#define ACX_MATCH_LEFTMOST_LONGEST 2
+
+/* enum Implementation (+ None), src/lib.rs:111-128.  A hint only: every value
+ * yields identical results (tests/test_ac.py:23-31).  On the device it selects
+ * the scan kernel: DFA = dense-DFA walk with hot rows in LDS preceded by the
+ * LDS q-gram prefilter when the pattern set admits one; NFA values force the
+ * plain chunked DFA walk (no prefilter); AUTO picks by pattern statistics. */
+#define ACX_IMPL_AUTO (-1)
+#define ACX_IMPL_NONCONTIGUOUS_NFA 0
+#define ACX_IMPL_CONTIGUOUS_NFA 1
+#define ACX_IMPL_DFA 2
+
+/* scan kernels (acx_info.kernel, acx_set_kernel) */
+#define ACX_KERNEL_AUTO 0
+#define ACX_KERNEL_DFA_WALK 1   /* K1a: chunked DFA walk, hot rows in LDS      */
+#define ACX_KERNEL_PREFILTER 2  /* K1b: LDS q-gram prefilter + DFA verification */
+
+/* One match: the tuple `(u64, usize, usize)` of src/lib.rs:234, 427. */
+typedef struct acx_match {
+    uint64_t pattern; /* index into the patterns iterable                     */
+    uint64_t start;   /* byte offset, or code-point index when codepoints != 0 */
+    uint64_t end;     /* exclusive                                            */
+} acx_match_t;
+
+typedef struct acx_automaton acx_automaton_t; /* owns host + device tables    */
+typedef struct acx_result acx_result_t;       /* owns device-resident results */
+
+typedef struct acx_info {
+    uint64_t n_patterns;
+    uint64_t n_states;
+    uint32_t n_classes;   /* byte equivalence classes                          */
+    uint32_t stride;      /* row length of the dense table (pow2 >= n_classes) */
+    uint32_t min_pattern_len;
+    uint32_t max_pattern_len;
+    uint64_t table_bytes; /* dense DFA in HBM                                  */
+    uint32_t lds_hot_rows;/* rows staged in LDS by K1a                         */
+    int32_t kernel;       /* ACX_KERNEL_* actually selected                    */
+    int32_t match_kind;
+    int32_t device;       /* HIP device ordinal the tables live on             */
+    uint32_t filter_q;    /* q-gram length of the K1b prefilter (0 = none)     */
+} acx_info_t;
+
+typedef struct acx_profile {
+    double scan_ms;        /* accumulated HIP-event time of the scan kernel (K1) */
+    uint64_t scan_launches;
+    double post_ms;        /* sort + resolve + fix-up kernels                   */
+    uint64_t scan_bytes;   /* haystack bytes scanned by those launches          */
+    uint64_t raw_occurrences; /* occurrences emitted by K1 before resolution    */
+} acx_profile_t;
+
+/* ---- process-wide ---- */
+int acx_version(void);
+const char *acx_last_error(void);
+int acx_device_count(int *n);
+int acx_set_device(int ordinal); /* device for subsequent acx_build on this thread */
+
+/* ---- construction: replaces AhoCorasickBuilder::new().kind(..).match_kind(..)
+ * .build(patterns) at src/lib.rs:186-215 (str) and 401-406 (bytes).
+ * `blob` is the concatenation of the pattern bytes (UTF-8 for str patterns),
+ * `offsets[n_patterns + 1]` delimits them.  Patterns are copied. */
+int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
+              int match_kind, int implementation, acx_automaton_t **out);
+void acx_free_automaton(acx_automaton_t *a);
+int acx_automaton_info(const acx_automaton_t *a, acx_info_t *out);
+int acx_set_kernel(acx_automaton_t *a, int kernel); /* override the selection  */
+
+/* ---- the hot path, host-memory form.  Replaces get_matches + collect:
+ * src/lib.rs:42-68 with consumers 229-249 (str: codepoints = 1 applies the
+ * get_byte_to_code_point fix-up of 73-88 on the device) and 422-434 (bytes).
+ * `hay` is borrowed for the call.  `*out` is library-owned (acx_free_matches).
+ * Order and content are bit-exact with the reference iterator. */
+int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len,
+             int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out);
+void acx_free_matches(acx_match_t *m);
+
+/* ---- batched host form (new API; parity definition:
+ * batch(hs)[i] == find(hs[i])).  `hay` is the concatenation
+ * of n_hay haystacks delimited by offsets[n_hay + 1]; counts[n_hay] receives
+ * the number of matches of each haystack; matches are grouped by haystack in
+ * order, offsets LOCAL to each haystack. */
+int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offsets,
+                   uint64_t n_hay, int overlapping, int codepoints,
+                   acx_match_t **out, uint64_t *n_out, uint64_t *counts);
+
+/* ---- device-resident form (what bench.py times).  d_hay is a device pointer
+ * to `len` bytes on the automaton's device.  Batches: either d_offsets
+ * (device, n_hay + 1 u64, ragged) or uniform_len > 0 (n_hay * uniform_len ==
+ * len) or neither (one haystack).  Results stay in HBM inside *out. */
+int acx_find_device(acx_automaton_t *a, const void *d_hay, uint64_t len,
+                    const uint64_t *d_offsets, uint64_t n_hay, uint64_t uniform_len,
+                    int overlapping, int codepoints, acx_result_t **out);
+uint64_t acx_result_count(const acx_result_t *r);
+const acx_match_t *acx_result_device_matches(const acx_result_t *r);
+const uint64_t *acx_result_device_counts(const acx_result_t *r); /* per haystack, or NULL */
+int acx_result_copy(const acx_result_t *r, acx_match_t *host_out);
+int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts);
+void acx_free_result(acx_result_t *r);
+
+/* ---- measurement hooks (HIP events on the library's stream) ---- */
+int acx_profile_enable(acx_automaton_t *a, int on);
+int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
+
+/* ---- device memory helpers so that a host without torch can stage data ---- */
+int acx_device_alloc(void **d_ptr, uint64_t bytes);
+int acx_device_free(void *d_ptr);
+int acx_device_upload(void *d_dst, const void *h_src, uint64_t bytes);
+int acx_device_download(void *h_dst, const void *d_src, uint64_t bytes);
+int acx_device_synchronize(void);
+
+/* ---- seeded synthetic haystacks generated in HBM (bench / tests).  Bit-exact
+ * twins of tests/gen.py gen_uniform (kind 0, alphabet a-z) and gen_textlike
+ * (kind 1, patterns of `a` planted every 1024 B). ---- */
+int acx_generate_haystack(acx_automaton_t *a, void *d_dst, uint64_t len, int kind,
+                          uint64_t seed, uint64_t stream_offset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACX_H */
