@@ -44,8 +44,10 @@ struct Workspace {
     uint32_t *flags = nullptr, *idx = nullptr;
     void *temp = nullptr;
     size_t temp_bytes = 0;
-    unsigned long long *counter = nullptr; // device
-    uint64_t *h_pinned = nullptr;          // pinned host scratch (4 x u64)
+    uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region
+    uint64_t *block_counts = nullptr; // device: one per scan workgroup
+    uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
+    uint64_t *h_pinned = nullptr;     // pinned host scratch (8 x u64)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
@@ -101,7 +103,8 @@ void free_ws(Workspace &w) {
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
-    (void)hipFree(w.counter); (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
+    (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
+    (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
     w = Workspace();
@@ -109,8 +112,10 @@ void free_ws(Workspace &w) {
 
 int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     Workspace &w = a->ws;
-    if (!w.counter) {
-        HIPCHK(hipMalloc((void **)&w.counter, 64));
+    if (!w.summary) {
+        HIPCHK(hipMalloc((void **)&w.summary, 64));
+        HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 2048));
+        HIPCHK(hipMalloc((void **)&w.region_off, 8 * 2049));
         HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
     }
     if (want <= w.cap) return ACX_OK;
@@ -197,16 +202,20 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
         if (rc) return bail(rc);
         Workspace &w = a->ws;
+        const uint32_t grid = a->kernel == ACX_KERNEL_PREFILTER
+                                  ? prefilter_grid(d_hay, len, a->n_cus)
+                                  : dfa_walk_grid(a->dev, len, a->n_cus);
         for (int attempt = 0; attempt < 3; attempt++) {
-            Sink K{w.keys[0], w.pids[0], w.counter, w.cap, key_mode};
-            HIPCHK_R(hipMemsetAsync(w.counter, 0, 8, st));
+            const uint64_t region_cap = w.cap / grid;
+            Sink K{w.keys[0], w.pids[0], w.block_counts, region_cap, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
             hipError_t e = a->kernel == ACX_KERNEL_PREFILTER
-                               ? launch_prefilter(a->dev, G, K, d_hay, len, a->n_cus, st)
-                               : launch_dfa_walk(a->dev, G, K, d_hay, len, a->n_cus, a->max_lds, st);
+                               ? launch_prefilter(a->dev, G, K, d_hay, len, grid, st)
+                               : launch_dfa_walk(a->dev, G, K, d_hay, len, grid, a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.counter, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, w.summary, w.region_off, st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 16, hipMemcpyDeviceToHost, st));
             HIPCHK_R(hipStreamSynchronize(st));
             if (a->prof) {
                 float ms = 0;
@@ -216,9 +225,15 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 a->profile.scan_bytes += len;
             }
             n_raw = w.h_pinned[0];
-            if (n_raw <= w.cap) break;
+            const uint64_t region_max = w.h_pinned[1];
+            if (region_max <= region_cap) {
+                if (n_raw)
+                    HIPCHK_R(sink_compact(w.keys[0], w.pids[0], w.region_off, grid, region_cap,
+                                          w.keys[1], w.pids[1], st));
+                break;
+            }
             if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
-            rc = ensure_occ_capacity(a, n_raw + n_raw / 16 + 1024);
+            rc = ensure_occ_capacity(a, (uint64_t)grid * (region_max + region_max / 8 + 64));
             if (rc) return bail(rc);
         }
         if (a->prof) a->profile.raw_occurrences += n_raw;
@@ -229,13 +244,14 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         Workspace &w = a->ws;
         if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
         int end_bit = std::min(64, 24 + bits_for(len));
-        HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[0], w.keys[1], w.pids[0],
-                                  w.pids[1], n_raw, end_bit, st));
-        HIPCHK_R(make_spans(a->dev, key_mode, w.keys[1], w.pids[1], w.S, w.E, n_raw, st));
+        // compacted occurrences are in keys[1]/pids[1]; sorted order goes to [0]
+        HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
+                                  w.pids[0], n_raw, end_bit, st));
+        HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
         if (overlapping) {
             n_final = n_raw;
             HIPCHK_R(hipMalloc((void **)&r->d_matches, n_final * sizeof(acx_match_t)));
-            HIPCHK_R(write_matches(w.pids[1], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
+            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
         } else {
             HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
             HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
@@ -245,7 +261,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             HIPCHK_R(hipStreamSynchronize(st));
             n_final = *(uint32_t *)(w.h_pinned + 1);
             HIPCHK_R(hipMalloc((void **)&r->d_matches, std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t)));
-            HIPCHK_R(write_matches(w.pids[1], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
+            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
         }
         r->n = n_final;
         if (n_final && (codepoints || segmented)) {

@@ -39,11 +39,16 @@ struct Segments {
 //   key_mode 2 (LeftmostLongest):        key = start << 24 | rank(pid)
 // Sorting by key ascending therefore yields exactly the order each match kind
 // consumes.
+// Slot allocation uses NO global atomics (one contended HBM word saturates at
+// ~88 atomics/us on MI355X): every workgroup owns the region
+// [blockIdx * region_cap, (blockIdx + 1) * region_cap) and hands out slots from
+// a counter in LDS; its final count goes to block_counts[blockIdx] (it keeps
+// counting past region_cap so that the host can size a retry exactly).
 struct Sink {
     uint64_t *keys;
     uint32_t *pids;
-    unsigned long long *counter; // total occurrences (keeps counting past cap)
-    uint64_t cap;
+    uint64_t *block_counts; // gridDim.x entries
+    uint64_t region_cap;
     int key_mode;
 };
 

@@ -42,7 +42,22 @@ __device__ __forceinline__ u32x4 load16_stream(const uint8_t *p) {
     return __builtin_nontemporal_load((const u32x4 *)p);
 }
 
-__device__ __forceinline__ void emit_one(const DevAutomaton &A, const Sink &K, uint32_t pid,
+// per-workgroup view of the sink: region base + LDS slot counter
+struct BlockSink {
+    uint64_t *keys;
+    uint32_t *pids;
+    uint32_t *lcount; // LDS
+    uint64_t region_cap;
+    int key_mode;
+};
+
+__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount) {
+    return BlockSink{K.keys + (uint64_t)blockIdx.x * K.region_cap,
+                     K.pids + (uint64_t)blockIdx.x * K.region_cap, lcount, K.region_cap,
+                     K.key_mode};
+}
+
+__device__ __forceinline__ void emit_one(const DevAutomaton &A, const BlockSink &K, uint32_t pid,
                                          uint64_t end) {
     uint64_t key;
     if (K.key_mode == 0) {
@@ -51,8 +66,8 @@ __device__ __forceinline__ void emit_one(const DevAutomaton &A, const Sink &K, u
         uint64_t start = end - A.plen[pid];
         key = (start << 24) | (K.key_mode == 1 ? pid : A.rank[pid]);
     }
-    unsigned long long slot = atomicAdd(K.counter, 1ull);
-    if (slot < K.cap) {
+    uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
+    if (slot < K.region_cap) {
         K.keys[slot] = key;
         K.pids[slot] = pid;
     }
@@ -60,7 +75,7 @@ __device__ __forceinline__ void emit_one(const DevAutomaton &A, const Sink &K, u
 
 // every pattern that ends at state s (own patterns, then the dictionary-suffix
 // chain: progressively shorter suffixes)
-__device__ __noinline__ void emit_state(const DevAutomaton &A, const Sink &K, uint32_t s,
+__device__ __noinline__ void emit_state(const DevAutomaton &A, const BlockSink &K, uint32_t s,
                                         uint64_t end) {
     for (uint32_t t = s; t != NONE; t = A.dlink[t]) {
         uint32_t b = A.own_off[t], e = A.own_off[t + 1];
@@ -69,7 +84,7 @@ __device__ __noinline__ void emit_state(const DevAutomaton &A, const Sink &K, ui
 }
 
 // only the patterns that end exactly at state s with depth(s) == length
-__device__ __noinline__ void emit_own(const DevAutomaton &A, const Sink &K, uint32_t s,
+__device__ __noinline__ void emit_own(const DevAutomaton &A, const BlockSink &K, uint32_t s,
                                       uint64_t end) {
     uint32_t b = A.own_off[s], e = A.own_off[s + 1];
     for (uint32_t k = b; k < e; k++) emit_one(A, K, A.own_pid[k], end);
@@ -96,9 +111,11 @@ __device__ __forceinline__ uint64_t segment_end(const Segments &G, uint64_t len,
 // ---------------------------------------------------------------------------
 // K1a: chunked DFA walk
 // ---------------------------------------------------------------------------
-// LDS layout: [0,256) byte classes; then hot rows as u16 entries:
+// LDS layout: [0,256) byte classes; [256,272) slot counter; then hot rows as
+// u16 entries:
 //   0xFFFF           -> target not representable, read the HBM table
 //   id | flags<<14   -> target id < 0x3FFF, flags = (OUT, OWN)
+constexpr size_t K1A_LDS_HEADER = 272;
 struct WalkCtx {
     const uint8_t *lcls;
     const uint16_t *lrows;
@@ -117,7 +134,7 @@ __device__ __forceinline__ uint32_t dfa_step(const DevAutomaton &A, const WalkCt
 
 template <bool EMIT>
 __device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const WalkCtx &W,
-                                              const Sink &K, const uint8_t *hay, uint64_t pos,
+                                              const BlockSink &K, const uint8_t *hay, uint64_t pos,
                                               uint64_t lim, uint32_t s) {
 #define ACX_STEP(BYTE, POS)                                            \
     {                                                                  \
@@ -147,13 +164,16 @@ __device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const WalkC
     return s;
 }
 
-__global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, Segments G, Sink K,
+__global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, Segments G, Sink GK,
                                                      const uint8_t *__restrict__ hay,
                                                      uint64_t len, uint32_t chunk,
                                                      uint32_t lds_rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lcls = smem;
-    uint16_t *lrows = (uint16_t *)(smem + 256);
+    uint32_t *lcount = (uint32_t *)(smem + 256);
+    uint16_t *lrows = (uint16_t *)(smem + K1A_LDS_HEADER);
+    if (threadIdx.x == 0) *lcount = 0;
+    const BlockSink K = block_sink(GK, lcount);
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
         ((uint32_t *)lcls)[i] = ((const uint32_t *)A.classes)[i];
     {
@@ -200,10 +220,12 @@ __global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, Segments G,
             }
         }
     }
+    __syncthreads();
+    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = *lcount;
 }
 
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds) {
-    size_t budget = max_lds > 4096 + 256 ? max_lds - 4096 - 256 : 0; // leave slack
+    size_t budget = max_lds > 4096 + K1A_LDS_HEADER ? max_lds - 4096 - K1A_LDS_HEADER : 0;
     size_t rows = budget / ((size_t)2 << stride2);
     if (rows > n_states) rows = n_states;
     if (rows > 0x3FFF) rows = 0x3FFF;
@@ -220,19 +242,24 @@ static uint32_t pick_chunk(uint32_t max_len, uint64_t len) {
     return (uint32_t)c;
 }
 
+uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus) {
+    uint32_t chunk = pick_chunk(A.max_len, len);
+    uint64_t nchunks = (len + chunk - 1) / chunk;
+    uint64_t blocks = (nchunks + 1023) / 1024;
+    if (blocks > (uint64_t)n_cus) blocks = n_cus;
+    return blocks ? (uint32_t)blocks : 1;
+}
+
 hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink &K,
-                           const uint8_t *d_hay, uint64_t len, int n_cus, size_t max_lds,
+                           const uint8_t *d_hay, uint64_t len, uint32_t grid, size_t max_lds,
                            hipStream_t st) {
     if (len == 0) return hipSuccess;
     uint32_t chunk = pick_chunk(A.max_len, len);
-    uint64_t nchunks = (len + chunk - 1) / chunk;
     uint32_t rows = A.hot_rows;
     uint32_t cap_rows = dfa_walk_hot_rows(A.n_states, A.stride2, max_lds);
     if (rows > cap_rows) rows = cap_rows;
-    size_t lds = 256 + (((size_t)rows << A.stride2) * 2 + 15) / 16 * 16;
-    uint64_t blocks = (nchunks + 1023) / 1024;
-    if (blocks > (uint64_t)n_cus) blocks = n_cus;
-    if (blocks == 0) blocks = 1;
+    size_t lds = K1A_LDS_HEADER + (((size_t)rows << A.stride2) * 2 + 15) / 16 * 16;
+    uint64_t blocks = grid;
     static bool attr_set = false;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void *)k1a_dfa_walk,
@@ -261,7 +288,8 @@ constexpr int K1B_ROWS = 4;
 constexpr uint32_t K1B_QCAP = 128;
 constexpr size_t K1B_LDS_BITMAP = (size_t)1 << (FILTER_BITS_LOG2 - 3);
 constexpr size_t K1B_LDS_CLS = K1B_LDS_BITMAP;
-constexpr size_t K1B_LDS_QUEUE = K1B_LDS_CLS + 256;
+constexpr size_t K1B_LDS_COUNT = K1B_LDS_CLS + 256;
+constexpr size_t K1B_LDS_QUEUE = K1B_LDS_COUNT + 16;
 constexpr size_t K1B_LDS_TOTAL = K1B_LDS_QUEUE + 16 * K1B_QCAP * 8;
 
 __device__ __forceinline__ uint32_t hash_mul24(uint32_t a, uint32_t k) {
@@ -270,7 +298,7 @@ __device__ __forceinline__ uint32_t hash_mul24(uint32_t a, uint32_t k) {
 
 // anchored verification of one candidate start position p
 __device__ __forceinline__ void verify_candidate(const DevAutomaton &A, const Segments &G,
-                                                 const Sink &K, const uint8_t *lcls,
+                                                 const BlockSink &K, const uint8_t *lcls,
                                                  const uint8_t *__restrict__ hay,
                                                  uint64_t len, uint64_t p) {
     uint64_t end = segment_end(G, len, p);
@@ -288,7 +316,7 @@ __device__ __forceinline__ void verify_candidate(const DevAutomaton &A, const Se
 }
 
 template <int Q>
-__global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, Segments G, Sink K,
+__global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, Segments G, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
     // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
@@ -298,6 +326,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, Segments G
     uint8_t *lcls = smem + K1B_LDS_CLS;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint64_t *queue = (uint64_t *)(smem + K1B_LDS_QUEUE) + wave * K1B_QCAP;
+    uint32_t *lcount = (uint32_t *)(smem + K1B_LDS_COUNT);
+    if (threadIdx.x == 0) *lcount = 0;
+    const BlockSink K = block_sink(GK, lcount);
     {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)lbits;
@@ -393,20 +424,27 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, Segments G
         uint64_t p = queue[lane];
         verify_candidate(A, G, K, lcls, hay + lead, len, p);
     }
+    __syncthreads();
+    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = *lcount;
 }
 
 size_t prefilter_lds_bytes() { return K1B_LDS_TOTAL; }
 
-hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
-                            const uint8_t *d_hay, uint64_t len, int n_cus, hipStream_t st) {
-    if (len == 0 || A.filter_q == 0) return hipSuccess;
+uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     uint64_t lead = (uintptr_t)d_hay & 15;
-    const uint8_t *base = d_hay - lead;
     uint64_t total = lead + len;
     uint64_t ntiles = (total + (uint64_t)K1B_ROWS * 1024 - 1) / ((uint64_t)K1B_ROWS * 1024);
     uint64_t blocks = (ntiles + 15) / 16;
     if (blocks > (uint64_t)n_cus) blocks = n_cus;
-    if (blocks == 0) blocks = 1;
+    return blocks ? (uint32_t)blocks : 1;
+}
+
+hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
+                            const uint8_t *d_hay, uint64_t len, uint32_t grid, hipStream_t st) {
+    if (len == 0 || A.filter_q == 0) return hipSuccess;
+    uint64_t lead = (uintptr_t)d_hay & 15;
+    const uint8_t *base = d_hay - lead;
+    uint64_t blocks = grid;
     uint32_t q = A.filter_q;
     static bool attr_set = false;
     if (!attr_set) {
@@ -429,6 +467,61 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink
     case 5: hipLaunchKernelGGL(k1b_prefilter<5>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
     default: hipLaunchKernelGGL(k1b_prefilter<6>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// sink bookkeeping: totals + compaction of the per-workgroup regions
+// ---------------------------------------------------------------------------
+// summary[0] = total occurrences, summary[1] = max per region, offsets[b] =
+// exclusive prefix of min(count, region_cap)
+__global__ __launch_bounds__(256) void k_sink_summary(const uint64_t *block_counts, uint32_t grid,
+                                                      uint64_t region_cap, uint64_t *summary,
+                                                      uint64_t *offsets) {
+    __shared__ uint64_t part[256];
+    // grid <= a few hundred: one thread per block, serial prefix by thread 0
+    uint64_t mx = 0;
+    for (uint32_t b = threadIdx.x; b < grid; b += 256) mx = block_counts[b] > mx ? block_counts[b] : mx;
+    part[threadIdx.x] = mx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t m = 0, run = 0;
+        for (int i = 0; i < 256; i++) m = part[i] > m ? part[i] : m;
+        for (uint32_t b = 0; b < grid; b++) {
+            offsets[b] = run;
+            uint64_t c = block_counts[b];
+            run += c < region_cap ? c : region_cap;
+        }
+        offsets[grid] = run;
+        summary[0] = run;
+        summary[1] = m;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_sink_compact(const uint64_t *keys, const uint32_t *pids,
+                                                      const uint64_t *offsets, uint64_t region_cap,
+                                                      uint64_t *keys_out, uint32_t *pids_out) {
+    uint64_t o0 = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - o0;
+    const uint64_t *k = keys + (uint64_t)blockIdx.x * region_cap;
+    const uint32_t *p = pids + (uint64_t)blockIdx.x * region_cap;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        keys_out[o0 + i] = k[i];
+        pids_out[o0 + i] = p[i];
+    }
+}
+
+hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
+                        uint64_t *summary, uint64_t *offsets, hipStream_t st) {
+    hipLaunchKernelGGL(k_sink_summary, dim3(1), dim3(256), 0, st, block_counts, grid, region_cap,
+                       summary, offsets);
+    return hipGetLastError();
+}
+
+hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint64_t *offsets,
+                        uint32_t grid, uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out,
+                        hipStream_t st) {
+    hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, keys, pids, offsets, region_cap,
+                       keys_out, pids_out);
     return hipGetLastError();
 }
 

@@ -12,13 +12,21 @@ namespace acx {
 
 // ---- K1: scan kernels (emit every occurrence of every pattern into the sink)
 // K1a: chunked DFA walk, class map + hot rows in LDS.
+uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus);
 hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink &K,
-                           const uint8_t *d_hay, uint64_t len, int n_cus,
+                           const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st);
 // K1b: LDS q-gram prefilter + anchored DFA verification.
+uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
 hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
-                            const uint8_t *d_hay, uint64_t len, int n_cus,
+                            const uint8_t *d_hay, uint64_t len, uint32_t grid,
                             hipStream_t st);
+// sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
+hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
+                        uint64_t *summary, uint64_t *offsets, hipStream_t st);
+hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint64_t *offsets,
+                        uint32_t grid, uint64_t region_cap, uint64_t *keys_out,
+                        uint32_t *pids_out, hipStream_t st);
 size_t prefilter_lds_bytes(); // dynamic LDS K1b needs (bitmap + class map + queues)
 // rows of the hot16 table K1a can stage for this automaton and LDS size
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds);
