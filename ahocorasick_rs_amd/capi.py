@@ -38,6 +38,18 @@ class Info(ctypes.Structure):
                 ("device", ctypes.c_int32), ("filter_q", ctypes.c_uint32)]
 
 
+class HostTables(ctypes.Structure):
+    _fields_ = [("n_patterns", ctypes.c_uint64), ("n_states", ctypes.c_uint64),
+                ("n_classes", ctypes.c_uint32), ("stride", ctypes.c_uint32),
+                ("min_pattern_len", ctypes.c_uint32), ("max_pattern_len", ctypes.c_uint32),
+                ("classes", ctypes.c_void_p), ("table", ctypes.c_void_p),
+                ("own_off", ctypes.c_void_p), ("own_pid", ctypes.c_void_p),
+                ("dlink", ctypes.c_void_p), ("level_start", ctypes.c_void_p),
+                ("pattern_len", ctypes.c_void_p), ("rank", ctypes.c_void_p),
+                ("filter_bitmap", ctypes.c_void_p), ("filter_q", ctypes.c_uint32),
+                ("filter_bits_log2", ctypes.c_uint32), ("filter_density", ctypes.c_double)]
+
+
 class Profile(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_double), ("scan_launches", ctypes.c_uint64),
                 ("post_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
@@ -80,6 +92,12 @@ def lib() -> ctypes.CDLL:
     L.acx_free_automaton.restype = None
     L.acx_automaton_info.argtypes = [vp, ctypes.POINTER(Info)]
     L.acx_set_kernel.argtypes = [vp, i32]
+    L.acx_compile_host.argtypes = [vp, vp, u64, i32, ctypes.POINTER(vp)]
+    L.acx_host_tables.argtypes = [vp, ctypes.POINTER(HostTables)]
+    L.acx_filter_hash.argtypes = [vp, ctypes.c_uint32]
+    L.acx_filter_hash.restype = ctypes.c_uint32
+    L.acx_free_host.argtypes = [vp]
+    L.acx_free_host.restype = None
     L.acx_find.argtypes = [vp, vp, u64, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
     L.acx_free_matches.argtypes = [vp]
     L.acx_free_matches.restype = None
@@ -143,6 +161,57 @@ def pack(patterns: Sequence[bytes]) -> Tuple[np.ndarray, np.ndarray]:
         off[1:] = np.cumsum([len(p) for p in patterns], dtype=np.uint64)
     blob = np.frombuffer(b"".join(bytes(p) for p in patterns) + b"\0" * 16, dtype=np.uint8).copy()
     return blob, off
+
+
+class HostAutomaton:
+    """acx_host_automaton_t: the compiled tables on the host (no device needed).
+    Arrays are numpy views valid while this object is alive."""
+
+    def __init__(self, patterns: Sequence[bytes], match_kind: int = MATCH_STANDARD):
+        blob, off = pack(patterns)
+        h = ctypes.c_void_p()
+        _check(lib().acx_compile_host(blob.ctypes.data, off.ctypes.data, len(patterns),
+                                      match_kind, ctypes.byref(h)))
+        self._h = h.value
+        t = HostTables()
+        _check(lib().acx_host_tables(self._h, ctypes.byref(t)))
+        self.t = t
+
+        def view(ptr, n, dtype):
+            if not n:
+                return np.zeros(0, dtype=dtype)
+            size = n * np.dtype(dtype).itemsize
+            buf = (ctypes.c_uint8 * size).from_address(ptr)
+            return np.frombuffer(buf, dtype=dtype, count=n)
+
+        self.n_states = int(t.n_states)
+        self.stride = int(t.stride)
+        self.classes = view(t.classes, 256, np.uint8)
+        self.table = view(t.table, self.n_states * self.stride, np.uint32).reshape(-1, self.stride)
+        self.own_off = view(t.own_off, self.n_states + 1, np.uint32)
+        self.own_pid = view(t.own_pid, int(t.n_patterns), np.uint32)
+        self.dlink = view(t.dlink, self.n_states, np.uint32)
+        self.level_start = view(t.level_start, int(t.max_pattern_len) + 2, np.uint32)
+        self.pattern_len = view(t.pattern_len, int(t.n_patterns), np.uint32)
+        self.rank = view(t.rank, int(t.n_patterns), np.uint32)
+        self.filter_bitmap = view(t.filter_bitmap, (1 << int(t.filter_bits_log2)) // 8
+                                  if t.filter_q else 0, np.uint8)
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().acx_free_host(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def filter_hash(gram: bytes) -> int:
+    b = np.frombuffer(bytes(gram) + b"\0" * 8, dtype=np.uint8)
+    return int(lib().acx_filter_hash(b.ctypes.data, len(gram)))
 
 
 class DeviceBuffer:

@@ -76,6 +76,10 @@ struct acx_automaton {
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
 
+struct acx_host_automaton {
+    Automaton host;
+};
+
 struct acx_result {
     int device = 0;
     acx_match_t *d_matches = nullptr;
@@ -440,6 +444,48 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     *out = a;
     return ACX_OK;
 }
+
+int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
+                     int match_kind, acx_host_automaton_t **out) {
+    if (!out) return fail(ACX_EINVAL, "null output pointer");
+    *out = nullptr;
+    if (n_patterns && (!offsets || (!blob && offsets[n_patterns] != offsets[0])))
+        return fail(ACX_EINVAL, "null pattern buffer");
+    acx_host_automaton *h = new (std::nothrow) acx_host_automaton();
+    if (!h) return fail(ACX_ENOMEM, "out of memory");
+    static const uint64_t zero_off[1] = {0};
+    int code = ACX_OK;
+    std::string err;
+    try {
+        err = compile(blob, n_patterns ? offsets : zero_off, n_patterns, match_kind, h->host, code);
+    } catch (const std::bad_alloc &) {
+        delete h;
+        return fail(ACX_ENOMEM, "out of host memory while compiling the automaton");
+    }
+    if (code != ACX_OK) { delete h; return fail(code, err); }
+    *out = h;
+    return ACX_OK;
+}
+
+int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
+    if (!h || !out) return fail(ACX_EINVAL, "null argument");
+    const Automaton &A = h->host;
+    out->n_patterns = A.n_patterns; out->n_states = A.n_states;
+    out->n_classes = A.n_classes; out->stride = A.stride;
+    out->min_pattern_len = A.min_len; out->max_pattern_len = A.max_len;
+    out->classes = A.classes; out->table = A.table.data();
+    out->own_off = A.own_off.data(); out->own_pid = A.own_pid.data();
+    out->dlink = A.dlink.data(); out->level_start = A.level_start.data();
+    out->pattern_len = A.plen.data(); out->rank = A.rank.data();
+    out->filter_bitmap = reinterpret_cast<const uint8_t *>(A.filterA.data());
+    out->filter_q = A.filter_q; out->filter_bits_log2 = FILTER_BITS_LOG2;
+    out->filter_density = A.filter_density;
+    return ACX_OK;
+}
+
+uint32_t acx_filter_hash(const uint8_t *gram, uint32_t q) { return gram_hash(gram, q); }
+
+void acx_free_host(acx_host_automaton_t *h) { delete h; }
 
 void acx_free_automaton(acx_automaton_t *a) {
     if (!a) return;

@@ -105,6 +105,32 @@ void acx_free_automaton(acx_automaton_t *a);
 int acx_automaton_info(const acx_automaton_t *a, acx_info_t *out);
 int acx_set_kernel(acx_automaton_t *a, int kernel); /* override the selection  */
 
+/* ---- host-only compilation (no device needed): the compiled tables exactly
+ * as they are uploaded to HBM.  For sizing an automaton before committing
+ * device memory, for tooling, and for the CPU-side tests of the compiler.
+ * This is NOT a matching path. ---- */
+typedef struct acx_host_automaton acx_host_automaton_t;
+typedef struct acx_host_tables {
+    uint64_t n_patterns, n_states;
+    uint32_t n_classes, stride, min_pattern_len, max_pattern_len;
+    const uint8_t *classes;       /* 256: byte -> class                              */
+    const uint32_t *table;        /* n_states * stride: id | OUT<<31 | OWN<<30       */
+    const uint32_t *own_off;      /* n_states + 1                                    */
+    const uint32_t *own_pid;      /* patterns ending exactly at a state, id order    */
+    const uint32_t *dlink;        /* dictionary-suffix link or 0xFFFFFFFF            */
+    const uint32_t *level_start;  /* max_pattern_len + 2: first BFS id of each depth */
+    const uint32_t *pattern_len;  /* n_patterns                                      */
+    const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
+    const uint8_t *filter_bitmap; /* 2^filter_bits_log2 bits (K1b prefilter)         */
+    uint32_t filter_q, filter_bits_log2;
+    double filter_density;
+} acx_host_tables_t;
+int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
+                     int match_kind, acx_host_automaton_t **out);
+int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
+uint32_t acx_filter_hash(const uint8_t *gram, uint32_t q); /* the K1b q-gram hash    */
+void acx_free_host(acx_host_automaton_t *h);
+
 /* ---- the hot path, host-memory form.  Replaces get_matches + collect:
  * src/lib.rs:42-68 with consumers 229-249 (str: codepoints = 1 applies the
  * get_byte_to_code_point fix-up of 73-88 on the device) and 422-434 (bytes).

@@ -1,0 +1,151 @@
+"""CPU-only checks of the product's host side: the C ABI loads and exports
+every declared symbol, the automaton compiler (C++) builds the right tables,
+argument validation mirrors the reference, and nothing matches on the CPU."""
+import os
+import random
+import re
+
+import numpy as np
+import pytest
+
+import gen
+from spec import occurrences
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+capi = pytest.importorskip("ahocorasick_rs_amd.capi")
+
+ID_MASK, FLAG_OUT, FLAG_OWN, NONE = 0x3FFFFFFF, 0x80000000, 0x40000000, 0xFFFFFFFF
+
+
+def test_c_abi_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "acx.h")).read()
+    names = sorted(set(re.findall(r"\b(acx_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(names) >= 25
+    L = capi.lib()
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.acx_version() == 1
+
+
+def walk_all_occurrences(h, hay: bytes):
+    """Test-side walker over the product's host tables (NOT a product path)."""
+    out, s = [], 0
+    for i, b in enumerate(hay):
+        e = int(h.table[s, h.classes[b]])
+        s = e & ID_MASK
+        if e & FLAG_OUT:
+            t = s
+            while t != NONE:
+                for k in range(h.own_off[t], h.own_off[t + 1]):
+                    pid = int(h.own_pid[k])
+                    out.append((pid, i + 1 - int(h.pattern_len[pid]), i + 1))
+                t = int(h.dlink[t])
+    return out
+
+
+def test_compiler_tables_enumerate_every_occurrence():
+    rng = random.Random(7)
+    for it in range(150):
+        alpha = [b"ab", b"abc", b"abcdefgh", bytes(range(256))][it % 4]
+        pats = [bytes(rng.choice(alpha) for _ in range(rng.randint(1, 6)))
+                for _ in range(rng.randint(1, 25))]
+        hay = bytes(rng.choice(alpha) for _ in range(rng.randint(0, 120)))
+        h = capi.HostAutomaton(pats)
+        got = walk_all_occurrences(h, hay)
+        want = sorted(occurrences(pats, hay), key=lambda m: (m[2], m[1], m[0]))
+        # per end position: longest first, duplicates in id order == sorted by (end, start, pid)
+        assert got == want
+        # structure: BFS ids are depth-monotone, flags consistent
+        ls = h.level_start
+        assert ls[0] == 0 and ls[-1] == h.n_states and all(ls[i] <= ls[i + 1] for i in range(len(ls) - 1))
+        for s in range(h.n_states):
+            own = h.own_off[s + 1] > h.own_off[s]
+            incoming = h.table[(h.table & ID_MASK) == s]
+            if len(incoming):
+                assert bool(incoming[0] & FLAG_OWN) == own
+                assert bool(incoming[0] & FLAG_OUT) == (own or h.dlink[s] != NONE)
+        h.close()
+
+
+def test_compiler_matches_survey_sizes():
+    # 10k a-z patterns len 5-12 seed 1 -> 63 277 states, 28 classes, stride 32
+    h = capi.HostAutomaton(gen.gen_patterns(10000, 5, 12, gen.AZ, 1))
+    assert (h.n_states, h.t.n_classes, h.stride) == (63277, 28, 32)
+    assert list(h.level_start[:4]) == [0, 1, 27, 703]
+    assert (h.t.min_pattern_len, h.t.max_pattern_len, h.t.filter_q) == (5, 12, 5)
+    # tie-break rank: (len desc, pid asc) is a permutation
+    order = np.argsort(h.rank)
+    lens = h.pattern_len[order]
+    assert np.all(lens[:-1] >= lens[1:])
+    same = lens[:-1] == lens[1:]
+    assert np.all(order[:-1][same] < order[1:][same])
+    h.close()
+
+
+def test_prefilter_bitmap_has_every_pattern_prefix():
+    for pats in ([b"a", b"bc"], [b"abc", b"zzzz"], gen.gen_patterns(500, 4, 9, gen.ALL_BYTES, 3),
+                 gen.gen_patterns(500, 6, 9, gen.AZ, 4)):
+        h = capi.HostAutomaton(pats)
+        q = int(h.t.filter_q)
+        assert q == min(6, min(len(p) for p in pats))
+        for p in pats:
+            hv = capi.filter_hash(p[:q])
+            lo = int.from_bytes(p[:min(q, 3)], "little")
+            hi = int.from_bytes(p[3:q], "little") if q > 3 else 0
+            assert hv == (lo * 0x9E3779 + hi * 0x85EBCB) & 0xFFFFFFFF
+            assert h.filter_bitmap[(hv >> 12) & 0x1FFFF] >> (hv >> 29) & 1
+        assert 0 < h.t.filter_density <= len(pats) / (1 << 20)
+        h.close()
+
+
+def test_compile_errors():
+    with pytest.raises(ValueError) as e:
+        capi.HostAutomaton([b"x", b""])
+    assert "empty pattern" in str(e.value)
+    h = capi.HostAutomaton([])  # zero patterns is legal
+    assert h.n_states == 1 and h.t.filter_q == 0
+    h.close()
+
+
+def test_extension_api_surface_and_validation():
+    ac = pytest.importorskip("ahocorasick_rs_amd")
+    assert ac.MATCHKIND_STANDARD == ac.MatchKind.Standard
+    assert ac.MATCHKIND_LEFTMOST_FIRST == ac.MatchKind.LeftmostFirst
+    assert ac.MATCHKIND_LEFTMOST_LONGEST == ac.MatchKind.LeftmostLongest
+    assert ac.MatchKind.Standard != ac.MatchKind.LeftmostFirst
+    assert repr(ac.Implementation.DFA) == "Implementation.DFA"
+    assert set(ac.__all__) >= {"AhoCorasick", "BytesAhoCorasick", "MatchKind", "Implementation"}
+    # validation happens before any device work (reference tests/test_ac.py:75-83,157-168)
+    with pytest.raises(TypeError):
+        ac.AhoCorasick(None)
+    with pytest.raises(TypeError):
+        ac.AhoCorasick(["x", 12])
+    with pytest.raises(TypeError):
+        ac.BytesAhoCorasick(None)
+    with pytest.raises(TypeError):
+        ac.BytesAhoCorasick([b"x", 12])
+    with pytest.raises(TypeError):
+        ac.BytesAhoCorasick([b"x", "y"])
+    for bad in ([""], ["", "xx"], ["xx", ""]):
+        for sp in (True, False):
+            with pytest.raises(ValueError) as e:
+                ac.AhoCorasick(bad, store_patterns=sp)
+            assert "You passed in an empty string as a pattern" in str(e.value)
+    for bad in ([b""], [b"", b"xx"], [b"xx", b""]):
+        with pytest.raises(ValueError) as e:
+            ac.BytesAhoCorasick(bad)
+        assert "You passed in an empty pattern" in str(e.value)
+    with pytest.raises(TypeError):
+        ac.AhoCorasick(["a"], matchkind="standard")
+    with pytest.raises(TypeError):
+        ac.AhoCorasick(["a"], implementation=2)
+
+
+@pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
+def test_no_cpu_fallback_without_a_device():
+    ac = pytest.importorskip("ahocorasick_rs_amd")
+    with pytest.raises(RuntimeError) as e:
+        ac.BytesAhoCorasick([b"hello"])
+    assert "no HIP device" in str(e.value)
+    with pytest.raises(Exception):
+        capi.Automaton([b"hello"])
