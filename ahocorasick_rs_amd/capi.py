@@ -46,8 +46,10 @@ class HostTables(ctypes.Structure):
                 ("own_off", ctypes.c_void_p), ("own_pid", ctypes.c_void_p),
                 ("dlink", ctypes.c_void_p), ("level_start", ctypes.c_void_p),
                 ("pattern_len", ctypes.c_void_p), ("rank", ctypes.c_void_p),
-                ("filter_bitmap", ctypes.c_void_p), ("filter_q", ctypes.c_uint32),
-                ("filter_bits_log2", ctypes.c_uint32), ("filter_density", ctypes.c_double)]
+                ("filter_xy", ctypes.c_void_p), ("prefix_table", ctypes.c_void_p),
+                ("filter_q", ctypes.c_uint32), ("filter_q2", ctypes.c_uint32),
+                ("filter_entries_log2", ctypes.c_uint32), ("prefix_table_log2", ctypes.c_uint32),
+                ("filter_density", ctypes.c_double)]
 
 
 class Profile(ctypes.Structure):
@@ -94,8 +96,10 @@ def lib() -> ctypes.CDLL:
     L.acx_set_kernel.argtypes = [vp, i32]
     L.acx_compile_host.argtypes = [vp, vp, u64, i32, ctypes.POINTER(vp)]
     L.acx_host_tables.argtypes = [vp, ctypes.POINTER(HostTables)]
-    L.acx_filter_hash.argtypes = [vp, ctypes.c_uint32]
+    L.acx_filter_hash.argtypes = [ctypes.c_uint32]
     L.acx_filter_hash.restype = ctypes.c_uint32
+    L.acx_prefix_slot.argtypes = [u64, ctypes.c_uint32]
+    L.acx_prefix_slot.restype = ctypes.c_uint32
     L.acx_free_host.argtypes = [vp]
     L.acx_free_host.restype = None
     L.acx_find.argtypes = [vp, vp, u64, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64)]
@@ -194,8 +198,10 @@ class HostAutomaton:
         self.level_start = view(t.level_start, int(t.max_pattern_len) + 2, np.uint32)
         self.pattern_len = view(t.pattern_len, int(t.n_patterns), np.uint32)
         self.rank = view(t.rank, int(t.n_patterns), np.uint32)
-        self.filter_bitmap = view(t.filter_bitmap, (1 << int(t.filter_bits_log2)) // 8
-                                  if t.filter_q else 0, np.uint8)
+        self.filter_xy = view(t.filter_xy, (2 << int(t.filter_entries_log2)) if t.filter_q else 0,
+                              np.uint32).reshape(-1, 2)
+        self.prefix_table = view(t.prefix_table, (4 << int(t.prefix_table_log2)) if t.filter_q else 0,
+                                 np.uint32).reshape(-1, 4)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -210,8 +216,13 @@ class HostAutomaton:
 
 
 def filter_hash(gram: bytes) -> int:
-    b = np.frombuffer(bytes(gram) + b"\0" * 8, dtype=np.uint8)
-    return int(lib().acx_filter_hash(b.ctypes.data, len(gram)))
+    """level-1 hash H of a (Q-1)-byte gram: entry = H >> 18, signature bits from H >> 9."""
+    return int(lib().acx_filter_hash(int.from_bytes(gram[:4], "little")))
+
+
+def prefix_slot(gram: bytes, log2: int) -> int:
+    """home slot of a Q2-byte gram in the level-2 prefix table."""
+    return int(lib().acx_prefix_slot(int.from_bytes(gram[:8], "little"), log2))
 
 
 class DeviceBuffer:

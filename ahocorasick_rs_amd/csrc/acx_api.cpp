@@ -63,6 +63,7 @@ struct acx_automaton {
     int device = 0;
     hipStream_t stream = nullptr;
     DevAutomaton dev{};
+    const DevAutomaton *d_dev = nullptr; // the same struct, resident in HBM
     std::vector<void *> allocs;
     int kernel = ACX_KERNEL_DFA_WALK;
     int n_cus = 1;
@@ -214,8 +215,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             Sink K{w.keys[0], w.pids[0], w.block_counts, region_cap, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
             hipError_t e = a->kernel == ACX_KERNEL_PREFILTER
-                               ? launch_prefilter(a->dev, G, K, d_hay, len, grid, st)
-                               : launch_dfa_walk(a->dev, G, K, d_hay, len, grid, a->max_lds, st);
+                               ? launch_prefilter(a->dev, a->d_dev, G, K, d_hay, len, grid, st)
+                               : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, grid, a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
             HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, w.summary, w.region_off, st));
@@ -400,6 +401,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     DevAutomaton &D = a->dev;
     D.n_patterns = H.n_patterns; D.n_states = H.n_states; D.stride2 = H.stride2;
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
+    D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
     // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile
     uint32_t hot_rows = dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024);
     std::vector<uint16_t> hot16(((size_t)hot_rows << H.stride2) + 8, 0xFFFF);
@@ -420,10 +422,12 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.plen, plen)
     UP(H.rank, rank)
     UP(H.filterA, filterA)
+    UP(H.ptab, ptab)
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)
 #undef UP
     if ((rc = upload(a, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
+    if ((rc = upload(a, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
     HIPCHK_A(hipStreamSynchronize(a->stream));
     a->table_bytes = H.table.size() * 4;
     // the big host copy of the table is no longer needed
@@ -477,13 +481,16 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->own_off = A.own_off.data(); out->own_pid = A.own_pid.data();
     out->dlink = A.dlink.data(); out->level_start = A.level_start.data();
     out->pattern_len = A.plen.data(); out->rank = A.rank.data();
-    out->filter_bitmap = reinterpret_cast<const uint8_t *>(A.filterA.data());
-    out->filter_q = A.filter_q; out->filter_bits_log2 = FILTER_BITS_LOG2;
+    out->filter_xy = A.filterA.data();
+    out->prefix_table = A.ptab.data();
+    out->filter_q = A.filter_q; out->filter_q2 = A.filter_q2;
+    out->filter_entries_log2 = FILTER_ENTRIES_LOG2; out->prefix_table_log2 = A.ptab_log2;
     out->filter_density = A.filter_density;
     return ACX_OK;
 }
 
-uint32_t acx_filter_hash(const uint8_t *gram, uint32_t q) { return gram_hash(gram, q); }
+uint32_t acx_filter_hash(uint32_t gram) { return filter_hash(gram); }
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t log2) { return prefix_slot(gram_hash2(gram), log2); }
 
 void acx_free_host(acx_host_automaton_t *h) { delete h; }
 

@@ -231,21 +231,54 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (uint32_t r = 0; r < n; r++) A.rank[idx[r]] = r;
     }
 
-    // ---- q-gram prefilter bitmap (K1b)
-    A.filter_q = 0;
+    // ---- K1b prefilter tables
+    A.filter_q = 0; A.filter_q2 = 0;
     if (n > 0) {
-        uint32_t q = std::min<uint32_t>(FILTER_MAX_Q, A.min_len);
-        A.filter_q = q;
+        const uint32_t Q = std::min<uint32_t>(FILTER_MAX_Q, A.min_len), g = Q - 1;
+        const uint32_t Q2 = std::min<uint32_t>(FILTER2_MAX_Q, A.min_len);
+        A.filter_q = Q; A.filter_q2 = Q2;
+        const uint32_t gmask = g == 4 ? 0xFFFFFFFFu : ((1u << (8 * g)) - 1);
         A.filterA.assign(FILTER_WORDS, 0);
-        uint8_t *bits = reinterpret_cast<uint8_t *>(A.filterA.data());
-        uint64_t set = 0;
         for (uint64_t i = 0; i < n; i++) {
-            uint32_t h = gram_hash(pb + A.offsets[i], q);
-            uint8_t &b = bits[gram_byte(h)];
-            uint8_t bit = (uint8_t)(1u << gram_bit(h));
-            if (!(b & bit)) { b |= bit; set++; }
+            const uint8_t *pp = pb + A.offsets[i];
+            uint32_t hx = filter_hash((uint32_t)gram_of(pp + 1, g) & gmask); // p[1..1+g)
+            uint32_t hy = filter_hash((uint32_t)gram_of(pp, g) & gmask);     // p[0..g)
+            A.filterA[2 * filter_entry(hx)] |= filter_sig(hx, pp[0]);
+            A.filterA[2 * filter_entry(hy) + 1] |= filter_sig(hy, pp[Q - 1]);
         }
-        A.filter_density = (double)set / (double)(1u << FILTER_BITS_LOG2);
+        uint64_t set = 0;
+        for (uint32_t e = 0; e < (1u << FILTER_ENTRIES_LOG2); e++)
+            set += __builtin_popcount(A.filterA[2 * e]);
+        A.filter_density = (double)set / (double)(32u << FILTER_ENTRIES_LOG2);
+
+        // prefix table: one entry per trie state of depth Q2, keyed by its Q2 bytes
+        uint32_t n_pref = A.level_start[Q2 + 1] - A.level_start[Q2];
+        uint32_t lg = 4;
+        while ((1u << lg) < 4 * n_pref) lg++;
+        A.ptab_log2 = lg;
+        A.ptab.assign((size_t)4 << lg, 0);
+        for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = 0xFFFFFFFFu;
+        const uint32_t pmask = (1u << lg) - 1;
+        for (uint64_t i = 0; i < n; i++) {
+            const uint8_t *pp = pb + A.offsets[i];
+            uint32_t st = 0;
+            for (uint32_t k = 0; k < Q2; k++)
+                st = A.table[(size_t)st * S + A.classes[pp[k]]] & ID_MASK;
+            uint64_t gram = gram_of(pp, Q2);
+            uint32_t val = st;
+            if (A.own_off[st + 1] > A.own_off[st]) val |= FLAG_OWN;
+            if (first_child[st + 1] > first_child[st]) val |= 0x80000000u; // has children
+            uint32_t idx = prefix_slot(gram_hash2(gram), lg);
+            for (;;) {
+                uint32_t *en = &A.ptab[4 * (size_t)idx];
+                if (en[2] == 0xFFFFFFFFu) {
+                    en[0] = (uint32_t)gram; en[1] = (uint32_t)(gram >> 32); en[2] = val;
+                    break;
+                }
+                if ((((uint64_t)en[1] << 32) | en[0]) == gram) break; // same prefix already there
+                idx = (idx + 1) & pmask;
+            }
+        }
     }
     return std::string();
 }

@@ -30,26 +30,56 @@ constexpr uint32_t FLAG_OWN = 0x40000000u; // target state ends a pattern itself
 constexpr uint32_t ID_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 
-// K1b prefilter geometry: ONE bitmap of 2^20 bits (128 KiB) resident in LDS.
-constexpr uint32_t FILTER_BITS_LOG2 = 20;
-constexpr uint32_t FILTER_WORDS = (1u << FILTER_BITS_LOG2) / 32;
-constexpr uint32_t FILTER_MAX_Q = 6;
-constexpr uint32_t HASH_K1 = 0x9E3779u; // 24-bit odd multipliers (v_mul_u32_u24)
-constexpr uint32_t HASH_K2 = 0x85EBCBu;
+// ---- K1b prefilter geometry and hashes (shared by the host compiler and the kernel)
+//
+// Level 1 (LDS, 128 KiB): 2^14 entries of two 32-bit words {X, Y}.  With
+// Q = min(5, shortest pattern) and g = Q - 1, every pattern prefix p[0..Q) sets
+// a two-bit signature in
+//     X[e(p[1..1+g))]: bits  p[0] & 31    and  (hs ^ p[0]) & 31
+//     Y[e(p[0..g))]:   bits  p[Q-1] & 31  and  (hs ^ p[Q-1]) & 31
+// (e = entry index, hs = 5 further bits of the same gram hash), so that the
+// haystack positions j (even) and j+1 share ONE 8-byte LDS read: both index
+// the table with the g-gram at j+1; position j tests X with byte j, position
+// j+1 tests Y with byte j+Q.  A position survives when BOTH signature bits are
+// set: true Q-byte prefix hits plus ~0.1 % collisions.
+// Level 2 (HBM, L2-resident): exact open-addressing table of the trie states
+// of depth Q2 = min(8, shortest pattern) keyed by those Q2 bytes.
+constexpr uint32_t FILTER_ENTRIES_LOG2 = 14;
+constexpr uint32_t FILTER_WORDS = 2u << FILTER_ENTRIES_LOG2; // u32 words of the X|Y table
+constexpr uint32_t FILTER_MAX_Q = 5;
+constexpr uint32_t FILTER2_MAX_Q = 8;
+constexpr uint32_t HASH_K1 = 0x9E3779u; // 24-bit odd multiplier (v_mad_u32_u24)
+constexpr uint32_t FILTER_SIG_SHIFT = 9; // hs = H >> 9
 
-// The hash both the host (bitmap construction) and K1b (lookup) use, over the
-// first q (1..6) bytes p[0..q) of a pattern / of the haystack window:
-//   lo = up to three bytes p[0..3)   (24 bits)   * K1
-//   hi = the remaining bytes p[3..q) (<= 24 bits) * K2      (mod 2^32)
-// Bits 12..28 of h address a byte of the bitmap, bits 29..31 the bit in it.
-static inline uint32_t gram_hash(const uint8_t *p, uint32_t q) {
-    uint32_t lo = 0, hi = 0;
-    for (uint32_t k = 0; k < q && k < 3; k++) lo |= (uint32_t)p[k] << (8 * k);
-    for (uint32_t k = 3; k < q; k++) hi |= (uint32_t)p[k] << (8 * (k - 3));
-    return lo * HASH_K1 + hi * HASH_K2;
+#if defined(__HIPCC__)
+#define ACX_HD __host__ __device__
+#else
+#define ACX_HD
+#endif
+
+// 32-bit hash of a g-gram W (little-endian, masked to g bytes)
+ACX_HD static inline uint32_t filter_hash(uint32_t W) { return (W & 0xFFFFFFu) * HASH_K1 + W; }
+ACX_HD static inline uint32_t filter_entry(uint32_t H) { return H >> (32 - FILTER_ENTRIES_LOG2); }
+// the two signature bits of byte b under gram hash H
+ACX_HD static inline uint32_t filter_sig(uint32_t H, uint32_t b) {
+    return (1u << (b & 31)) | (1u << (((H >> FILTER_SIG_SHIFT) ^ b) & 31));
 }
-static inline uint32_t gram_byte(uint32_t h) { return (h >> 12) & 0x1FFFFu; }
-static inline uint32_t gram_bit(uint32_t h) { return h >> 29; }
+// 32-bit hash of a Q2-gram (little-endian in a u64, masked to Q2 bytes)
+ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
+    uint32_t h = (uint32_t)gram * 0x85EBCA6Bu + (uint32_t)(gram >> 32) * 0xC2B2AE35u;
+    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
+    return h;
+}
+// slot of a Q2-gram in the prefix table (2^log2 entries)
+ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
+    uint32_t m = (h2 ^ (h2 >> 7)) * 0x9E3779B1u;
+    return log2 ? m >> (32 - log2) : 0;
+}
+static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
+    uint64_t g = 0;
+    for (uint32_t k = 0; k < q; k++) g |= (uint64_t)p[k] << (8 * k);
+    return g;
+}
 
 struct Automaton {
     int match_kind = 0;
@@ -66,9 +96,14 @@ struct Automaton {
     std::vector<uint32_t> plen;        // n_patterns
     std::vector<uint32_t> rank;        // n_patterns: rank in (len desc, pid asc)
     // prefilter
-    uint32_t filter_q = 0;             // gram length (1..6), 0 = no patterns
-    std::vector<uint32_t> filterA;     // FILTER_WORDS (little-endian bytes of the bitmap)
-    double filter_density = 0.0;       // fraction of bits set
+    uint32_t filter_q = 0;             // level-1 prefix length Q (1..5), 0 = no patterns
+    uint32_t filter_q2 = 0;            // level-2 prefix length Q2 (1..8)
+    std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
+    double filter_density = 0.0;       // fraction of X bits set
+    // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:
+    //   {gram lo, gram hi, state id | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty), 0}
+    std::vector<uint32_t> ptab;
+    uint32_t ptab_log2 = 0;
     // pattern bytes (kept for the synthetic text generator)
     std::vector<uint8_t> blob;
     std::vector<uint64_t> offsets;

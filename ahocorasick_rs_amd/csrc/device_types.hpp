@@ -15,7 +15,8 @@ struct DevAutomaton {
     const uint32_t *level_start; // max_len + 2
     const uint32_t *plen;        // n_patterns
     const uint32_t *rank;        // n_patterns
-    const uint32_t *filterA;     // FILTER_WORDS: q-gram bitmap of the K1b prefilter
+    const uint32_t *filterA;     // FILTER_WORDS: level-1 {X, Y} table of the K1b prefilter
+    const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, 0)
     const uint8_t *pat_blob;     // pattern bytes (generator only)
     const uint64_t *pat_off;     // n_patterns + 1
     uint64_t n_patterns;
@@ -23,7 +24,9 @@ struct DevAutomaton {
     uint32_t stride2;
     uint32_t min_len, max_len;
     uint32_t hot_rows;           // rows present in hot16
-    uint32_t filter_q;           // 0 (no patterns) .. 6
+    uint32_t filter_q;           // level-1 prefix length, 0 (no patterns) .. 5
+    uint32_t filter_q2;          // level-2/3 prefix length, .. 8
+    uint32_t ptab_log2;
 };
 
 // How the byte stream is cut into haystacks.

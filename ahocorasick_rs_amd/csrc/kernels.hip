@@ -22,6 +22,7 @@
 // This is integer, HBM-bound work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 
 #include <rocprim/rocprim.hpp>
@@ -57,14 +58,17 @@ __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount)
                      K.key_mode};
 }
 
-__device__ __forceinline__ void emit_one(const DevAutomaton &A, const BlockSink &K, uint32_t pid,
+// The emit paths are cold and out of line; they read the automaton through a
+// pointer to its device-resident copy so that the kernels never have to spill
+// their by-value kernel arguments to scratch for them.
+__device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink K, uint32_t pid,
                                          uint64_t end) {
     uint64_t key;
     if (K.key_mode == 0) {
-        key = (end << 24) | A.rank[pid];
+        key = (end << 24) | A->rank[pid];
     } else {
-        uint64_t start = end - A.plen[pid];
-        key = (start << 24) | (K.key_mode == 1 ? pid : A.rank[pid]);
+        uint64_t start = end - A->plen[pid];
+        key = (start << 24) | (K.key_mode == 1 ? pid : A->rank[pid]);
     }
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
     if (slot < K.region_cap) {
@@ -75,19 +79,19 @@ __device__ __forceinline__ void emit_one(const DevAutomaton &A, const BlockSink 
 
 // every pattern that ends at state s (own patterns, then the dictionary-suffix
 // chain: progressively shorter suffixes)
-__device__ __noinline__ void emit_state(const DevAutomaton &A, const BlockSink &K, uint32_t s,
+__device__ __noinline__ void emit_state(const DevAutomaton *A, const BlockSink K, uint32_t s,
                                         uint64_t end) {
-    for (uint32_t t = s; t != NONE; t = A.dlink[t]) {
-        uint32_t b = A.own_off[t], e = A.own_off[t + 1];
-        for (uint32_t k = b; k < e; k++) emit_one(A, K, A.own_pid[k], end);
+    for (uint32_t t = s; t != NONE; t = A->dlink[t]) {
+        uint32_t b = A->own_off[t], e = A->own_off[t + 1];
+        for (uint32_t k = b; k < e; k++) emit_one(A, K, A->own_pid[k], end);
     }
 }
 
 // only the patterns that end exactly at state s with depth(s) == length
-__device__ __noinline__ void emit_own(const DevAutomaton &A, const BlockSink &K, uint32_t s,
+__device__ __noinline__ void emit_own(const DevAutomaton *A, const BlockSink K, uint32_t s,
                                       uint64_t end) {
-    uint32_t b = A.own_off[s], e = A.own_off[s + 1];
-    for (uint32_t k = b; k < e; k++) emit_one(A, K, A.own_pid[k], end);
+    uint32_t b = A->own_off[s], e = A->own_off[s + 1];
+    for (uint32_t k = b; k < e; k++) emit_one(A, K, A->own_pid[k], end);
 }
 
 // first index i in [0, n] with off[i] > x
@@ -133,14 +137,15 @@ __device__ __forceinline__ uint32_t dfa_step(const DevAutomaton &A, const WalkCt
 }
 
 template <bool EMIT>
-__device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const WalkCtx &W,
-                                              const BlockSink &K, const uint8_t *hay, uint64_t pos,
-                                              uint64_t lim, uint32_t s) {
+__device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const DevAutomaton *Ad,
+                                              const WalkCtx &W, const BlockSink &K,
+                                              const uint8_t *hay, uint64_t pos, uint64_t lim,
+                                              uint32_t s) {
 #define ACX_STEP(BYTE, POS)                                            \
     {                                                                  \
         uint32_t e_ = dfa_step(A, W, s, (BYTE));                       \
         s = e_ & ID_MASK;                                              \
-        if (EMIT && (e_ & FLAG_OUT)) emit_state(A, K, s, (POS) + 1);   \
+        if (EMIT && (e_ & FLAG_OUT)) emit_state(Ad, K, s, (POS) + 1);  \
     }
     while (pos < lim && ((uintptr_t)(hay + pos) & 15)) {
         ACX_STEP(hay[pos], pos);
@@ -164,7 +169,8 @@ __device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const WalkC
     return s;
 }
 
-__global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, Segments G, Sink GK,
+__global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, const DevAutomaton *Ad,
+                                                     Segments G, Sink GK,
                                                      const uint8_t *__restrict__ hay,
                                                      uint64_t len, uint32_t chunk,
                                                      uint32_t lds_rows) {
@@ -207,8 +213,8 @@ __global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, Segments G,
             uint64_t lim = c1 < nb ? c1 : nb;
             bool emit = pos >= c0;
             if (!emit && c0 < lim) lim = c0;
-            s = emit ? walk_span<true>(A, W, K, hay, pos, lim, s)
-                     : walk_span<false>(A, W, K, hay, pos, lim, s);
+            s = emit ? walk_span<true>(A, Ad, W, K, hay, pos, lim, s)
+                     : walk_span<false>(A, Ad, W, K, hay, pos, lim, s);
             pos = lim;
             if (pos == nb) { // a new haystack starts here: fresh start state
                 s = 0;
@@ -250,9 +256,9 @@ uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus) {
     return blocks ? (uint32_t)blocks : 1;
 }
 
-hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink &K,
-                           const uint8_t *d_hay, uint64_t len, uint32_t grid, size_t max_lds,
-                           hipStream_t st) {
+hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                           const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
+                           size_t max_lds, hipStream_t st) {
     if (len == 0) return hipSuccess;
     uint32_t chunk = pick_chunk(A.max_len, len);
     uint32_t rows = A.hot_rows;
@@ -268,167 +274,334 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink 
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(k1a_dfa_walk, dim3((uint32_t)blocks), dim3(1024), lds, st, A, G, K,
+    hipLaunchKernelGGL(k1a_dfa_walk, dim3((uint32_t)blocks), dim3(1024), lds, st, A, Ad, G, K,
                        d_hay, len, chunk, rows);
     return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------
-// K1b: LDS q-gram prefilter + anchored DFA verification
+// K1b: LDS prefix prefilter -> exact prefix table -> anchored DFA walk
 // ---------------------------------------------------------------------------
-// Geometry: 1024-thread workgroups (16 waves), one per CU, persistent.
-// A wave owns tiles of K1B_ROWS rows; one row = 64 lanes x 16 B = 1 KiB read by
-// ONE coalesced global_load_dwordx4 per lane.  Lane l tests the 16 positions
-// that start inside its 16 bytes; the bytes it needs beyond them (up to 5) come
-// from lane l+1 by cross-lane shuffle.
-//
-// LDS: [0, 128 KiB) bitmap (1 bit per hashed q-gram of a pattern prefix),
-//      then 256 B class map, then 16 per-wave candidate queues (128 x u64).
+// Geometry: 1024-thread workgroups (16 waves), one per CU, persistent.  A wave
+// owns tiles of K1B_ROWS rows; one row = 64 lanes x 16 B = 1 KiB read by ONE
+// coalesced global_load_dwordx4 per lane; the wave's next tile is prefetched
+// into registers while the current one is processed.  Lane l tests the 16
+// positions that start inside its 16 bytes; the bytes it needs beyond them (up
+// to 8) come from lane l+1 by cross-lane shuffle.  Levels (hashes: automaton.hpp):
+//   L1  {X,Y} signature table in LDS (128 KiB): positions j, j+1 share ONE
+//       ds_read_b64 addressed by the (Q-1)-gram at j+1 and test a two-bit
+//       signature each; ~8 VALU + 0.5 LDS reads per haystack byte.  Survivors
+//       (true Q-byte prefix hits + ~0.1 % collisions) are ballot-compacted into
+//       the wave's queue Q1 (tile-relative u16 offsets).
+//   L2  exact probe of the depth-Q2 prefix table (HBM, L2-resident), software-
+//       pipelined over tiles so that no wave waits on it: tile t's survivors
+//       re-read their 8-byte window (phase A, tile t+1), fetch their home slot
+//       (phase B, t+2), compare (phase C, t+3).  Hits go to the persistent Q2.
+//   L3  64 prefix hits at a time: anchored walk of the dense DFA table from the
+//       depth-Q2 state, emitting every pattern that starts at that position.
+// All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
-constexpr uint32_t K1B_QCAP = 128;
-constexpr size_t K1B_LDS_BITMAP = (size_t)1 << (FILTER_BITS_LOG2 - 3);
-constexpr size_t K1B_LDS_CLS = K1B_LDS_BITMAP;
-constexpr size_t K1B_LDS_COUNT = K1B_LDS_CLS + 256;
-constexpr size_t K1B_LDS_QUEUE = K1B_LDS_COUNT + 16;
-constexpr size_t K1B_LDS_TOTAL = K1B_LDS_QUEUE + 16 * K1B_QCAP * 8;
+constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane)
+constexpr uint32_t K1B_Q2CAP = 128; // < 64 left over + <= 64 pushed per tile
+constexpr uint32_t K1B_LEVELS = 64;
+constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t PREFIX_RETRY = 0xFFFFFFFEu; // home slot held another gram: probe again in L3
+constexpr uint32_t FLAG_KIDS = 0x80000000u;    // prefix-table entry: state has children
+
+struct K1bLds {
+    uint32_t xy[FILTER_WORDS];
+    uint8_t cls[256];
+    uint32_t count;
+    uint32_t pad[3];
+    uint32_t level_start[K1B_LEVELS];
+    uint16_t q1[16][K1B_Q1CAP];
+    uint64_t q2pos[16][K1B_Q2CAP];
+    uint32_t q2st[16][K1B_Q2CAP];
+};
+static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
 
 __device__ __forceinline__ uint32_t hash_mul24(uint32_t a, uint32_t k) {
     return __umul24(a, k); // v_mul_u32_u24: uses bits [23:0] of each operand
 }
 
-// anchored verification of one candidate start position p
-__device__ __forceinline__ void verify_candidate(const DevAutomaton &A, const Segments &G,
-                                                 const BlockSink &K, const uint8_t *lcls,
-                                                 const uint8_t *__restrict__ hay,
-                                                 uint64_t len, uint64_t p) {
+// 8 bytes of the stream at position p (zero beyond the end)
+__device__ __forceinline__ uint64_t load_window(const uint8_t *__restrict__ stream, uint64_t len,
+                                                uint64_t p) {
+    uint64_t w = 0;
+    if (p + 8 <= len) {
+        __builtin_memcpy(&w, stream + p, 8);
+    } else {
+        for (uint32_t k = 0; k < 8 && p + k < len; k++) w |= (uint64_t)stream[p + k] << (8 * k);
+    }
+    return w;
+}
+
+// L3: anchored walk for a prefix hit at stream position p (st = prefix-table
+// value, or PREFIX_RETRY when the home slot was taken by another gram).
+// (A is the device-resident copy of the automaton; its fields are wave-uniform
+// scalar loads.)
+__device__ __forceinline__ void deep_walk(const DevAutomaton *A, const Segments &G,
+                                          const BlockSink &K, const K1bLds *L,
+                                          const uint8_t *__restrict__ stream, uint64_t len,
+                                          uint64_t p, uint32_t st) {
+    const uint32_t q = A->filter_q2;
     uint64_t end = segment_end(G, len, p);
     uint64_t maxd = end - p;
-    if (maxd > A.max_len) maxd = A.max_len;
-    uint32_t s = 0;
-    for (uint32_t d = 0; d < maxd; d++) {
-        uint32_t c = lcls[hay[p + d]];
-        uint32_t e = A.table[((size_t)s << A.stride2) + c];
+    if (maxd > A->max_len) maxd = A->max_len;
+    if (maxd < q) return; // the prefix would straddle the end of its haystack
+    if (st == PREFIX_RETRY) {
+        const uint64_t w = load_window(stream, len, p);
+        const uint64_t gram = q >= 8 ? w : (w & ((1ull << (8 * q)) - 1));
+        const uint32_t lg = A->ptab_log2;
+        uint32_t idx = prefix_slot(gram_hash2(gram), lg);
+        const uint32_t mask = (1u << lg) - 1;
+        const uint32_t *ptab = A->ptab;
+        for (;;) {
+            const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
+            if (e.z == PREFIX_EMPTY) return;
+            if ((((uint64_t)e.y << 32) | e.x) == gram) { st = e.z; break; }
+            idx = (idx + 1) & mask;
+        }
+    }
+    uint32_t s = st & ID_MASK;
+    if (st & FLAG_OWN) emit_own(A, K, s, p + q);
+    if (!(st & FLAG_KIDS)) return;
+    const uint32_t *table = A->table;
+    const uint32_t *lstart = A->level_start;
+    const uint32_t stride2 = A->stride2;
+    for (uint32_t d = q; d < maxd; d++) {
+        uint32_t c = L->cls[stream[p + d]];
+        uint32_t e = table[((size_t)s << stride2) + c];
         uint32_t t = e & ID_MASK;
-        if (t < A.level_start[d + 1]) return; // not a trie edge: no pattern continues
+        uint32_t ls = d + 1 < K1B_LEVELS ? L->level_start[d + 1] : lstart[d + 1];
+        if (t < ls) return; // not a trie edge: no pattern continues
         if (e & FLAG_OWN) emit_own(A, K, t, p + d + 1);
         s = t;
     }
 }
 
 template <int Q>
-__global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, Segments G, Sink GK,
+__global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevAutomaton *Ad,
+                                                      Segments G, Sink GK,
                                                       const uint8_t *__restrict__ hay,
-                                                      uint64_t len, uint64_t lead) {
+                                                      uint64_t len, uint64_t lead,
+                                                      uint32_t ablate) {
     // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
     // stream and are never candidates.  Stream position = index - lead.
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint8_t *lbits = smem;
-    uint8_t *lcls = smem + K1B_LDS_CLS;
+    __shared__ __attribute__((aligned(16))) K1bLds L;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    uint64_t *queue = (uint64_t *)(smem + K1B_LDS_QUEUE) + wave * K1B_QCAP;
-    uint32_t *lcount = (uint32_t *)(smem + K1B_LDS_COUNT);
-    if (threadIdx.x == 0) *lcount = 0;
-    const BlockSink K = block_sink(GK, lcount);
+    uint16_t *q1 = L.q1[wave];
+    uint64_t *q2pos = L.q2pos[wave];
+    uint32_t *q2st = L.q2st[wave];
+    if (threadIdx.x == 0) L.count = 0;
+    const BlockSink K = block_sink(GK, &L.count);
     {
         const uint4 *src = (const uint4 *)A.filterA;
-        uint4 *dst = (uint4 *)lbits;
-        for (uint32_t i = threadIdx.x; i < K1B_LDS_BITMAP / 16; i += blockDim.x) dst[i] = src[i];
+        uint4 *dst = (uint4 *)L.xy;
+        for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
         for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
-            ((uint32_t *)lcls)[i] = ((const uint32_t *)A.classes)[i];
+            ((uint32_t *)L.cls)[i] = ((const uint32_t *)A.classes)[i];
+        for (uint32_t i = threadIdx.x; i < K1B_LEVELS; i += blockDim.x)
+            L.level_start[i] = i < A.max_len + 2 ? A.level_start[i] : A.n_states;
     }
     __syncthreads();
 
+    constexpr int GB = Q - 1; // bytes of the shared gram
+    constexpr uint32_t GMASK = GB >= 4 ? 0xFFFFFFFFu : ((1u << (8 * GB)) - 1u);
+    const uint8_t *stream = hay + lead;
     const uint64_t total = lead + len;          // bytes addressable from `hay`
     const uint64_t total16 = (total + 15) & ~15ull;
-    // last index at which a pattern can still start
-    const uint64_t last_start = total >= A.min_len ? total - A.min_len : 0;
+    const uint64_t last_start = total >= A.min_len ? total - A.min_len : 0; // last index a pattern can start at
     const bool any_start = total >= lead + A.min_len;
     const uint64_t tile_bytes = (uint64_t)K1B_ROWS * 1024;
-    const uint64_t ntiles = (total + tile_bytes - 1) / tile_bytes;
+    const uint64_t ntiles = any_start ? (total + tile_bytes - 1) / tile_bytes : 0;
     const uint64_t gw = (uint64_t)blockIdx.x * 16 + wave;
     const uint64_t nw = (uint64_t)gridDim.x * 16;
-    uint32_t qcount = 0; // wave-uniform
+    const uint32_t q2len = A.filter_q2;
+    const uint64_t q2mask = q2len >= 8 ? ~0ull : ((1ull << (8 * q2len)) - 1);
+    const uint32_t ptab_log2 = A.ptab_log2;
+    uint32_t q1c = 0, q2c = 0; // wave-uniform queue fills
 
-    for (uint64_t tile = gw; tile < ntiles && any_start; tile += nw) {
-        const uint64_t tbase = tile * tile_bytes;
-        u32x4 v[K1B_ROWS + 1];
-#pragma unroll
-        for (int r = 0; r <= K1B_ROWS; r++) {
-            uint64_t off = tbase + (uint64_t)r * 1024 + lane * 16;
-            // row K1B_ROWS is only needed by lane 63 (its look-ahead = lane 0's bytes)
-            bool need = (r < K1B_ROWS || lane == 0) && off < total16;
-            v[r] = need ? load16_stream(hay + off) : (u32x4)(0u);
+    // ---- level-2 pipeline registers (tile-synchronous, one entry per lane)
+    uint32_t nB = 0, nC = 0;            // wave-uniform counts
+    uint64_t tbA = 0, tbB = 0, tbC = 0; // tile bases of the entries in Q1 / phase B / phase C
+    uint64_t winB = 0, gramC = 0;
+    uint32_t offB = 0, offC = 0;
+    uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
+
+    // push (p, st) of the lanes with found == true onto Q2
+#define K1B_Q2_PUSH(FOUND, P, ST)                                                                \
+    {                                                                                            \
+        unsigned long long fm_ = __ballot(FOUND);                                                \
+        if (FOUND) {                                                                             \
+            uint32_t slot_ = q2c + __builtin_amdgcn_mbcnt_hi(                                    \
+                                       (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
+            q2pos[slot_] = (P);                                                                  \
+            q2st[slot_] = (ST);                                                                  \
+        }                                                                                        \
+        q2c += (uint32_t)__popcll(fm_);                                                          \
+        __builtin_amdgcn_wave_barrier();                                                         \
+    }
+    // level 3 on the 64 most recent entries of Q2
+#define K1B_Q2_DRAIN()                                                                           \
+    while (q2c >= 64) {                                                                          \
+        q2c -= 64;                                                                               \
+        uint64_t pp_ = q2pos[q2c + lane];                                                        \
+        uint32_t ss_ = q2st[q2c + lane];                                                         \
+        __builtin_amdgcn_wave_barrier();                                                         \
+        if (!(ablate & 2)) deep_walk(Ad, G, K, &L, stream, len, pp_, ss_);                       \
+    }
+
+    // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
+    // the stream) so that exactly five loads are in flight per prefetch: garbage
+    // read for out-of-range blocks only ever feeds positions that are masked off.
+    // nxtL = the 8 bytes that follow the tile (lane 63's look-ahead), read by all
+    // lanes from one address.
+    const uint64_t last_block = total16 - 16;
+    u32x4 nxt0, nxt1, nxt2, nxt3;
+    uint2 nxtL;
+#define K1B_ISSUE_ROW(DST, TILE, R)                                                              \
+    {                                                                                            \
+        uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
+        DST = load16_stream(hay + (off_ < last_block ? off_ : last_block));                      \
+    }
+#define K1B_ISSUE_TILE(TILE)                                                                     \
+    K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2)       \
+    K1B_ISSUE_ROW(nxt3, TILE, 3)                                                                 \
+    {                                                                                            \
+        uint64_t off_ = ((TILE) + 1) * tile_bytes;                                               \
+        nxtL = *(const uint2 *)(hay + (off_ < last_block ? off_ : last_block));                  \
+    }
+    K1B_ISSUE_TILE(gw)
+
+    // three extra iterations drain the level-2 pipeline
+    for (uint64_t tile = gw; tile < ntiles + 3 * nw; tile += nw) {
+        // Everything loaded during the previous iteration (the tile prefetch and the
+        // level-2 windows/slots) is consumed from here on.  Passing the tile through
+        // an empty asm makes the compiler wait for those loads HERE, before the next
+        // prefetch is issued, instead of with a vmcnt(0) in the middle of level 1
+        // that would also wait for the prefetch and serialise load and compute.
+        u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
+        uint2 vL = nxtL;
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
+        // ---- phase C: compare the slots fetched one tile ago with their grams
+        if (nC) {
+            bool act = lane < nC;
+            bool same = (((uint64_t)entC.y << 32) | entC.x) == gramC;
+            bool found = act && entC.z != PREFIX_EMPTY;
+            uint32_t st = same ? entC.z : PREFIX_RETRY;
+            K1B_Q2_PUSH(found, tbC + offC - lead, st)
+            K1B_Q2_DRAIN()
         }
-#pragma unroll
-        for (int r = 0; r < K1B_ROWS; r++) {
-            // look-ahead dwords: lane l+1's first two dwords (lane 63: next row's lane 0)
-            uint32_t nx = __shfl_down(v[r].x, 1), ny = __shfl_down(v[r].y, 1);
-            uint32_t rx = __shfl(v[r + 1].x, 0), ry = __shfl(v[r + 1].y, 0);
-            uint32_t d[6] = {v[r].x, v[r].y, v[r].z, v[r].w, lane == 63 ? rx : nx,
-                             lane == 63 ? ry : ny};
-            // 32-bit little-endian windows starting at byte j
-            uint32_t w[16 + (Q > 4 ? (Q == 5 ? 1 : 3) : 0)];
-#pragma unroll
-            for (int j = 0; j < (int)(sizeof(w) / sizeof(w[0])); j++) {
-                w[j] = (j & 3) == 0 ? d[j >> 2]
-                                    : __builtin_amdgcn_alignbyte(d[(j >> 2) + 1], d[j >> 2], j & 3);
+        // ---- phase B: hash the windows fetched one tile ago, fetch their home slots
+        if (nB) {
+            if (lane < nB) {
+                gramC = winB & q2mask;
+                uint32_t idx = prefix_slot(gram_hash2(gramC), ptab_log2);
+                entC = *(const uint4 *)(A.ptab + (size_t)idx * 4);
             }
-            uint32_t m = 0;
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                uint32_t h;
-                if (Q == 1) h = hash_mul24(w[j] & 0xFFu, HASH_K1);
-                else if (Q == 2) h = hash_mul24(w[j] & 0xFFFFu, HASH_K1);
-                else if (Q == 3) h = hash_mul24(w[j], HASH_K1);
-                else if (Q == 4) h = hash_mul24(w[j], HASH_K1) + hash_mul24(w[j] >> 24, HASH_K2);
-                else if (Q == 5) h = hash_mul24(w[j], HASH_K1) + hash_mul24(w[j + 1] >> 16, HASH_K2);
-                else h = hash_mul24(w[j], HASH_K1) + hash_mul24(w[j + 3], HASH_K2);
-                uint32_t byte = lbits[(h >> 12) & 0x1FFFFu]; // bits 12..28 -> byte of the bitmap
-                uint32_t t = byte >> (h >> 29);              // bits 29..31 -> bit in that byte
-                m = __builtin_amdgcn_alignbit(t, m, 1);      // shift the verdict in at bit 31
+            offC = offB;
+        }
+        nC = nB; tbC = tbB;
+        // ---- phase A: fetch the 8-byte windows of the previous tile's survivors
+        if (ablate & 1) q1c = 0;
+        if (q1c) {
+            if (lane < q1c) {
+                offB = q1[lane];
+                winB = load_window(stream, len, tbA + offB - lead);
             }
-            m >>= 16; // position j -> bit j
-            // mask positions outside [lead, last_start]
-            const uint64_t p0 = tbase + (uint64_t)r * 1024 + lane * 16;
-            if (p0 < lead || p0 + 15 > last_start) {
-                uint32_t keep = 0;
-#pragma unroll
-                for (int j = 0; j < 16; j++)
-                    if (p0 + j >= lead && p0 + j <= last_start) keep |= 1u << j;
-                m &= keep;
+        }
+        nB = q1c; tbB = tbA; q1c = 0;
+        __builtin_amdgcn_wave_barrier();
+        if (tile >= ntiles) continue;
+
+        // ---- level 1 on this tile
+        const uint64_t tbase = tile * tile_bytes;
+        tbA = tbase;
+        K1B_ISSUE_TILE(tile + nw) // prefetch the wave's next tile
+        uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
+#define K1B_ROW(RI, VR, RX, RY, MROW)                                                            \
+        {                                                                                        \
+            /* look-ahead dwords: lane l+1's first two dwords (lane 63: next row's lane 0) */    \
+            uint32_t nx_ = __shfl_down(VR.x, 1), ny_ = __shfl_down(VR.y, 1);                     \
+            uint32_t rx_ = (RX), ry_ = (RY);                                                     \
+            uint32_t d_[6] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_,                    \
+                              lane == 63 ? ry_ : ny_};                                           \
+            uint32_t w_[20];                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 20; j++) {                                     \
+                w_[j] = (j & 3) == 0 ? d_[j >> 2]                                                \
+                                     : __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3); \
+            }                                                                                    \
+            uint32_t m_ = 0;                                                                     \
+            if (!(ablate & 4)) {                                                                 \
+                _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                              \
+                    uint32_t W_ = w_[j + 1] & GMASK;                                             \
+                    uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                                  \
+                    const uint2 e_ = *(const uint2 *)((const uint8_t *)L.xy +                    \
+                        ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u))); \
+                    uint32_t hs_ = H_ >> FILTER_SIG_SHIFT;                                       \
+                    uint32_t bx_ = w_[j], by_ = w_[j + Q];                                       \
+                    uint32_t tx_ = (e_.x >> (bx_ & 31)) & (e_.x >> ((hs_ ^ bx_) & 31));          \
+                    uint32_t ty_ = (e_.y >> (by_ & 31)) & (e_.y >> ((hs_ ^ by_) & 31));          \
+                    m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */  \
+                    m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */  \
+                }                                                                                \
+                m_ >>= 16;                                                                       \
+            } else {                                                                             \
+                m_ = (d_[0] ^ d_[1] ^ d_[2] ^ d_[3] ^ d_[4]) == 0x12345678u ? 1u : 0u;           \
+            }                                                                                    \
+            const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                      \
+            if (p0_ < lead || p0_ + 15 > last_start) {                                           \
+                uint32_t keep_ = 0;                                                              \
+                _Pragma("unroll") for (int j = 0; j < 16; j++)                                   \
+                    if (p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j;              \
+                m_ &= keep_;                                                                     \
+            }                                                                                    \
+            MROW = m_;                                                                           \
+        }
+        K1B_ROW(0, v0, __shfl(v1.x, 0), __shfl(v1.y, 0), mrow0)
+        K1B_ROW(1, v1, __shfl(v2.x, 0), __shfl(v2.y, 0), mrow1)
+        K1B_ROW(2, v2, __shfl(v3.x, 0), __shfl(v3.y, 0), mrow2)
+        K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+        // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
+        uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
+        while (true) {
+            unsigned long long act = __ballot((mlo | mhi) != 0);
+            if (!act) break;
+            uint32_t np = __popcll(act);
+            if (q1c + np > K1B_Q1CAP) {
+                // queue pressure (dense survivors): levels 2 and 3 of everything in Q1, synchronously
+                bool found = false;
+                uint64_t p = 0;
+                if (lane < q1c) { p = tbase + q1[lane] - lead; found = true; }
+                K1B_Q2_PUSH(found, p, PREFIX_RETRY)
+                K1B_Q2_DRAIN()
+                q1c = 0;
             }
-            // ballot-compact survivors into the wave's LDS queue, one per lane per round
-            while (true) {
-                unsigned long long act = __ballot(m != 0);
-                if (!act) break;
-                if (m) {
-                    uint32_t j = __builtin_ctz(m);
-                    m &= m - 1;
-                    uint32_t slot = qcount + __builtin_amdgcn_mbcnt_hi(
-                                                 (uint32_t)(act >> 32),
-                                                 __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
-                    queue[slot] = p0 + j - lead; // stream position
-                }
-                qcount += __popcll(act);
-                __builtin_amdgcn_wave_barrier();
-                if (qcount >= 64) {
-                    qcount -= 64;
-                    uint64_t p = queue[qcount + lane];
-                    verify_candidate(A, G, K, lcls, hay + lead, len, p);
-                }
+            if (mlo | mhi) {
+                uint32_t pos;
+                if (mlo) { pos = __builtin_ctz(mlo); mlo &= mlo - 1; }
+                else { pos = 32 + __builtin_ctz(mhi); mhi &= mhi - 1; }
+                uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+                q1[slot] = (uint16_t)(((pos >> 4) << 10) + lane * 16 + (pos & 15)); // offset in the tile
             }
+            q1c += np;
+            __builtin_amdgcn_wave_barrier();
         }
     }
     __builtin_amdgcn_wave_barrier();
-    if (lane < qcount) {
-        uint64_t p = queue[lane];
-        verify_candidate(A, G, K, lcls, hay + lead, len, p);
-    }
+    if (lane < q2c && !(ablate & 2)) deep_walk(Ad, G, K, &L, stream, len, q2pos[lane], q2st[lane]);
     __syncthreads();
-    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = *lcount;
+    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = L.count;
+#undef K1B_ISSUE_ROW
+#undef K1B_ISSUE_TILE
+#undef K1B_Q2_PUSH
+#undef K1B_Q2_DRAIN
+#undef K1B_ROW
 }
 
-size_t prefilter_lds_bytes() { return K1B_LDS_TOTAL; }
+size_t prefilter_lds_bytes() { return sizeof(K1bLds); }
 
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     uint64_t lead = (uintptr_t)d_hay & 15;
@@ -439,33 +612,29 @@ uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     return blocks ? (uint32_t)blocks : 1;
 }
 
-hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
-                            const uint8_t *d_hay, uint64_t len, uint32_t grid, hipStream_t st) {
+static uint32_t ablation_flags() {
+    static int v = -1;
+    if (v < 0) {
+        const char *e = std::getenv("ACX_ABLATE"); // profiling only: 1 = level 1 only, 2 = skip level 3, 4 = loads only
+        v = e ? std::atoi(e) : 0;
+    }
+    return (uint32_t)v;
+}
+
+hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
+                            hipStream_t st) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
-    uint64_t blocks = grid;
-    uint32_t q = A.filter_q;
-    static bool attr_set = false;
-    if (!attr_set) {
-        const void *fns[6] = {(const void *)k1b_prefilter<1>, (const void *)k1b_prefilter<2>,
-                              (const void *)k1b_prefilter<3>, (const void *)k1b_prefilter<4>,
-                              (const void *)k1b_prefilter<5>, (const void *)k1b_prefilter<6>};
-        for (auto f : fns) {
-            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               (int)K1B_LDS_TOTAL);
-            if (e != hipSuccess) return e;
-        }
-        attr_set = true;
-    }
-    dim3 g((uint32_t)blocks), b(1024);
-    switch (q) {
-    case 1: hipLaunchKernelGGL(k1b_prefilter<1>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
-    case 2: hipLaunchKernelGGL(k1b_prefilter<2>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
-    case 3: hipLaunchKernelGGL(k1b_prefilter<3>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
-    case 4: hipLaunchKernelGGL(k1b_prefilter<4>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
-    case 5: hipLaunchKernelGGL(k1b_prefilter<5>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
-    default: hipLaunchKernelGGL(k1b_prefilter<6>, g, b, K1B_LDS_TOTAL, st, A, G, K, base, len, lead); break;
+    dim3 g(grid), b(1024);
+    uint32_t ab = ablation_flags();
+    switch (A.filter_q) {
+    case 1: hipLaunchKernelGGL(k1b_prefilter<1>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
+    case 2: hipLaunchKernelGGL(k1b_prefilter<2>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
+    case 3: hipLaunchKernelGGL(k1b_prefilter<3>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
+    case 4: hipLaunchKernelGGL(k1b_prefilter<4>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
+    default: hipLaunchKernelGGL(k1b_prefilter<5>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
     }
     return hipGetLastError();
 }

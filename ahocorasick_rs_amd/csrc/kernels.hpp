@@ -13,13 +13,14 @@ namespace acx {
 // ---- K1: scan kernels (emit every occurrence of every pattern into the sink)
 // K1a: chunked DFA walk, class map + hot rows in LDS.
 uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus);
-hipError_t launch_dfa_walk(const DevAutomaton &A, const Segments &G, const Sink &K,
-                           const uint8_t *d_hay, uint64_t len, uint32_t grid,
+// Ad: device-resident copy of A (read by the cold, out-of-line emit paths)
+hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                           const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st);
 // K1b: LDS q-gram prefilter + anchored DFA verification.
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
-hipError_t launch_prefilter(const DevAutomaton &A, const Segments &G, const Sink &K,
-                            const uint8_t *d_hay, uint64_t len, uint32_t grid,
+hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                             hipStream_t st);
 // sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,

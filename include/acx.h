@@ -121,14 +121,18 @@ typedef struct acx_host_tables {
     const uint32_t *level_start;  /* max_pattern_len + 2: first BFS id of each depth */
     const uint32_t *pattern_len;  /* n_patterns                                      */
     const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
-    const uint8_t *filter_bitmap; /* 2^filter_bits_log2 bits (K1b prefilter)         */
-    uint32_t filter_q, filter_bits_log2;
-    double filter_density;
+    const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} words */
+    const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi,
+                                     state | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty), 0} */
+    uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2          */
+    uint32_t filter_entries_log2, prefix_table_log2;
+    double filter_density;        /* fraction of X bits set                            */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);
 int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
-uint32_t acx_filter_hash(const uint8_t *gram, uint32_t q); /* the K1b q-gram hash    */
+uint32_t acx_filter_hash(uint32_t gram);   /* level-1 hash of a little-endian (Q-1)-gram   */
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t log2); /* home slot of a Q2-gram       */
 void acx_free_host(acx_host_automaton_t *h);
 
 /* ---- the hot path, host-memory form.  Replaces get_matches + collect:

@@ -72,7 +72,7 @@ def test_compiler_matches_survey_sizes():
     h = capi.HostAutomaton(gen.gen_patterns(10000, 5, 12, gen.AZ, 1))
     assert (h.n_states, h.t.n_classes, h.stride) == (63277, 28, 32)
     assert list(h.level_start[:4]) == [0, 1, 27, 703]
-    assert (h.t.min_pattern_len, h.t.max_pattern_len, h.t.filter_q) == (5, 12, 5)
+    assert (h.t.min_pattern_len, h.t.max_pattern_len, h.t.filter_q, h.t.filter_q2) == (5, 12, 5, 5)
     # tie-break rank: (len desc, pid asc) is a permutation
     order = np.argsort(h.rank)
     lens = h.pattern_len[order]
@@ -82,19 +82,36 @@ def test_compiler_matches_survey_sizes():
     h.close()
 
 
-def test_prefilter_bitmap_has_every_pattern_prefix():
+def test_prefilter_tables_have_every_pattern_prefix():
     for pats in ([b"a", b"bc"], [b"abc", b"zzzz"], gen.gen_patterns(500, 4, 9, gen.ALL_BYTES, 3),
-                 gen.gen_patterns(500, 6, 9, gen.AZ, 4)):
+                 gen.gen_patterns(500, 6, 9, gen.AZ, 4), gen.gen_patterns(300, 9, 12, gen.AZ, 5)):
         h = capi.HostAutomaton(pats)
-        q = int(h.t.filter_q)
-        assert q == min(6, min(len(p) for p in pats))
+        minlen = min(len(p) for p in pats)
+        q, q2 = int(h.t.filter_q), int(h.t.filter_q2)
+        assert (q, q2) == (min(5, minlen), min(8, minlen))
+        g = q - 1
+        lg = int(h.t.prefix_table_log2)
         for p in pats:
-            hv = capi.filter_hash(p[:q])
-            lo = int.from_bytes(p[:min(q, 3)], "little")
-            hi = int.from_bytes(p[3:q], "little") if q > 3 else 0
-            assert hv == (lo * 0x9E3779 + hi * 0x85EBCB) & 0xFFFFFFFF
-            assert h.filter_bitmap[(hv >> 12) & 0x1FFFF] >> (hv >> 29) & 1
-        assert 0 < h.t.filter_density <= len(pats) / (1 << 20)
+            # level 1: two signature bits in X[e(p[1..1+g))] for p[0], in Y[e(p[0..g))] for p[q-1]
+            for gram, byte, col in ((p[1:1 + g], p[0], 0), (p[0:g], p[q - 1], 1)):
+                H = capi.filter_hash(gram)
+                W = int.from_bytes(gram, "little")
+                assert H == ((W & 0xFFFFFF) * 0x9E3779 + W) & 0xFFFFFFFF
+                sig = (1 << (byte & 31)) | (1 << (((H >> 9) ^ byte) & 31))
+                assert int(h.filter_xy[H >> 18, col]) & sig == sig
+            # level 2: the Q2-byte prefix is in the open-addressing table, reachable from its home slot
+            gram = int.from_bytes(p[:q2], "little")
+            idx = capi.prefix_slot(p[:q2], lg)
+            while True:
+                lo, hi, st, _ = (int(x) for x in h.prefix_table[idx])
+                assert st != 0xFFFFFFFF, "pattern prefix missing from the prefix table"
+                if (hi << 32 | lo) == gram:
+                    break
+                idx = (idx + 1) & ((1 << lg) - 1)
+            sid = st & ID_MASK
+            assert h.level_start[q2] <= sid < h.level_start[q2 + 1]
+            assert bool(st & FLAG_OWN) == (len(p) == q2 or any(len(o) == q2 and o == p[:q2] for o in pats))
+        assert 0 < h.t.filter_density <= 2 * len(pats) / (32 << 14)
         h.close()
 
 
