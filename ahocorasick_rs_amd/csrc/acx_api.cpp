@@ -36,6 +36,59 @@ int hipfail(hipError_t e, const char *what) {
         if (e__ != hipSuccess) return hipfail(e__, #expr); \
     } while (0)
 
+// Small process-wide cache of device buffers for results, so that a find call
+// does not pay hipMalloc/hipFree (each tens of microseconds and a device sync).
+struct BufCache {
+    struct Ent { void *p; size_t bytes; int dev; };
+    std::mutex mu;
+    std::vector<Ent> free_list;
+    size_t cached = 0;
+    static constexpr size_t MAX_CACHED = (size_t)2 << 30;
+    hipError_t get(void **out, size_t bytes, int dev) {
+        bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            int best = -1;
+            for (int i = 0; i < (int)free_list.size(); i++)
+                if (free_list[i].dev == dev && free_list[i].bytes >= bytes &&
+                    free_list[i].bytes <= bytes * 4 + 65536 &&
+                    (best < 0 || free_list[i].bytes < free_list[best].bytes))
+                    best = i;
+            if (best >= 0) {
+                *out = free_list[best].p;
+                cached -= free_list[best].bytes;
+                free_list.erase(free_list.begin() + best);
+                return hipSuccess;
+            }
+        }
+        // round up so that slightly larger requests can reuse the buffer later
+        size_t alloc = bytes + bytes / 4;
+        alloc = (alloc + 4095) / 4096 * 4096;
+        hipError_t e = hipMalloc(out, alloc);
+        if (e == hipSuccess) {
+            std::lock_guard<std::mutex> lk(mu);
+            sizes.push_back({*out, alloc, dev});
+        }
+        return e;
+    }
+    void put(void *p, int dev) {
+        if (!p) return;
+        std::lock_guard<std::mutex> lk(mu);
+        size_t bytes = 0;
+        for (auto &e : sizes) if (e.p == p) { bytes = e.bytes; break; }
+        if (!bytes || cached + bytes > MAX_CACHED || free_list.size() >= 16) {
+            for (size_t i = 0; i < sizes.size(); i++) if (sizes[i].p == p) { sizes.erase(sizes.begin() + i); break; }
+            (void)hipSetDevice(dev);
+            (void)hipFree(p);
+            return;
+        }
+        free_list.push_back({p, bytes, dev});
+        cached += bytes;
+    }
+    std::vector<Ent> sizes; // every live buffer handed out by get()
+};
+BufCache g_bufs;
+
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -44,12 +97,18 @@ struct Workspace {
     uint32_t *flags = nullptr, *idx = nullptr;
     void *temp = nullptr;
     size_t temp_bytes = 0;
-    uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region
+    uint64_t *hkeys = nullptr;        // K1b prefix hits: position / prefix-table value,
+    uint32_t *hpids = nullptr;        //   same capacity and region scheme as keys[0]/pids[0]
+    uint64_t *hit_counts = nullptr;   // device: one per K1b workgroup
+    uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region, [2..3] same for hits
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
     uint64_t *h_pinned = nullptr;     // pinned host scratch (8 x u64)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
+    uint32_t *bcnt = nullptr, *boff = nullptr, *bfill = nullptr; // bucket sort: nb + 1 each
+    uint64_t bucket_cap = 0;
+    uint32_t *big = nullptr;       // device flag: a bucket was too dense for the bucket sort
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
     uint64_t hay_cap = 0;
     uint64_t *offsets = nullptr;
@@ -109,6 +168,8 @@ void free_ws(Workspace &w) {
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
+    (void)hipFree(w.hkeys); (void)hipFree(w.hpids); (void)hipFree(w.hit_counts);
+    (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bfill); (void)hipFree(w.big);
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
@@ -119,8 +180,10 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     Workspace &w = a->ws;
     if (!w.summary) {
         HIPCHK(hipMalloc((void **)&w.summary, 64));
-        HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 2048));
-        HIPCHK(hipMalloc((void **)&w.region_off, 8 * 2049));
+        HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
+        HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
+        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 2048));
+        HIPCHK(hipMalloc((void **)&w.big, 64));
         HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
     }
     if (want <= w.cap) return ACX_OK;
@@ -131,11 +194,15 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
+    (void)hipFree(w.hkeys); (void)hipFree(w.hpids);
     w.S = w.E = w.M = nullptr; w.flags = w.idx = nullptr; w.temp = nullptr; w.cap = 0;
+    w.hkeys = nullptr; w.hpids = nullptr;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&w.keys[i], cap * 8));
         HIPCHK(hipMalloc((void **)&w.pids[i], cap * 4));
     }
+    HIPCHK(hipMalloc((void **)&w.hkeys, cap * 8));
+    HIPCHK(hipMalloc((void **)&w.hpids, cap * 4));
     HIPCHK(hipMalloc((void **)&w.S, cap * 8));
     HIPCHK(hipMalloc((void **)&w.E, cap * 8));
     HIPCHK(hipMalloc((void **)&w.M, cap * 8));
@@ -159,6 +226,25 @@ int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
         w.block_cap = nblocks_plus1;
     }
     size_t need = scan_temp_bytes(nblocks_plus1) + 256;
+    if (need > w.temp_bytes) {
+        (void)hipFree(w.temp); w.temp = nullptr;
+        HIPCHK(hipMalloc(&w.temp, need));
+        w.temp_bytes = need;
+    }
+    return ACX_OK;
+}
+
+int ensure_buckets(acx_automaton *a, uint64_t nb1) {
+    Workspace &w = a->ws;
+    if (nb1 > w.bucket_cap) {
+        (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bfill);
+        w.bcnt = w.boff = w.bfill = nullptr; w.bucket_cap = 0;
+        HIPCHK(hipMalloc((void **)&w.bcnt, nb1 * 4));
+        HIPCHK(hipMalloc((void **)&w.boff, nb1 * 4));
+        HIPCHK(hipMalloc((void **)&w.bfill, nb1 * 4));
+        w.bucket_cap = nb1;
+    }
+    size_t need = bucket_temp_bytes(nb1) + 256;
     if (need > w.temp_bytes) {
         (void)hipFree(w.temp); w.temp = nullptr;
         HIPCHK(hipMalloc(&w.temp, need));
@@ -198,7 +284,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         if (e__ != hipSuccess) return bail(hipfail(e__, #expr)); \
     } while (0)
     if (segmented) {
-        HIPCHK_R(hipMalloc((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8));
+        HIPCHK_R(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
         HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
     }
     uint64_t n_raw = 0;
@@ -207,20 +293,29 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
         if (rc) return bail(rc);
         Workspace &w = a->ws;
-        const uint32_t grid = a->kernel == ACX_KERNEL_PREFILTER
-                                  ? prefilter_grid(d_hay, len, a->n_cus)
-                                  : dfa_walk_grid(a->dev, len, a->n_cus);
+        const bool pre = a->kernel == ACX_KERNEL_PREFILTER;
+        // K1b emits prefix hits into (hkeys, hpids); k_walk_hits turns them into
+        // occurrences.  K1a emits occurrences directly.
+        const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
+                                       : dfa_walk_grid(a->dev, len, a->n_cus);
+        const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // occurrence regions
         for (int attempt = 0; attempt < 3; attempt++) {
             const uint64_t region_cap = w.cap / grid;
+            const uint64_t hit_cap = w.cap / scan_grid;
             Sink K{w.keys[0], w.pids[0], w.block_counts, region_cap, key_mode};
+            Sink H{w.hkeys, w.hpids, w.hit_counts, hit_cap, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
-            hipError_t e = a->kernel == ACX_KERNEL_PREFILTER
-                               ? launch_prefilter(a->dev, a->d_dev, G, K, d_hay, len, grid, st)
-                               : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, grid, a->max_lds, st);
+            hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, st)
+                               : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid,
+                                                 a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+            if (pre) {
+                HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, K, d_hay, len, st));
+                HIPCHK_R(sink_summary(w.hit_counts, scan_grid, hit_cap, w.summary + 2, w.region_off, st));
+            }
             HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, w.summary, w.region_off, st));
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 16, hipMemcpyDeviceToHost, st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
             HIPCHK_R(hipStreamSynchronize(st));
             if (a->prof) {
                 float ms = 0;
@@ -231,14 +326,19 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             }
             n_raw = w.h_pinned[0];
             const uint64_t region_max = w.h_pinned[1];
-            if (region_max <= region_cap) {
+            const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
+            if (region_max <= region_cap && hit_max <= hit_cap) {
                 if (n_raw)
                     HIPCHK_R(sink_compact(w.keys[0], w.pids[0], w.region_off, grid, region_cap,
                                           w.keys[1], w.pids[1], st));
                 break;
             }
             if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
-            rc = ensure_occ_capacity(a, (uint64_t)grid * (region_max + region_max / 8 + 64));
+            uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64),
+                                     (uint64_t)scan_grid * (hit_max + hit_max / 8 + 64));
+            // hits that overflowed were dropped, so the occurrence count is a lower bound: be generous
+            if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
+            rc = ensure_occ_capacity(a, want);
             if (rc) return bail(rc);
         }
         if (a->prof) a->profile.raw_occurrences += n_raw;
@@ -248,26 +348,52 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     if (n_raw > 0) {
         Workspace &w = a->ws;
         if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-        int end_bit = std::min(64, 24 + bits_for(len));
-        // compacted occurrences are in keys[1]/pids[1]; sorted order goes to [0]
-        HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
-                                  w.pids[0], n_raw, end_bit, st));
-        HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
-        if (overlapping) {
-            n_final = n_raw;
-            HIPCHK_R(hipMalloc((void **)&r->d_matches, n_final * sizeof(acx_match_t)));
-            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
-        } else {
-            HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
-            HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
-            HIPCHK_R(resolve_greedy(w.S, w.E, w.M, w.flags, n_raw, st));
-            HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned + 1, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
-            HIPCHK_R(hipStreamSynchronize(st));
-            n_final = *(uint32_t *)(w.h_pinned + 1);
-            HIPCHK_R(hipMalloc((void **)&r->d_matches, std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t)));
-            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
+        const int rank_bits = (int)a->dev.rank_bits;
+        // Sparse occurrences: bucket sort by 4 KiB of stream position; dense ones (or a
+        // bucket sort that met an over-full bucket): rocPRIM radix sort of the used key bits.
+        const uint32_t bshift = (uint32_t)rank_bits + 12;
+        const uint64_t nb = (len >> 12) + 2;
+        bool use_bucket = n_raw <= 8 * nb && nb < (1ull << 31);
+        if (use_bucket) {
+            int rc = ensure_buckets(a, nb + 1);
+            if (rc) return bail(rc);
         }
+        for (int pass = 0; pass < 2; pass++) {
+            // compacted occurrences are in keys[1]/pids[1]; sorted order goes to [0]
+            if (use_bucket) {
+                HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
+                HIPCHK_R(hipMemsetAsync(w.bfill, 0, (nb + 1) * 4, st));
+                HIPCHK_R(hipMemsetAsync(w.big, 0, 4, st));
+                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
+                                                 w.pids[0], n_raw, bshift, (uint32_t)nb, w.bcnt, w.boff,
+                                                 w.bfill, w.big, st));
+            } else {
+                int end_bit = std::min(64, rank_bits + bits_for(len));
+                HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
+                                          w.pids[0], n_raw, end_bit, st));
+            }
+            HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
+            if (overlapping) {
+                n_final = n_raw;
+            } else {
+                HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+                HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
+                HIPCHK_R(resolve_greedy(w.S, w.E, w.M, w.flags, n_raw, st));
+                HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
+                HIPCHK_R(hipMemcpyAsync(w.h_pinned + 4, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
+            }
+            if (use_bucket) HIPCHK_R(hipMemcpyAsync(w.h_pinned + 5, w.big, 4, hipMemcpyDeviceToHost, st));
+            if (use_bucket || !overlapping) HIPCHK_R(hipStreamSynchronize(st));
+            if (use_bucket && *(uint32_t *)(w.h_pinned + 5)) { use_bucket = false; continue; } // too dense
+            if (!overlapping) n_final = *(uint32_t *)(w.h_pinned + 4);
+            break;
+        }
+        HIPCHK_R(g_bufs.get((void **)&r->d_matches, std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t),
+                            a->device));
+        if (overlapping)
+            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
+        else
+            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
         r->n = n_final;
         if (n_final && (codepoints || segmented)) {
             if (codepoints) {
@@ -402,6 +528,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.n_patterns = H.n_patterns; D.n_states = H.n_states; D.stride2 = H.stride2;
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
     D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
+    D.rank_bits = (uint32_t)std::max(1, bits_for(H.n_patterns ? H.n_patterns - 1 : 0));
     // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile
     uint32_t hot_rows = dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024);
     std::vector<uint16_t> hot16(((size_t)hot_rows << H.stride2) + 8, 0xFFFF);
@@ -578,9 +705,8 @@ int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts) {
 
 void acx_free_result(acx_result_t *r) {
     if (!r) return;
-    (void)hipSetDevice(r->device);
-    (void)hipFree(r->d_matches);
-    (void)hipFree(r->d_counts);
+    g_bufs.put(r->d_matches, r->device);
+    g_bufs.put(r->d_counts, r->device);
     delete r;
 }
 

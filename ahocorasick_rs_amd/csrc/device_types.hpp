@@ -26,6 +26,7 @@ struct DevAutomaton {
     uint32_t hot_rows;           // rows present in hot16
     uint32_t filter_q;           // level-1 prefix length, 0 (no patterns) .. 5
     uint32_t filter_q2;          // level-2/3 prefix length, .. 8
+    uint32_t rank_bits;          // bits of the tie-break field of an occurrence key
     uint32_t ptab_log2;
 };
 
@@ -37,9 +38,11 @@ struct Segments {
 };
 
 // Raw occurrence sink of the scan kernels.
-//   key_mode 0 (Standard / overlapping): key = end   << 24 | rank(pid)
-//   key_mode 1 (LeftmostFirst):          key = start << 24 | pid
-//   key_mode 2 (LeftmostLongest):        key = start << 24 | rank(pid)
+//   key_mode 0 (Standard / overlapping): key = end   << rank_bits | rank(pid)
+//   key_mode 1 (LeftmostFirst):          key = start << rank_bits | pid
+//   key_mode 2 (LeftmostLongest):        key = start << rank_bits | rank(pid)
+// (rank_bits = bits needed for n_patterns - 1, so that the radix sort and the
+// bucket sort see as few key bits as possible)
 // Sorting by key ascending therefore yields exactly the order each match kind
 // consumes.
 // Slot allocation uses NO global atomics (one contended HBM word saturates at

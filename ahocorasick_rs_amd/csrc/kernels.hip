@@ -65,10 +65,10 @@ __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink 
                                          uint64_t end) {
     uint64_t key;
     if (K.key_mode == 0) {
-        key = (end << 24) | A->rank[pid];
+        key = (end << A->rank_bits) | A->rank[pid];
     } else {
         uint64_t start = end - A->plen[pid];
-        key = (start << 24) | (K.key_mode == 1 ? pid : A->rank[pid]);
+        key = (start << A->rank_bits) | (K.key_mode == 1 ? pid : A->rank[pid]);
     }
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
     if (slot < K.region_cap) {
@@ -296,27 +296,24 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //   L2  exact probe of the depth-Q2 prefix table (HBM, L2-resident), software-
 //       pipelined over tiles so that no wave waits on it: tile t's survivors
 //       re-read their 8-byte window (phase A, tile t+1), fetch their home slot
-//       (phase B, t+2), compare (phase C, t+3).  Hits go to the persistent Q2.
-//   L3  64 prefix hits at a time: anchored walk of the dense DFA table from the
-//       depth-Q2 state, emitting every pattern that starts at that position.
+//       (phase B, t+2), compare (phase C, t+3).  Hits (position, depth-Q2 state)
+//       leave through the sink: the scan kernel never walks the DFA itself, so
+//       its waves never sit in the long dependent-load chains of a walk.
+//   L3  (separate kernel k_walk_hits, one thread per prefix hit): anchored walk
+//       of the dense DFA table from the depth-Q2 state, emitting every pattern
+//       that starts at that position into the occurrence sink.
 // All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
 constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane)
-constexpr uint32_t K1B_Q2CAP = 128; // < 64 left over + <= 64 pushed per tile
-constexpr uint32_t K1B_LEVELS = 64;
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PREFIX_RETRY = 0xFFFFFFFEu; // home slot held another gram: probe again in L3
 constexpr uint32_t FLAG_KIDS = 0x80000000u;    // prefix-table entry: state has children
 
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
-    uint8_t cls[256];
     uint32_t count;
     uint32_t pad[3];
-    uint32_t level_start[K1B_LEVELS];
     uint16_t q1[16][K1B_Q1CAP];
-    uint64_t q2pos[16][K1B_Q2CAP];
-    uint32_t q2st[16][K1B_Q2CAP];
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
 
@@ -338,46 +335,63 @@ __device__ __forceinline__ uint64_t load_window(const uint8_t *__restrict__ stre
 
 // L3: anchored walk for a prefix hit at stream position p (st = prefix-table
 // value, or PREFIX_RETRY when the home slot was taken by another gram).
-// (A is the device-resident copy of the automaton; its fields are wave-uniform
-// scalar loads.)
-__device__ __forceinline__ void deep_walk(const DevAutomaton *A, const Segments &G,
-                                          const BlockSink &K, const K1bLds *L,
+__device__ __forceinline__ void deep_walk(const DevAutomaton &A, const DevAutomaton *Ad,
+                                          const Segments &G, const BlockSink &K,
                                           const uint8_t *__restrict__ stream, uint64_t len,
                                           uint64_t p, uint32_t st) {
-    const uint32_t q = A->filter_q2;
+    const uint32_t q = A.filter_q2;
     uint64_t end = segment_end(G, len, p);
     uint64_t maxd = end - p;
-    if (maxd > A->max_len) maxd = A->max_len;
+    if (maxd > A.max_len) maxd = A.max_len;
     if (maxd < q) return; // the prefix would straddle the end of its haystack
     if (st == PREFIX_RETRY) {
         const uint64_t w = load_window(stream, len, p);
         const uint64_t gram = q >= 8 ? w : (w & ((1ull << (8 * q)) - 1));
-        const uint32_t lg = A->ptab_log2;
-        uint32_t idx = prefix_slot(gram_hash2(gram), lg);
-        const uint32_t mask = (1u << lg) - 1;
-        const uint32_t *ptab = A->ptab;
+        uint32_t idx = prefix_slot(gram_hash2(gram), A.ptab_log2);
+        const uint32_t mask = (1u << A.ptab_log2) - 1;
         for (;;) {
-            const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
+            const uint4 e = *(const uint4 *)(A.ptab + (size_t)idx * 4);
             if (e.z == PREFIX_EMPTY) return;
             if ((((uint64_t)e.y << 32) | e.x) == gram) { st = e.z; break; }
             idx = (idx + 1) & mask;
         }
     }
     uint32_t s = st & ID_MASK;
-    if (st & FLAG_OWN) emit_own(A, K, s, p + q);
+    if (st & FLAG_OWN) emit_own(Ad, K, s, p + q);
     if (!(st & FLAG_KIDS)) return;
-    const uint32_t *table = A->table;
-    const uint32_t *lstart = A->level_start;
-    const uint32_t stride2 = A->stride2;
     for (uint32_t d = q; d < maxd; d++) {
-        uint32_t c = L->cls[stream[p + d]];
-        uint32_t e = table[((size_t)s << stride2) + c];
+        uint32_t c = A.classes[stream[p + d]];
+        uint32_t e = A.table[((size_t)s << A.stride2) + c];
         uint32_t t = e & ID_MASK;
-        uint32_t ls = d + 1 < K1B_LEVELS ? L->level_start[d + 1] : lstart[d + 1];
-        if (t < ls) return; // not a trie edge: no pattern continues
-        if (e & FLAG_OWN) emit_own(A, K, t, p + d + 1);
+        if (t < A.level_start[d + 1]) return; // not a trie edge: no pattern continues
+        if (e & FLAG_OWN) emit_own(Ad, K, t, p + d + 1);
         s = t;
     }
+}
+
+constexpr uint32_t K_WALK_SPLIT = 16;
+
+// One thread per prefix hit of K1b.  Hits live in the per-workgroup regions of
+// the scan's sink (H); occurrences go to the occurrence sink (GK).
+__global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAutomaton *Ad,
+                                                   Segments G, Sink H, uint32_t h_grid, Sink GK,
+                                                   const uint8_t *__restrict__ stream,
+                                                   uint64_t len) {
+    __shared__ uint32_t lcount;
+    if (threadIdx.x == 0) lcount = 0;
+    __syncthreads();
+    const BlockSink K = block_sink(GK, &lcount);
+    // K_WALK_SPLIT workgroups share one hit region
+    for (uint32_t b = blockIdx.x / K_WALK_SPLIT; b < h_grid; b += gridDim.x / K_WALK_SPLIT) {
+        uint64_t n = H.block_counts[b];
+        if (n > H.region_cap) n = H.region_cap;
+        const uint64_t *pos = H.keys + (uint64_t)b * H.region_cap;
+        const uint32_t *st = H.pids + (uint64_t)b * H.region_cap;
+        for (uint64_t i = (blockIdx.x % K_WALK_SPLIT) * 256 + threadIdx.x; i < n; i += K_WALK_SPLIT * 256)
+            deep_walk(A, Ad, G, K, stream, len, pos[i], st[i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = lcount;
 }
 
 template <int Q>
@@ -391,18 +405,12 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     __shared__ __attribute__((aligned(16))) K1bLds L;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
-    uint64_t *q2pos = L.q2pos[wave];
-    uint32_t *q2st = L.q2st[wave];
     if (threadIdx.x == 0) L.count = 0;
-    const BlockSink K = block_sink(GK, &L.count);
+    const BlockSink K = block_sink(GK, &L.count); // sink of prefix hits: key = position, pid = state
     {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
-        for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
-            ((uint32_t *)L.cls)[i] = ((const uint32_t *)A.classes)[i];
-        for (uint32_t i = threadIdx.x; i < K1B_LEVELS; i += blockDim.x)
-            L.level_start[i] = i < A.max_len + 2 ? A.level_start[i] : A.n_states;
     }
     __syncthreads();
 
@@ -420,7 +428,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint32_t q2len = A.filter_q2;
     const uint64_t q2mask = q2len >= 8 ? ~0ull : ((1ull << (8 * q2len)) - 1);
     const uint32_t ptab_log2 = A.ptab_log2;
-    uint32_t q1c = 0, q2c = 0; // wave-uniform queue fills
+    uint32_t q1c = 0; // wave-uniform queue fill
 
     // ---- level-2 pipeline registers (tile-synchronous, one entry per lane)
     uint32_t nB = 0, nC = 0;            // wave-uniform counts
@@ -429,27 +437,21 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     uint32_t offB = 0, offC = 0;
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
 
-    // push (p, st) of the lanes with found == true onto Q2
-#define K1B_Q2_PUSH(FOUND, P, ST)                                                                \
+    // hand the prefix hits (p, st) of the lanes with found == true to the sink:
+    // one LDS atomic per wave reserves the slots
+#define K1B_HIT_PUSH(FOUND, P, ST)                                                               \
     {                                                                                            \
         unsigned long long fm_ = __ballot(FOUND);                                                \
-        if (FOUND) {                                                                             \
-            uint32_t slot_ = q2c + __builtin_amdgcn_mbcnt_hi(                                    \
-                                       (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
-            q2pos[slot_] = (P);                                                                  \
-            q2st[slot_] = (ST);                                                                  \
+        if (fm_) {                                                                               \
+            uint32_t base_ = 0;                                                                  \
+            if (lane == (uint32_t)__builtin_ctzll(fm_)) base_ = atomicAdd(K.lcount, (uint32_t)__popcll(fm_)); \
+            base_ = __shfl(base_, __builtin_ctzll(fm_));                                         \
+            if (FOUND) {                                                                         \
+                uint32_t slot_ = base_ + __builtin_amdgcn_mbcnt_hi(                              \
+                                             (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
+                if (slot_ < K.region_cap) { K.keys[slot_] = (P); K.pids[slot_] = (ST); }         \
+            }                                                                                    \
         }                                                                                        \
-        q2c += (uint32_t)__popcll(fm_);                                                          \
-        __builtin_amdgcn_wave_barrier();                                                         \
-    }
-    // level 3 on the 64 most recent entries of Q2
-#define K1B_Q2_DRAIN()                                                                           \
-    while (q2c >= 64) {                                                                          \
-        q2c -= 64;                                                                               \
-        uint64_t pp_ = q2pos[q2c + lane];                                                        \
-        uint32_t ss_ = q2st[q2c + lane];                                                         \
-        __builtin_amdgcn_wave_barrier();                                                         \
-        if (!(ablate & 2)) deep_walk(Ad, G, K, &L, stream, len, pp_, ss_);                       \
     }
 
     // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
@@ -490,8 +492,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             bool same = (((uint64_t)entC.y << 32) | entC.x) == gramC;
             bool found = act && entC.z != PREFIX_EMPTY;
             uint32_t st = same ? entC.z : PREFIX_RETRY;
-            K1B_Q2_PUSH(found, tbC + offC - lead, st)
-            K1B_Q2_DRAIN()
+            if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st)
         }
         // ---- phase B: hash the windows fetched one tile ago, fetch their home slots
         if (nB) {
@@ -570,12 +571,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             if (!act) break;
             uint32_t np = __popcll(act);
             if (q1c + np > K1B_Q1CAP) {
-                // queue pressure (dense survivors): levels 2 and 3 of everything in Q1, synchronously
-                bool found = false;
-                uint64_t p = 0;
-                if (lane < q1c) { p = tbase + q1[lane] - lead; found = true; }
-                K1B_Q2_PUSH(found, p, PREFIX_RETRY)
-                K1B_Q2_DRAIN()
+                // queue pressure (dense survivors): hand everything in Q1 to the walk
+                // kernel unprobed (it probes the prefix table itself)
+                bool found = lane < q1c;
+                uint64_t p = found ? tbase + q1[lane] - lead : 0;
+                K1B_HIT_PUSH(found, p, PREFIX_RETRY)
                 q1c = 0;
             }
             if (mlo | mhi) {
@@ -590,14 +590,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             __builtin_amdgcn_wave_barrier();
         }
     }
-    __builtin_amdgcn_wave_barrier();
-    if (lane < q2c && !(ablate & 2)) deep_walk(Ad, G, K, &L, stream, len, q2pos[lane], q2st[lane]);
     __syncthreads();
     if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = L.count;
 #undef K1B_ISSUE_ROW
 #undef K1B_ISSUE_TILE
-#undef K1B_Q2_PUSH
-#undef K1B_Q2_DRAIN
+#undef K1B_HIT_PUSH
 #undef K1B_ROW
 }
 
@@ -610,6 +607,16 @@ uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     uint64_t blocks = (ntiles + 15) / 16;
     if (blocks > (uint64_t)n_cus) blocks = n_cus;
     return blocks ? (uint32_t)blocks : 1;
+}
+
+uint32_t walk_hits_grid(uint32_t hit_grid) { return hit_grid * K_WALK_SPLIT; }
+
+hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                            const Sink &hits, uint32_t hit_grid, const Sink &occ,
+                            const uint8_t *d_hay, uint64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(k_walk_hits, dim3(walk_hits_grid(hit_grid)), dim3(256), 0, st, A, Ad, G, hits,
+                       hit_grid, occ, d_hay, len);
+    return hipGetLastError();
 }
 
 static uint32_t ablation_flags() {
@@ -642,27 +649,41 @@ hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const
 // ---------------------------------------------------------------------------
 // sink bookkeeping: totals + compaction of the per-workgroup regions
 // ---------------------------------------------------------------------------
-// summary[0] = total occurrences, summary[1] = max per region, offsets[b] =
-// exclusive prefix of min(count, region_cap)
-__global__ __launch_bounds__(256) void k_sink_summary(const uint64_t *block_counts, uint32_t grid,
-                                                      uint64_t region_cap, uint64_t *summary,
-                                                      uint64_t *offsets) {
-    __shared__ uint64_t part[256];
-    // grid <= a few hundred: one thread per block, serial prefix by thread 0
-    uint64_t mx = 0;
-    for (uint32_t b = threadIdx.x; b < grid; b += 256) mx = block_counts[b] > mx ? block_counts[b] : mx;
-    part[threadIdx.x] = mx;
+// summary[0] = total occurrences kept, summary[1] = max count of a region,
+// offsets[b] = exclusive prefix of min(count, region_cap), offsets[grid] = total
+__global__ __launch_bounds__(1024) void k_sink_summary(const uint64_t *block_counts, uint32_t grid,
+                                                       uint64_t region_cap, uint64_t *summary,
+                                                       uint64_t *offsets) {
+    // one workgroup; thread t owns the regions [t * per, (t + 1) * per)
+    using scan_t = rocprim::block_scan<uint64_t, 1024>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    __shared__ uint64_t red[16];
+    const uint32_t per = (grid + 1023) / 1024;
+    const uint32_t b0 = threadIdx.x * per;
+    uint64_t mine = 0, mx = 0;
+    for (uint32_t b = b0; b < b0 + per && b < grid; b++) {
+        uint64_t c = block_counts[b];
+        mx = c > mx ? c : mx;
+        mine += c < region_cap ? c : region_cap;
+    }
+    uint64_t excl = 0;
+    scan_t().exclusive_scan(mine, excl, (uint64_t)0, scan_tmp);
+    uint64_t run = excl;
+    for (uint32_t b = b0; b < b0 + per && b < grid; b++) {
+        offsets[b] = run;
+        uint64_t c = block_counts[b];
+        run += c < region_cap ? c : region_cap;
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t other = __shfl_down(mx, o);
+        mx = other > mx ? other : mx;
+    }
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
+    if (threadIdx.x == 1023) { offsets[grid] = run; summary[0] = run; }
     if (threadIdx.x == 0) {
-        uint64_t m = 0, run = 0;
-        for (int i = 0; i < 256; i++) m = part[i] > m ? part[i] : m;
-        for (uint32_t b = 0; b < grid; b++) {
-            offsets[b] = run;
-            uint64_t c = block_counts[b];
-            run += c < region_cap ? c : region_cap;
-        }
-        offsets[grid] = run;
-        summary[0] = run;
+        uint64_t m = 0;
+        for (int i = 0; i < 16; i++) m = red[i] > m ? red[i] : m;
         summary[1] = m;
     }
 }
@@ -681,7 +702,7 @@ __global__ __launch_bounds__(256) void k_sink_compact(const uint64_t *keys, cons
 
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         uint64_t *summary, uint64_t *offsets, hipStream_t st) {
-    hipLaunchKernelGGL(k_sink_summary, dim3(1), dim3(256), 0, st, block_counts, grid, region_cap,
+    hipLaunchKernelGGL(k_sink_summary, dim3(1), dim3(1024), 0, st, block_counts, grid, region_cap,
                        summary, offsets);
     return hipGetLastError();
 }
@@ -691,6 +712,73 @@ hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint64
                         hipStream_t st) {
     hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, keys, pids, offsets, region_cap,
                        keys_out, pids_out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K2a: bucket sort of the occurrences by stream position
+// ---------------------------------------------------------------------------
+// Occurrences are sparse (about one per KiB on the headline workload), so a
+// full 64-bit radix sort is wasted work: one counting pass by 4 KiB bucket of
+// the position, a scan, a scatter and a per-bucket insertion sort order them.
+// A bucket with more than BUCKET_MAX occurrences sets *big (dense inputs): the
+// host then falls back to the rocPRIM radix sort.
+constexpr uint32_t BUCKET_MAX = 64;
+
+__global__ void k_bucket_count(const uint64_t *keys, uint64_t n, uint32_t shift, uint32_t *cnt) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) atomicAdd(&cnt[keys[i] >> shift], 1u);
+}
+
+__global__ void k_bucket_scatter(const uint64_t *keys, const uint32_t *pids, uint64_t n,
+                                 uint32_t shift, const uint32_t *off, uint32_t *fill,
+                                 uint64_t *keys_out, uint32_t *pids_out) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint64_t k = keys[i];
+    uint32_t b = (uint32_t)(k >> shift);
+    uint32_t slot = off[b] + atomicAdd(&fill[b], 1u);
+    keys_out[slot] = k;
+    pids_out[slot] = pids[i];
+}
+
+__global__ void k_bucket_sort(uint64_t *keys, uint32_t *pids, const uint32_t *off, uint32_t nb,
+                              uint32_t *big) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= nb) return;
+    uint32_t lo = off[b], hi = off[b + 1];
+    if (hi - lo > BUCKET_MAX) { *big = 1; return; }
+    for (uint32_t i = lo + 1; i < hi; i++) {
+        uint64_t k = keys[i];
+        uint32_t p = pids[i];
+        uint32_t j = i;
+        while (j > lo && keys[j - 1] > k) { keys[j] = keys[j - 1]; pids[j] = pids[j - 1]; j--; }
+        keys[j] = k; pids[j] = p;
+    }
+}
+
+size_t bucket_temp_bytes(uint64_t nb) {
+    size_t b = 0;
+    (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u,
+                                  (size_t)nb + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
+    return b;
+}
+
+// cnt / off / fill: nb + 1 u32 each (cnt and fill zeroed by the caller).
+hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
+                                   uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
+                                   uint64_t n, uint32_t shift, uint32_t nb, uint32_t *cnt,
+                                   uint32_t *off, uint32_t *fill, uint32_t *big, hipStream_t st) {
+    if (!n) return hipSuccess;
+    uint32_t blocks = (uint32_t)((n + 255) / 256);
+    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, keys_in, n, shift, cnt);
+    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, cnt, off, 0u, (size_t)nb + 1,
+                                           rocprim::plus<uint32_t>(), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, keys_in, pids_in, n, shift,
+                       off, fill, keys_out, pids_out);
+    hipLaunchKernelGGL(k_bucket_sort, dim3((nb + 255) / 256), dim3(256), 0, st, keys_out, pids_out,
+                       off, nb, big);
     return hipGetLastError();
 }
 
@@ -716,7 +804,7 @@ __global__ void k_make_spans(DevAutomaton A, int key_mode, const uint64_t *keys,
                              const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    uint64_t x = keys[i] >> 24;
+    uint64_t x = keys[i] >> A.rank_bits;
     uint64_t l = A.plen[pids[i]];
     if (key_mode == 0) { E[i] = x; S[i] = x - l; }
     else { S[i] = x; E[i] = x + l; }
