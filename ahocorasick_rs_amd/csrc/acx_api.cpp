@@ -106,7 +106,8 @@ struct Workspace {
     uint64_t *h_pinned = nullptr;     // pinned host scratch (8 x u64)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
-    uint32_t *bcnt = nullptr, *boff = nullptr, *bfill = nullptr; // bucket sort: nb + 1 each
+    uint32_t *bcnt = nullptr, *boff = nullptr;  // bucket sort: nb + 1 each
+    uint32_t *ranks[2] = {nullptr, nullptr};    // arrival rank of an occurrence in its bucket
     uint64_t bucket_cap = 0;
     uint32_t *big = nullptr;       // device flag: a bucket was too dense for the bucket sort
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
@@ -132,6 +133,7 @@ struct acx_automaton {
     std::mutex stage_mu; // guards the host staging buffers (taken before mu)
     Workspace ws;
     bool prof = false;
+    bool dense_output = false; // last call produced too many occurrences for the bucket sort
     acx_profile_t profile{};
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
 };
@@ -169,7 +171,8 @@ void free_ws(Workspace &w) {
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
     (void)hipFree(w.hkeys); (void)hipFree(w.hpids); (void)hipFree(w.hit_counts);
-    (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bfill); (void)hipFree(w.big);
+    (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.big);
+    (void)hipFree(w.ranks[0]); (void)hipFree(w.ranks[1]);
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
@@ -189,8 +192,8 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     if (want <= w.cap) return ACX_OK;
     uint64_t cap = std::max<uint64_t>(want, 1u << 16);
     for (int i = 0; i < 2; i++) {
-        (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]);
-        w.keys[i] = nullptr; w.pids[i] = nullptr;
+        (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); (void)hipFree(w.ranks[i]);
+        w.keys[i] = nullptr; w.pids[i] = nullptr; w.ranks[i] = nullptr;
     }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
@@ -200,6 +203,7 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&w.keys[i], cap * 8));
         HIPCHK(hipMalloc((void **)&w.pids[i], cap * 4));
+        HIPCHK(hipMalloc((void **)&w.ranks[i], cap * 4));
     }
     HIPCHK(hipMalloc((void **)&w.hkeys, cap * 8));
     HIPCHK(hipMalloc((void **)&w.hpids, cap * 4));
@@ -237,11 +241,10 @@ int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
 int ensure_buckets(acx_automaton *a, uint64_t nb1) {
     Workspace &w = a->ws;
     if (nb1 > w.bucket_cap) {
-        (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bfill);
-        w.bcnt = w.boff = w.bfill = nullptr; w.bucket_cap = 0;
+        (void)hipFree(w.bcnt); (void)hipFree(w.boff);
+        w.bcnt = w.boff = nullptr; w.bucket_cap = 0;
         HIPCHK(hipMalloc((void **)&w.bcnt, nb1 * 4));
         HIPCHK(hipMalloc((void **)&w.boff, nb1 * 4));
-        HIPCHK(hipMalloc((void **)&w.bfill, nb1 * 4));
         w.bucket_cap = nb1;
     }
     size_t need = bucket_temp_bytes(nb1) + 256;
@@ -289,6 +292,9 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     }
     uint64_t n_raw = 0;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
+    uint32_t bshift = 0;
+    uint64_t nb = 0;
+    bool use_bucket = false;
     if (len > 0 && a->host.n_patterns > 0) {
         int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
         if (rc) return bail(rc);
@@ -299,11 +305,23 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
                                        : dfa_walk_grid(a->dev, len, a->n_cus);
         const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // occurrence regions
+        // Bucket sort of the occurrences by 4 KiB of stream position: the emitting kernel
+        // counts per bucket.  Automata that produced dense output last time skip it.
+        bshift = (uint32_t)a->dev.rank_bits + 12;
+        nb = (len >> 12) + 2;
+        static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
+        use_bucket = !a->dense_output && !no_bucket_env && nb < (1ull << 31);
+        if (use_bucket) {
+            rc = ensure_buckets(a, nb + 1);
+            if (rc) return bail(rc);
+        }
         for (int attempt = 0; attempt < 3; attempt++) {
             const uint64_t region_cap = w.cap / grid;
             const uint64_t hit_cap = w.cap / scan_grid;
-            Sink K{w.keys[0], w.pids[0], w.block_counts, region_cap, key_mode};
-            Sink H{w.hkeys, w.hpids, w.hit_counts, hit_cap, key_mode};
+            if (use_bucket) HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
+            Sink K{w.keys[0], w.pids[0], use_bucket ? w.ranks[0] : nullptr,
+                   use_bucket ? w.bcnt : nullptr, w.block_counts, region_cap, bshift, key_mode};
+            Sink H{w.hkeys, w.hpids, nullptr, nullptr, w.hit_counts, hit_cap, 0, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
             hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, st)
                                : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid,
@@ -329,8 +347,9 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
             if (region_max <= region_cap && hit_max <= hit_cap) {
                 if (n_raw)
-                    HIPCHK_R(sink_compact(w.keys[0], w.pids[0], w.region_off, grid, region_cap,
-                                          w.keys[1], w.pids[1], st));
+                    HIPCHK_R(sink_compact(w.keys[0], w.pids[0], use_bucket ? w.ranks[0] : nullptr,
+                                          w.region_off, grid, region_cap, w.keys[1], w.pids[1],
+                                          w.ranks[1], st));
                 break;
             }
             if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
@@ -341,7 +360,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             rc = ensure_occ_capacity(a, want);
             if (rc) return bail(rc);
         }
-        if (a->prof) a->profile.raw_occurrences += n_raw;
+        if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += w.h_pinned[2]; }
     }
     if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
     uint64_t n_final = 0;
@@ -351,22 +370,15 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         const int rank_bits = (int)a->dev.rank_bits;
         // Sparse occurrences: bucket sort by 4 KiB of stream position; dense ones (or a
         // bucket sort that met an over-full bucket): rocPRIM radix sort of the used key bits.
-        const uint32_t bshift = (uint32_t)rank_bits + 12;
-        const uint64_t nb = (len >> 12) + 2;
-        bool use_bucket = n_raw <= 8 * nb && nb < (1ull << 31);
-        if (use_bucket) {
-            int rc = ensure_buckets(a, nb + 1);
-            if (rc) return bail(rc);
-        }
+        if (use_bucket && n_raw > 8 * nb) use_bucket = false; // dense: straight to the radix sort
+        a->dense_output = n_raw > 8 * nb;
         for (int pass = 0; pass < 2; pass++) {
             // compacted occurrences are in keys[1]/pids[1]; sorted order goes to [0]
             if (use_bucket) {
-                HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
-                HIPCHK_R(hipMemsetAsync(w.bfill, 0, (nb + 1) * 4, st));
                 HIPCHK_R(hipMemsetAsync(w.big, 0, 4, st));
                 HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
-                                                 w.pids[0], n_raw, bshift, (uint32_t)nb, w.bcnt, w.boff,
-                                                 w.bfill, w.big, st));
+                                                 w.pids[0], w.ranks[1], n_raw, bshift, (uint32_t)nb,
+                                                 w.bcnt, w.boff, w.big, st));
             } else {
                 int end_bit = std::min(64, rank_bits + bits_for(len));
                 HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
@@ -384,7 +396,11 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             }
             if (use_bucket) HIPCHK_R(hipMemcpyAsync(w.h_pinned + 5, w.big, 4, hipMemcpyDeviceToHost, st));
             if (use_bucket || !overlapping) HIPCHK_R(hipStreamSynchronize(st));
-            if (use_bucket && *(uint32_t *)(w.h_pinned + 5)) { use_bucket = false; continue; } // too dense
+            if (use_bucket && *(uint32_t *)(w.h_pinned + 5)) { // a bucket was too dense
+                use_bucket = false;
+                a->dense_output = true;
+                continue;
+            }
             if (!overlapping) n_final = *(uint32_t *)(w.h_pinned + 4);
             break;
         }
@@ -544,12 +560,15 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(hot16, hot16)
     UP(H.own_off, own_off)
     UP(H.own_pid, own_pid)
+    UP(H.own1, own1)
     UP(H.dlink, dlink)
     UP(H.level_start, level_start)
     UP(H.plen, plen)
     UP(H.rank, rank)
     UP(H.filterA, filterA)
     UP(H.ptab, ptab)
+    UP(H.blist, blist)
+    H.blob.resize(H.blob.size() + 16, 0); // the walk kernel compares 8 bytes at a time
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)
 #undef UP

@@ -191,6 +191,12 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         std::vector<uint32_t> fill(A.own_off.begin(), A.own_off.end() - 1);
         for (uint64_t i = 0; i < n; i++) A.own_pid[fill[newid[term_node[i]]]++] = (uint32_t)i;
     }
+    A.own1.assign(n_nodes, OWN1_NONE);
+    for (uint32_t s = 0; s < n_nodes; s++) {
+        uint32_t c = A.own_off[s + 1] - A.own_off[s];
+        if (c == 1) A.own1[s] = A.own_pid[A.own_off[s]];
+        else if (c > 1) A.own1[s] = OWN1_MANY;
+    }
     // free construction scratch early (large automata)
     em = EdgeMap(); e_parent = {}; e_child = {}; e_byte = {}; c_off = {}; c_edge = {};
     order = {}; newid = {}; term_node = {};
@@ -259,11 +265,37 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         A.ptab.assign((size_t)4 << lg, 0);
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = 0xFFFFFFFFu;
         const uint32_t pmask = (1u << lg) - 1;
+        // Patterns below each depth-Q2 state: a prefix hit is verified by comparing the rest
+        // of each of them with the haystack (no dependent DFA walk).  Entry word 3 is the
+        // only pattern's id, or 0x80000000 | index into blist = {count, pid, pid, ...}.
+        std::vector<uint32_t> pref_state(n), below(n_nodes, 0), lpos(n_nodes, 0);
         for (uint64_t i = 0; i < n; i++) {
             const uint8_t *pp = pb + A.offsets[i];
             uint32_t st = 0;
             for (uint32_t k = 0; k < Q2; k++)
                 st = A.table[(size_t)st * S + A.classes[pp[k]]] & ID_MASK;
+            pref_state[i] = st;
+            below[st]++;
+        }
+        A.blist.clear();
+        for (uint64_t i = 0; i < n; i++) {
+            uint32_t st = pref_state[i];
+            if (below[st] > 1 && lpos[st] == 0) {
+                lpos[st] = (uint32_t)A.blist.size() + 1; // +1: 0 means "not yet placed"
+                A.blist.push_back(below[st]);
+                A.blist.resize(A.blist.size() + below[st], 0xFFFFFFFFu);
+            }
+        }
+        {
+            std::vector<uint32_t> fill(n_nodes, 0);
+            for (uint64_t i = 0; i < n; i++) { // pattern id order inside every list
+                uint32_t st = pref_state[i];
+                if (below[st] > 1) A.blist[lpos[st] + fill[st]++] = (uint32_t)i;
+            }
+        }
+        for (uint64_t i = 0; i < n; i++) {
+            const uint8_t *pp = pb + A.offsets[i];
+            uint32_t st = pref_state[i];
             uint64_t gram = gram_of(pp, Q2);
             uint32_t val = st;
             if (A.own_off[st + 1] > A.own_off[st]) val |= FLAG_OWN;
@@ -273,6 +305,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                 uint32_t *en = &A.ptab[4 * (size_t)idx];
                 if (en[2] == 0xFFFFFFFFu) {
                     en[0] = (uint32_t)gram; en[1] = (uint32_t)(gram >> 32); en[2] = val;
+                    en[3] = below[st] == 1 ? (uint32_t)i : (0x80000000u | (lpos[st] - 1));
                     break;
                 }
                 if ((((uint64_t)en[1] << 32) | en[0]) == gram) break; // same prefix already there

@@ -29,6 +29,8 @@ constexpr uint32_t FLAG_OUT = 0x80000000u; // target state reports >= 1 pattern
 constexpr uint32_t FLAG_OWN = 0x40000000u; // target state ends a pattern itself
 constexpr uint32_t ID_MASK = 0x3FFFFFFFu;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t OWN1_NONE = 0xFFFFFFFFu; // own1[s]: no pattern ends exactly at s
+constexpr uint32_t OWN1_MANY = 0xFFFFFFFEu; // own1[s]: several do (duplicates): use the CSR list
 
 // ---- K1b prefilter geometry and hashes (shared by the host compiler and the kernel)
 //
@@ -91,6 +93,7 @@ struct Automaton {
     std::vector<uint32_t> table;       // n_states * stride
     std::vector<uint32_t> own_off;     // n_states + 1
     std::vector<uint32_t> own_pid;     // patterns ending exactly at the state, id order
+    std::vector<uint32_t> own1;        // n_states: single own pattern / OWN1_NONE / OWN1_MANY
     std::vector<uint32_t> dlink;       // nearest proper suffix state with own patterns, or NONE
     std::vector<uint32_t> level_start; // max_len + 2 entries
     std::vector<uint32_t> plen;        // n_patterns
@@ -101,7 +104,9 @@ struct Automaton {
     std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
     double filter_density = 0.0;       // fraction of X bits set
     // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:
-    //   {gram lo, gram hi, state id | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty), 0}
+    //   {gram lo, gram hi, state id | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty),
+    //    the only pattern with this prefix, or 0x80000000 | index into blist}
+    std::vector<uint32_t> blist;       // {count, pid, pid, ...} per prefix shared by several patterns
     std::vector<uint32_t> ptab;
     uint32_t ptab_log2 = 0;
     // pattern bytes (kept for the synthetic text generator)

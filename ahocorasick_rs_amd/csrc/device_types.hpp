@@ -11,12 +11,14 @@ struct DevAutomaton {
     const uint8_t *classes;      // 256
     const uint32_t *own_off;     // n_states + 1
     const uint32_t *own_pid;
+    const uint32_t *own1;        // n_states: the state's only own pattern, OWN1_NONE or OWN1_MANY
     const uint32_t *dlink;       // n_states
     const uint32_t *level_start; // max_len + 2
     const uint32_t *plen;        // n_patterns
     const uint32_t *rank;        // n_patterns
     const uint32_t *filterA;     // FILTER_WORDS: level-1 {X, Y} table of the K1b prefilter
-    const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, 0)
+    const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, pid or list)
+    const uint32_t *blist;       // candidate lists of prefixes shared by several patterns
     const uint8_t *pat_blob;     // pattern bytes (generator only)
     const uint64_t *pat_off;     // n_patterns + 1
     uint64_t n_patterns;
@@ -53,8 +55,11 @@ struct Segments {
 struct Sink {
     uint64_t *keys;
     uint32_t *pids;
+    uint32_t *ranks;        // arrival rank of the occurrence inside its bucket (or null)
+    uint32_t *bucket_cnt;   // per 4 KiB-of-position bucket counters (or null: no bucket sort)
     uint64_t *block_counts; // gridDim.x entries
     uint64_t region_cap;
+    uint32_t bucket_shift;  // bucket = key >> bucket_shift
     int key_mode;
 };
 

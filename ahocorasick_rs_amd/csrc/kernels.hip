@@ -47,15 +47,33 @@ __device__ __forceinline__ u32x4 load16_stream(const uint8_t *p) {
 struct BlockSink {
     uint64_t *keys;
     uint32_t *pids;
+    uint32_t *ranks;
+    uint32_t *bucket_cnt;
     uint32_t *lcount; // LDS
     uint64_t region_cap;
+    uint32_t bucket_shift;
     int key_mode;
 };
 
 __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount) {
-    return BlockSink{K.keys + (uint64_t)blockIdx.x * K.region_cap,
-                     K.pids + (uint64_t)blockIdx.x * K.region_cap, lcount, K.region_cap,
-                     K.key_mode};
+    const uint64_t base = (uint64_t)blockIdx.x * K.region_cap;
+    return BlockSink{K.keys + base, K.pids + base, K.ranks ? K.ranks + base : nullptr, K.bucket_cnt,
+                     lcount, K.region_cap, K.bucket_shift, K.key_mode};
+}
+
+// store one occurrence; with a bucket counter attached, also take the
+// occurrence's arrival rank inside its bucket (ONE global atomic, the address
+// is shared by the ~4 occurrences of a 4 KiB stretch only), which later turns
+// the bucket sort's scatter into plain stores
+__device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid) {
+    uint32_t r = 0;
+    if (K.bucket_cnt) r = atomicAdd(&K.bucket_cnt[key >> K.bucket_shift], 1u);
+    uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
+    if (slot < K.region_cap) {
+        K.keys[slot] = key;
+        K.pids[slot] = pid;
+        if (K.ranks) K.ranks[slot] = r;
+    }
 }
 
 // The emit paths are cold and out of line; they read the automaton through a
@@ -70,11 +88,7 @@ __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink 
         uint64_t start = end - A->plen[pid];
         key = (start << A->rank_bits) | (K.key_mode == 1 ? pid : A->rank[pid]);
     }
-    uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
-    if (slot < K.region_cap) {
-        K.keys[slot] = key;
-        K.pids[slot] = pid;
-    }
+    emit_key(K, key, pid);
 }
 
 // every pattern that ends at state s (own patterns, then the dictionary-suffix
@@ -87,11 +101,20 @@ __device__ __noinline__ void emit_state(const DevAutomaton *A, const BlockSink K
     }
 }
 
-// only the patterns that end exactly at state s with depth(s) == length
-__device__ __noinline__ void emit_own(const DevAutomaton *A, const BlockSink K, uint32_t s,
-                                      uint64_t end) {
-    uint32_t b = A->own_off[s], e = A->own_off[s + 1];
-    for (uint32_t k = b; k < e; k++) emit_one(A, K, A->own_pid[k], end);
+// only the patterns that end exactly at state s with depth(s) == length;
+// start / end are both known to the anchored walk
+__device__ __forceinline__ void emit_own_span(const DevAutomaton &A, const BlockSink &K, uint32_t s,
+                                              uint64_t start, uint64_t end) {
+    uint32_t one = A.own1[s];
+    uint32_t b = 0, e = 1;
+    if (one == OWN1_MANY) { b = A.own_off[s]; e = A.own_off[s + 1]; }
+    for (uint32_t k = b; k < e; k++) {
+        uint32_t pid = one == OWN1_MANY ? A.own_pid[k] : one;
+        uint64_t key = K.key_mode == 0   ? (end << A.rank_bits) | A.rank[pid]
+                       : K.key_mode == 1 ? (start << A.rank_bits) | pid
+                                         : (start << A.rank_bits) | A.rank[pid];
+        emit_key(K, key, pid);
+    }
 }
 
 // first index i in [0, n] with off[i] > x
@@ -299,16 +322,13 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //       (phase B, t+2), compare (phase C, t+3).  Hits (position, depth-Q2 state)
 //       leave through the sink: the scan kernel never walks the DFA itself, so
 //       its waves never sit in the long dependent-load chains of a walk.
-//   L3  (separate kernel k_walk_hits, one thread per prefix hit): anchored walk
-//       of the dense DFA table from the depth-Q2 state, emitting every pattern
-//       that starts at that position into the occurrence sink.
+//   L3  (separate kernel k_walk_hits, one thread per prefix hit): the few
+//       patterns that own that prefix are settled by comparing their remaining
+//       bytes with the haystack; matches go to the occurrence sink.
 // All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
 constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane)
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t PREFIX_RETRY = 0xFFFFFFFEu; // home slot held another gram: probe again in L3
-constexpr uint32_t FLAG_KIDS = 0x80000000u;    // prefix-table entry: state has children
-
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
     uint32_t count;
@@ -333,18 +353,25 @@ __device__ __forceinline__ uint64_t load_window(const uint8_t *__restrict__ stre
     return w;
 }
 
-// L3: anchored walk for a prefix hit at stream position p (st = prefix-table
-// value, or PREFIX_RETRY when the home slot was taken by another gram).
-__device__ __forceinline__ void deep_walk(const DevAutomaton &A, const DevAutomaton *Ad,
-                                          const Segments &G, const BlockSink &K,
-                                          const uint8_t *__restrict__ stream, uint64_t len,
-                                          uint64_t p, uint32_t st) {
+// A prefix hit handed to the walk kernel is (position, code), code = word 3 of
+// the prefix-table entry: the id of the only pattern with that prefix, or
+// HIT_LIST | index into blist ({count, pid, ...}); HIT_RETRY when the home
+// slot held another gram (the walk kernel probes the table again first).
+constexpr uint32_t HIT_LIST = 0x80000000u;
+constexpr uint32_t HIT_RETRY = 0xFFFFFFFFu;
+
+// L3: verify a prefix hit at stream position p: the first Q2 bytes are known to
+// match, so every candidate pattern is settled by comparing its remaining bytes
+// with the haystack -- independent loads, no dependent DFA walk.  Emits every
+// pattern that starts at p.
+__device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments &G,
+                                           const BlockSink &K, const uint8_t *__restrict__ stream,
+                                           uint64_t len, uint64_t p, uint32_t code,
+                                           uint32_t ablate) {
     const uint32_t q = A.filter_q2;
-    uint64_t end = segment_end(G, len, p);
-    uint64_t maxd = end - p;
-    if (maxd > A.max_len) maxd = A.max_len;
-    if (maxd < q) return; // the prefix would straddle the end of its haystack
-    if (st == PREFIX_RETRY) {
+    const uint64_t room = segment_end(G, len, p) - p;
+    if (room < q) return; // the prefix would straddle the end of its haystack
+    if (code == HIT_RETRY) {
         const uint64_t w = load_window(stream, len, p);
         const uint64_t gram = q >= 8 ? w : (w & ((1ull << (8 * q)) - 1));
         uint32_t idx = prefix_slot(gram_hash2(gram), A.ptab_log2);
@@ -352,20 +379,33 @@ __device__ __forceinline__ void deep_walk(const DevAutomaton &A, const DevAutoma
         for (;;) {
             const uint4 e = *(const uint4 *)(A.ptab + (size_t)idx * 4);
             if (e.z == PREFIX_EMPTY) return;
-            if ((((uint64_t)e.y << 32) | e.x) == gram) { st = e.z; break; }
+            if ((((uint64_t)e.y << 32) | e.x) == gram) { code = e.w; break; }
             idx = (idx + 1) & mask;
         }
     }
-    uint32_t s = st & ID_MASK;
-    if (st & FLAG_OWN) emit_own(Ad, K, s, p + q);
-    if (!(st & FLAG_KIDS)) return;
-    for (uint32_t d = q; d < maxd; d++) {
-        uint32_t c = A.classes[stream[p + d]];
-        uint32_t e = A.table[((size_t)s << A.stride2) + c];
-        uint32_t t = e & ID_MASK;
-        if (t < A.level_start[d + 1]) return; // not a trie edge: no pattern continues
-        if (e & FLAG_OWN) emit_own(Ad, K, t, p + d + 1);
-        s = t;
+    const bool list = (code & HIT_LIST) != 0;
+    const uint32_t li = code & ~HIT_LIST;
+    const uint32_t n = list ? A.blist[li] : 1;
+    for (uint32_t k = 0; k < n; k++) {
+        const uint32_t pid = list ? A.blist[li + 1 + k] : code;
+        const uint32_t L = A.plen[pid];
+        const uint64_t po = A.pat_off[pid];
+        const uint32_t rk = A.rank[pid];
+        bool ok = L <= room;
+        for (uint32_t d = q; ok && d < L; d += 8) {
+            uint64_t a = load_window(stream, len, p + d);
+            uint64_t b;
+            __builtin_memcpy(&b, A.pat_blob + po + d, 8); // pat_blob is padded by 16 bytes
+            uint32_t nbytes = L - d < 8 ? L - d : 8;
+            uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
+            ok = ((a ^ b) & m) == 0;
+        }
+        if (ok && !(ablate & 32)) {
+            uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
+                           : K.key_mode == 1 ? (p << A.rank_bits) | pid
+                                             : (p << A.rank_bits) | rk;
+            emit_key(K, key, pid);
+        }
     }
 }
 
@@ -376,19 +416,22 @@ constexpr uint32_t K_WALK_SPLIT = 16;
 __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAutomaton *Ad,
                                                    Segments G, Sink H, uint32_t h_grid, Sink GK,
                                                    const uint8_t *__restrict__ stream,
-                                                   uint64_t len) {
+                                                   uint64_t len, uint32_t ablate) {
     __shared__ uint32_t lcount;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
+    (void)Ad;
     const BlockSink K = block_sink(GK, &lcount);
     // K_WALK_SPLIT workgroups share one hit region
     for (uint32_t b = blockIdx.x / K_WALK_SPLIT; b < h_grid; b += gridDim.x / K_WALK_SPLIT) {
         uint64_t n = H.block_counts[b];
         if (n > H.region_cap) n = H.region_cap;
         const uint64_t *pos = H.keys + (uint64_t)b * H.region_cap;
-        const uint32_t *st = H.pids + (uint64_t)b * H.region_cap;
-        for (uint64_t i = (blockIdx.x % K_WALK_SPLIT) * 256 + threadIdx.x; i < n; i += K_WALK_SPLIT * 256)
-            deep_walk(A, Ad, G, K, stream, len, pos[i], st[i]);
+        const uint32_t *code = H.pids + (uint64_t)b * H.region_cap;
+        for (uint64_t i = (blockIdx.x % K_WALK_SPLIT) * 256 + threadIdx.x; i < n; i += K_WALK_SPLIT * 256) {
+            if (ablate & 64) { if (pos[i] == 0x123456789ull && code[i] == 77) emit_key(K, 1, 1); continue; }
+            verify_hit(A, G, K, stream, len, pos[i], code[i], ablate);
+        }
     }
     __syncthreads();
     if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = lcount;
@@ -465,7 +508,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
 #define K1B_ISSUE_ROW(DST, TILE, R)                                                              \
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
-        DST = load16_stream(hay + (off_ < last_block ? off_ : last_block));                      \
+        const uint8_t *ptr_ = hay + (off_ < last_block ? off_ : last_block);                     \
+        DST = (ablate & 16) ? *(const u32x4 *)ptr_ : load16_stream(ptr_);                        \
     }
 #define K1B_ISSUE_TILE(TILE)                                                                     \
     K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2)       \
@@ -491,7 +535,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             bool act = lane < nC;
             bool same = (((uint64_t)entC.y << 32) | entC.x) == gramC;
             bool found = act && entC.z != PREFIX_EMPTY;
-            uint32_t st = same ? entC.z : PREFIX_RETRY;
+            uint32_t st = same ? entC.w : HIT_RETRY;
             if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st)
         }
         // ---- phase B: hash the windows fetched one tile ago, fetch their home slots
@@ -575,7 +619,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
                 // kernel unprobed (it probes the prefix table itself)
                 bool found = lane < q1c;
                 uint64_t p = found ? tbase + q1[lane] - lead : 0;
-                K1B_HIT_PUSH(found, p, PREFIX_RETRY)
+                K1B_HIT_PUSH(found, p, HIT_RETRY)
                 q1c = 0;
             }
             if (mlo | mhi) {
@@ -609,16 +653,6 @@ uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     return blocks ? (uint32_t)blocks : 1;
 }
 
-uint32_t walk_hits_grid(uint32_t hit_grid) { return hit_grid * K_WALK_SPLIT; }
-
-hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &hits, uint32_t hit_grid, const Sink &occ,
-                            const uint8_t *d_hay, uint64_t len, hipStream_t st) {
-    hipLaunchKernelGGL(k_walk_hits, dim3(walk_hits_grid(hit_grid)), dim3(256), 0, st, A, Ad, G, hits,
-                       hit_grid, occ, d_hay, len);
-    return hipGetLastError();
-}
-
 static uint32_t ablation_flags() {
     static int v = -1;
     if (v < 0) {
@@ -626,6 +660,16 @@ static uint32_t ablation_flags() {
         v = e ? std::atoi(e) : 0;
     }
     return (uint32_t)v;
+}
+
+uint32_t walk_hits_grid(uint32_t hit_grid) { return hit_grid * K_WALK_SPLIT; }
+
+hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
+                            const Sink &hits, uint32_t hit_grid, const Sink &occ,
+                            const uint8_t *d_hay, uint64_t len, hipStream_t st) {
+    hipLaunchKernelGGL(k_walk_hits, dim3(walk_hits_grid(hit_grid)), dim3(256), 0, st, A, Ad, G, hits,
+                       hit_grid, occ, d_hay, len, ablation_flags());
+    return hipGetLastError();
 }
 
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
@@ -689,14 +733,17 @@ __global__ __launch_bounds__(1024) void k_sink_summary(const uint64_t *block_cou
 }
 
 __global__ __launch_bounds__(256) void k_sink_compact(const uint64_t *keys, const uint32_t *pids,
-                                                      const uint64_t *offsets, uint64_t region_cap,
-                                                      uint64_t *keys_out, uint32_t *pids_out) {
+                                                      const uint32_t *ranks, const uint64_t *offsets,
+                                                      uint64_t region_cap, uint64_t *keys_out,
+                                                      uint32_t *pids_out, uint32_t *ranks_out) {
     uint64_t o0 = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - o0;
     const uint64_t *k = keys + (uint64_t)blockIdx.x * region_cap;
     const uint32_t *p = pids + (uint64_t)blockIdx.x * region_cap;
+    const uint32_t *r = ranks ? ranks + (uint64_t)blockIdx.x * region_cap : nullptr;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
         keys_out[o0 + i] = k[i];
         pids_out[o0 + i] = p[i];
+        if (r) ranks_out[o0 + i] = r[i];
     }
 }
 
@@ -707,11 +754,11 @@ hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t re
     return hipGetLastError();
 }
 
-hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint64_t *offsets,
-                        uint32_t grid, uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out,
-                        hipStream_t st) {
-    hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, keys, pids, offsets, region_cap,
-                       keys_out, pids_out);
+hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint32_t *ranks,
+                        const uint64_t *offsets, uint32_t grid, uint64_t region_cap,
+                        uint64_t *keys_out, uint32_t *pids_out, uint32_t *ranks_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, keys, pids, ranks, offsets,
+                       region_cap, keys_out, pids_out, ranks_out);
     return hipGetLastError();
 }
 
@@ -719,25 +766,21 @@ hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint64
 // K2a: bucket sort of the occurrences by stream position
 // ---------------------------------------------------------------------------
 // Occurrences are sparse (about one per KiB on the headline workload), so a
-// full 64-bit radix sort is wasted work: one counting pass by 4 KiB bucket of
-// the position, a scan, a scatter and a per-bucket insertion sort order them.
+// full 64-bit radix sort is wasted work: the scan kernels count per 4 KiB
+// bucket of the position while they emit (emit_key); a scan of the counters, a
+// scatter and a per-bucket insertion sort then order everything.
 // A bucket with more than BUCKET_MAX occurrences sets *big (dense inputs): the
 // host then falls back to the rocPRIM radix sort.
 constexpr uint32_t BUCKET_MAX = 64;
 
-__global__ void k_bucket_count(const uint64_t *keys, uint64_t n, uint32_t shift, uint32_t *cnt) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) atomicAdd(&cnt[keys[i] >> shift], 1u);
-}
-
-__global__ void k_bucket_scatter(const uint64_t *keys, const uint32_t *pids, uint64_t n,
-                                 uint32_t shift, const uint32_t *off, uint32_t *fill,
+// slot = bucket offset + the arrival rank taken at emission: no atomics here
+__global__ void k_bucket_scatter(const uint64_t *keys, const uint32_t *pids, const uint32_t *ranks,
+                                 uint64_t n, uint32_t shift, const uint32_t *off,
                                  uint64_t *keys_out, uint32_t *pids_out) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t k = keys[i];
-    uint32_t b = (uint32_t)(k >> shift);
-    uint32_t slot = off[b] + atomicAdd(&fill[b], 1u);
+    uint32_t slot = off[(uint32_t)(k >> shift)] + ranks[i];
     keys_out[slot] = k;
     pids_out[slot] = pids[i];
 }
@@ -764,19 +807,19 @@ size_t bucket_temp_bytes(uint64_t nb) {
     return b;
 }
 
-// cnt / off / fill: nb + 1 u32 each (cnt and fill zeroed by the caller).
+// cnt (filled by the scan kernels' emission) / off: nb + 1 u32 each.
 hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                                    uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
-                                   uint64_t n, uint32_t shift, uint32_t nb, uint32_t *cnt,
-                                   uint32_t *off, uint32_t *fill, uint32_t *big, hipStream_t st) {
+                                   const uint32_t *ranks_in, uint64_t n, uint32_t shift, uint32_t nb,
+                                   const uint32_t *cnt, uint32_t *off, uint32_t *big,
+                                   hipStream_t st) {
     if (!n) return hipSuccess;
     uint32_t blocks = (uint32_t)((n + 255) / 256);
-    hipLaunchKernelGGL(k_bucket_count, dim3(blocks), dim3(256), 0, st, keys_in, n, shift, cnt);
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, cnt, off, 0u, (size_t)nb + 1,
                                            rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, keys_in, pids_in, n, shift,
-                       off, fill, keys_out, pids_out);
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, keys_in, pids_in, ranks_in, n,
+                       shift, off, keys_out, pids_out);
     hipLaunchKernelGGL(k_bucket_sort, dim3((nb + 255) / 256), dim3(256), 0, st, keys_out, pids_out,
                        off, nb, big);
     return hipGetLastError();

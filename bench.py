@@ -162,6 +162,8 @@ def main() -> None:
                 "scan_kernel": capi.KERNEL_NAMES[info.kernel],
                 "matches_per_gpu_step": int(n_matches),
                 "matches_total": int(total_matches),
+                "raw_occurrences_per_step": int(prof.raw_occurrences // max(prof.scan_launches, 1)),
+                "prefix_hits_per_step": int(prof.prefix_hits // max(prof.scan_launches, 1)),
                 "percent_of_hbm_roofline": round(100.0 * value / (HBM_PEAK_GBPS * world), 2),
             },
             "roofline": {

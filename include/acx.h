@@ -87,6 +87,7 @@ typedef struct acx_profile {
     double post_ms;        /* sort + resolve + fix-up kernels                   */
     uint64_t scan_bytes;   /* haystack bytes scanned by those launches          */
     uint64_t raw_occurrences; /* occurrences emitted by K1 before resolution    */
+    uint64_t prefix_hits;     /* K1b: prefix hits handed to the walk kernel      */
 } acx_profile_t;
 
 /* ---- process-wide ---- */

@@ -1,0 +1,103 @@
+"""N > 1 path on CPU: world_size-2 gloo processes, sharding + count all-gather.
+The scan itself needs a GPU, so each rank's shard is matched by the ORACLE here
+(test infrastructure standing in for the device); what is under test is the
+product's sharding / offset logic (ahocorasick_rs_amd/distributed.py)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _OracleAutomaton:
+    """find_batch() with the product's signature, computed by the oracle."""
+
+    def __init__(self, pats, mk):
+        from oracle_lib import KIND_DFA, Oracle
+        self.o = Oracle(pats, mk, KIND_DFA)
+
+    def find_batch(self, hays, overlapping=False, codepoints=False):
+        per = [self.o.find_raw(h, overlapping) for h in hays]
+        counts = np.array([len(p) for p in per], dtype=np.uint64)
+        allm = np.concatenate(per) if per else np.zeros((0, 3), np.uint64)
+        return allm, counts
+
+
+def _worker(rank, world, port, ret):
+    sys.path.insert(0, HERE)
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib.util
+    import torch.distributed as dist
+    spec = importlib.util.spec_from_file_location(
+        "acx_distributed", os.path.join(os.path.dirname(HERE), "ahocorasick_rs_amd", "distributed.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    import gen
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pats = gen.gen_patterns(300, 3, 8, gen.AZ, 21)
+    hay = gen.gen_textlike(101 * 512, 13, pats)  # ONE stream cut into 101 haystacks: shard-count independent
+    hays = [hay[i * 512:(i + 1) * 512].tobytes() for i in range(101)]
+    res = D.find_batch_sharded(_OracleAutomaton(pats, 0), hays)
+    ret[rank] = (res["lo"], res["hi"], res["matches"].tolist(), res["counts"].tolist(),
+                 res["rank_counts"], res["global_offset"], res["global_total"])
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_batch_equals_unsharded(world):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    sys.path.insert(0, HERE)
+    import gen
+    pats = gen.gen_patterns(300, 3, 8, gen.AZ, 21)
+    hay = gen.gen_textlike(101 * 512, 13, pats)
+    hays = [hay[i * 512:(i + 1) * 512].tobytes() for i in range(101)]
+    whole, whole_counts = _OracleAutomaton(pats, 0).find_batch(hays)
+    # shards are contiguous, ordered, and cover everything; the union in rank order is the whole
+    los = [ret[r][0] for r in range(world)]
+    his = [ret[r][1] for r in range(world)]
+    assert los[0] == 0 and his[-1] == 101 and all(his[r] == los[r + 1] for r in range(world - 1))
+    cat = sum((ret[r][2] for r in range(world)), [])
+    assert cat == whole.tolist()
+    assert sum((ret[r][3] for r in range(world)), []) == whole_counts.tolist()
+    counts = [len(ret[r][2]) for r in range(world)]
+    for r in range(world):
+        assert ret[r][4] == counts                      # all-gathered counts agree on every rank
+        assert ret[r][5] == sum(counts[:r])             # global offset of this shard's matches
+        assert ret[r][6] == len(whole)                  # global total
+        # the shard's matches sit at [offset, offset + count) of the global list
+        assert whole.tolist()[ret[r][5]:ret[r][5] + counts[r]] == ret[r][2]
+
+
+def test_shard_range_properties():
+    sys.path.insert(0, os.path.dirname(HERE))
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "acx_distributed", os.path.join(os.path.dirname(HERE), "ahocorasick_rs_amd", "distributed.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    for n in (0, 1, 7, 8, 1048576):
+        for w in (1, 2, 3, 8):
+            rs = [D.shard_range(n, r, w) for r in range(w)]
+            assert rs[0][0] == 0 and rs[-1][1] == n
+            assert all(rs[i][1] == rs[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in rs]
+            assert max(sizes) - min(sizes) <= 1
+    assert D.exclusive_offsets([3, 0, 5]) == [0, 3, 3]
+    with pytest.raises(ValueError):
+        D.shard_range(10, 2, 2)
