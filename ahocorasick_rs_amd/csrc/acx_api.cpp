@@ -97,8 +97,8 @@ struct Workspace {
     uint32_t *flags = nullptr, *idx = nullptr;
     void *temp = nullptr;
     size_t temp_bytes = 0;
-    uint64_t *hkeys = nullptr;        // K1b prefix hits: position / prefix-table value,
-    uint32_t *hpids = nullptr;        //   same capacity and region scheme as keys[0]/pids[0]
+    uint4 *recs = nullptr;            // occurrence sink: cap records of 16 B in per-workgroup regions
+    uint4 *hrecs = nullptr;           // K1b prefix-hit sink: cap records of 32 B
     uint64_t *hit_counts = nullptr;   // device: one per K1b workgroup
     uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region, [2..3] same for hits
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
@@ -107,7 +107,6 @@ struct Workspace {
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
     uint32_t *bcnt = nullptr, *boff = nullptr;  // bucket sort: nb + 1 each
-    uint32_t *ranks[2] = {nullptr, nullptr};    // arrival rank of an occurrence in its bucket
     uint64_t bucket_cap = 0;
     uint32_t *big = nullptr;       // device flag: a bucket was too dense for the bucket sort
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
@@ -170,9 +169,9 @@ void free_ws(Workspace &w) {
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
-    (void)hipFree(w.hkeys); (void)hipFree(w.hpids); (void)hipFree(w.hit_counts);
+    (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.big);
-    (void)hipFree(w.ranks[0]); (void)hipFree(w.ranks[1]);
+
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
@@ -192,21 +191,20 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     if (want <= w.cap) return ACX_OK;
     uint64_t cap = std::max<uint64_t>(want, 1u << 16);
     for (int i = 0; i < 2; i++) {
-        (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); (void)hipFree(w.ranks[i]);
-        w.keys[i] = nullptr; w.pids[i] = nullptr; w.ranks[i] = nullptr;
+        (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]);
+        w.keys[i] = nullptr; w.pids[i] = nullptr;
     }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
-    (void)hipFree(w.hkeys); (void)hipFree(w.hpids);
+    (void)hipFree(w.recs); (void)hipFree(w.hrecs);
     w.S = w.E = w.M = nullptr; w.flags = w.idx = nullptr; w.temp = nullptr; w.cap = 0;
-    w.hkeys = nullptr; w.hpids = nullptr;
+    w.recs = nullptr; w.hrecs = nullptr;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&w.keys[i], cap * 8));
         HIPCHK(hipMalloc((void **)&w.pids[i], cap * 4));
-        HIPCHK(hipMalloc((void **)&w.ranks[i], cap * 4));
     }
-    HIPCHK(hipMalloc((void **)&w.hkeys, cap * 8));
-    HIPCHK(hipMalloc((void **)&w.hpids, cap * 4));
+    HIPCHK(hipMalloc((void **)&w.recs, cap * 16));
+    HIPCHK(hipMalloc((void **)&w.hrecs, cap * 32));
     HIPCHK(hipMalloc((void **)&w.S, cap * 8));
     HIPCHK(hipMalloc((void **)&w.E, cap * 8));
     HIPCHK(hipMalloc((void **)&w.M, cap * 8));
@@ -292,8 +290,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     }
     uint64_t n_raw = 0;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
-    uint32_t bshift = 0;
-    uint64_t nb = 0;
+    uint32_t bshift = 0, occ_grid = 0;
+    uint64_t nb = 0, occ_region_cap = 0;
     bool use_bucket = false;
     if (len > 0 && a->host.n_patterns > 0) {
         int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
@@ -319,9 +317,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             const uint64_t region_cap = w.cap / grid;
             const uint64_t hit_cap = w.cap / scan_grid;
             if (use_bucket) HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
-            Sink K{w.keys[0], w.pids[0], use_bucket ? w.ranks[0] : nullptr,
-                   use_bucket ? w.bcnt : nullptr, w.block_counts, region_cap, bshift, key_mode};
-            Sink H{w.hkeys, w.hpids, nullptr, nullptr, w.hit_counts, hit_cap, 0, key_mode};
+            Sink K{w.recs, use_bucket ? w.bcnt : nullptr, w.block_counts, region_cap, bshift, key_mode};
+            Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
             hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, st)
                                : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid,
@@ -346,10 +343,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             const uint64_t region_max = w.h_pinned[1];
             const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
             if (region_max <= region_cap && hit_max <= hit_cap) {
-                if (n_raw)
-                    HIPCHK_R(sink_compact(w.keys[0], w.pids[0], use_bucket ? w.ranks[0] : nullptr,
-                                          w.region_off, grid, region_cap, w.keys[1], w.pids[1],
-                                          w.ranks[1], st));
+                occ_grid = grid; occ_region_cap = region_cap;
                 break;
             }
             if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
@@ -373,13 +367,15 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         if (use_bucket && n_raw > 8 * nb) use_bucket = false; // dense: straight to the radix sort
         a->dense_output = n_raw > 8 * nb;
         for (int pass = 0; pass < 2; pass++) {
-            // compacted occurrences are in keys[1]/pids[1]; sorted order goes to [0]
+            // the sorted (key, pid) arrays go to keys[0]/pids[0]
             if (use_bucket) {
                 HIPCHK_R(hipMemsetAsync(w.big, 0, 4, st));
-                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
-                                                 w.pids[0], w.ranks[1], n_raw, bshift, (uint32_t)nb,
-                                                 w.bcnt, w.boff, w.big, st));
+                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.recs, w.block_counts, occ_grid,
+                                                 occ_region_cap, w.keys[0], w.pids[0], bshift,
+                                                 (uint32_t)nb, w.bcnt, w.boff, w.big, st));
             } else {
+                HIPCHK_R(sink_compact(w.recs, w.region_off, occ_grid, occ_region_cap, w.keys[1],
+                                      w.pids[1], st));
                 int end_bit = std::min(64, rank_bits + bits_for(len));
                 HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
                                           w.pids[0], n_raw, end_bit, st));

@@ -2,6 +2,8 @@
 #pragma once
 #include <cstdint>
 
+#include <hip/hip_runtime.h>
+
 namespace acx {
 
 // Device-resident automaton (all pointers are device pointers).
@@ -39,26 +41,25 @@ struct Segments {
     uint64_t uniform_len;    // > 0: every haystack has this length
 };
 
-// Raw occurrence sink of the scan kernels.
+// Sink of the scan kernels: 16-byte records in per-workgroup regions.
+//   occurrence record  {key lo, key hi, pid, arrival rank in its bucket}
+//   prefix-hit record  two quads: {pos lo, pos hi, code, 0} {16 haystack bytes at pos}
+// Occurrence keys:
 //   key_mode 0 (Standard / overlapping): key = end   << rank_bits | rank(pid)
 //   key_mode 1 (LeftmostFirst):          key = start << rank_bits | pid
 //   key_mode 2 (LeftmostLongest):        key = start << rank_bits | rank(pid)
-// (rank_bits = bits needed for n_patterns - 1, so that the radix sort and the
-// bucket sort see as few key bits as possible)
-// Sorting by key ascending therefore yields exactly the order each match kind
-// consumes.
-// Slot allocation uses NO global atomics (one contended HBM word saturates at
+// (rank_bits = bits needed for n_patterns - 1.)  Sorting by key ascending yields
+// exactly the order each match kind consumes.
+// Slot allocation uses NO contended global atomic (one HBM word saturates at
 // ~88 atomics/us on MI355X): every workgroup owns the region
 // [blockIdx * region_cap, (blockIdx + 1) * region_cap) and hands out slots from
 // a counter in LDS; its final count goes to block_counts[blockIdx] (it keeps
 // counting past region_cap so that the host can size a retry exactly).
 struct Sink {
-    uint64_t *keys;
-    uint32_t *pids;
-    uint32_t *ranks;        // arrival rank of the occurrence inside its bucket (or null)
+    uint4 *recs;            // region_cap * quads uint4 per region
     uint32_t *bucket_cnt;   // per 4 KiB-of-position bucket counters (or null: no bucket sort)
     uint64_t *block_counts; // gridDim.x entries
-    uint64_t region_cap;
+    uint64_t region_cap;    // records per region
     uint32_t bucket_shift;  // bucket = key >> bucket_shift
     int key_mode;
 };

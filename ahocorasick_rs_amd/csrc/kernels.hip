@@ -45,9 +45,7 @@ __device__ __forceinline__ u32x4 load16_stream(const uint8_t *p) {
 
 // per-workgroup view of the sink: region base + LDS slot counter
 struct BlockSink {
-    uint64_t *keys;
-    uint32_t *pids;
-    uint32_t *ranks;
+    uint4 *recs;
     uint32_t *bucket_cnt;
     uint32_t *lcount; // LDS
     uint64_t region_cap;
@@ -55,25 +53,20 @@ struct BlockSink {
     int key_mode;
 };
 
-__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount) {
-    const uint64_t base = (uint64_t)blockIdx.x * K.region_cap;
-    return BlockSink{K.keys + base, K.pids + base, K.ranks ? K.ranks + base : nullptr, K.bucket_cnt,
-                     lcount, K.region_cap, K.bucket_shift, K.key_mode};
+__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount, uint32_t quads = 1) {
+    return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, K.bucket_cnt, lcount,
+                     K.region_cap, K.bucket_shift, K.key_mode};
 }
 
-// store one occurrence; with a bucket counter attached, also take the
-// occurrence's arrival rank inside its bucket (ONE global atomic, the address
-// is shared by the ~4 occurrences of a 4 KiB stretch only), which later turns
-// the bucket sort's scatter into plain stores
+// store one occurrence (ONE 16-byte store); with a bucket counter attached,
+// also take the occurrence's arrival rank inside its bucket (one global atomic,
+// the address is shared by the ~4 occurrences of a 4 KiB stretch only), which
+// later turns the bucket sort's scatter into plain stores
 __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid) {
     uint32_t r = 0;
     if (K.bucket_cnt) r = atomicAdd(&K.bucket_cnt[key >> K.bucket_shift], 1u);
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
-    if (slot < K.region_cap) {
-        K.keys[slot] = key;
-        K.pids[slot] = pid;
-        if (K.ranks) K.ranks[slot] = r;
-    }
+    if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
 }
 
 // The emit paths are cold and out of line; they read the automaton through a
@@ -366,14 +359,15 @@ constexpr uint32_t HIT_RETRY = 0xFFFFFFFFu;
 // pattern that starts at p.
 __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments &G,
                                            const BlockSink &K, const uint8_t *__restrict__ stream,
-                                           uint64_t len, uint64_t p, uint32_t code,
-                                           uint32_t ablate) {
+                                           uint64_t len, uint64_t p, uint32_t code, uint64_t w0,
+                                           uint64_t w1, uint32_t ablate) {
+    // (w0, w1) = the 16 haystack bytes at p, carried with the hit by K1b so that short
+    // patterns are verified without touching the (by now cold) haystack again
     const uint32_t q = A.filter_q2;
     const uint64_t room = segment_end(G, len, p) - p;
     if (room < q) return; // the prefix would straddle the end of its haystack
     if (code == HIT_RETRY) {
-        const uint64_t w = load_window(stream, len, p);
-        const uint64_t gram = q >= 8 ? w : (w & ((1ull << (8 * q)) - 1));
+        const uint64_t gram = q >= 8 ? w0 : (w0 & ((1ull << (8 * q)) - 1));
         uint32_t idx = prefix_slot(gram_hash2(gram), A.ptab_log2);
         const uint32_t mask = (1u << A.ptab_log2) - 1;
         for (;;) {
@@ -393,7 +387,9 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
         const uint32_t rk = A.rank[pid];
         bool ok = L <= room;
         for (uint32_t d = q; ok && d < L; d += 8) {
-            uint64_t a = load_window(stream, len, p + d);
+            uint64_t a = d == 8  ? w1
+                         : d < 8 ? (d ? (w0 >> (8 * d)) | (w1 << (64 - 8 * d)) : w0)
+                                 : load_window(stream, len, p + d);
             uint64_t b;
             __builtin_memcpy(&b, A.pat_blob + po + d, 8); // pat_blob is padded by 16 bytes
             uint32_t nbytes = L - d < 8 ? L - d : 8;
@@ -426,11 +422,12 @@ __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAuto
     for (uint32_t b = blockIdx.x / K_WALK_SPLIT; b < h_grid; b += gridDim.x / K_WALK_SPLIT) {
         uint64_t n = H.block_counts[b];
         if (n > H.region_cap) n = H.region_cap;
-        const uint64_t *pos = H.keys + (uint64_t)b * H.region_cap;
-        const uint32_t *code = H.pids + (uint64_t)b * H.region_cap;
+        const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
         for (uint64_t i = (blockIdx.x % K_WALK_SPLIT) * 256 + threadIdx.x; i < n; i += K_WALK_SPLIT * 256) {
-            if (ablate & 64) { if (pos[i] == 0x123456789ull && code[i] == 77) emit_key(K, 1, 1); continue; }
-            verify_hit(A, G, K, stream, len, pos[i], code[i], ablate);
+            const uint4 h = rec[2 * i], w = rec[2 * i + 1];
+            if (ablate & 64) { if (h.x == 0x12345678u && w.y == 77) emit_key(K, 1, 1); continue; }
+            verify_hit(A, G, K, stream, len, ((uint64_t)h.y << 32) | h.x, h.z,
+                       ((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z, ablate);
         }
     }
     __syncthreads();
@@ -449,7 +446,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
     if (threadIdx.x == 0) L.count = 0;
-    const BlockSink K = block_sink(GK, &L.count); // sink of prefix hits: key = position, pid = state
+    const BlockSink K = block_sink(GK, &L.count, 2); // sink of prefix hits (two quads per record)
     {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
@@ -476,13 +473,13 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     // ---- level-2 pipeline registers (tile-synchronous, one entry per lane)
     uint32_t nB = 0, nC = 0;            // wave-uniform counts
     uint64_t tbA = 0, tbB = 0, tbC = 0; // tile bases of the entries in Q1 / phase B / phase C
-    uint64_t winB = 0, gramC = 0;
+    uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
     uint32_t offB = 0, offC = 0;
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
 
     // hand the prefix hits (p, st) of the lanes with found == true to the sink:
     // one LDS atomic per wave reserves the slots
-#define K1B_HIT_PUSH(FOUND, P, ST)                                                               \
+#define K1B_HIT_PUSH(FOUND, P, ST, W0, W1)                                                       \
     {                                                                                            \
         unsigned long long fm_ = __ballot(FOUND);                                                \
         if (fm_) {                                                                               \
@@ -492,7 +489,12 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             if (FOUND) {                                                                         \
                 uint32_t slot_ = base_ + __builtin_amdgcn_mbcnt_hi(                              \
                                              (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
-                if (slot_ < K.region_cap) { K.keys[slot_] = (P); K.pids[slot_] = (ST); }         \
+                if (slot_ < K.region_cap) {                                                      \
+                    uint64_t p_ = (P), a_ = (W0), b_ = (W1);                                     \
+                    K.recs[2 * slot_] = make_uint4((uint32_t)p_, (uint32_t)(p_ >> 32), (ST), 0); \
+                    K.recs[2 * slot_ + 1] = make_uint4((uint32_t)a_, (uint32_t)(a_ >> 32),       \
+                                                       (uint32_t)b_, (uint32_t)(b_ >> 32));      \
+                }                                                                                \
             }                                                                                    \
         }                                                                                        \
     }
@@ -533,19 +535,18 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         // ---- phase C: compare the slots fetched one tile ago with their grams
         if (nC) {
             bool act = lane < nC;
-            bool same = (((uint64_t)entC.y << 32) | entC.x) == gramC;
+            bool same = (((uint64_t)entC.y << 32) | entC.x) == (winC & q2mask);
             bool found = act && entC.z != PREFIX_EMPTY;
             uint32_t st = same ? entC.w : HIT_RETRY;
-            if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st)
+            if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st, winC, winC1)
         }
         // ---- phase B: hash the windows fetched one tile ago, fetch their home slots
         if (nB) {
             if (lane < nB) {
-                gramC = winB & q2mask;
-                uint32_t idx = prefix_slot(gram_hash2(gramC), ptab_log2);
+                uint32_t idx = prefix_slot(gram_hash2(winB & q2mask), ptab_log2);
                 entC = *(const uint4 *)(A.ptab + (size_t)idx * 4);
             }
-            offC = offB;
+            offC = offB; winC = winB; winC1 = winB1;
         }
         nC = nB; tbC = tbB;
         // ---- phase A: fetch the 8-byte windows of the previous tile's survivors
@@ -554,6 +555,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             if (lane < q1c) {
                 offB = q1[lane];
                 winB = load_window(stream, len, tbA + offB - lead);
+                winB1 = load_window(stream, len, tbA + offB - lead + 8);
             }
         }
         nB = q1c; tbB = tbA; q1c = 0;
@@ -619,7 +621,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
                 // kernel unprobed (it probes the prefix table itself)
                 bool found = lane < q1c;
                 uint64_t p = found ? tbase + q1[lane] - lead : 0;
-                K1B_HIT_PUSH(found, p, HIT_RETRY)
+                uint64_t a0 = found ? load_window(stream, len, p) : 0;
+                uint64_t a1 = found ? load_window(stream, len, p + 8) : 0;
+                K1B_HIT_PUSH(found, p, HIT_RETRY, a0, a1)
                 q1c = 0;
             }
             if (mlo | mhi) {
@@ -732,18 +736,16 @@ __global__ __launch_bounds__(1024) void k_sink_summary(const uint64_t *block_cou
     }
 }
 
-__global__ __launch_bounds__(256) void k_sink_compact(const uint64_t *keys, const uint32_t *pids,
-                                                      const uint32_t *ranks, const uint64_t *offsets,
+// AoS regions -> dense SoA (key, pid) arrays (input of the radix sort)
+__global__ __launch_bounds__(256) void k_sink_compact(const uint4 *recs, const uint64_t *offsets,
                                                       uint64_t region_cap, uint64_t *keys_out,
-                                                      uint32_t *pids_out, uint32_t *ranks_out) {
+                                                      uint32_t *pids_out) {
     uint64_t o0 = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - o0;
-    const uint64_t *k = keys + (uint64_t)blockIdx.x * region_cap;
-    const uint32_t *p = pids + (uint64_t)blockIdx.x * region_cap;
-    const uint32_t *r = ranks ? ranks + (uint64_t)blockIdx.x * region_cap : nullptr;
+    const uint4 *r = recs + (uint64_t)blockIdx.x * region_cap;
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        keys_out[o0 + i] = k[i];
-        pids_out[o0 + i] = p[i];
-        if (r) ranks_out[o0 + i] = r[i];
+        uint4 v = r[i];
+        keys_out[o0 + i] = ((uint64_t)v.y << 32) | v.x;
+        pids_out[o0 + i] = v.z;
     }
 }
 
@@ -754,11 +756,10 @@ hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t re
     return hipGetLastError();
 }
 
-hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint32_t *ranks,
-                        const uint64_t *offsets, uint32_t grid, uint64_t region_cap,
-                        uint64_t *keys_out, uint32_t *pids_out, uint32_t *ranks_out, hipStream_t st) {
-    hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, keys, pids, ranks, offsets,
-                       region_cap, keys_out, pids_out, ranks_out);
+hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
+                        uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st) {
+    hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, recs, offsets, region_cap,
+                       keys_out, pids_out);
     return hipGetLastError();
 }
 
@@ -773,16 +774,22 @@ hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint32
 // host then falls back to the rocPRIM radix sort.
 constexpr uint32_t BUCKET_MAX = 64;
 
-// slot = bucket offset + the arrival rank taken at emission: no atomics here
-__global__ void k_bucket_scatter(const uint64_t *keys, const uint32_t *pids, const uint32_t *ranks,
-                                 uint64_t n, uint32_t shift, const uint32_t *off,
-                                 uint64_t *keys_out, uint32_t *pids_out) {
-    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    uint64_t k = keys[i];
-    uint32_t slot = off[(uint32_t)(k >> shift)] + ranks[i];
-    keys_out[slot] = k;
-    pids_out[slot] = pids[i];
+// straight from the sink regions: slot = bucket offset + the arrival rank taken
+// at emission -- no atomics, no separate compaction pass
+__global__ __launch_bounds__(256) void k_bucket_scatter(const uint4 *recs, const uint64_t *block_counts,
+                                                        uint64_t region_cap, uint32_t shift,
+                                                        const uint32_t *off, uint64_t *keys_out,
+                                                        uint32_t *pids_out) {
+    uint64_t n = block_counts[blockIdx.x];
+    if (n > region_cap) n = region_cap;
+    const uint4 *r = recs + (uint64_t)blockIdx.x * region_cap;
+    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+        uint4 v = r[i];
+        uint64_t k = ((uint64_t)v.y << 32) | v.x;
+        uint32_t slot = off[(uint32_t)(k >> shift)] + v.w;
+        keys_out[slot] = k;
+        pids_out[slot] = v.z;
+    }
 }
 
 __global__ void k_bucket_sort(uint64_t *keys, uint32_t *pids, const uint32_t *off, uint32_t nb,
@@ -808,17 +815,15 @@ size_t bucket_temp_bytes(uint64_t nb) {
 }
 
 // cnt (filled by the scan kernels' emission) / off: nb + 1 u32 each.
-hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
-                                   uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
-                                   const uint32_t *ranks_in, uint64_t n, uint32_t shift, uint32_t nb,
+hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *recs,
+                                   const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
+                                   uint64_t *keys_out, uint32_t *pids_out, uint32_t shift, uint32_t nb,
                                    const uint32_t *cnt, uint32_t *off, uint32_t *big,
                                    hipStream_t st) {
-    if (!n) return hipSuccess;
-    uint32_t blocks = (uint32_t)((n + 255) / 256);
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, cnt, off, 0u, (size_t)nb + 1,
                                            rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(blocks), dim3(256), 0, st, keys_in, pids_in, ranks_in, n,
+    hipLaunchKernelGGL(k_bucket_scatter, dim3(grid), dim3(256), 0, st, recs, block_counts, region_cap,
                        shift, off, keys_out, pids_out);
     hipLaunchKernelGGL(k_bucket_sort, dim3((nb + 255) / 256), dim3(256), 0, st, keys_out, pids_out,
                        off, nb, big);

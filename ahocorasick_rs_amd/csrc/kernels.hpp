@@ -25,9 +25,8 @@ hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const
 // sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         uint64_t *summary, uint64_t *offsets, hipStream_t st);
-hipError_t sink_compact(const uint64_t *keys, const uint32_t *pids, const uint32_t *ranks,
-                        const uint64_t *offsets, uint32_t grid, uint64_t region_cap,
-                        uint64_t *keys_out, uint32_t *pids_out, uint32_t *ranks_out, hipStream_t st);
+hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
+                        uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st);
 // K1b emits prefix hits (position, depth-Q2 state); this kernel walks them into
 // occurrences.  `hits` is K1b's sink (hit_grid regions), `occ` the occurrence
 // sink with walk_hits_grid(hit_grid) regions.
@@ -44,15 +43,15 @@ size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                             uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
                             uint64_t n, int end_bit, hipStream_t st);
-// bucket sort (sparse occurrences): bucket = key >> shift, nb buckets.  cnt[nb + 1]
-// was filled by the scan kernels' emission (Sink::bucket_cnt), ranks_in holds each
-// occurrence's arrival rank in its bucket; off[nb + 1] is scratch; *big (zeroed by
-// the caller) is set when a bucket is too dense, in which case the output is
-// unusable (use sort_occurrences)
+// bucket sort (sparse occurrences), straight from the sink regions: bucket = key >> shift,
+// nb buckets.  cnt[nb + 1] was filled by the scan kernels' emission (Sink::bucket_cnt) and
+// every record carries its arrival rank in its bucket; off[nb + 1] is scratch; *big
+// (zeroed by the caller) is set when a bucket is too dense, in which case the output is
+// unusable (compact + sort_occurrences instead)
 size_t bucket_temp_bytes(uint64_t nb);
-hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
-                                   uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
-                                   const uint32_t *ranks_in, uint64_t n, uint32_t shift, uint32_t nb,
+hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *recs,
+                                   const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
+                                   uint64_t *keys_out, uint32_t *pids_out, uint32_t shift, uint32_t nb,
                                    const uint32_t *cnt, uint32_t *off, uint32_t *big, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
