@@ -247,10 +247,10 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         A.filterA.assign(FILTER_WORDS, 0);
         for (uint64_t i = 0; i < n; i++) {
             const uint8_t *pp = pb + A.offsets[i];
-            uint32_t hx = filter_hash((uint32_t)gram_of(pp + 1, g) & gmask); // p[1..1+g)
-            uint32_t hy = filter_hash((uint32_t)gram_of(pp, g) & gmask);     // p[0..g)
-            A.filterA[2 * filter_entry(hx)] |= filter_sig(hx, pp[0]);
-            A.filterA[2 * filter_entry(hy) + 1] |= filter_sig(hy, pp[Q - 1]);
+            uint32_t wx = (uint32_t)gram_of(pp + 1, g) & gmask; // p[1..1+g)
+            uint32_t wy = (uint32_t)gram_of(pp, g) & gmask;     // p[0..g)
+            A.filterA[2 * filter_entry(filter_hash(wx))] |= filter_sig(wx, pp[0]);
+            A.filterA[2 * filter_entry(filter_hash(wy)) + 1] |= filter_sig(wy, pp[Q - 1]);
         }
         uint64_t set = 0;
         for (uint32_t e = 0; e < (1u << FILTER_ENTRIES_LOG2); e++)

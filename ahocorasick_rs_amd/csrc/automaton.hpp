@@ -37,9 +37,9 @@ constexpr uint32_t OWN1_MANY = 0xFFFFFFFEu; // own1[s]: several do (duplicates):
 // Level 1 (LDS, 128 KiB): 2^14 entries of two 32-bit words {X, Y}.  With
 // Q = min(5, shortest pattern) and g = Q - 1, every pattern prefix p[0..Q) sets
 // a two-bit signature in
-//     X[e(p[1..1+g))]: bits  p[0] & 31    and  (hs ^ p[0]) & 31
-//     Y[e(p[0..g))]:   bits  p[Q-1] & 31  and  (hs ^ p[Q-1]) & 31
-// (e = entry index, hs = 5 further bits of the same gram hash), so that the
+//     X[e(p[1..1+g))]: bits  p[0] & 31    and  p[1] & 31   (the gram's first byte)
+//     Y[e(p[0..g))]:   bits  p[Q-1] & 31  and  p[0] & 31   (the gram's first byte)
+// (e = entry index of the gram; Q = 1 degenerates to a single bit), so that the
 // haystack positions j (even) and j+1 share ONE 8-byte LDS read: both index
 // the table with the g-gram at j+1; position j tests X with byte j, position
 // j+1 tests Y with byte j+Q.  A position survives when BOTH signature bits are
@@ -51,7 +51,6 @@ constexpr uint32_t FILTER_WORDS = 2u << FILTER_ENTRIES_LOG2; // u32 words of the
 constexpr uint32_t FILTER_MAX_Q = 5;
 constexpr uint32_t FILTER2_MAX_Q = 8;
 constexpr uint32_t HASH_K1 = 0x9E3779u; // 24-bit odd multiplier (v_mad_u32_u24)
-constexpr uint32_t FILTER_SIG_SHIFT = 9; // hs = H >> 9
 
 #if defined(__HIPCC__)
 #define ACX_HD __host__ __device__
@@ -62,9 +61,10 @@ constexpr uint32_t FILTER_SIG_SHIFT = 9; // hs = H >> 9
 // 32-bit hash of a g-gram W (little-endian, masked to g bytes)
 ACX_HD static inline uint32_t filter_hash(uint32_t W) { return (W & 0xFFFFFFu) * HASH_K1 + W; }
 ACX_HD static inline uint32_t filter_entry(uint32_t H) { return H >> (32 - FILTER_ENTRIES_LOG2); }
-// the two signature bits of byte b under gram hash H
-ACX_HD static inline uint32_t filter_sig(uint32_t H, uint32_t b) {
-    return (1u << (b & 31)) | (1u << (((H >> FILTER_SIG_SHIFT) ^ b) & 31));
+// the two signature bits of byte b with the (masked) gram W: the kernel shifts the
+// table word right by b and by W (the hardware uses the low 5 bits of each)
+ACX_HD static inline uint32_t filter_sig(uint32_t W, uint32_t b) {
+    return (1u << (b & 31)) | (1u << (W & 31));
 }
 // 32-bit hash of a Q2-gram (little-endian in a u64, masked to Q2 bytes)
 ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {

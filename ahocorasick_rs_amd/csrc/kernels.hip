@@ -567,29 +567,35 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         tbA = tbase;
         K1B_ISSUE_TILE(tile + nw) // prefetch the wave's next tile
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
+        // a register whose LOW byte is byte k of the lane's 24-byte view: an odd window,
+        // a dword, or a dword shifted by 16 (only bits [4:0] are consumed)
+#define K1B_BYTE_REG(k) (((k) & 1) ? w_[(k)] : (((k) & 2) ? d_[(k) >> 2] >> 16 : d_[(k) >> 2]))
 #define K1B_ROW(RI, VR, RX, RY, MROW)                                                            \
         {                                                                                        \
-            /* look-ahead dwords: lane l+1's first two dwords (lane 63: next row's lane 0) */    \
-            uint32_t nx_ = __shfl_down(VR.x, 1), ny_ = __shfl_down(VR.y, 1);                     \
-            uint32_t rx_ = (RX), ry_ = (RY);                                                     \
-            uint32_t d_[6] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_,                    \
-                              lane == 63 ? ry_ : ny_};                                           \
+            /* look-ahead dwords: lane l+1's first two dwords by DPP wave_shl:1 (one VALU op   */\
+            /* each, no LDS); lane 63 takes them from the next row's lane 0 (scalar)          */\
+            uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);         \
+            uint32_t ny_ = __builtin_amdgcn_update_dpp(0u, VR.y, 0x130, 0xf, 0xf, true);         \
+            const uint32_t rx_ = (RX), ry_ = (RY); /* evaluated by ALL lanes (readfirstlane) */  \
+            uint32_t d4_ = lane == 63 ? rx_ : nx_, d5_ = lane == 63 ? ry_ : ny_;                 \
+            uint32_t d_[6] = {VR.x, VR.y, VR.z, VR.w, d4_, d5_};                                 \
+            /* w_[j] (odd j): the 4 bytes starting at byte j (4-gram of pair j-1; its low     */\
+            /* byte is also the Y signature byte of pair j-5)                                 */\
             uint32_t w_[20];                                                                     \
-            _Pragma("unroll") for (int j = 0; j < 20; j++) {                                     \
-                w_[j] = (j & 3) == 0 ? d_[j >> 2]                                                \
-                                     : __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3); \
-            }                                                                                    \
+            _Pragma("unroll") for (int j = 1; j < 20; j += 2)                                    \
+                w_[j] = __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3);         \
             uint32_t m_ = 0;                                                                     \
             if (!(ablate & 4)) {                                                                 \
                 _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                              \
-                    uint32_t W_ = w_[j + 1] & GMASK;                                             \
-                    uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                                  \
+                    const uint32_t W_ = w_[j + 1] & GMASK;                                       \
+                    const uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                            \
                     const uint2 e_ = *(const uint2 *)((const uint8_t *)L.xy +                    \
                         ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u))); \
-                    uint32_t hs_ = H_ >> FILTER_SIG_SHIFT;                                       \
-                    uint32_t bx_ = w_[j], by_ = w_[j + Q];                                       \
-                    uint32_t tx_ = (e_.x >> (bx_ & 31)) & (e_.x >> ((hs_ ^ bx_) & 31));          \
-                    uint32_t ty_ = (e_.y >> (by_ & 31)) & (e_.y >> ((hs_ ^ by_) & 31));          \
+                    /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */  \
+                    const uint32_t bx_ = K1B_BYTE_REG(j);                                        \
+                    const uint32_t by_ = K1B_BYTE_REG(j + Q);                                    \
+                    const uint32_t tx_ = (e_.x >> (bx_ & 31)) & (e_.x >> (W_ & 31));             \
+                    const uint32_t ty_ = (e_.y >> (by_ & 31)) & (e_.y >> (W_ & 31));             \
                     m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */  \
                     m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */  \
                 }                                                                                \
@@ -597,8 +603,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             } else {                                                                             \
                 m_ = (d_[0] ^ d_[1] ^ d_[2] ^ d_[3] ^ d_[4]) == 0x12345678u ? 1u : 0u;           \
             }                                                                                    \
-            const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                      \
-            if (p0_ < lead || p0_ + 15 > last_start) {                                           \
+            if (!interior) {                                                                     \
+                const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
                 uint32_t keep_ = 0;                                                              \
                 _Pragma("unroll") for (int j = 0; j < 16; j++)                                   \
                     if (p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j;              \
@@ -606,9 +612,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             }                                                                                    \
             MROW = m_;                                                                           \
         }
-        K1B_ROW(0, v0, __shfl(v1.x, 0), __shfl(v1.y, 0), mrow0)
-        K1B_ROW(1, v1, __shfl(v2.x, 0), __shfl(v2.y, 0), mrow1)
-        K1B_ROW(2, v2, __shfl(v3.x, 0), __shfl(v3.y, 0), mrow2)
+        // every position of an interior tile is a legal start: no per-row masking
+        const bool interior = tbase >= lead && tbase + tile_bytes <= last_start;
+        K1B_ROW(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
+        K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
+        K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
         K1B_ROW(3, v3, vL.x, vL.y, mrow3)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
         uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
@@ -644,6 +652,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
 #undef K1B_ISSUE_TILE
 #undef K1B_HIT_PUSH
 #undef K1B_ROW
+#undef K1B_BYTE_REG
 }
 
 size_t prefilter_lds_bytes() { return sizeof(K1bLds); }
