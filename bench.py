@@ -45,6 +45,8 @@ def main() -> None:
     ap.add_argument("--dist", choices=["T", "U"], default="T",
                     help="T text-like (headline), U iid-uniform a-z")
     ap.add_argument("--kernel", choices=["auto", "dfa_walk", "prefilter"], default="auto")
+    ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
+                    help="auto: cfg2 single haystack at N=1, cfg3 batch of 8 KiB haystacks at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-bytes", type=int, default=GIB)
     args = ap.parse_args()
@@ -66,7 +68,7 @@ def main() -> None:
     capi.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
         import torch.distributed as dist
         dist.init_process_group(backend="nccl", device_id=dev)
 
@@ -82,11 +84,11 @@ def main() -> None:
     nbytes = args.bytes
     hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     kind, seed = (1, 11) if args.dist == "T" else (0, 12)
-    if world > 1:
+    if world > 1 or args.workload == "batch":
         seed = 13  # cfg3: ONE global stream cut into 8 KiB haystacks, sharded by rank
     torch.cuda.synchronize()
     ac.generate(hay.data_ptr(), nbytes, kind, seed, stream_offset=rank * nbytes)
-    batch = world > 1
+    batch = world > 1 if args.workload == "auto" else args.workload == "batch"
     uniform_len = 8192 if batch else 0
     n_hay = nbytes // uniform_len if batch else 0
     if batch and nbytes % uniform_len:
