@@ -384,9 +384,14 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             if (overlapping) {
                 n_final = n_raw;
             } else {
-                HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+                // Standard: sorted by end, so the running max of the ends IS the array of ends
+                const uint64_t *M = w.E;
+                if (key_mode != 0) {
+                    HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+                    M = w.M;
+                }
                 HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
-                HIPCHK_R(resolve_greedy(w.S, w.E, w.M, w.flags, n_raw, st));
+                HIPCHK_R(resolve_greedy(w.S, w.E, M, w.flags, n_raw, st));
                 HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
                 HIPCHK_R(hipMemcpyAsync(w.h_pinned + 4, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
             }

@@ -69,6 +69,24 @@ __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint3
     if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
 }
 
+// Wave-aggregated variant for code where many lanes emit together (walk kernel):
+// one LDS atomic per wave reserves the slots; `ok` may differ per lane.
+__device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid) {
+    unsigned long long fm = __ballot(ok);
+    if (!fm) return;
+    uint32_t r = 0;
+    if (ok && K.bucket_cnt) r = atomicAdd(&K.bucket_cnt[key >> K.bucket_shift], 1u);
+    const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
+    uint32_t base = 0;
+    if ((threadIdx.x & 63) == leader) base = atomicAdd(K.lcount, (uint32_t)__popcll(fm));
+    base = __shfl(base, leader);
+    if (ok) {
+        uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
+                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+        if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
+    }
+}
+
 // The emit paths are cold and out of line; they read the automaton through a
 // pointer to its device-resident copy so that the kernels never have to spill
 // their by-value kernel arguments to scratch for them.
@@ -396,12 +414,10 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
             uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
             ok = ((a ^ b) & m) == 0;
         }
-        if (ok && !(ablate & 32)) {
-            uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
-                           : K.key_mode == 1 ? (p << A.rank_bits) | pid
-                                             : (p << A.rank_bits) | rk;
-            emit_key(K, key, pid);
-        }
+        uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
+                       : K.key_mode == 1 ? (p << A.rank_bits) | pid
+                                         : (p << A.rank_bits) | rk;
+        emit_key_agg(K, ok && !(ablate & 32), key, pid);
     }
 }
 
@@ -511,7 +527,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
         const uint8_t *ptr_ = hay + (off_ < last_block ? off_ : last_block);                     \
-        DST = (ablate & 16) ? *(const u32x4 *)ptr_ : load16_stream(ptr_);                        \
+        DST = (ablate & 16) ? *(const u32x4 *)ptr_ : load16_stream(ptr_); /* 16: plain loads */  \
     }
 #define K1B_ISSUE_TILE(TILE)                                                                     \
     K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2)       \
