@@ -175,7 +175,7 @@ def main() -> None:
                 "peak": HBM_PEAK_GBPS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": None,
+                "traffic": measured_traffic(info, nbytes, args.dist, batch),
                 "kernel_ms": round(scan_ms, 4),
                 "algorithmic_bytes": int(algo_bytes),
             },
@@ -186,6 +186,26 @@ def main() -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def measured_traffic(info, nbytes, dist_name, batch):
+    """HBM bytes per launch of the dominant kernel from the PMC passes of the SAME command
+    (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction; produced by
+    tools/collect_profiles.sh and committed under profiles/).  null when no measurement of this
+    exact configuration is on file."""
+    try:
+        best = None
+        for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
+            f = os.path.join(ROOT, "profiles", d, "pmc_traffic.json")
+            if os.path.exists(f):
+                t = json.load(open(f))
+                kern = "k1b_prefilter" if info.kernel == 2 else "k1a_dfa_walk"
+                if (t.get("kernel") == kern and t.get("workload_bytes") == nbytes
+                        and t.get("dist") == dist_name and not batch):
+                    best = int(t["traffic_bytes"])
+        return best
+    except Exception:
+        return None
 
 
 def cpu_baseline(patterns, hay_t, sample_bytes, gpu_matches, nbytes):
