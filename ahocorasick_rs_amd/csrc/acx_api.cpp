@@ -569,6 +569,11 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.filterA, filterA)
     UP(H.ptab, ptab)
     UP(H.blist, blist)
+    {
+        const uint32_t *pi = nullptr;
+        if ((rc = upload(a, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
+        D.pinfo = reinterpret_cast<const uint4 *>(pi);
+    }
     H.blob.resize(H.blob.size() + 16, 0); // the walk kernel compares 8 bytes at a time
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)

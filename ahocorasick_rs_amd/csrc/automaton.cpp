@@ -277,6 +277,15 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             pref_state[i] = st;
             below[st]++;
         }
+        A.pinfo.assign((size_t)4 * n, 0);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint8_t *pp = pb + A.offsets[i];
+            uint32_t L = A.plen[i];
+            uint8_t tail[12] = {0};
+            for (uint32_t k = 0; k < 12 && Q2 + k < L; k++) tail[k] = pp[Q2 + k];
+            A.pinfo[4 * i] = A.rank[i] | (std::min<uint32_t>(L, 255) << 24);
+            std::memcpy(&A.pinfo[4 * i + 1], tail, 12);
+        }
         A.blist.clear();
         for (uint64_t i = 0; i < n; i++) {
             uint32_t st = pref_state[i];

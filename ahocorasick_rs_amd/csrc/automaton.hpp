@@ -107,6 +107,9 @@ struct Automaton {
     //   {gram lo, gram hi, state id | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty),
     //    the only pattern with this prefix, or 0x80000000 | index into blist}
     std::vector<uint32_t> blist;       // {count, pid, pid, ...} per prefix shared by several patterns
+    // per pattern, 4 u32: {rank | min(len, 255) << 24, the 12 bytes that follow its first Q2 bytes}
+    // -- everything the walk kernel needs to settle a short candidate with ONE 16-byte load
+    std::vector<uint32_t> pinfo;
     std::vector<uint32_t> ptab;
     uint32_t ptab_log2 = 0;
     // pattern bytes (kept for the synthetic text generator)

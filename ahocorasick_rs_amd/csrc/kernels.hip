@@ -70,19 +70,41 @@ __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint3
 }
 
 // Wave-aggregated variant for code where many lanes emit together (walk kernel):
-// one LDS atomic per wave reserves the slots; `ok` may differ per lane.
+// one LDS atomic per wave reserves the slots, and ONE global atomic per run of
+// adjacent emitting lanes that fall into the same bucket takes the bucket ranks
+// (hits arrive grouped by 4 KiB tile, so a run is typically a whole tile: device-
+// scope atomics with return are the expensive part of emission).
 __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid) {
-    unsigned long long fm = __ballot(ok);
+    const unsigned long long fm = __ballot(ok);
     if (!fm) return;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below_me = (1ull << lane) - 1;
     uint32_t r = 0;
-    if (ok && K.bucket_cnt) r = atomicAdd(&K.bucket_cnt[key >> K.bucket_shift], 1u);
+    if (K.bucket_cnt) {
+        const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
+        // previous emitting lane and its bucket
+        const unsigned long long below = fm & below_me;
+        const uint32_t prev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
+        const uint32_t pb = __shfl(bucket, prev);
+        const bool head = ok && (!below || pb != bucket);
+        const unsigned long long hm = __ballot(head);
+        // my run = emitting lanes from my head lane up to (not including) the next head
+        const unsigned long long upto_me = below_me | (1ull << lane);
+        const uint32_t hl = 63u - (uint32_t)__builtin_clzll((hm & upto_me) | 1ull);
+        const unsigned long long above = hl >= 63 ? 0ull : (hm & ~((2ull << hl) - 1));
+        const unsigned long long run_end = above ? ((1ull << __builtin_ctzll(above)) - 1) : ~0ull;
+        const unsigned long long run = fm & run_end & ~((1ull << hl) - 1);
+        uint32_t base = 0;
+        if (head) base = atomicAdd(&K.bucket_cnt[bucket], (uint32_t)__popcll(run));
+        base = __shfl(base, hl);
+        r = base + (uint32_t)__popcll(run & below_me);
+    }
     const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
-    uint32_t base = 0;
-    if ((threadIdx.x & 63) == leader) base = atomicAdd(K.lcount, (uint32_t)__popcll(fm));
-    base = __shfl(base, leader);
+    uint32_t sbase = 0;
+    if (lane == leader) sbase = atomicAdd(K.lcount, (uint32_t)__popcll(fm));
+    sbase = __shfl(sbase, leader);
     if (ok) {
-        uint32_t slot = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32),
-                                                         __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+        uint32_t slot = sbase + (uint32_t)__popcll(fm & below_me);
         if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
     }
 }
@@ -400,19 +422,32 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
     const uint32_t n = list ? A.blist[li] : 1;
     for (uint32_t k = 0; k < n; k++) {
         const uint32_t pid = list ? A.blist[li + 1 + k] : code;
-        const uint32_t L = A.plen[pid];
-        const uint64_t po = A.pat_off[pid];
-        const uint32_t rk = A.rank[pid];
+        // ONE 16-byte load: rank, length (if < 255) and the 12 bytes after the first q
+        const uint4 pi = A.pinfo[pid];
+        const uint32_t rk = pi.x & 0xFFFFFFu;
+        uint32_t L = pi.x >> 24;
+        if (L == 255) L = A.plen[pid];
         bool ok = L <= room;
-        for (uint32_t d = q; ok && d < L; d += 8) {
-            uint64_t a = d == 8  ? w1
-                         : d < 8 ? (d ? (w0 >> (8 * d)) | (w1 << (64 - 8 * d)) : w0)
-                                 : load_window(stream, len, p + d);
-            uint64_t b;
-            __builtin_memcpy(&b, A.pat_blob + po + d, 8); // pat_blob is padded by 16 bytes
-            uint32_t nbytes = L - d < 8 ? L - d : 8;
-            uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
-            ok = ((a ^ b) & m) == 0;
+        if (ok && L > q) {
+            // haystack bytes q.. from the carried window (16 - q of them), pattern bytes from pinfo
+            const uint32_t have = 16 - q;                 // carried bytes beyond the prefix
+            const uint32_t need = L - q < 12 ? L - q : 12; // bytes checkable against pinfo
+            uint64_t h0 = q < 8 ? (q ? (w0 >> (8 * q)) | (w1 << (64 - 8 * q)) : w0) : (w1 >> (8 * (q - 8)));
+            uint64_t h1 = q < 8 ? (q ? (w1 >> (8 * q)) : w1) : 0;
+            uint64_t p0 = ((uint64_t)pi.z << 32) | pi.y, p1 = pi.w;
+            uint32_t n0 = need < have ? need : have;       // bytes compared from the carried window
+            uint64_t m0 = n0 >= 8 ? ~0ull : ((1ull << (8 * n0)) - 1);
+            uint64_t m1 = n0 > 8 ? ((1ull << (8 * (n0 - 8))) - 1) : 0;
+            ok = (((h0 ^ p0) & m0) | ((h1 ^ p1) & m1)) == 0;
+            // whatever lies beyond the carried window / pinfo (long patterns): compare in place
+            for (uint32_t d = q + n0; ok && d < L; d += 8) {
+                uint64_t a = load_window(stream, len, p + d);
+                uint64_t b;
+                __builtin_memcpy(&b, A.pat_blob + A.pat_off[pid] + d, 8); // pat_blob is padded by 16 bytes
+                uint32_t nbytes = L - d < 8 ? L - d : 8;
+                uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
+                ok = ((a ^ b) & m) == 0;
+            }
         }
         uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
                        : K.key_mode == 1 ? (p << A.rank_bits) | pid
