@@ -107,7 +107,10 @@ struct Workspace {
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
     uint32_t *bcnt = nullptr, *boff = nullptr;  // bucket sort: nb + 1 each
+    uint32_t *bacc = nullptr, *bout = nullptr;  // bucket resolve: reported per bucket, its prefix
+    acx_match_t *final = nullptr;               // final matches of the bucket path (cap entries)
     uint64_t bucket_cap = 0;
+    bool bcnt_clean = false;                    // bcnt is all zero (left so by the tile kernels)
     uint32_t *big = nullptr;       // device flag: a bucket was too dense for the bucket sort
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
     uint64_t hay_cap = 0;
@@ -164,13 +167,15 @@ int upload(acx_automaton *a, const T *src, size_t count, const T **dst) {
     return ACX_OK;
 }
 
-void free_ws(Workspace &w) {
+void free_ws(Workspace &w, int device) {
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.big);
+    (void)hipFree(w.bacc); (void)hipFree(w.bout);
+    g_bufs.put(w.final, device);
 
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
@@ -197,6 +202,7 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.recs); (void)hipFree(w.hrecs);
+    if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
     w.S = w.E = w.M = nullptr; w.flags = w.idx = nullptr; w.temp = nullptr; w.cap = 0;
     w.recs = nullptr; w.hrecs = nullptr;
     for (int i = 0; i < 2; i++) {
@@ -239,10 +245,13 @@ int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
 int ensure_buckets(acx_automaton *a, uint64_t nb1) {
     Workspace &w = a->ws;
     if (nb1 > w.bucket_cap) {
-        (void)hipFree(w.bcnt); (void)hipFree(w.boff);
-        w.bcnt = w.boff = nullptr; w.bucket_cap = 0;
+        (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bacc); (void)hipFree(w.bout);
+        w.bcnt = w.boff = w.bacc = w.bout = nullptr; w.bucket_cap = 0;
         HIPCHK(hipMalloc((void **)&w.bcnt, nb1 * 4));
         HIPCHK(hipMalloc((void **)&w.boff, nb1 * 4));
+        HIPCHK(hipMalloc((void **)&w.bacc, nb1 * 4));
+        HIPCHK(hipMalloc((void **)&w.bout, nb1 * 4));
+        w.bcnt_clean = false;
         w.bucket_cap = nb1;
     }
     size_t need = bucket_temp_bytes(nb1) + 256;
@@ -261,6 +270,10 @@ int bits_for(uint64_t x) { // number of bits needed to represent x
 }
 
 // The whole device pipeline.  d_hay: device pointer, len bytes.
+//
+//   scan (K1a, or K1b + walk)  ->  occurrence sink (regions)        [+ bucket counters]
+//   sparse output:  bucket sort -> bucket resolve -> final matches    ONE host round trip
+//   dense output:   compact -> radix sort -> spans -> resolve -> ...  (two round trips)
 int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
              int overlapping, int codepoints, acx_result **out) {
     *out = nullptr;
@@ -288,35 +301,29 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         HIPCHK_R(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
         HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
     }
-    uint64_t n_raw = 0;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
-    uint32_t bshift = 0, occ_grid = 0;
-    uint64_t nb = 0, occ_region_cap = 0;
-    bool use_bucket = false;
+    uint64_t n_final = 0;
     if (len > 0 && a->host.n_patterns > 0) {
         int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
         if (rc) return bail(rc);
         Workspace &w = a->ws;
         const bool pre = a->kernel == ACX_KERNEL_PREFILTER;
-        // K1b emits prefix hits into (hkeys, hpids); k_walk_hits turns them into
-        // occurrences.  K1a emits occurrences directly.
+        // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
         const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
                                        : dfa_walk_grid(a->dev, len, a->n_cus);
         const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // occurrence regions
-        // Bucket sort of the occurrences by 4 KiB of stream position: the emitting kernel
-        // counts per bucket.  Automata that produced dense output last time skip it.
-        bshift = (uint32_t)a->dev.rank_bits + 12;
-        nb = (len >> 12) + 2;
+        const int rank_bits = (int)a->dev.rank_bits;
+        const uint32_t bshift = (uint32_t)rank_bits + 12; // buckets of 4 KiB of stream position
+        const uint64_t nb = (len >> 12) + 2;
         static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
-        use_bucket = !a->dense_output && !no_bucket_env && nb < (1ull << 31);
-        if (use_bucket) {
-            rc = ensure_buckets(a, nb + 1);
-            if (rc) return bail(rc);
-        }
-        for (int attempt = 0; attempt < 3; attempt++) {
-            const uint64_t region_cap = w.cap / grid;
-            const uint64_t hit_cap = w.cap / scan_grid;
-            if (use_bucket) HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
+        bool use_bucket = !a->dense_output && !no_bucket_env && nb < (1ull << 31);
+        if (use_bucket && (rc = ensure_buckets(a, nb + 1)) != ACX_OK) return bail(rc);
+        uint64_t n_raw = 0;
+        for (int attempt = 0;; attempt++) {
+            if (attempt == 4) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
+            const uint64_t region_cap = w.cap / grid, hit_cap = w.cap / scan_grid;
+            if (use_bucket && !w.bcnt_clean) HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
+            if (use_bucket) w.bcnt_clean = false;
             Sink K{w.recs, use_bucket ? w.bcnt : nullptr, w.block_counts, region_cap, bshift, key_mode};
             Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
@@ -325,13 +332,24 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                                  a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-            if (pre) {
-                HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, K, d_hay, len, st));
-                HIPCHK_R(sink_summary(w.hit_counts, scan_grid, hit_cap, w.summary + 2, w.region_off, st));
+            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, K, d_hay, len, st));
+            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, pre ? w.hit_counts : nullptr, scan_grid,
+                                  hit_cap, w.summary, w.region_off, (uint32_t *)(w.summary + 5), st));
+            if (use_bucket) {
+                // sort, resolve and write without knowing the occurrence count on the host
+                if (!w.final) HIPCHK_R(g_bufs.get((void **)&w.final, w.cap * sizeof(acx_match_t), a->device));
+                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.recs, w.block_counts, grid,
+                                                 region_cap, w.keys[0], w.pids[0], bshift, (uint32_t)nb,
+                                                 w.bcnt, w.boff, (uint32_t *)(w.summary + 5), st));
+                HIPCHK_R(bucket_resolve_write(a->dev, key_mode, overlapping != 0, w.keys[0], w.pids[0],
+                                              w.keys[1], w.pids[1], w.boff, (uint32_t)nb, bshift,
+                                              (uint8_t *)w.flags, (uint8_t *)w.flags + w.cap, w.bcnt,
+                                              w.bacc, w.bout, w.final,
+                                              w.summary + 4, (uint32_t *)(w.summary + 5), st));
             }
-            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, w.summary, w.region_off, st));
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 48, hipMemcpyDeviceToHost, st));
             HIPCHK_R(hipStreamSynchronize(st));
+            if (use_bucket) w.bcnt_clean = true; // the tile kernels zeroed the emission counters
             if (a->prof) {
                 float ms = 0;
                 HIPCHK_R(hipEventElapsedTime(&ms, a->ev[0], a->ev[1]));
@@ -340,83 +358,62 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 a->profile.scan_bytes += len;
             }
             n_raw = w.h_pinned[0];
-            const uint64_t region_max = w.h_pinned[1];
-            const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
-            if (region_max <= region_cap && hit_max <= hit_cap) {
-                occ_grid = grid; occ_region_cap = region_cap;
-                break;
-            }
-            if (attempt == 2) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
-            uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64),
-                                     (uint64_t)scan_grid * (hit_max + hit_max / 8 + 64));
-            // hits that overflowed were dropped, so the occurrence count is a lower bound: be generous
-            if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
-            rc = ensure_occ_capacity(a, want);
-            if (rc) return bail(rc);
-        }
-        if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += w.h_pinned[2]; }
-    }
-    if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
-    uint64_t n_final = 0;
-    if (n_raw > 0) {
-        Workspace &w = a->ws;
-        if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-        const int rank_bits = (int)a->dev.rank_bits;
-        // Sparse occurrences: bucket sort by 4 KiB of stream position; dense ones (or a
-        // bucket sort that met an over-full bucket): rocPRIM radix sort of the used key bits.
-        if (use_bucket && n_raw > 8 * nb) use_bucket = false; // dense: straight to the radix sort
-        a->dense_output = n_raw > 8 * nb;
-        for (int pass = 0; pass < 2; pass++) {
-            // the sorted (key, pid) arrays go to keys[0]/pids[0]
-            if (use_bucket) {
-                HIPCHK_R(hipMemsetAsync(w.big, 0, 4, st));
-                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.recs, w.block_counts, occ_grid,
-                                                 occ_region_cap, w.keys[0], w.pids[0], bshift,
-                                                 (uint32_t)nb, w.bcnt, w.boff, w.big, st));
-            } else {
-                HIPCHK_R(sink_compact(w.recs, w.region_off, occ_grid, occ_region_cap, w.keys[1],
-                                      w.pids[1], st));
-                int end_bit = std::min(64, rank_bits + bits_for(len));
-                HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1],
-                                          w.pids[0], n_raw, end_bit, st));
-            }
-            HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
-            if (overlapping) {
-                n_final = n_raw;
-            } else {
-                // Standard: sorted by end, so the running max of the ends IS the array of ends
-                const uint64_t *M = w.E;
-                if (key_mode != 0) {
-                    HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
-                    M = w.M;
-                }
-                HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
-                HIPCHK_R(resolve_greedy(w.S, w.E, M, w.flags, n_raw, st));
-                HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
-                HIPCHK_R(hipMemcpyAsync(w.h_pinned + 4, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
-            }
-            if (use_bucket) HIPCHK_R(hipMemcpyAsync(w.h_pinned + 5, w.big, 4, hipMemcpyDeviceToHost, st));
-            if (use_bucket || !overlapping) HIPCHK_R(hipStreamSynchronize(st));
-            if (use_bucket && *(uint32_t *)(w.h_pinned + 5)) { // a bucket was too dense
-                use_bucket = false;
-                a->dense_output = true;
+            const uint64_t region_max = w.h_pinned[1], hit_max = pre ? w.h_pinned[3] : 0;
+            if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
+                uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64),
+                                         (uint64_t)scan_grid * (hit_max + hit_max / 8 + 64));
+                // hits that overflowed were dropped, so the occurrence count is a lower bound
+                if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
+                if ((rc = ensure_occ_capacity(a, want)) != ACX_OK) return bail(rc);
                 continue;
             }
-            if (!overlapping) n_final = *(uint32_t *)(w.h_pinned + 4);
+            if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += w.h_pinned[2]; }
+            if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
+            a->dense_output = n_raw > 8 * nb;
+            if (use_bucket && (uint32_t)w.h_pinned[5]) { // a bucket was too dense for the bucket sort
+                use_bucket = false;
+                a->dense_output = true;
+            }
+            if (use_bucket) {
+                n_final = w.h_pinned[4];
+                r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
+                w.final = nullptr;
+            } else if (n_raw > 0) {
+                // ---- dense path: compact -> radix sort on the used key bits -> resolve
+                if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+                HIPCHK_R(sink_compact(w.recs, w.region_off, grid, region_cap, w.keys[1], w.pids[1], st));
+                int end_bit = std::min(64, rank_bits + bits_for(len));
+                HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1], w.pids[0],
+                                          n_raw, end_bit, st));
+                HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
+                if (overlapping) {
+                    n_final = n_raw;
+                } else {
+                    // Standard: sorted by end, so the running max of the ends IS the array of ends
+                    const uint64_t *M = w.E;
+                    if (key_mode != 0) {
+                        HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+                        M = w.M;
+                    }
+                    HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
+                    HIPCHK_R(resolve_greedy(w.S, w.E, M, w.flags, n_raw, st));
+                    HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
+                    HIPCHK_R(hipMemcpyAsync(w.h_pinned + 6, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
+                    HIPCHK_R(hipStreamSynchronize(st));
+                    n_final = *(uint32_t *)(w.h_pinned + 6);
+                }
+                HIPCHK_R(g_bufs.get((void **)&r->d_matches,
+                                    std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t), a->device));
+                HIPCHK_R(write_matches(w.pids[0], w.S, w.E, overlapping ? nullptr : w.flags,
+                                       overlapping ? nullptr : w.idx, r->d_matches, n_raw, st));
+            }
             break;
         }
-        HIPCHK_R(g_bufs.get((void **)&r->d_matches, std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t),
-                            a->device));
-        if (overlapping)
-            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, nullptr, nullptr, r->d_matches, n_raw, st));
-        else
-            HIPCHK_R(write_matches(w.pids[0], w.S, w.E, w.flags, w.idx, r->d_matches, n_raw, st));
         r->n = n_final;
         if (n_final && (codepoints || segmented)) {
             if (codepoints) {
                 uint64_t nb1 = (len + 1023) / 1024 + 1;
-                int rc = ensure_blocks(a, nb1);
-                if (rc) return bail(rc);
+                if ((rc = ensure_blocks(a, nb1)) != ACX_OK) return bail(rc);
                 HIPCHK_R(count_lead_bytes(d_hay, len, w.blockcnt, st));
                 HIPCHK_R(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
             }
@@ -651,7 +648,7 @@ void acx_free_automaton(acx_automaton_t *a) {
     (void)hipSetDevice(a->device);
     if (a->stream) (void)hipStreamSynchronize(a->stream);
     for (void *p : a->allocs) (void)hipFree(p);
-    free_ws(a->ws);
+    free_ws(a->ws, a->device);
     for (auto &ev : a->ev) if (ev) (void)hipEventDestroy(ev);
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;

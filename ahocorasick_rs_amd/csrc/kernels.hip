@@ -757,30 +757,35 @@ hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const
 // ---------------------------------------------------------------------------
 // sink bookkeeping: totals + compaction of the per-workgroup regions
 // ---------------------------------------------------------------------------
-// summary[0] = total occurrences kept, summary[1] = max count of a region,
-// offsets[b] = exclusive prefix of min(count, region_cap), offsets[grid] = total
-__global__ __launch_bounds__(1024) void k_sink_summary(const uint64_t *block_counts, uint32_t grid,
-                                                       uint64_t region_cap, uint64_t *summary,
-                                                       uint64_t *offsets) {
-    // one workgroup; thread t owns the regions [t * per, (t + 1) * per)
+// One workgroup per sink (blockIdx 0: occurrences, 1: prefix hits):
+// summary[2 b] = total records kept, summary[2 b + 1] = max count of a region,
+// offsets[r] = exclusive prefix of min(count, region_cap), offsets[grid] = total (sink 0 only).
+// *abort_flag (the abort flag of the bucket path) = an occurrence region overflowed.
+struct SinkView { const uint64_t *block_counts; uint32_t grid; uint64_t region_cap; };
+__global__ __launch_bounds__(1024) void k_sink_summary(SinkView occ, SinkView hit, uint64_t *summary,
+                                                       uint64_t *offsets, uint32_t *abort_flag) {
+    // thread t owns the regions [t * per, (t + 1) * per)
     using scan_t = rocprim::block_scan<uint64_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     __shared__ uint64_t red[16];
-    const uint32_t per = (grid + 1023) / 1024;
+    const SinkView V = blockIdx.x == 0 ? occ : hit;
+    if (blockIdx.x != 0) offsets = nullptr;
+    summary += 2 * blockIdx.x;
+    const uint32_t per = (V.grid + 1023) / 1024;
     const uint32_t b0 = threadIdx.x * per;
     uint64_t mine = 0, mx = 0;
-    for (uint32_t b = b0; b < b0 + per && b < grid; b++) {
-        uint64_t c = block_counts[b];
+    for (uint32_t b = b0; b < b0 + per && b < V.grid; b++) {
+        uint64_t c = V.block_counts[b];
         mx = c > mx ? c : mx;
-        mine += c < region_cap ? c : region_cap;
+        mine += c < V.region_cap ? c : V.region_cap;
     }
     uint64_t excl = 0;
     scan_t().exclusive_scan(mine, excl, (uint64_t)0, scan_tmp);
     uint64_t run = excl;
-    for (uint32_t b = b0; b < b0 + per && b < grid; b++) {
-        offsets[b] = run;
-        uint64_t c = block_counts[b];
-        run += c < region_cap ? c : region_cap;
+    for (uint32_t b = b0; b < b0 + per && b < V.grid; b++) {
+        if (offsets) offsets[b] = run;
+        uint64_t c = V.block_counts[b];
+        run += c < V.region_cap ? c : V.region_cap;
     }
     for (int o = 32; o > 0; o >>= 1) {
         uint64_t other = __shfl_down(mx, o);
@@ -788,11 +793,13 @@ __global__ __launch_bounds__(1024) void k_sink_summary(const uint64_t *block_cou
     }
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
     __syncthreads();
-    if (threadIdx.x == 1023) { offsets[grid] = run; summary[0] = run; }
+    if (threadIdx.x == 1023) { if (offsets) offsets[V.grid] = run; summary[0] = run; }
     if (threadIdx.x == 0) {
         uint64_t m = 0;
         for (int i = 0; i < 16; i++) m = red[i] > m ? red[i] : m;
         summary[1] = m;
+        // a region overflowed: the kernels queued behind this one must not trust the counters
+        if (blockIdx.x == 0) *abort_flag = m > V.region_cap ? 1u : 0u;
     }
 }
 
@@ -809,10 +816,13 @@ __global__ __launch_bounds__(256) void k_sink_compact(const uint4 *recs, const u
     }
 }
 
+// hit_counts may be null (K1a: no prefix-hit sink): summary[2..3] are then left alone
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
-                        uint64_t *summary, uint64_t *offsets, hipStream_t st) {
-    hipLaunchKernelGGL(k_sink_summary, dim3(1), dim3(1024), 0, st, block_counts, grid, region_cap,
-                       summary, offsets);
+                        const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
+                        uint64_t *summary, uint64_t *offsets, uint32_t *abort_flag, hipStream_t st) {
+    hipLaunchKernelGGL(k_sink_summary, dim3(hit_counts ? 2 : 1), dim3(1024), 0, st,
+                       SinkView{block_counts, grid, region_cap}, SinkView{hit_counts, hit_grid, hit_cap},
+                       summary, offsets, abort_flag);
     return hipGetLastError();
 }
 
@@ -828,10 +838,10 @@ hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t gri
 // ---------------------------------------------------------------------------
 // Occurrences are sparse (about one per KiB on the headline workload), so a
 // full 64-bit radix sort is wasted work: the scan kernels count per 4 KiB
-// bucket of the position while they emit (emit_key); a scan of the counters, a
-// scatter and a per-bucket insertion sort then order everything.
-// A bucket with more than BUCKET_MAX occurrences sets *big (dense inputs): the
-// host then falls back to the rocPRIM radix sort.
+// bucket of the position while they emit (emit_key); a scan of the counters and a
+// scatter group them by bucket, the tile kernels (K2b) order and resolve them.
+// A bucket with more than BUCKET_MAX occurrences (or a tile with more than TILE_MAX)
+// sets *big (dense inputs): the host then falls back to the rocPRIM radix sort.
 constexpr uint32_t BUCKET_MAX = 64;
 
 // straight from the sink regions: slot = bucket offset + the arrival rank taken
@@ -839,7 +849,8 @@ constexpr uint32_t BUCKET_MAX = 64;
 __global__ __launch_bounds__(256) void k_bucket_scatter(const uint4 *recs, const uint64_t *block_counts,
                                                         uint64_t region_cap, uint32_t shift,
                                                         const uint32_t *off, uint64_t *keys_out,
-                                                        uint32_t *pids_out) {
+                                                        uint32_t *pids_out, const uint32_t *abort_flag) {
+    if (*abort_flag) return;
     uint64_t n = block_counts[blockIdx.x];
     if (n > region_cap) n = region_cap;
     const uint4 *r = recs + (uint64_t)blockIdx.x * region_cap;
@@ -849,21 +860,6 @@ __global__ __launch_bounds__(256) void k_bucket_scatter(const uint4 *recs, const
         uint32_t slot = off[(uint32_t)(k >> shift)] + v.w;
         keys_out[slot] = k;
         pids_out[slot] = v.z;
-    }
-}
-
-__global__ void k_bucket_sort(uint64_t *keys, uint32_t *pids, const uint32_t *off, uint32_t nb,
-                              uint32_t *big) {
-    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b >= nb) return;
-    uint32_t lo = off[b], hi = off[b + 1];
-    if (hi - lo > BUCKET_MAX) { *big = 1; return; }
-    for (uint32_t i = lo + 1; i < hi; i++) {
-        uint64_t k = keys[i];
-        uint32_t p = pids[i];
-        uint32_t j = i;
-        while (j > lo && keys[j - 1] > k) { keys[j] = keys[j - 1]; pids[j] = pids[j - 1]; j--; }
-        keys[j] = k; pids[j] = p;
     }
 }
 
@@ -884,9 +880,7 @@ hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *r
                                            rocprim::plus<uint32_t>(), st);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k_bucket_scatter, dim3(grid), dim3(256), 0, st, recs, block_counts, region_cap,
-                       shift, off, keys_out, pids_out);
-    hipLaunchKernelGGL(k_bucket_sort, dim3((nb + 255) / 256), dim3(256), 0, st, keys_out, pids_out,
-                       off, nb, big);
+                       shift, off, keys_out, pids_out, big);
     return hipGetLastError();
 }
 
@@ -1005,6 +999,227 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_write_matches, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
                        pids, S, E, flags, idx, out, n);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K2b: tile kernels -- sort, resolve and write the bucketed occurrences
+// ---------------------------------------------------------------------------
+// After the bucket scatter the launch geometry of everything that follows depends only on
+// the number of buckets (known to the host), never on the number of occurrences (known only
+// to the device), so the whole post stage is queued behind the scan without a host round
+// trip.  A workgroup owns a tile of TILE_BUCKETS consecutive buckets (256 KiB of stream
+// position); its occurrences (at most TILE_MAX, else *big -> radix-sort fallback) are
+// staged in LDS so that the per-bucket serial work runs at LDS latency and every global
+// access is coalesced.
+//   k_tile_sort     per-bucket insertion sort; sync-point flag of every occurrence
+//   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point; tile totals
+//   k_tile_scan     exclusive scan of the tile totals (one workgroup)
+//   k_tile_write    compaction into the final (pattern, start, end) records
+constexpr uint32_t TILE_BUCKETS = 64;
+constexpr uint32_t TILE_MAX = 1024;
+constexpr uint32_t DST_NONE = 0xFFFFFFFFu;
+
+__device__ __forceinline__ void span_of(const DevAutomaton &A, int key_mode, uint64_t key, uint32_t pid,
+                                        uint64_t *s, uint64_t *e) {
+    const uint64_t x = key >> A.rank_bits, l = A.plen[pid];
+    if (key_mode == 0) { *e = x; *s = x - l; }
+    else { *s = x; *e = x + l; }
+}
+
+// Occurrence i is a "sync point" when every earlier occurrence (in sorted order) ends at or
+// before its start: whatever the greedy did before, i is reported.
+__global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode, int overlapping,
+                                                   const uint64_t *keys_in, const uint32_t *pids_in,
+                                                   const uint32_t *off, uint32_t nb, uint32_t shift,
+                                                   uint64_t *keys_out, uint32_t *pids_out,
+                                                   uint8_t *syncf, uint32_t *bcnt, uint32_t *big) {
+    __shared__ uint64_t k[TILE_MAX];
+    __shared__ uint32_t p[TILE_MAX];
+    __shared__ uint32_t bo[TILE_BUCKETS + 1];
+    __shared__ uint32_t stop;
+    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
+    if (t <= TILE_BUCKETS) bo[t] = off[min(B0 + t, nb)];
+    if (t < TILE_BUCKETS && B0 + t < nb) bcnt[B0 + t] = 0; // leave the emission counters clean
+    if (t == 0) stop = *big;
+    __syncthreads();
+    const uint32_t lo = bo[0], n = bo[TILE_BUCKETS] - lo;
+    if (stop) return; // *big doubles as the abort flag of the whole bucket path
+    if (n > TILE_MAX) { if (t == 0) *big = 1; return; }
+    for (uint32_t i = t; i < n; i += 256) { k[i] = keys_in[lo + i]; p[i] = pids_in[lo + i]; }
+    __syncthreads();
+    if (t < TILE_BUCKETS) {
+        const uint32_t a = bo[t] - lo, e = bo[t + 1] - lo;
+        if (e - a > BUCKET_MAX) *big = 1; // dense: the insertion sort would be quadratic
+        else for (uint32_t i = a + 1; i < e; i++) {
+            uint64_t kk = k[i];
+            uint32_t pp = p[i], j = i;
+            while (j > a && k[j - 1] > kk) { k[j] = k[j - 1]; p[j] = p[j - 1]; j--; }
+            k[j] = kk; p[j] = pp;
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 256) {
+        const uint64_t key = k[i];
+        const uint32_t pid = p[i];
+        keys_out[lo + i] = key;
+        pids_out[lo + i] = pid;
+        if (overlapping) continue;
+        uint64_t s, e, mx = 0; // mx: largest end among the occurrences before i
+        span_of(A, key_mode, key, pid, &s, &e);
+        if (key_mode == 0) { // sorted by end: the previous end is the maximum
+            if (i > 0) mx = k[i - 1] >> A.rank_bits;
+            else if (lo > 0) { // the last non-empty bucket before the tile (not sorted yet: scan it)
+                for (uint32_t j = off[(uint32_t)(keys_in[lo - 1] >> shift)]; j < lo; j++)
+                    mx = max(mx, keys_in[j] >> A.rank_bits);
+            }
+        } else { // sorted by start: only occurrences that start within max_len of s can end beyond it
+            bool open = true;
+            for (uint32_t j = i; j > 0;) {
+                j--;
+                const uint64_t sj = k[j] >> A.rank_bits;
+                if (sj + A.max_len <= s) { open = false; break; }
+                mx = max(mx, sj + A.plen[p[j]]);
+            }
+            const uint64_t p0 = s > A.max_len ? s - A.max_len : 0;
+            if (open && lo > 0 && (p0 >> 12) < B0)
+                for (uint32_t j = off[(uint32_t)(p0 >> 12)]; j < lo; j++)
+                    mx = max(mx, (keys_in[j] >> A.rank_bits) + A.plen[pids_in[j]]);
+        }
+        syncf[lo + i] = mx <= s ? 1 : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mode, int overlapping,
+                                                      const uint64_t *keys, const uint32_t *pids,
+                                                      const uint8_t *syncf, const uint32_t *off,
+                                                      uint32_t nb, uint8_t *accf, uint32_t *btot,
+                                                      const uint32_t *abort_flag) {
+    __shared__ uint32_t rel[TILE_MAX]; // key position relative to the tile's first byte
+    __shared__ uint32_t len[TILE_MAX];
+    __shared__ uint8_t sy[TILE_MAX], ac[TILE_MAX];
+    __shared__ uint32_t bo[TILE_BUCKETS + 1];
+    __shared__ uint32_t stop;
+    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
+    if (t <= TILE_BUCKETS) bo[t] = off[min(B0 + t, nb)];
+    if (t == 0) stop = *abort_flag;
+    __syncthreads();
+    if (stop) return;
+    const uint32_t lo = bo[0], n = bo[TILE_BUCKETS] - lo;
+    const uint64_t base = (uint64_t)B0 << 12;
+    uint32_t cnt = 0; // reported occurrences of bucket t (wave 0 only)
+    if (overlapping) {
+        if (t < TILE_BUCKETS) cnt = bo[t + 1] - bo[t];
+    } else {
+        for (uint32_t i = t; i < n; i += 256) {
+            const uint32_t pid = pids[lo + i];
+            rel[i] = (uint32_t)((keys[lo + i] >> A.rank_bits) - base);
+            len[i] = A.plen[pid];
+            sy[i] = syncf[lo + i];
+        }
+        __syncthreads();
+        const uint32_t a = t < TILE_BUCKETS ? bo[t] - lo : 0, e = t < TILE_BUCKETS ? bo[t + 1] - lo : 0;
+        if (e > a) {
+            // re-derive the greedy chain from the nearest sync point at or before a
+            uint32_t j = a;
+            while (j > 0 && !sy[j]) j--;
+            uint64_t pos = 0; // end of the last reported match
+            if (!sy[j]) { // the chain enters the tile from before it: follow it in HBM (rare)
+                uint64_t g = lo;
+                while (g > 0 && !syncf[--g]) {}
+                for (; g < lo; g++) {
+                    uint64_t s, en;
+                    span_of(A, key_mode, keys[g], pids[g], &s, &en);
+                    if (s >= pos) pos = en;
+                }
+            }
+            for (uint32_t q = j; q < e; q++) {
+                const uint64_t x = base + rel[q], l = len[q];
+                const uint64_t s = key_mode == 0 ? x - l : x, en = key_mode == 0 ? x : x + l;
+                const bool take = s >= pos;
+                if (take) pos = en;
+                if (q >= a) { ac[q] = take; cnt += take; }
+            }
+        }
+        __syncthreads();
+        for (uint32_t i = t; i < n; i += 256) accf[lo + i] = ac[i];
+    }
+    static_assert(TILE_BUCKETS == 64, "one wave owns the buckets of a tile");
+    if (t < 64) {
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (t == 0) btot[blockIdx.x] = cnt;
+    }
+}
+
+// bbase = exclusive scan of btot[0, tiles); *total = their sum.  One workgroup.
+__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *btot, uint32_t tiles, uint32_t *bbase,
+                                                    uint64_t *total, const uint32_t *abort_flag) {
+    using scan_t = rocprim::block_scan<uint32_t, 1024>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    if (*abort_flag) return;
+    const uint32_t t = threadIdx.x, per = (tiles + 1023) / 1024, g0 = t * per;
+    uint32_t mine = 0, excl = 0;
+    for (uint32_t g = g0; g < g0 + per && g < tiles; g++) mine += btot[g];
+    scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
+    for (uint32_t g = g0; g < g0 + per && g < tiles; g++) { bbase[g] = excl; excl += btot[g]; }
+    if (t == 1023) *total = excl;
+}
+
+__global__ __launch_bounds__(256) void k_tile_write(DevAutomaton A, int key_mode, int overlapping,
+                                                    const uint64_t *keys, const uint32_t *pids,
+                                                    const uint8_t *accf, const uint32_t *off, uint32_t nb,
+                                                    const uint32_t *bbase, acx_match_t *out,
+                                                    const uint32_t *abort_flag) {
+    __shared__ __attribute__((aligned(16))) uint8_t ac[TILE_MAX];
+    __shared__ uint32_t dst[TILE_MAX];
+    using scan_t = rocprim::block_scan<uint32_t, 256>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
+    if (*abort_flag) return; // stable by now: written by kernels that completed
+    const uint32_t lo = off[min(B0, nb)], n = off[min(B0 + TILE_BUCKETS, nb)] - lo;
+    const uint32_t base = bbase[blockIdx.x];
+    if (overlapping) {
+        for (uint32_t i = t; i < n; i += 256) dst[i] = base + i;
+    } else {
+        for (uint32_t i = t; i < TILE_MAX; i += 256) ac[i] = i < n ? accf[lo + i] : 0;
+        __syncthreads();
+        // thread t owns the 4 occurrences [4 t, 4 t + 4)
+        static_assert(TILE_MAX == 4 * 256, "4 occurrences per thread");
+        const uint32_t mine = __popc(*(const uint32_t *)&ac[t * 4]);
+        uint32_t excl = 0;
+        scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
+        uint32_t d = base + excl;
+        for (uint32_t q = t * 4; q < t * 4 + 4; q++) dst[q] = ac[q] ? d++ : DST_NONE;
+    }
+    __syncthreads();
+    for (uint32_t i = t; i < n; i += 256) {
+        const uint32_t d = dst[i];
+        if (d == DST_NONE) continue;
+        const uint32_t pid = pids[lo + i];
+        uint64_t s, e;
+        span_of(A, key_mode, keys[lo + i], pid, &s, &e);
+        out[d].pattern = pid; out[d].start = s; out[d].end = e;
+    }
+}
+
+// Sort (within buckets), resolve and compact the bucketed occurrences keys_in/pids_in
+// (bucket offsets off[nb + 1]) into out[]; *total receives the number of matches.
+// keys_tmp/pids_tmp: n entries; syncf/accf: n bytes each; btot/bbase: one u32 per tile.
+hipError_t bucket_resolve_write(const DevAutomaton &A, int key_mode, bool overlapping,
+                                const uint64_t *keys_in, const uint32_t *pids_in, uint64_t *keys_tmp,
+                                uint32_t *pids_tmp, const uint32_t *off, uint32_t nb, uint32_t shift,
+                                uint8_t *syncf, uint8_t *accf, uint32_t *bcnt, uint32_t *btot,
+                                uint32_t *bbase, acx_match_t *out, uint64_t *total,
+                                uint32_t *abort_flag, hipStream_t st) {
+    const uint32_t tiles = (nb + TILE_BUCKETS - 1) / TILE_BUCKETS;
+    const int ov = overlapping ? 1 : 0;
+    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_in, pids_in, off,
+                       nb, shift, keys_tmp, pids_tmp, syncf, bcnt, abort_flag);
+    hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_tmp, pids_tmp,
+                       syncf, off, nb, accf, btot, abort_flag);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, btot, tiles, bbase, total, abort_flag);
+    hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_tmp, pids_tmp, accf,
+                       off, nb, bbase, out, abort_flag);
     return hipGetLastError();
 }
 

@@ -24,7 +24,8 @@ hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const
                             hipStream_t st);
 // sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
-                        uint64_t *summary, uint64_t *offsets, hipStream_t st);
+                        const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
+                        uint64_t *summary, uint64_t *offsets, uint32_t *abort_flag, hipStream_t st);
 hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
                         uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st);
 // K1b emits prefix hits (position, depth-Q2 state); this kernel walks them into
@@ -43,16 +44,25 @@ size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                             uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
                             uint64_t n, int end_bit, hipStream_t st);
-// bucket sort (sparse occurrences), straight from the sink regions: bucket = key >> shift,
+// bucket grouping (sparse occurrences), straight from the sink regions: bucket = key >> shift,
 // nb buckets.  cnt[nb + 1] was filled by the scan kernels' emission (Sink::bucket_cnt) and
-// every record carries its arrival rank in its bucket; off[nb + 1] is scratch; *big
-// (zeroed by the caller) is set when a bucket is too dense, in which case the output is
-// unusable (compact + sort_occurrences instead)
+// every record carries its arrival rank in its bucket; off[nb + 1] receives the bucket
+// offsets.  *big is the abort flag of the whole bucket path (region overflow, dense output).
 size_t bucket_temp_bytes(uint64_t nb);
 hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *recs,
                                    const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                                    uint64_t *keys_out, uint32_t *pids_out, uint32_t shift, uint32_t nb,
                                    const uint32_t *cnt, uint32_t *off, uint32_t *big, hipStream_t st);
+// tile kernels: order within buckets, resolve the match kind, compact into out[]; the launch
+// geometry depends on nb only, so no host round trip is needed before them.  Zeroes bcnt.
+// keys_tmp/pids_tmp: n entries; syncf/accf: n bytes each; btot/bbase: one u32 per 64 buckets;
+// *total receives the number of matches.
+hipError_t bucket_resolve_write(const DevAutomaton &A, int key_mode, bool overlapping,
+                                const uint64_t *keys_in, const uint32_t *pids_in, uint64_t *keys_tmp,
+                                uint32_t *pids_tmp, const uint32_t *off, uint32_t nb, uint32_t shift,
+                                uint8_t *syncf, uint8_t *accf, uint32_t *bcnt, uint32_t *btot,
+                                uint32_t *bbase, acx_match_t *out, uint64_t *total,
+                                uint32_t *abort_flag, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,
