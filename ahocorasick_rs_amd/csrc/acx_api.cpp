@@ -90,7 +90,7 @@ struct BufCache {
 BufCache g_bufs;
 
 struct Workspace {
-    uint64_t cap = 0; // occurrence capacity
+    uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
     uint32_t *pids[2] = {nullptr, nullptr};
     uint64_t *S = nullptr, *E = nullptr, *M = nullptr;
@@ -98,20 +98,21 @@ struct Workspace {
     void *temp = nullptr;
     size_t temp_bytes = 0;
     uint4 *recs = nullptr;            // occurrence sink: cap records of 16 B in per-workgroup regions
-    uint4 *hrecs = nullptr;           // K1b prefix-hit sink: cap records of 32 B
+    uint4 *hrecs = nullptr;           // K1b prefix-hit sink: hit_total records of 32 B
+    uint64_t hit_total = 0;
     uint64_t *hit_counts = nullptr;   // device: one per K1b workgroup
-    uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region, [2..3] same for hits
+    uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region, [2..3] same for
+                                      // hits, [4] matches written, [5] abort flag of the sparse path
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
     uint64_t *h_pinned = nullptr;     // pinned host scratch (8 x u64)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
-    uint32_t *bcnt = nullptr, *boff = nullptr;  // bucket sort: nb + 1 each
-    uint32_t *bacc = nullptr, *bout = nullptr;  // bucket resolve: reported per bucket, its prefix
-    acx_match_t *final = nullptr;               // final matches of the bucket path (cap entries)
-    uint64_t bucket_cap = 0;
-    bool bcnt_clean = false;                    // bcnt is all zero (left so by the tile kernels)
-    uint32_t *big = nullptr;       // device flag: a bucket was too dense for the bucket sort
+    TileSpace T{};                    // sparse path (slot mode + tile kernels)
+    uint64_t tile_buckets = 0;        // buckets T is allocated for
+    bool sparse_dirty = true;         // T.bcnt / the abort flag are not known to be zero
+    acx_match_t *final = nullptr;     // sparse path: output buffer the next call writes into
+    uint64_t final_cap = 0;
     uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
     uint64_t hay_cap = 0;
     uint64_t *offsets = nullptr;
@@ -135,9 +136,16 @@ struct acx_automaton {
     std::mutex stage_mu; // guards the host staging buffers (taken before mu)
     Workspace ws;
     bool prof = false;
-    bool dense_output = false; // last call produced too many occurrences for the bucket sort
+    int dense_hold = 0; // > 0: the output was too dense for the sparse path; calls left in region mode
     acx_profile_t profile{};
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    // pipelined sparse path: the scan of chunk c + 1 (stream) overlaps the verification and
+    // tile kernels of chunk c (post_stream); chunk_ev[c] = scan of chunk c done
+    static constexpr int MAX_CHUNKS = 8;
+    hipStream_t post_stream = nullptr;
+    hipEvent_t chunk_ev[MAX_CHUNKS] = {};
+    hipEvent_t post_ev = nullptr; // the post stream caught up (start of a call)
+    int flag_idx = 0;             // which of the two abort flags the next sparse attempt uses
 };
 
 struct acx_host_automaton {
@@ -167,14 +175,22 @@ int upload(acx_automaton *a, const T *src, size_t count, const T **dst) {
     return ACX_OK;
 }
 
+void free_tiles(Workspace &w) {
+    TileSpace &T = w.T;
+    (void)hipFree(T.slots); (void)hipFree(T.bcnt); (void)hipFree(T.tkeys); (void)hipFree(T.tpids);
+    (void)hipFree(T.syncf); (void)hipFree(T.accf); (void)hipFree(T.tile_n); (void)hipFree(T.btot);
+    (void)hipFree(T.bbase);
+    T = TileSpace{};
+    w.tile_buckets = 0;
+}
+
 void free_ws(Workspace &w, int device) {
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
     (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
-    (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.big);
-    (void)hipFree(w.bacc); (void)hipFree(w.bout);
+    free_tiles(w);
     g_bufs.put(w.final, device);
 
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
@@ -183,16 +199,32 @@ void free_ws(Workspace &w, int device) {
     w = Workspace();
 }
 
-int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
+int ensure_common(acx_automaton *a) {
     Workspace &w = a->ws;
     if (!w.summary) {
         HIPCHK(hipMalloc((void **)&w.summary, 64));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
-        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 2048));
-        HIPCHK(hipMalloc((void **)&w.big, 64));
+        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 1024 * acx_automaton::MAX_CHUNKS));
         HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
+        w.sparse_dirty = true;
     }
+    return ACX_OK;
+}
+
+// prefix-hit sink of K1b
+int ensure_hits(acx_automaton *a, uint64_t want) {
+    Workspace &w = a->ws;
+    if (want <= w.hit_total) return ACX_OK;
+    (void)hipFree(w.hrecs); w.hrecs = nullptr; w.hit_total = 0;
+    HIPCHK(hipMalloc((void **)&w.hrecs, want * 32));
+    w.hit_total = want;
+    return ACX_OK;
+}
+
+// dense path: occurrence regions + everything the radix sort / resolve pipeline needs
+int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
+    Workspace &w = a->ws;
     if (want <= w.cap) return ACX_OK;
     uint64_t cap = std::max<uint64_t>(want, 1u << 16);
     for (int i = 0; i < 2; i++) {
@@ -201,16 +233,15 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
-    (void)hipFree(w.recs); (void)hipFree(w.hrecs);
-    if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+    (void)hipFree(w.recs);
     w.S = w.E = w.M = nullptr; w.flags = w.idx = nullptr; w.temp = nullptr; w.cap = 0;
-    w.recs = nullptr; w.hrecs = nullptr;
+    w.temp_bytes = 0;
+    w.recs = nullptr;
     for (int i = 0; i < 2; i++) {
         HIPCHK(hipMalloc((void **)&w.keys[i], cap * 8));
         HIPCHK(hipMalloc((void **)&w.pids[i], cap * 4));
     }
     HIPCHK(hipMalloc((void **)&w.recs, cap * 16));
-    HIPCHK(hipMalloc((void **)&w.hrecs, cap * 32));
     HIPCHK(hipMalloc((void **)&w.S, cap * 8));
     HIPCHK(hipMalloc((void **)&w.E, cap * 8));
     HIPCHK(hipMalloc((void **)&w.M, cap * 8));
@@ -219,6 +250,32 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     w.temp_bytes = std::max(sort_temp_bytes(cap), scan_temp_bytes(cap)) + 256;
     HIPCHK(hipMalloc(&w.temp, w.temp_bytes));
     w.cap = cap;
+    return ACX_OK;
+}
+
+// sparse path: slots and tile arrays for nb buckets
+int ensure_tiles(acx_automaton *a, uint64_t nb) {
+    Workspace &w = a->ws;
+    TileSpace &T = w.T;
+    const uint64_t tiles = (nb + TILE_BUCKETS - 1) / TILE_BUCKETS;
+    if (nb > w.tile_buckets) {
+        free_tiles(w);
+        if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+        const uint64_t ents = tiles * TILE_MAX;
+        HIPCHK(hipMalloc((void **)&T.slots, nb * BUCKET_SLOTS * 16));
+        HIPCHK(hipMalloc((void **)&T.bcnt, (nb + 1) * 4));
+        HIPCHK(hipMalloc((void **)&T.tkeys, ents * 8));
+        HIPCHK(hipMalloc((void **)&T.tpids, ents * 4));
+        HIPCHK(hipMalloc((void **)&T.syncf, ents));
+        HIPCHK(hipMalloc((void **)&T.accf, ents));
+        HIPCHK(hipMalloc((void **)&T.tile_n, tiles * 4));
+        HIPCHK(hipMalloc((void **)&T.btot, tiles * 4));
+        HIPCHK(hipMalloc((void **)&T.bbase, tiles * 4));
+        w.tile_buckets = nb;
+        w.sparse_dirty = true;
+    }
+    T.n_buckets = (uint32_t)nb;
+    T.n_tiles = (uint32_t)tiles;
     return ACX_OK;
 }
 
@@ -242,38 +299,27 @@ int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
     return ACX_OK;
 }
 
-int ensure_buckets(acx_automaton *a, uint64_t nb1) {
-    Workspace &w = a->ws;
-    if (nb1 > w.bucket_cap) {
-        (void)hipFree(w.bcnt); (void)hipFree(w.boff); (void)hipFree(w.bacc); (void)hipFree(w.bout);
-        w.bcnt = w.boff = w.bacc = w.bout = nullptr; w.bucket_cap = 0;
-        HIPCHK(hipMalloc((void **)&w.bcnt, nb1 * 4));
-        HIPCHK(hipMalloc((void **)&w.boff, nb1 * 4));
-        HIPCHK(hipMalloc((void **)&w.bacc, nb1 * 4));
-        HIPCHK(hipMalloc((void **)&w.bout, nb1 * 4));
-        w.bcnt_clean = false;
-        w.bucket_cap = nb1;
-    }
-    size_t need = bucket_temp_bytes(nb1) + 256;
-    if (need > w.temp_bytes) {
-        (void)hipFree(w.temp); w.temp = nullptr;
-        HIPCHK(hipMalloc(&w.temp, need));
-        w.temp_bytes = need;
-    }
-    return ACX_OK;
-}
-
 int bits_for(uint64_t x) { // number of bits needed to represent x
     int b = 0;
     while (x) { b++; x >>= 1; }
     return b;
 }
 
+void add_scan_profile(acx_automaton *a, uint64_t len) {
+    if (!a->prof) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, a->ev[0], a->ev[1]) != hipSuccess) return;
+    a->profile.scan_ms += ms;
+    a->profile.scan_launches++;
+    a->profile.scan_bytes += len;
+}
+
 // The whole device pipeline.  d_hay: device pointer, len bytes.
 //
-//   scan (K1a, or K1b + walk)  ->  occurrence sink (regions)        [+ bucket counters]
-//   sparse output:  bucket sort -> bucket resolve -> final matches    ONE host round trip
-//   dense output:   compact -> radix sort -> spans -> resolve -> ...  (two round trips)
+//   sparse output (default): scan (K1a, or K1b + walk) emits into bucket slots -> tile kernels
+//                            (sort, resolve, scan, write) -> final matches   ONE host round trip
+//   dense output:            scan emits into regions -> compact -> radix sort -> spans ->
+//                            resolve -> offsets -> write                      (two round trips)
 int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
              int overlapping, int codepoints, acx_result **out) {
     *out = nullptr;
@@ -303,83 +349,159 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     }
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     uint64_t n_final = 0;
+    bool pending = segmented; // work queued on the stream that nobody waited for yet
     if (len > 0 && a->host.n_patterns > 0) {
-        int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64));
+        int rc = ensure_common(a);
         if (rc) return bail(rc);
         Workspace &w = a->ws;
         const bool pre = a->kernel == ACX_KERNEL_PREFILTER;
         // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
         const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
                                        : dfa_walk_grid(a->dev, len, a->n_cus);
-        const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // occurrence regions
+        const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // emitting workgroups
         const int rank_bits = (int)a->dev.rank_bits;
-        const uint32_t bshift = (uint32_t)rank_bits + 12; // buckets of 4 KiB of stream position
-        const uint64_t nb = (len >> 12) + 2;
+        const uint32_t bshift = (uint32_t)rank_bits + BUCKET_BITS;
+        const uint64_t nb = (len >> BUCKET_BITS) + 2; // buckets of 4 KiB of stream position
         static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
-        bool use_bucket = !a->dense_output && !no_bucket_env && nb < (1ull << 31);
-        if (use_bucket && (rc = ensure_buckets(a, nb + 1)) != ACX_OK) return bail(rc);
+        bool sparse = a->dense_hold == 0 && !no_bucket_env && nb < (1ull << 31);
+        if (pre && (rc = ensure_hits(a, std::max<uint64_t>(1u << 16, len / 64))) != ACX_OK) return bail(rc);
         uint64_t n_raw = 0;
         for (int attempt = 0;; attempt++) {
-            if (attempt == 4) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
-            const uint64_t region_cap = w.cap / grid, hit_cap = w.cap / scan_grid;
-            if (use_bucket && !w.bcnt_clean) HIPCHK_R(hipMemsetAsync(w.bcnt, 0, (nb + 1) * 4, st));
-            if (use_bucket) w.bcnt_clean = false;
-            Sink K{w.recs, use_bucket ? w.bcnt : nullptr, w.block_counts, region_cap, bshift, key_mode};
-            Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode};
+            if (attempt == 5) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
+            // Chunked sparse path (ACX_CHUNKS=n, experiments only): K1b in n launches, each chunk's
+            // walk + tile kernels on the post stream underneath the next chunk's scan.  Measured
+            // on MI355X: no gain -- K1b's 16 waves x 128 VGPRs per CU fill the register file, so
+            // the other kernels only get on the CUs when a K1b workgroup retires.
+            static const int chunk_env = std::getenv("ACX_CHUNKS") ? std::atoi(std::getenv("ACX_CHUNKS")) : 1;
+            const int chunks = sparse && pre ? std::max(1, std::min(chunk_env, (int)acx_automaton::MAX_CHUNKS)) : 1;
+            const uint64_t hit_regions = (uint64_t)scan_grid * chunks; // every chunk has its own hit regions
+            const uint64_t hit_cap = pre ? w.hit_total / hit_regions : 0;
+            Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode, nullptr, nullptr};
+            if (sparse) {
+                // ---- sparse output: slot mode + tile kernels, ONE host round trip
+                if ((rc = ensure_tiles(a, nb)) != ACX_OK) return bail(rc);
+                const TileSpace &T = w.T;
+                const uint64_t out_cap = (uint64_t)T.n_tiles * TILE_MAX;
+                if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+                if (!w.final) {
+                    HIPCHK_R(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
+                    w.final_cap = out_cap;
+                }
+                if (w.sparse_dirty) {
+                    HIPCHK_R(hipMemsetAsync(T.bcnt, 0, (nb + 1) * 4, st));
+                    HIPCHK_R(hipMemsetAsync(w.summary + 5, 0, 16, st));
+                }
+                w.sparse_dirty = true;
+                // two abort flags used in turn: this attempt's tile kernels clear the other one
+                uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + a->flag_idx);
+                uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (a->flag_idx ^ 1));
+                a->flag_idx ^= 1;
+                Sink K{nullptr, T.bcnt, w.block_counts, 0, bshift, key_mode, T.slots, abort_flag};
+                if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
+                if (!pre) {
+                    hipError_t e = launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid, a->max_lds, st);
+                    if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
+                    if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+                    HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, 0, T.n_tiles, true, true, nullptr,
+                                       0, 0, w.final, w.summary, abort_flag, next_flag, st));
+                    HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 56, hipMemcpyDeviceToHost, st));
+                    HIPCHK_R(hipStreamSynchronize(st));
+                } else {
+                    // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon
+                    // as its scan is done, i.e. underneath the scan of the next chunk.  After the
+                    // scan of K1b tiles [0, t1) every bucket below t1 - 1 is final (a key position
+                    // never precedes the start of its occurrence), so the post stage trails by a tile.
+                    const uint64_t k_tiles = prefilter_tiles(d_hay, len);
+                    const uint64_t per = ((k_tiles + chunks - 1) / chunks + TILE_BUCKETS - 1) / TILE_BUCKETS * TILE_BUCKETS;
+                    hipStream_t ps = chunks > 1 ? a->post_stream : st;
+                    if (ps != st) {
+                        HIPCHK_R(hipEventRecord(a->post_ev, st)); // memsets above / earlier work on st
+                        HIPCHK_R(hipStreamWaitEvent(ps, a->post_ev, 0));
+                    }
+                    uint32_t tile0 = 0;
+                    bool first = true;
+                    for (int c = 0; c < chunks; c++) {
+                        const uint64_t t0 = std::min<uint64_t>((uint64_t)c * per, k_tiles);
+                        const uint64_t t1 = c == chunks - 1 ? k_tiles : std::min<uint64_t>(t0 + per, k_tiles);
+                        const bool last = c == chunks - 1;
+                        if (t1 == t0 && !last) continue;
+                        Sink Hc = H;
+                        Hc.recs = w.hrecs + (uint64_t)c * scan_grid * hit_cap * 2;
+                        Hc.block_counts = w.hit_counts + (uint64_t)c * scan_grid;
+                        hipError_t e = launch_prefilter(a->dev, a->d_dev, G, Hc, d_hay, len, scan_grid, t0, t1, st);
+                        if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
+                        if (last && a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
+                        if (ps != st) {
+                            HIPCHK_R(hipEventRecord(a->chunk_ev[c], st));
+                            HIPCHK_R(hipStreamWaitEvent(ps, a->chunk_ev[c], 0));
+                        }
+                        HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, Hc, scan_grid, std::max(1u, walk_hits_grid(1) / (uint32_t)chunks), K,
+                                                  d_hay, len, ps));
+                        const uint32_t tile1 = last ? T.n_tiles
+                                                    : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
+                        HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, tile0, std::max(tile0, tile1), first,
+                                           last, Hc.block_counts, scan_grid, hit_cap, w.final, w.summary, abort_flag,
+                                           next_flag, ps));
+                        tile0 = std::max(tile0, tile1);
+                        first = false;
+                    }
+                    HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 56, hipMemcpyDeviceToHost, ps));
+                    HIPCHK_R(hipStreamSynchronize(ps));
+                    if (ps != st) HIPCHK_R(hipStreamSynchronize(st));
+                }
+                w.sparse_dirty = false; // the tile kernels left the counters and the next flag clean
+                add_scan_profile(a, len);
+                const bool aborted = *(uint32_t *)(w.h_pinned + 5 + (a->flag_idx ^ 1)) != 0;
+                const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
+                if (aborted) { // the sparse path gave up
+                    if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo
+                        rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64));
+                        if (rc) return bail(rc);
+                    } else { // a bucket or a tile overflowed: dense output, use the region mode
+                        sparse = false;
+                        a->dense_hold = 8;
+                    }
+                    continue;
+                }
+                n_raw = w.h_pinned[0];
+                n_final = w.h_pinned[4];
+                r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
+                w.final = nullptr;
+                break;
+            }
+            // ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
+            if ((rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64))) != ACX_OK) return bail(rc);
+            const uint64_t region_cap = w.cap / grid;
+            Sink K{w.recs, nullptr, w.block_counts, region_cap, bshift, key_mode, nullptr, nullptr};
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
-            hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, st)
+            hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, 0, ~0ull, st)
                                : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid,
                                                  a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, K, d_hay, len, st));
+            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, 0, K, d_hay, len, st));
             HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, pre ? w.hit_counts : nullptr, scan_grid,
-                                  hit_cap, w.summary, w.region_off, (uint32_t *)(w.summary + 5), st));
-            if (use_bucket) {
-                // sort, resolve and write without knowing the occurrence count on the host
-                if (!w.final) HIPCHK_R(g_bufs.get((void **)&w.final, w.cap * sizeof(acx_match_t), a->device));
-                HIPCHK_R(bucket_sort_occurrences(w.temp, w.temp_bytes, w.recs, w.block_counts, grid,
-                                                 region_cap, w.keys[0], w.pids[0], bshift, (uint32_t)nb,
-                                                 w.bcnt, w.boff, (uint32_t *)(w.summary + 5), st));
-                HIPCHK_R(bucket_resolve_write(a->dev, key_mode, overlapping != 0, w.keys[0], w.pids[0],
-                                              w.keys[1], w.pids[1], w.boff, (uint32_t)nb, bshift,
-                                              (uint8_t *)w.flags, (uint8_t *)w.flags + w.cap, w.bcnt,
-                                              w.bacc, w.bout, w.final,
-                                              w.summary + 4, (uint32_t *)(w.summary + 5), st));
-            }
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 48, hipMemcpyDeviceToHost, st));
+                                  hit_cap, w.summary, w.region_off, st));
+            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
             HIPCHK_R(hipStreamSynchronize(st));
-            if (use_bucket) w.bcnt_clean = true; // the tile kernels zeroed the emission counters
-            if (a->prof) {
-                float ms = 0;
-                HIPCHK_R(hipEventElapsedTime(&ms, a->ev[0], a->ev[1]));
-                a->profile.scan_ms += ms;
-                a->profile.scan_launches++;
-                a->profile.scan_bytes += len;
-            }
+            add_scan_profile(a, len);
             n_raw = w.h_pinned[0];
             const uint64_t region_max = w.h_pinned[1], hit_max = pre ? w.h_pinned[3] : 0;
             if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
-                uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64),
-                                         (uint64_t)scan_grid * (hit_max + hit_max / 8 + 64));
+                if (hit_max > hit_cap) {
+                    rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64));
+                    if (rc) return bail(rc);
+                }
                 // hits that overflowed were dropped, so the occurrence count is a lower bound
+                uint64_t want = (uint64_t)grid * (region_max + region_max / 8 + 64);
                 if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
                 if ((rc = ensure_occ_capacity(a, want)) != ACX_OK) return bail(rc);
                 continue;
             }
-            if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += w.h_pinned[2]; }
             if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
-            a->dense_output = n_raw > 8 * nb;
-            if (use_bucket && (uint32_t)w.h_pinned[5]) { // a bucket was too dense for the bucket sort
-                use_bucket = false;
-                a->dense_output = true;
-            }
-            if (use_bucket) {
-                n_final = w.h_pinned[4];
-                r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
-                w.final = nullptr;
-            } else if (n_raw > 0) {
-                // ---- dense path: compact -> radix sort on the used key bits -> resolve
+            if (n_raw > 8 * nb) a->dense_hold = 8;
+            else if (a->dense_hold > 0) a->dense_hold--;
+            if (n_raw > 0) {
                 if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
                 HIPCHK_R(sink_compact(w.recs, w.region_off, grid, region_cap, w.keys[1], w.pids[1], st));
                 int end_bit = std::min(64, rank_bits + bits_for(len));
@@ -406,9 +528,11 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                     std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t), a->device));
                 HIPCHK_R(write_matches(w.pids[0], w.S, w.E, overlapping ? nullptr : w.flags,
                                        overlapping ? nullptr : w.idx, r->d_matches, n_raw, st));
+                pending = true;
             }
             break;
         }
+        if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += pre ? w.h_pinned[2] : 0; }
         r->n = n_final;
         if (n_final && (codepoints || segmented)) {
             if (codepoints) {
@@ -422,16 +546,18 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                   r->d_counts, st));
             else
                 HIPCHK_R(to_code_points(d_hay, len, w.blockpre, r->d_matches, n_final, st));
+            pending = true;
         }
         if (a->prof) {
             HIPCHK_R(hipEventRecord(a->ev[2], st));
             HIPCHK_R(hipStreamSynchronize(st));
+            pending = false;
             float ms = 0;
             HIPCHK_R(hipEventElapsedTime(&ms, a->ev[1], a->ev[2]));
             a->profile.post_ms += ms;
         }
     }
-    HIPCHK_R(hipStreamSynchronize(st));
+    if (pending) HIPCHK_R(hipStreamSynchronize(st));
 #undef HIPCHK_R
     *out = r;
     return ACX_OK;
@@ -536,6 +662,9 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     }
     HIPCHK_A(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
     for (auto &ev : a->ev) HIPCHK_A(hipEventCreate(&ev));
+    HIPCHK_A(hipStreamCreateWithFlags(&a->post_stream, hipStreamNonBlocking));
+    for (auto &ev : a->chunk_ev) HIPCHK_A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIPCHK_A(hipEventCreateWithFlags(&a->post_ev, hipEventDisableTiming));
 
     Automaton &H = a->host;
     DevAutomaton &D = a->dev;
@@ -650,6 +779,9 @@ void acx_free_automaton(acx_automaton_t *a) {
     for (void *p : a->allocs) (void)hipFree(p);
     free_ws(a->ws, a->device);
     for (auto &ev : a->ev) if (ev) (void)hipEventDestroy(ev);
+    for (auto &ev : a->chunk_ev) if (ev) (void)hipEventDestroy(ev);
+    if (a->post_ev) (void)hipEventDestroy(a->post_ev);
+    if (a->post_stream) { (void)hipStreamSynchronize(a->post_stream); (void)hipStreamDestroy(a->post_stream); }
     if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }

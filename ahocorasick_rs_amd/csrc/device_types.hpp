@@ -51,18 +51,42 @@ struct Segments {
 //   key_mode 2 (LeftmostLongest):        key = start << rank_bits | rank(pid)
 // (rank_bits = bits needed for n_patterns - 1.)  Sorting by key ascending yields
 // exactly the order each match kind consumes.
-// Slot allocation uses NO contended global atomic (one HBM word saturates at
-// ~88 atomics/us on MI355X): every workgroup owns the region
-// [blockIdx * region_cap, (blockIdx + 1) * region_cap) and hands out slots from
+// Region mode (dense output, prefix hits): slot allocation uses NO contended global
+// atomic (one HBM word saturates at ~88 atomics/us on MI355X): every workgroup owns the
+// region [blockIdx * region_cap, (blockIdx + 1) * region_cap) and hands out slots from
 // a counter in LDS; its final count goes to block_counts[blockIdx] (it keeps
 // counting past region_cap so that the host can size a retry exactly).
+// Slot mode (sparse output, slots != null): an occurrence goes straight to slot
+// `arrival rank` of its 4 KiB-of-position bucket (bucket_cnt is the rank counter: an
+// address is shared by the few occurrences of one bucket only); a full bucket sets
+// *abort_flag and the host redoes the call in region mode.
+constexpr uint32_t BUCKET_SLOTS = 32;  // occurrence slots per bucket
+constexpr uint32_t BUCKET_BITS = 12;   // bucket = 4 KiB of stream position
+constexpr uint32_t TILE_BUCKETS = 64;  // buckets per workgroup of the tile kernels (K2b)
+constexpr uint32_t TILE_MAX = 1024;    // occurrences per tile (held in LDS)
 struct Sink {
     uint4 *recs;            // region_cap * quads uint4 per region
-    uint32_t *bucket_cnt;   // per 4 KiB-of-position bucket counters (or null: no bucket sort)
+    uint32_t *bucket_cnt;   // slot mode: per-bucket arrival counters
     uint64_t *block_counts; // gridDim.x entries
     uint64_t region_cap;    // records per region
     uint32_t bucket_shift;  // bucket = key >> bucket_shift
     int key_mode;
+    uint4 *slots;           // slot mode: n_buckets * BUCKET_SLOTS records {key lo, key hi, pid, 0}
+    uint32_t *abort_flag;   // slot mode: set when the sparse path cannot hold the output
+};
+
+// Storage of the sparse path, sized by the number of buckets / tiles of the stream.
+struct TileSpace {
+    uint4 *slots;       // n_buckets * BUCKET_SLOTS (filled by the scan's emission)
+    uint32_t *bcnt;     // n_buckets + 1 arrival counters
+    uint64_t *tkeys;    // tiles * TILE_MAX: keys of a tile, sorted
+    uint32_t *tpids;    // tiles * TILE_MAX
+    uint8_t *syncf;     // tiles * TILE_MAX: occurrence is a sync point of the greedy
+    uint8_t *accf;      // tiles * TILE_MAX: occurrence is reported
+    uint32_t *tile_n;   // occurrences of each tile
+    uint32_t *btot;     // reported occurrences of each tile
+    uint32_t *bbase;    // exclusive prefix of btot
+    uint32_t n_buckets, n_tiles;
 };
 
 } // namespace acx

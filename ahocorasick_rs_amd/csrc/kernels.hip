@@ -51,36 +51,48 @@ struct BlockSink {
     uint64_t region_cap;
     uint32_t bucket_shift;
     int key_mode;
+    uint4 *slots;
+    uint32_t *abort_flag;
 };
 
 __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount, uint32_t quads = 1) {
     return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, K.bucket_cnt, lcount,
-                     K.region_cap, K.bucket_shift, K.key_mode};
+                     K.region_cap, K.bucket_shift, K.key_mode, K.slots, K.abort_flag};
 }
 
-// store one occurrence (ONE 16-byte store); with a bucket counter attached,
-// also take the occurrence's arrival rank inside its bucket (one global atomic,
-// the address is shared by the ~4 occurrences of a 4 KiB stretch only), which
-// later turns the bucket sort's scatter into plain stores
+// slot mode: the occurrence with arrival rank r of its bucket
+__device__ __forceinline__ void store_slot(const BlockSink &K, uint32_t bucket, uint32_t r, uint64_t key,
+                                           uint32_t pid) {
+    if (r < BUCKET_SLOTS)
+        K.slots[(uint64_t)bucket * BUCKET_SLOTS + r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
+    else
+        *K.abort_flag = 1;
+}
+
+// store one occurrence (ONE 16-byte store).  Slot mode: take the occurrence's arrival
+// rank inside its bucket (one global atomic, the address is shared by the ~4 occurrences
+// of a 4 KiB stretch only) and store into that slot.  Region mode: next slot of the region.
 __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid) {
-    uint32_t r = 0;
-    if (K.bucket_cnt) r = atomicAdd(&K.bucket_cnt[key >> K.bucket_shift], 1u);
+    if (K.slots) {
+        const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
+        store_slot(K, bucket, atomicAdd(&K.bucket_cnt[bucket], 1u), key, pid);
+        return;
+    }
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
-    if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
+    if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
 }
 
-// Wave-aggregated variant for code where many lanes emit together (walk kernel):
-// one LDS atomic per wave reserves the slots, and ONE global atomic per run of
-// adjacent emitting lanes that fall into the same bucket takes the bucket ranks
-// (hits arrive grouped by 4 KiB tile, so a run is typically a whole tile: device-
-// scope atomics with return are the expensive part of emission).
+// Wave-aggregated variant for code where many lanes emit together (walk kernel).
+// Slot mode: ONE global atomic per run of adjacent emitting lanes that fall into the
+// same bucket takes the bucket ranks (hits arrive grouped by 4 KiB tile, so a run is
+// typically a whole tile: device-scope atomics with return are the expensive part of
+// emission).  Region mode: one LDS atomic per wave reserves the slots.
 __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid) {
     const unsigned long long fm = __ballot(ok);
     if (!fm) return;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below_me = (1ull << lane) - 1;
-    uint32_t r = 0;
-    if (K.bucket_cnt) {
+    if (K.slots) {
         const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
         // previous emitting lane and its bucket
         const unsigned long long below = fm & below_me;
@@ -97,7 +109,8 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
         uint32_t base = 0;
         if (head) base = atomicAdd(&K.bucket_cnt[bucket], (uint32_t)__popcll(run));
         base = __shfl(base, hl);
-        r = base + (uint32_t)__popcll(run & below_me);
+        if (ok) store_slot(K, bucket, base + (uint32_t)__popcll(run & below_me), key, pid);
+        return;
     }
     const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
     uint32_t sbase = 0;
@@ -105,7 +118,7 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
     sbase = __shfl(sbase, leader);
     if (ok) {
         uint32_t slot = sbase + (uint32_t)__popcll(fm & below_me);
-        if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, r);
+        if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
     }
 }
 
@@ -456,25 +469,28 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
     }
 }
 
-constexpr uint32_t K_WALK_SPLIT = 16;
+constexpr uint32_t K_WALK_SPLIT = 16; // workgroups per hit region of an unchunked call
 
 // One thread per prefix hit of K1b.  Hits live in the per-workgroup regions of
 // the scan's sink (H); occurrences go to the occurrence sink (GK).
 __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAutomaton *Ad,
-                                                   Segments G, Sink H, uint32_t h_grid, Sink GK,
-                                                   const uint8_t *__restrict__ stream,
+                                                   Segments G, Sink H, uint32_t h_grid, uint32_t split,
+                                                   Sink GK, const uint8_t *__restrict__ stream,
                                                    uint64_t len, uint32_t ablate) {
     __shared__ uint32_t lcount;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
     (void)Ad;
     const BlockSink K = block_sink(GK, &lcount);
-    // K_WALK_SPLIT workgroups share one hit region
-    for (uint32_t b = blockIdx.x / K_WALK_SPLIT; b < h_grid; b += gridDim.x / K_WALK_SPLIT) {
+    // `split` workgroups share one hit region
+    for (uint32_t b = blockIdx.x / split; b < h_grid; b += gridDim.x / split) {
         uint64_t n = H.block_counts[b];
-        if (n > H.region_cap) n = H.region_cap;
+        if (n > H.region_cap) { // hits were dropped: the host grows the hit sink and redoes the call
+            n = H.region_cap;
+            if (GK.abort_flag && threadIdx.x == 0) *GK.abort_flag = 1;
+        }
         const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
-        for (uint64_t i = (blockIdx.x % K_WALK_SPLIT) * 256 + threadIdx.x; i < n; i += K_WALK_SPLIT * 256) {
+        for (uint64_t i = (blockIdx.x % split) * 256 + threadIdx.x; i < n; i += split * 256) {
             const uint4 h = rec[2 * i], w = rec[2 * i + 1];
             if (ablate & 64) { if (h.x == 0x12345678u && w.y == 77) emit_key(K, 1, 1); continue; }
             verify_hit(A, G, K, stream, len, ((uint64_t)h.y << 32) | h.x, h.z,
@@ -490,8 +506,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
                                                       Segments G, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead,
+                                                      uint64_t tile_begin, uint64_t tile_end,
                                                       uint32_t ablate) {
-    // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
+    // Scans the 4 KiB tiles [tile_begin, tile_end) of the stream (a chunk of a pipelined
+    // call, or everything).  `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
     // stream and are never candidates.  Stream position = index - lead.
     __shared__ __attribute__((aligned(16))) K1bLds L;
     const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -513,8 +531,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint64_t last_start = total >= A.min_len ? total - A.min_len : 0; // last index a pattern can start at
     const bool any_start = total >= lead + A.min_len;
     const uint64_t tile_bytes = (uint64_t)K1B_ROWS * 1024;
-    const uint64_t ntiles = any_start ? (total + tile_bytes - 1) / tile_bytes : 0;
-    const uint64_t gw = (uint64_t)blockIdx.x * 16 + wave;
+    const uint64_t all_tiles = any_start ? (total + tile_bytes - 1) / tile_bytes : 0;
+    const uint64_t ntiles = all_tiles < tile_end ? all_tiles : tile_end;
+    const uint64_t gw = tile_begin + (uint64_t)blockIdx.x * 16 + wave;
     const uint64_t nw = (uint64_t)gridDim.x * 16;
     const uint32_t q2len = A.filter_q2;
     const uint64_t q2mask = q2len >= 8 ? ~0ull : ((1ull << (8 * q2len)) - 1);
@@ -729,28 +748,37 @@ static uint32_t ablation_flags() {
 uint32_t walk_hits_grid(uint32_t hit_grid) { return hit_grid * K_WALK_SPLIT; }
 
 hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &hits, uint32_t hit_grid, const Sink &occ,
+                            const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
                             const uint8_t *d_hay, uint64_t len, hipStream_t st) {
-    hipLaunchKernelGGL(k_walk_hits, dim3(walk_hits_grid(hit_grid)), dim3(256), 0, st, A, Ad, G, hits,
-                       hit_grid, occ, d_hay, len, ablation_flags());
+    if (split == 0 || split > K_WALK_SPLIT) split = K_WALK_SPLIT;
+    hipLaunchKernelGGL(k_walk_hits, dim3(hit_grid * split), dim3(256), 0, st, A, Ad, G, hits, hit_grid,
+                       split, occ, d_hay, len, ablation_flags());
     return hipGetLastError();
+}
+
+uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
+    const uint64_t total = ((uintptr_t)d_hay & 15) + len;
+    return (total + (uint64_t)K1B_ROWS * 1024 - 1) / ((uint64_t)K1B_ROWS * 1024);
 }
 
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            hipStream_t st) {
+                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
     uint32_t ab = ablation_flags();
+#define ACX_K1B(Q)                                                                                    \
+    hipLaunchKernelGGL(k1b_prefilter<Q>, g, b, 0, st, A, Ad, G, K, base, len, lead, tile_begin, tile_end, ab)
     switch (A.filter_q) {
-    case 1: hipLaunchKernelGGL(k1b_prefilter<1>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
-    case 2: hipLaunchKernelGGL(k1b_prefilter<2>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
-    case 3: hipLaunchKernelGGL(k1b_prefilter<3>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
-    case 4: hipLaunchKernelGGL(k1b_prefilter<4>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
-    default: hipLaunchKernelGGL(k1b_prefilter<5>, g, b, 0, st, A, Ad, G, K, base, len, lead, ab); break;
+    case 1: ACX_K1B(1); break;
+    case 2: ACX_K1B(2); break;
+    case 3: ACX_K1B(3); break;
+    case 4: ACX_K1B(4); break;
+    default: ACX_K1B(5); break;
     }
+#undef ACX_K1B
     return hipGetLastError();
 }
 
@@ -760,10 +788,9 @@ hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const
 // One workgroup per sink (blockIdx 0: occurrences, 1: prefix hits):
 // summary[2 b] = total records kept, summary[2 b + 1] = max count of a region,
 // offsets[r] = exclusive prefix of min(count, region_cap), offsets[grid] = total (sink 0 only).
-// *abort_flag (the abort flag of the bucket path) = an occurrence region overflowed.
 struct SinkView { const uint64_t *block_counts; uint32_t grid; uint64_t region_cap; };
 __global__ __launch_bounds__(1024) void k_sink_summary(SinkView occ, SinkView hit, uint64_t *summary,
-                                                       uint64_t *offsets, uint32_t *abort_flag) {
+                                                       uint64_t *offsets) {
     // thread t owns the regions [t * per, (t + 1) * per)
     using scan_t = rocprim::block_scan<uint64_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
@@ -798,8 +825,6 @@ __global__ __launch_bounds__(1024) void k_sink_summary(SinkView occ, SinkView hi
         uint64_t m = 0;
         for (int i = 0; i < 16; i++) m = red[i] > m ? red[i] : m;
         summary[1] = m;
-        // a region overflowed: the kernels queued behind this one must not trust the counters
-        if (blockIdx.x == 0) *abort_flag = m > V.region_cap ? 1u : 0u;
     }
 }
 
@@ -819,10 +844,10 @@ __global__ __launch_bounds__(256) void k_sink_compact(const uint4 *recs, const u
 // hit_counts may be null (K1a: no prefix-hit sink): summary[2..3] are then left alone
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
-                        uint64_t *summary, uint64_t *offsets, uint32_t *abort_flag, hipStream_t st) {
+                        uint64_t *summary, uint64_t *offsets, hipStream_t st) {
     hipLaunchKernelGGL(k_sink_summary, dim3(hit_counts ? 2 : 1), dim3(1024), 0, st,
                        SinkView{block_counts, grid, region_cap}, SinkView{hit_counts, hit_grid, hit_cap},
-                       summary, offsets, abort_flag);
+                       summary, offsets);
     return hipGetLastError();
 }
 
@@ -830,57 +855,6 @@ hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t gri
                         uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st) {
     hipLaunchKernelGGL(k_sink_compact, dim3(grid), dim3(256), 0, st, recs, offsets, region_cap,
                        keys_out, pids_out);
-    return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------
-// K2a: bucket sort of the occurrences by stream position
-// ---------------------------------------------------------------------------
-// Occurrences are sparse (about one per KiB on the headline workload), so a
-// full 64-bit radix sort is wasted work: the scan kernels count per 4 KiB
-// bucket of the position while they emit (emit_key); a scan of the counters and a
-// scatter group them by bucket, the tile kernels (K2b) order and resolve them.
-// A bucket with more than BUCKET_MAX occurrences (or a tile with more than TILE_MAX)
-// sets *big (dense inputs): the host then falls back to the rocPRIM radix sort.
-constexpr uint32_t BUCKET_MAX = 64;
-
-// straight from the sink regions: slot = bucket offset + the arrival rank taken
-// at emission -- no atomics, no separate compaction pass
-__global__ __launch_bounds__(256) void k_bucket_scatter(const uint4 *recs, const uint64_t *block_counts,
-                                                        uint64_t region_cap, uint32_t shift,
-                                                        const uint32_t *off, uint64_t *keys_out,
-                                                        uint32_t *pids_out, const uint32_t *abort_flag) {
-    if (*abort_flag) return;
-    uint64_t n = block_counts[blockIdx.x];
-    if (n > region_cap) n = region_cap;
-    const uint4 *r = recs + (uint64_t)blockIdx.x * region_cap;
-    for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-        uint4 v = r[i];
-        uint64_t k = ((uint64_t)v.y << 32) | v.x;
-        uint32_t slot = off[(uint32_t)(k >> shift)] + v.w;
-        keys_out[slot] = k;
-        pids_out[slot] = v.z;
-    }
-}
-
-size_t bucket_temp_bytes(uint64_t nb) {
-    size_t b = 0;
-    (void)rocprim::exclusive_scan(nullptr, b, (const uint32_t *)nullptr, (uint32_t *)nullptr, 0u,
-                                  (size_t)nb + 1, rocprim::plus<uint32_t>(), (hipStream_t)0);
-    return b;
-}
-
-// cnt (filled by the scan kernels' emission) / off: nb + 1 u32 each.
-hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *recs,
-                                   const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
-                                   uint64_t *keys_out, uint32_t *pids_out, uint32_t shift, uint32_t nb,
-                                   const uint32_t *cnt, uint32_t *off, uint32_t *big,
-                                   hipStream_t st) {
-    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, cnt, off, 0u, (size_t)nb + 1,
-                                           rocprim::plus<uint32_t>(), st);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_bucket_scatter, dim3(grid), dim3(256), 0, st, recs, block_counts, region_cap,
-                       shift, off, keys_out, pids_out, big);
     return hipGetLastError();
 }
 
@@ -1003,22 +977,25 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 }
 
 // ---------------------------------------------------------------------------
-// K2b: tile kernels -- sort, resolve and write the bucketed occurrences
+// K2b: sparse path -- tile kernels over the bucket slots
 // ---------------------------------------------------------------------------
-// After the bucket scatter the launch geometry of everything that follows depends only on
-// the number of buckets (known to the host), never on the number of occurrences (known only
-// to the device), so the whole post stage is queued behind the scan without a host round
-// trip.  A workgroup owns a tile of TILE_BUCKETS consecutive buckets (256 KiB of stream
-// position); its occurrences (at most TILE_MAX, else *big -> radix-sort fallback) are
-// staged in LDS so that the per-bucket serial work runs at LDS latency and every global
-// access is coalesced.
-//   k_tile_sort     per-bucket insertion sort; sync-point flag of every occurrence
-//   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point; tile totals
-//   k_tile_scan     exclusive scan of the tile totals (one workgroup)
+// In slot mode the scan's emission has already grouped the occurrences by 4 KiB bucket
+// of their key position (Sink::slots).  The launch geometry of everything that follows
+// depends only on the number of buckets (known to the host), never on the number of
+// occurrences (known only to the device), so the whole post stage is queued behind the
+// scan without a host round trip.  A workgroup owns a tile of TILE_BUCKETS consecutive
+// buckets (256 KiB of stream position); its occurrences (at most TILE_MAX, else the
+// abort flag -> region mode + radix sort) are staged in LDS so that the per-bucket serial
+// work runs at LDS latency and every global access is coalesced.
+//   k_tile_sort     gather the slots, per-bucket insertion sort, sync-point flag of
+//                   every occurrence
+//   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point;
+//                   reported count of the tile
+//   k_tile_scan     exclusive scan of the tile counts, totals (one workgroup)
 //   k_tile_write    compaction into the final (pattern, start, end) records
-constexpr uint32_t TILE_BUCKETS = 64;
-constexpr uint32_t TILE_MAX = 1024;
 constexpr uint32_t DST_NONE = 0xFFFFFFFFu;
+static_assert(TILE_BUCKETS == 64, "one wave owns the buckets of a tile");
+static_assert(TILE_MAX == 4 * 256, "k_tile_write: 4 occurrences per thread");
 
 __device__ __forceinline__ void span_of(const DevAutomaton &A, int key_mode, uint64_t key, uint32_t pid,
                                         uint64_t *s, uint64_t *e) {
@@ -1027,31 +1004,67 @@ __device__ __forceinline__ void span_of(const DevAutomaton &A, int key_mode, uin
     else { *s = x; *e = x + l; }
 }
 
+// bo[0 .. 64] = offsets of the tile's buckets inside the tile (wave 0; the caller syncs)
+__device__ __forceinline__ void tile_offsets(const TileSpace &T, uint32_t B0, uint32_t *bo) {
+    const uint32_t t = threadIdx.x;
+    if (t < 64) {
+        uint32_t c = B0 + t < T.n_buckets ? T.bcnt[B0 + t] : 0;
+        c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS; // overfull: the emitter raised the abort flag
+        uint32_t incl = c;
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((int)t >= o) incl += v;
+        }
+        bo[t + 1] = incl;
+        if (t == 0) bo[0] = 0;
+    }
+}
+
+// largest end among the (unsorted) occurrences of the buckets [b0, b1)
+__device__ __forceinline__ uint64_t raw_max_end(const DevAutomaton &A, int key_mode, const TileSpace &T,
+                                                uint32_t b0, uint32_t b1) {
+    uint64_t mx = 0;
+    for (uint32_t b = b0; b < b1; b++) {
+        uint32_t c = T.bcnt[b];
+        c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS;
+        for (uint32_t r = 0; r < c; r++) {
+            const uint4 v = T.slots[(uint64_t)b * BUCKET_SLOTS + r];
+            uint64_t s, e;
+            span_of(A, key_mode, ((uint64_t)v.y << 32) | v.x, v.z, &s, &e);
+            mx = max(mx, e);
+        }
+    }
+    return mx;
+}
+
 // Occurrence i is a "sync point" when every earlier occurrence (in sorted order) ends at or
 // before its start: whatever the greedy did before, i is reported.
 __global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode, int overlapping,
-                                                   const uint64_t *keys_in, const uint32_t *pids_in,
-                                                   const uint32_t *off, uint32_t nb, uint32_t shift,
-                                                   uint64_t *keys_out, uint32_t *pids_out,
-                                                   uint8_t *syncf, uint32_t *bcnt, uint32_t *big) {
+                                                   TileSpace T, uint32_t tile0, uint32_t *abort_flag) {
     __shared__ uint64_t k[TILE_MAX];
     __shared__ uint32_t p[TILE_MAX];
     __shared__ uint32_t bo[TILE_BUCKETS + 1];
     __shared__ uint32_t stop;
-    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
-    if (t <= TILE_BUCKETS) bo[t] = off[min(B0 + t, nb)];
-    if (t < TILE_BUCKETS && B0 + t < nb) bcnt[B0 + t] = 0; // leave the emission counters clean
-    if (t == 0) stop = *big;
+    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x, B0 = tile * TILE_BUCKETS;
+    tile_offsets(T, B0, bo);
+    if (t == 0) stop = *abort_flag;
     __syncthreads();
-    const uint32_t lo = bo[0], n = bo[TILE_BUCKETS] - lo;
-    if (stop) return; // *big doubles as the abort flag of the whole bucket path
-    if (n > TILE_MAX) { if (t == 0) *big = 1; return; }
-    for (uint32_t i = t; i < n; i += 256) { k[i] = keys_in[lo + i]; p[i] = pids_in[lo + i]; }
+    const uint32_t n = bo[TILE_BUCKETS];
+    if (stop) return;
+    if (n > TILE_MAX) { if (t == 0) *abort_flag = 1; return; }
+    if (t == 0) T.tile_n[tile] = n;
+    { // gather: four threads per bucket
+        const uint32_t bq = t >> 2, a = bo[bq], c = bo[bq + 1] - a;
+        for (uint32_t r = t & 3; r < c; r += 4) {
+            const uint4 v = T.slots[(uint64_t)(B0 + bq) * BUCKET_SLOTS + r];
+            k[a + r] = ((uint64_t)v.y << 32) | v.x;
+            p[a + r] = v.z;
+        }
+    }
     __syncthreads();
     if (t < TILE_BUCKETS) {
-        const uint32_t a = bo[t] - lo, e = bo[t + 1] - lo;
-        if (e - a > BUCKET_MAX) *big = 1; // dense: the insertion sort would be quadratic
-        else for (uint32_t i = a + 1; i < e; i++) {
+        const uint32_t a = bo[t], e = bo[t + 1];
+        for (uint32_t i = a + 1; i < e; i++) {
             uint64_t kk = k[i];
             uint32_t pp = p[i], j = i;
             while (j > a && k[j - 1] > kk) { k[j] = k[j - 1]; p[j] = p[j - 1]; j--; }
@@ -1059,20 +1072,19 @@ __global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode,
         }
     }
     __syncthreads();
+    const uint64_t gi = (uint64_t)tile * TILE_MAX;
     for (uint32_t i = t; i < n; i += 256) {
         const uint64_t key = k[i];
         const uint32_t pid = p[i];
-        keys_out[lo + i] = key;
-        pids_out[lo + i] = pid;
+        T.tkeys[gi + i] = key;
+        T.tpids[gi + i] = pid;
         if (overlapping) continue;
         uint64_t s, e, mx = 0; // mx: largest end among the occurrences before i
         span_of(A, key_mode, key, pid, &s, &e);
         if (key_mode == 0) { // sorted by end: the previous end is the maximum
             if (i > 0) mx = k[i - 1] >> A.rank_bits;
-            else if (lo > 0) { // the last non-empty bucket before the tile (not sorted yet: scan it)
-                for (uint32_t j = off[(uint32_t)(keys_in[lo - 1] >> shift)]; j < lo; j++)
-                    mx = max(mx, keys_in[j] >> A.rank_bits);
-            }
+            else if ((s >> BUCKET_BITS) < B0) // anything before the tile that ends beyond s ends in these buckets
+                mx = raw_max_end(A, key_mode, T, (uint32_t)(s >> BUCKET_BITS), B0);
         } else { // sorted by start: only occurrences that start within max_len of s can end beyond it
             bool open = true;
             for (uint32_t j = i; j > 0;) {
@@ -1082,55 +1094,59 @@ __global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode,
                 mx = max(mx, sj + A.plen[p[j]]);
             }
             const uint64_t p0 = s > A.max_len ? s - A.max_len : 0;
-            if (open && lo > 0 && (p0 >> 12) < B0)
-                for (uint32_t j = off[(uint32_t)(p0 >> 12)]; j < lo; j++)
-                    mx = max(mx, (keys_in[j] >> A.rank_bits) + A.plen[pids_in[j]]);
+            if (open && (p0 >> BUCKET_BITS) < B0)
+                mx = max(mx, raw_max_end(A, key_mode, T, (uint32_t)(p0 >> BUCKET_BITS), B0));
         }
-        syncf[lo + i] = mx <= s ? 1 : 0;
+        T.syncf[gi + i] = mx <= s ? 1 : 0;
     }
 }
 
 __global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mode, int overlapping,
-                                                      const uint64_t *keys, const uint32_t *pids,
-                                                      const uint8_t *syncf, const uint32_t *off,
-                                                      uint32_t nb, uint8_t *accf, uint32_t *btot,
+                                                      TileSpace T, uint32_t tile0,
                                                       const uint32_t *abort_flag) {
     __shared__ uint32_t rel[TILE_MAX]; // key position relative to the tile's first byte
     __shared__ uint32_t len[TILE_MAX];
     __shared__ uint8_t sy[TILE_MAX], ac[TILE_MAX];
     __shared__ uint32_t bo[TILE_BUCKETS + 1];
     __shared__ uint32_t stop;
-    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
-    if (t <= TILE_BUCKETS) bo[t] = off[min(B0 + t, nb)];
+    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x, B0 = tile * TILE_BUCKETS;
+    tile_offsets(T, B0, bo);
     if (t == 0) stop = *abort_flag;
     __syncthreads();
     if (stop) return;
-    const uint32_t lo = bo[0], n = bo[TILE_BUCKETS] - lo;
-    const uint64_t base = (uint64_t)B0 << 12;
+    const uint32_t n = bo[TILE_BUCKETS];
+    const uint64_t base = (uint64_t)B0 << BUCKET_BITS, gi = (uint64_t)tile * TILE_MAX;
     uint32_t cnt = 0; // reported occurrences of bucket t (wave 0 only)
     if (overlapping) {
         if (t < TILE_BUCKETS) cnt = bo[t + 1] - bo[t];
     } else {
         for (uint32_t i = t; i < n; i += 256) {
-            const uint32_t pid = pids[lo + i];
-            rel[i] = (uint32_t)((keys[lo + i] >> A.rank_bits) - base);
-            len[i] = A.plen[pid];
-            sy[i] = syncf[lo + i];
+            rel[i] = (uint32_t)((T.tkeys[gi + i] >> A.rank_bits) - base);
+            len[i] = A.plen[T.tpids[gi + i]];
+            sy[i] = T.syncf[gi + i];
         }
         __syncthreads();
-        const uint32_t a = t < TILE_BUCKETS ? bo[t] - lo : 0, e = t < TILE_BUCKETS ? bo[t + 1] - lo : 0;
+        const uint32_t a = t < TILE_BUCKETS ? bo[t] : 0, e = t < TILE_BUCKETS ? bo[t + 1] : 0;
         if (e > a) {
             // re-derive the greedy chain from the nearest sync point at or before a
             uint32_t j = a;
             while (j > 0 && !sy[j]) j--;
             uint64_t pos = 0; // end of the last reported match
             if (!sy[j]) { // the chain enters the tile from before it: follow it in HBM (rare)
-                uint64_t g = lo;
-                while (g > 0 && !syncf[--g]) {}
-                for (; g < lo; g++) {
-                    uint64_t s, en;
-                    span_of(A, key_mode, keys[g], pids[g], &s, &en);
-                    if (s >= pos) pos = en;
+                uint32_t tt = tile, q = 0;
+                for (;;) { // the first occurrence of the stream is a sync point: this terminates
+                    while (q == 0) q = T.tile_n[--tt];
+                    q--;
+                    if (T.syncf[(uint64_t)tt * TILE_MAX + q]) break;
+                }
+                for (; tt < tile; tt++, q = 0) {
+                    const uint32_t nn = T.tile_n[tt];
+                    for (; q < nn; q++) {
+                        uint64_t s, en;
+                        span_of(A, key_mode, T.tkeys[(uint64_t)tt * TILE_MAX + q],
+                                T.tpids[(uint64_t)tt * TILE_MAX + q], &s, &en);
+                        if (s >= pos) pos = en;
+                    }
                 }
             }
             for (uint32_t q = j; q < e; q++) {
@@ -1142,49 +1158,81 @@ __global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mo
             }
         }
         __syncthreads();
-        for (uint32_t i = t; i < n; i += 256) accf[lo + i] = ac[i];
+        for (uint32_t i = t; i < n; i += 256) T.accf[gi + i] = ac[i];
     }
-    static_assert(TILE_BUCKETS == 64, "one wave owns the buckets of a tile");
     if (t < 64) {
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-        if (t == 0) btot[blockIdx.x] = cnt;
+        if (t == 0) T.btot[tile] = cnt;
     }
 }
 
-// bbase = exclusive scan of btot[0, tiles); *total = their sum.  One workgroup.
-__global__ __launch_bounds__(1024) void k_tile_scan(const uint32_t *btot, uint32_t tiles, uint32_t *bbase,
-                                                    uint64_t *total, const uint32_t *abort_flag) {
+// One workgroup, for the tiles [tile0, tile1) of one chunk of the call (chunks run in order):
+// bbase = exclusive scan of btot continuing the previous chunk's; summary[0] = occurrences,
+// summary[4] = reported matches, summary[2] / [3] = prefix hits kept / largest hit region, all
+// accumulated over the chunks.  The last chunk clears the abort flag the NEXT call will use.
+__global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0, uint32_t tile1, int first,
+                                                    const uint64_t *hit_counts, uint32_t hit_grid,
+                                                    uint64_t hit_cap, uint64_t *summary,
+                                                    const uint32_t *abort_flag, uint32_t *next_flag) {
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
-    if (*abort_flag) return;
-    const uint32_t t = threadIdx.x, per = (tiles + 1023) / 1024, g0 = t * per;
+    __shared__ uint64_t red[3][16];
+    const uint32_t t = threadIdx.x;
+    const bool stop = *abort_flag != 0; // stable: its writers completed
+    const uint64_t n_before = first ? 0 : summary[0], h_before = first ? 0 : summary[2],
+                   hmax_before = first ? 0 : summary[3];
+    const uint32_t base = first ? 0 : (uint32_t)summary[4];
+    uint64_t hsum = 0, hmax = 0, nsum = 0;
+    if (hit_counts)
+        for (uint32_t g = t; g < hit_grid; g += 1024) {
+            const uint64_t c = hit_counts[g];
+            hmax = max(hmax, c);
+            hsum += c < hit_cap ? c : hit_cap;
+        }
+    const uint32_t per = (tile1 - tile0 + 1023) / 1024, g0 = tile0 + t * per;
     uint32_t mine = 0, excl = 0;
-    for (uint32_t g = g0; g < g0 + per && g < tiles; g++) mine += btot[g];
+    if (!stop)
+        for (uint32_t g = g0; g < g0 + per && g < tile1; g++) { mine += T.btot[g]; nsum += T.tile_n[g]; }
     scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
-    for (uint32_t g = g0; g < g0 + per && g < tiles; g++) { bbase[g] = excl; excl += btot[g]; }
-    if (t == 1023) *total = excl;
+    excl += base;
+    if (!stop)
+        for (uint32_t g = g0; g < g0 + per && g < tile1; g++) { T.bbase[g] = excl; excl += T.btot[g]; }
+    for (int o = 32; o > 0; o >>= 1) {
+        hsum += __shfl_down(hsum, o);
+        nsum += __shfl_down(nsum, o);
+        hmax = max(hmax, __shfl_down(hmax, o));
+    }
+    if ((t & 63) == 0) { red[0][t >> 6] = hsum; red[1][t >> 6] = hmax; red[2][t >> 6] = nsum; }
+    __syncthreads();
+    if (t == 1023) summary[4] = excl;
+    if (t == 0) {
+        uint64_t a = h_before, b = hmax_before, c = n_before;
+        for (int i = 0; i < 16; i++) { a += red[0][i]; b = max(b, red[1][i]); c += red[2][i]; }
+        summary[2] = a; summary[3] = b; summary[0] = c;
+        if (next_flag) *next_flag = 0;
+    }
 }
 
+// zero_lo..zero_hi: the arrival counters this launch leaves clean for the next call
 __global__ __launch_bounds__(256) void k_tile_write(DevAutomaton A, int key_mode, int overlapping,
-                                                    const uint64_t *keys, const uint32_t *pids,
-                                                    const uint8_t *accf, const uint32_t *off, uint32_t nb,
-                                                    const uint32_t *bbase, acx_match_t *out,
+                                                    TileSpace T, uint32_t tile0, uint32_t zero_lo,
+                                                    uint32_t zero_hi, acx_match_t *out,
                                                     const uint32_t *abort_flag) {
     __shared__ __attribute__((aligned(16))) uint8_t ac[TILE_MAX];
     __shared__ uint32_t dst[TILE_MAX];
     using scan_t = rocprim::block_scan<uint32_t, 256>;
     __shared__ typename scan_t::storage_type scan_tmp;
-    const uint32_t t = threadIdx.x, B0 = blockIdx.x * TILE_BUCKETS;
-    if (*abort_flag) return; // stable by now: written by kernels that completed
-    const uint32_t lo = off[min(B0, nb)], n = off[min(B0 + TILE_BUCKETS, nb)] - lo;
-    const uint32_t base = bbase[blockIdx.x];
+    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x;
+    for (uint32_t i = zero_lo + blockIdx.x * 256 + t; i < zero_hi; i += gridDim.x * 256) T.bcnt[i] = 0;
+    if (*abort_flag) return; // stable by now: its writers completed
+    const uint32_t n = T.tile_n[tile], base = T.bbase[tile];
+    const uint64_t gi = (uint64_t)tile * TILE_MAX;
     if (overlapping) {
         for (uint32_t i = t; i < n; i += 256) dst[i] = base + i;
     } else {
-        for (uint32_t i = t; i < TILE_MAX; i += 256) ac[i] = i < n ? accf[lo + i] : 0;
+        for (uint32_t i = t; i < TILE_MAX; i += 256) ac[i] = i < n ? T.accf[gi + i] : 0;
         __syncthreads();
         // thread t owns the 4 occurrences [4 t, 4 t + 4)
-        static_assert(TILE_MAX == 4 * 256, "4 occurrences per thread");
         const uint32_t mine = __popc(*(const uint32_t *)&ac[t * 4]);
         uint32_t excl = 0;
         scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
@@ -1195,31 +1243,35 @@ __global__ __launch_bounds__(256) void k_tile_write(DevAutomaton A, int key_mode
     for (uint32_t i = t; i < n; i += 256) {
         const uint32_t d = dst[i];
         if (d == DST_NONE) continue;
-        const uint32_t pid = pids[lo + i];
+        const uint32_t pid = T.tpids[gi + i];
         uint64_t s, e;
-        span_of(A, key_mode, keys[lo + i], pid, &s, &e);
+        span_of(A, key_mode, T.tkeys[gi + i], pid, &s, &e);
         out[d].pattern = pid; out[d].start = s; out[d].end = e;
     }
 }
 
-// Sort (within buckets), resolve and compact the bucketed occurrences keys_in/pids_in
-// (bucket offsets off[nb + 1]) into out[]; *total receives the number of matches.
-// keys_tmp/pids_tmp: n entries; syncf/accf: n bytes each; btot/bbase: one u32 per tile.
-hipError_t bucket_resolve_write(const DevAutomaton &A, int key_mode, bool overlapping,
-                                const uint64_t *keys_in, const uint32_t *pids_in, uint64_t *keys_tmp,
-                                uint32_t *pids_tmp, const uint32_t *off, uint32_t nb, uint32_t shift,
-                                uint8_t *syncf, uint8_t *accf, uint32_t *bcnt, uint32_t *btot,
-                                uint32_t *bbase, acx_match_t *out, uint64_t *total,
-                                uint32_t *abort_flag, hipStream_t st) {
-    const uint32_t tiles = (nb + TILE_BUCKETS - 1) / TILE_BUCKETS;
+// Sort (within buckets), resolve and compact the slotted occurrences of the tiles
+// [tile0, tile1) into out[] (capacity n_tiles * TILE_MAX suffices for a whole call).  Chunks of
+// one call come in tile order; `first` / `last` mark the ends.  summary[0] = occurrences,
+// [2] = prefix hits kept, [3] = largest hit region, [4] = matches written (accumulated over the
+// chunks); *abort_flag != 0: the output did not fit the sparse path (or hits were dropped) and
+// out[] / summary[0], [4] are meaningless.  The last chunk zeroes T.bcnt and *next_flag.
+hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
+                     uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
+                     uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
+                     uint32_t *abort_flag, uint32_t *next_flag, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
-    hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_in, pids_in, off,
-                       nb, shift, keys_tmp, pids_tmp, syncf, bcnt, abort_flag);
-    hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_tmp, pids_tmp,
-                       syncf, off, nb, accf, btot, abort_flag);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, btot, tiles, bbase, total, abort_flag);
-    hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, keys_tmp, pids_tmp, accf,
-                       off, nb, bbase, out, abort_flag);
+    const uint32_t tiles = tile1 - tile0;
+    if (tiles) {
+        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0, abort_flag);
+        hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0,
+                           abort_flag);
+    }
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, tile0, tile1, first ? 1 : 0, hit_counts,
+                       hit_grid, hit_cap, summary, abort_flag, last ? next_flag : nullptr);
+    if (tiles)
+        hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0, 0u,
+                           last ? T.n_buckets + 1 : 0u, out, abort_flag);
     return hipGetLastError();
 }
 

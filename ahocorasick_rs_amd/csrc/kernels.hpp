@@ -19,13 +19,15 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
                            size_t max_lds, hipStream_t st);
 // K1b: LDS q-gram prefilter + anchored DFA verification.
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
+// scans the 4 KiB tiles [tile_begin, tile_end) of the stream (prefilter_tiles() in all)
+uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len);
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            hipStream_t st);
+                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st);
 // sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
-                        uint64_t *summary, uint64_t *offsets, uint32_t *abort_flag, hipStream_t st);
+                        uint64_t *summary, uint64_t *offsets, hipStream_t st);
 hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
                         uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st);
 // K1b emits prefix hits (position, depth-Q2 state); this kernel walks them into
@@ -33,7 +35,7 @@ hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t gri
 // sink with walk_hits_grid(hit_grid) regions.
 uint32_t walk_hits_grid(uint32_t hit_grid);
 hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &hits, uint32_t hit_grid, const Sink &occ,
+                            const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
                             const uint8_t *d_hay, uint64_t len, hipStream_t st);
 size_t prefilter_lds_bytes(); // dynamic LDS K1b needs (bitmap + class map + queues)
 // rows of the hot16 table K1a can stage for this automaton and LDS size
@@ -44,25 +46,17 @@ size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                             uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
                             uint64_t n, int end_bit, hipStream_t st);
-// bucket grouping (sparse occurrences), straight from the sink regions: bucket = key >> shift,
-// nb buckets.  cnt[nb + 1] was filled by the scan kernels' emission (Sink::bucket_cnt) and
-// every record carries its arrival rank in its bucket; off[nb + 1] receives the bucket
-// offsets.  *big is the abort flag of the whole bucket path (region overflow, dense output).
-size_t bucket_temp_bytes(uint64_t nb);
-hipError_t bucket_sort_occurrences(void *temp, size_t temp_bytes, const uint4 *recs,
-                                   const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
-                                   uint64_t *keys_out, uint32_t *pids_out, uint32_t shift, uint32_t nb,
-                                   const uint32_t *cnt, uint32_t *off, uint32_t *big, hipStream_t st);
-// tile kernels: order within buckets, resolve the match kind, compact into out[]; the launch
-// geometry depends on nb only, so no host round trip is needed before them.  Zeroes bcnt.
-// keys_tmp/pids_tmp: n entries; syncf/accf: n bytes each; btot/bbase: one u32 per 64 buckets;
-// *total receives the number of matches.
-hipError_t bucket_resolve_write(const DevAutomaton &A, int key_mode, bool overlapping,
-                                const uint64_t *keys_in, const uint32_t *pids_in, uint64_t *keys_tmp,
-                                uint32_t *pids_tmp, const uint32_t *off, uint32_t nb, uint32_t shift,
-                                uint8_t *syncf, uint8_t *accf, uint32_t *bcnt, uint32_t *btot,
-                                uint32_t *bbase, acx_match_t *out, uint64_t *total,
-                                uint32_t *abort_flag, hipStream_t st);
+// sparse path (slot mode): tile kernels -- order within buckets, resolve the match kind,
+// compact into out[] (capacity n_tiles * TILE_MAX).  The launch geometry depends on the
+// number of buckets only, so no host round trip is needed before them.  A call may be cut
+// into chunks of tiles [tile0, tile1) that arrive in order (first / last mark the ends).
+// summary[0] = occurrences, [2] = prefix hits kept, [3] = largest hit region, [4] = matches;
+// *abort_flag != 0 afterwards: the output did not fit the sparse path (or hits were dropped).
+// The last chunk leaves T.bcnt and *next_flag zeroed for the next call.
+hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
+                     uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
+                     uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
+                     uint32_t *abort_flag, uint32_t *next_flag, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,
