@@ -177,7 +177,7 @@ int upload(acx_automaton *a, const T *src, size_t count, const T **dst) {
 
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
-    (void)hipFree(T.slots); (void)hipFree(T.bcnt); (void)hipFree(T.tkeys); (void)hipFree(T.tpids);
+    (void)hipFree(T.slots); (void)hipFree(T.bcnt); (void)hipFree(T.trecs);
     (void)hipFree(T.syncf); (void)hipFree(T.accf); (void)hipFree(T.tile_n); (void)hipFree(T.btot);
     (void)hipFree(T.bbase);
     T = TileSpace{};
@@ -264,8 +264,7 @@ int ensure_tiles(acx_automaton *a, uint64_t nb) {
         const uint64_t ents = tiles * TILE_MAX;
         HIPCHK(hipMalloc((void **)&T.slots, nb * BUCKET_SLOTS * 16));
         HIPCHK(hipMalloc((void **)&T.bcnt, (nb + 1) * 4));
-        HIPCHK(hipMalloc((void **)&T.tkeys, ents * 8));
-        HIPCHK(hipMalloc((void **)&T.tpids, ents * 4));
+        HIPCHK(hipMalloc((void **)&T.trecs, ents * 16));
         HIPCHK(hipMalloc((void **)&T.syncf, ents));
         HIPCHK(hipMalloc((void **)&T.accf, ents));
         HIPCHK(hipMalloc((void **)&T.tile_n, tiles * 4));

@@ -260,6 +260,9 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // prefix table: one entry per trie state of depth Q2, keyed by its Q2 bytes
         uint32_t n_pref = A.level_start[Q2 + 1] - A.level_start[Q2];
         uint32_t lg = 4;
+        // load <= 1/4.  Sparser would save the walk kernel dependent probes (a probe beyond the
+        // home slot stalls its whole wave), but measured on MI355X a table beyond ~1 MiB costs
+        // K1b more (its level-2 gathers start missing L2) than the walk kernel gains.
         while ((1u << lg) < 4 * n_pref) lg++;
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);
@@ -308,7 +311,6 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             uint64_t gram = gram_of(pp, Q2);
             uint32_t val = st;
             if (A.own_off[st + 1] > A.own_off[st]) val |= FLAG_OWN;
-            if (first_child[st + 1] > first_child[st]) val |= 0x80000000u; // has children
             uint32_t idx = prefix_slot(gram_hash2(gram), lg);
             for (;;) {
                 uint32_t *en = &A.ptab[4 * (size_t)idx];
@@ -320,6 +322,14 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                 if ((((uint64_t)en[1] << 32) | en[0]) == gram) break; // same prefix already there
                 idx = (idx + 1) & pmask;
             }
+        }
+        // PREFIX_MORE on a home slot: some prefix that hashes here lives further along the probe
+        // sequence.  Without it a home slot holding a different gram proves absence (one probe).
+        for (size_t e = 0; e < ((size_t)1 << lg); e++) {
+            if (A.ptab[4 * e + 2] == 0xFFFFFFFFu) continue;
+            uint64_t gram = ((uint64_t)A.ptab[4 * e + 1] << 32) | A.ptab[4 * e];
+            uint32_t home = prefix_slot(gram_hash2(gram), lg);
+            if (home != e) A.ptab[4 * (size_t)home + 2] |= PREFIX_MORE;
         }
     }
     return std::string();

@@ -72,6 +72,9 @@ ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
     h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
     return h;
 }
+// prefix-table entry, word 2: empty marker / "more prefixes with this home slot further along"
+constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
+constexpr uint32_t PREFIX_MORE = 0x80000000u;
 // slot of a Q2-gram in the prefix table (2^log2 entries)
 ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
     uint32_t m = (h2 ^ (h2 >> 7)) * 0x9E3779B1u;
@@ -104,7 +107,7 @@ struct Automaton {
     std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
     double filter_density = 0.0;       // fraction of X bits set
     // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:
-    //   {gram lo, gram hi, state id | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty),
+    //   {gram lo, gram hi, state id | OWN<<30 | PREFIX_MORE (0xFFFFFFFF = empty),
     //    the only pattern with this prefix, or 0x80000000 | index into blist}
     std::vector<uint32_t> blist;       // {count, pid, pid, ...} per prefix shared by several patterns
     // per pattern, 4 u32: {rank | min(len, 255) << 24, the 12 bytes that follow its first Q2 bytes}

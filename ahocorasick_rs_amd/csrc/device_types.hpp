@@ -43,7 +43,7 @@ struct Segments {
 };
 
 // Sink of the scan kernels: 16-byte records in per-workgroup regions.
-//   occurrence record  {key lo, key hi, pid, arrival rank in its bucket}
+//   occurrence record  {key lo, key hi, pid, pattern length}
 //   prefix-hit record  two quads: {pos lo, pos hi, code, 0} {16 haystack bytes at pos}
 // Occurrence keys:
 //   key_mode 0 (Standard / overlapping): key = end   << rank_bits | rank(pid)
@@ -62,8 +62,8 @@ struct Segments {
 // *abort_flag and the host redoes the call in region mode.
 constexpr uint32_t BUCKET_SLOTS = 32;  // occurrence slots per bucket
 constexpr uint32_t BUCKET_BITS = 12;   // bucket = 4 KiB of stream position
-constexpr uint32_t TILE_BUCKETS = 64;  // buckets per workgroup of the tile kernels (K2b)
-constexpr uint32_t TILE_MAX = 1024;    // occurrences per tile (held in LDS)
+constexpr uint32_t TILE_BUCKETS = 32;  // buckets per workgroup of the tile kernels (K2b)
+constexpr uint32_t TILE_MAX = 512;     // occurrences per tile (held in LDS)
 struct Sink {
     uint4 *recs;            // region_cap * quads uint4 per region
     uint32_t *bucket_cnt;   // slot mode: per-bucket arrival counters
@@ -71,7 +71,7 @@ struct Sink {
     uint64_t region_cap;    // records per region
     uint32_t bucket_shift;  // bucket = key >> bucket_shift
     int key_mode;
-    uint4 *slots;           // slot mode: n_buckets * BUCKET_SLOTS records {key lo, key hi, pid, 0}
+    uint4 *slots;           // slot mode: n_buckets * BUCKET_SLOTS records {key lo, key hi, pid, len}
     uint32_t *abort_flag;   // slot mode: set when the sparse path cannot hold the output
 };
 
@@ -79,8 +79,7 @@ struct Sink {
 struct TileSpace {
     uint4 *slots;       // n_buckets * BUCKET_SLOTS (filled by the scan's emission)
     uint32_t *bcnt;     // n_buckets + 1 arrival counters
-    uint64_t *tkeys;    // tiles * TILE_MAX: keys of a tile, sorted
-    uint32_t *tpids;    // tiles * TILE_MAX
+    uint4 *trecs;       // tiles * TILE_MAX: the occurrences of a tile, sorted {key lo, key hi, pid, len}
     uint8_t *syncf;     // tiles * TILE_MAX: occurrence is a sync point of the greedy
     uint8_t *accf;      // tiles * TILE_MAX: occurrence is reported
     uint32_t *tile_n;   // occurrences of each tile

@@ -62,9 +62,9 @@ __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount,
 
 // slot mode: the occurrence with arrival rank r of its bucket
 __device__ __forceinline__ void store_slot(const BlockSink &K, uint32_t bucket, uint32_t r, uint64_t key,
-                                           uint32_t pid) {
+                                           uint32_t pid, uint32_t plen) {
     if (r < BUCKET_SLOTS)
-        K.slots[(uint64_t)bucket * BUCKET_SLOTS + r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
+        K.slots[(uint64_t)bucket * BUCKET_SLOTS + r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
     else
         *K.abort_flag = 1;
 }
@@ -72,14 +72,15 @@ __device__ __forceinline__ void store_slot(const BlockSink &K, uint32_t bucket, 
 // store one occurrence (ONE 16-byte store).  Slot mode: take the occurrence's arrival
 // rank inside its bucket (one global atomic, the address is shared by the ~4 occurrences
 // of a 4 KiB stretch only) and store into that slot.  Region mode: next slot of the region.
-__device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid) {
+// (records carry the pattern's length so that nothing downstream has to gather it again)
+__device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid, uint32_t plen) {
     if (K.slots) {
         const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
-        store_slot(K, bucket, atomicAdd(&K.bucket_cnt[bucket], 1u), key, pid);
+        store_slot(K, bucket, atomicAdd(&K.bucket_cnt[bucket], 1u), key, pid, plen);
         return;
     }
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
-    if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
+    if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
 }
 
 // Wave-aggregated variant for code where many lanes emit together (walk kernel).
@@ -87,7 +88,8 @@ __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint3
 // same bucket takes the bucket ranks (hits arrive grouped by 4 KiB tile, so a run is
 // typically a whole tile: device-scope atomics with return are the expensive part of
 // emission).  Region mode: one LDS atomic per wave reserves the slots.
-__device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid) {
+__device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid,
+                                             uint32_t plen) {
     const unsigned long long fm = __ballot(ok);
     if (!fm) return;
     const uint32_t lane = threadIdx.x & 63;
@@ -109,7 +111,7 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
         uint32_t base = 0;
         if (head) base = atomicAdd(&K.bucket_cnt[bucket], (uint32_t)__popcll(run));
         base = __shfl(base, hl);
-        if (ok) store_slot(K, bucket, base + (uint32_t)__popcll(run & below_me), key, pid);
+        if (ok) store_slot(K, bucket, base + (uint32_t)__popcll(run & below_me), key, pid, plen);
         return;
     }
     const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
@@ -118,7 +120,7 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
     sbase = __shfl(sbase, leader);
     if (ok) {
         uint32_t slot = sbase + (uint32_t)__popcll(fm & below_me);
-        if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, 0);
+        if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
     }
 }
 
@@ -128,13 +130,14 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
 __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink K, uint32_t pid,
                                          uint64_t end) {
     uint64_t key;
+    const uint32_t plen = A->plen[pid];
     if (K.key_mode == 0) {
         key = (end << A->rank_bits) | A->rank[pid];
     } else {
-        uint64_t start = end - A->plen[pid];
+        uint64_t start = end - plen;
         key = (start << A->rank_bits) | (K.key_mode == 1 ? pid : A->rank[pid]);
     }
-    emit_key(K, key, pid);
+    emit_key(K, key, pid, plen);
 }
 
 // every pattern that ends at state s (own patterns, then the dictionary-suffix
@@ -159,7 +162,7 @@ __device__ __forceinline__ void emit_own_span(const DevAutomaton &A, const Block
         uint64_t key = K.key_mode == 0   ? (end << A.rank_bits) | A.rank[pid]
                        : K.key_mode == 1 ? (start << A.rank_bits) | pid
                                          : (start << A.rank_bits) | A.rank[pid];
-        emit_key(K, key, pid);
+        emit_key(K, key, pid, (uint32_t)(end - start));
     }
 }
 
@@ -374,7 +377,6 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 // All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
 constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane)
-constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
     uint32_t count;
@@ -420,6 +422,7 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
     const uint64_t room = segment_end(G, len, p) - p;
     if (room < q) return; // the prefix would straddle the end of its haystack
     if (code == HIT_RETRY) {
+        if (ablate & 128) return; // profiling only: drop the hits that need a second probe
         const uint64_t gram = q >= 8 ? w0 : (w0 & ((1ull << (8 * q)) - 1));
         uint32_t idx = prefix_slot(gram_hash2(gram), A.ptab_log2);
         const uint32_t mask = (1u << A.ptab_log2) - 1;
@@ -465,7 +468,7 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
         uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
                        : K.key_mode == 1 ? (p << A.rank_bits) | pid
                                          : (p << A.rank_bits) | rk;
-        emit_key_agg(K, ok && !(ablate & 32), key, pid);
+        emit_key_agg(K, ok && !(ablate & 32), key, pid, L);
     }
 }
 
@@ -492,7 +495,7 @@ __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAuto
         const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
         for (uint64_t i = (blockIdx.x % split) * 256 + threadIdx.x; i < n; i += split * 256) {
             const uint4 h = rec[2 * i], w = rec[2 * i + 1];
-            if (ablate & 64) { if (h.x == 0x12345678u && w.y == 77) emit_key(K, 1, 1); continue; }
+            if (ablate & 64) { if (h.x == 0x12345678u && w.y == 77) emit_key(K, 1, 1, 1); continue; }
             verify_hit(A, G, K, stream, len, ((uint64_t)h.y << 32) | h.x, h.z,
                        ((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z, ablate);
         }
@@ -606,7 +609,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         if (nC) {
             bool act = lane < nC;
             bool same = (((uint64_t)entC.y << 32) | entC.x) == (winC & q2mask);
-            bool found = act && entC.z != PREFIX_EMPTY;
+            // a home slot holding another gram proves absence unless PREFIX_MORE is set
+            bool found = act && entC.z != PREFIX_EMPTY && (same || (entC.z & PREFIX_MORE));
             uint32_t st = same ? entC.w : HIT_RETRY;
             if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st, winC, winC1)
         }
@@ -984,9 +988,11 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // depends only on the number of buckets (known to the host), never on the number of
 // occurrences (known only to the device), so the whole post stage is queued behind the
 // scan without a host round trip.  A workgroup owns a tile of TILE_BUCKETS consecutive
-// buckets (256 KiB of stream position); its occurrences (at most TILE_MAX, else the
+// buckets (128 KiB of stream position); its occurrences (at most TILE_MAX, else the
 // abort flag -> region mode + radix sort) are staged in LDS so that the per-bucket serial
-// work runs at LDS latency and every global access is coalesced.
+// work runs at LDS latency and every global access is coalesced.  These kernels are
+// latency chains (a few dependent HBM round trips per tile), so the workgroups are small
+// (one wave, 8 KiB of LDS): all tiles of a GiB are resident at once.
 //   k_tile_sort     gather the slots, per-bucket insertion sort, sync-point flag of
 //                   every occurrence
 //   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point;
@@ -994,43 +1000,44 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 //   k_tile_scan     exclusive scan of the tile counts, totals (one workgroup)
 //   k_tile_write    compaction into the final (pattern, start, end) records
 constexpr uint32_t DST_NONE = 0xFFFFFFFFu;
-static_assert(TILE_BUCKETS == 64, "one wave owns the buckets of a tile");
-static_assert(TILE_MAX == 4 * 256, "k_tile_write: 4 occurrences per thread");
+constexpr uint32_t TILE_THREADS = 64;
+constexpr uint32_t TILE_PER_THREAD = TILE_MAX / TILE_THREADS; // k_tile_write
+static_assert(TILE_BUCKETS <= 64, "one wave owns the buckets of a tile");
+static_assert(TILE_THREADS % TILE_BUCKETS == 0 && TILE_PER_THREAD % 4 == 0, "tile geometry");
 
-__device__ __forceinline__ void span_of(const DevAutomaton &A, int key_mode, uint64_t key, uint32_t pid,
-                                        uint64_t *s, uint64_t *e) {
-    const uint64_t x = key >> A.rank_bits, l = A.plen[pid];
-    if (key_mode == 0) { *e = x; *s = x - l; }
-    else { *s = x; *e = x + l; }
+// span of an occurrence record {key lo, key hi, pid, pattern length}
+__device__ __forceinline__ void span_of(uint32_t rank_bits, int key_mode, uint4 v, uint64_t *s, uint64_t *e) {
+    const uint64_t x = (((uint64_t)v.y << 32) | v.x) >> rank_bits;
+    if (key_mode == 0) { *e = x; *s = x - v.w; }
+    else { *s = x; *e = x + v.w; }
 }
 
-// bo[0 .. 64] = offsets of the tile's buckets inside the tile (wave 0; the caller syncs)
+// bo[0 .. TILE_BUCKETS] = offsets of the tile's buckets inside the tile (wave 0; the caller syncs)
 __device__ __forceinline__ void tile_offsets(const TileSpace &T, uint32_t B0, uint32_t *bo) {
     const uint32_t t = threadIdx.x;
     if (t < 64) {
-        uint32_t c = B0 + t < T.n_buckets ? T.bcnt[B0 + t] : 0;
+        uint32_t c = t < TILE_BUCKETS && B0 + t < T.n_buckets ? T.bcnt[B0 + t] : 0;
         c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS; // overfull: the emitter raised the abort flag
         uint32_t incl = c;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o);
             if ((int)t >= o) incl += v;
         }
-        bo[t + 1] = incl;
+        if (t < TILE_BUCKETS) bo[t + 1] = incl;
         if (t == 0) bo[0] = 0;
     }
 }
 
 // largest end among the (unsorted) occurrences of the buckets [b0, b1)
-__device__ __forceinline__ uint64_t raw_max_end(const DevAutomaton &A, int key_mode, const TileSpace &T,
+__device__ __forceinline__ uint64_t raw_max_end(uint32_t rank_bits, int key_mode, const TileSpace &T,
                                                 uint32_t b0, uint32_t b1) {
     uint64_t mx = 0;
     for (uint32_t b = b0; b < b1; b++) {
         uint32_t c = T.bcnt[b];
         c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS;
         for (uint32_t r = 0; r < c; r++) {
-            const uint4 v = T.slots[(uint64_t)b * BUCKET_SLOTS + r];
             uint64_t s, e;
-            span_of(A, key_mode, ((uint64_t)v.y << 32) | v.x, v.z, &s, &e);
+            span_of(rank_bits, key_mode, T.slots[(uint64_t)b * BUCKET_SLOTS + r], &s, &e);
             mx = max(mx, e);
         }
     }
@@ -1039,10 +1046,11 @@ __device__ __forceinline__ uint64_t raw_max_end(const DevAutomaton &A, int key_m
 
 // Occurrence i is a "sync point" when every earlier occurrence (in sorted order) ends at or
 // before its start: whatever the greedy did before, i is reported.
-__global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode, int overlapping,
-                                                   TileSpace T, uint32_t tile0, uint32_t *abort_flag) {
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_sort(uint32_t rank_bits, uint32_t max_len,
+                                                            int key_mode, int overlapping, TileSpace T,
+                                                            uint32_t tile0, uint32_t *abort_flag) {
     __shared__ uint64_t k[TILE_MAX];
-    __shared__ uint32_t p[TILE_MAX];
+    __shared__ uint2 pl[TILE_MAX]; // {pid, pattern length}
     __shared__ uint32_t bo[TILE_BUCKETS + 1];
     __shared__ uint32_t stop;
     const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x, B0 = tile * TILE_BUCKETS;
@@ -1053,57 +1061,59 @@ __global__ __launch_bounds__(256) void k_tile_sort(DevAutomaton A, int key_mode,
     if (stop) return;
     if (n > TILE_MAX) { if (t == 0) *abort_flag = 1; return; }
     if (t == 0) T.tile_n[tile] = n;
-    { // gather: four threads per bucket
-        const uint32_t bq = t >> 2, a = bo[bq], c = bo[bq + 1] - a;
-        for (uint32_t r = t & 3; r < c; r += 4) {
+    { // gather: TILE_THREADS / 64 threads per bucket
+        constexpr uint32_t TPB = TILE_THREADS / TILE_BUCKETS;
+        const uint32_t bq = t / TPB, a = bo[bq], c = bo[bq + 1] - a;
+        for (uint32_t r = t % TPB; r < c; r += TPB) {
             const uint4 v = T.slots[(uint64_t)(B0 + bq) * BUCKET_SLOTS + r];
             k[a + r] = ((uint64_t)v.y << 32) | v.x;
-            p[a + r] = v.z;
+            pl[a + r] = make_uint2(v.z, v.w);
         }
     }
     __syncthreads();
     if (t < TILE_BUCKETS) {
         const uint32_t a = bo[t], e = bo[t + 1];
         for (uint32_t i = a + 1; i < e; i++) {
-            uint64_t kk = k[i];
-            uint32_t pp = p[i], j = i;
-            while (j > a && k[j - 1] > kk) { k[j] = k[j - 1]; p[j] = p[j - 1]; j--; }
-            k[j] = kk; p[j] = pp;
+            const uint64_t kk = k[i];
+            const uint2 pp = pl[i];
+            uint32_t j = i;
+            while (j > a && k[j - 1] > kk) { k[j] = k[j - 1]; pl[j] = pl[j - 1]; j--; }
+            k[j] = kk; pl[j] = pp;
         }
     }
     __syncthreads();
     const uint64_t gi = (uint64_t)tile * TILE_MAX;
-    for (uint32_t i = t; i < n; i += 256) {
+    for (uint32_t i = t; i < n; i += TILE_THREADS) {
         const uint64_t key = k[i];
-        const uint32_t pid = p[i];
-        T.tkeys[gi + i] = key;
-        T.tpids[gi + i] = pid;
+        const uint2 pp = pl[i];
+        T.trecs[gi + i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pp.x, pp.y);
         if (overlapping) continue;
-        uint64_t s, e, mx = 0; // mx: largest end among the occurrences before i
-        span_of(A, key_mode, key, pid, &s, &e);
+        const uint64_t x = key >> rank_bits;
+        const uint64_t s = key_mode == 0 ? x - pp.y : x;
+        uint64_t mx = 0; // largest end among the occurrences before i
         if (key_mode == 0) { // sorted by end: the previous end is the maximum
-            if (i > 0) mx = k[i - 1] >> A.rank_bits;
+            if (i > 0) mx = k[i - 1] >> rank_bits;
             else if ((s >> BUCKET_BITS) < B0) // anything before the tile that ends beyond s ends in these buckets
-                mx = raw_max_end(A, key_mode, T, (uint32_t)(s >> BUCKET_BITS), B0);
+                mx = raw_max_end(rank_bits, key_mode, T, (uint32_t)(s >> BUCKET_BITS), B0);
         } else { // sorted by start: only occurrences that start within max_len of s can end beyond it
             bool open = true;
             for (uint32_t j = i; j > 0;) {
                 j--;
-                const uint64_t sj = k[j] >> A.rank_bits;
-                if (sj + A.max_len <= s) { open = false; break; }
-                mx = max(mx, sj + A.plen[p[j]]);
+                const uint64_t sj = k[j] >> rank_bits;
+                if (sj + max_len <= s) { open = false; break; }
+                mx = max(mx, sj + pl[j].y);
             }
-            const uint64_t p0 = s > A.max_len ? s - A.max_len : 0;
+            const uint64_t p0 = s > max_len ? s - max_len : 0;
             if (open && (p0 >> BUCKET_BITS) < B0)
-                mx = max(mx, raw_max_end(A, key_mode, T, (uint32_t)(p0 >> BUCKET_BITS), B0));
+                mx = max(mx, raw_max_end(rank_bits, key_mode, T, (uint32_t)(p0 >> BUCKET_BITS), B0));
         }
         T.syncf[gi + i] = mx <= s ? 1 : 0;
     }
 }
 
-__global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mode, int overlapping,
-                                                      TileSpace T, uint32_t tile0,
-                                                      const uint32_t *abort_flag) {
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_resolve(uint32_t rank_bits, int key_mode,
+                                                               int overlapping, TileSpace T, uint32_t tile0,
+                                                               const uint32_t *abort_flag) {
     __shared__ uint32_t rel[TILE_MAX]; // key position relative to the tile's first byte
     __shared__ uint32_t len[TILE_MAX];
     __shared__ uint8_t sy[TILE_MAX], ac[TILE_MAX];
@@ -1120,9 +1130,10 @@ __global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mo
     if (overlapping) {
         if (t < TILE_BUCKETS) cnt = bo[t + 1] - bo[t];
     } else {
-        for (uint32_t i = t; i < n; i += 256) {
-            rel[i] = (uint32_t)((T.tkeys[gi + i] >> A.rank_bits) - base);
-            len[i] = A.plen[T.tpids[gi + i]];
+        for (uint32_t i = t; i < n; i += TILE_THREADS) {
+            const uint4 v = T.trecs[gi + i];
+            rel[i] = (uint32_t)(((((uint64_t)v.y << 32) | v.x) >> rank_bits) - base);
+            len[i] = v.w;
             sy[i] = T.syncf[gi + i];
         }
         __syncthreads();
@@ -1143,8 +1154,7 @@ __global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mo
                     const uint32_t nn = T.tile_n[tt];
                     for (; q < nn; q++) {
                         uint64_t s, en;
-                        span_of(A, key_mode, T.tkeys[(uint64_t)tt * TILE_MAX + q],
-                                T.tpids[(uint64_t)tt * TILE_MAX + q], &s, &en);
+                        span_of(rank_bits, key_mode, T.trecs[(uint64_t)tt * TILE_MAX + q], &s, &en);
                         if (s >= pos) pos = en;
                     }
                 }
@@ -1158,7 +1168,7 @@ __global__ __launch_bounds__(256) void k_tile_resolve(DevAutomaton A, int key_mo
             }
         }
         __syncthreads();
-        for (uint32_t i = t; i < n; i += 256) T.accf[gi + i] = ac[i];
+        for (uint32_t i = t; i < n; i += TILE_THREADS) T.accf[gi + i] = ac[i];
     }
     if (t < 64) {
         for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
@@ -1191,12 +1201,19 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0,
         }
     const uint32_t per = (tile1 - tile0 + 1023) / 1024, g0 = tile0 + t * per;
     uint32_t mine = 0, excl = 0;
+    // (unrolled so that the loads of several tiles are in flight together)
     if (!stop)
-        for (uint32_t g = g0; g < g0 + per && g < tile1; g++) { mine += T.btot[g]; nsum += T.tile_n[g]; }
+        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < tile1; g++) {
+            mine += T.btot[g];
+            nsum += T.tile_n[g];
+        }
     scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
     excl += base;
     if (!stop)
-        for (uint32_t g = g0; g < g0 + per && g < tile1; g++) { T.bbase[g] = excl; excl += T.btot[g]; }
+        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < tile1; g++) {
+            T.bbase[g] = excl;
+            excl += T.btot[g];
+        }
     for (int o = 32; o > 0; o >>= 1) {
         hsum += __shfl_down(hsum, o);
         nsum += __shfl_down(nsum, o);
@@ -1214,39 +1231,41 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0,
 }
 
 // zero_lo..zero_hi: the arrival counters this launch leaves clean for the next call
-__global__ __launch_bounds__(256) void k_tile_write(DevAutomaton A, int key_mode, int overlapping,
-                                                    TileSpace T, uint32_t tile0, uint32_t zero_lo,
-                                                    uint32_t zero_hi, acx_match_t *out,
-                                                    const uint32_t *abort_flag) {
+__global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, int overlapping,
+                                                             TileSpace T, uint32_t tile0, uint32_t zero_lo,
+                                                             uint32_t zero_hi, acx_match_t *out,
+                                                             const uint32_t *abort_flag) {
     __shared__ __attribute__((aligned(16))) uint8_t ac[TILE_MAX];
     __shared__ uint32_t dst[TILE_MAX];
-    using scan_t = rocprim::block_scan<uint32_t, 256>;
+    using scan_t = rocprim::block_scan<uint32_t, TILE_THREADS>;
     __shared__ typename scan_t::storage_type scan_tmp;
     const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x;
-    for (uint32_t i = zero_lo + blockIdx.x * 256 + t; i < zero_hi; i += gridDim.x * 256) T.bcnt[i] = 0;
+    for (uint32_t i = zero_lo + blockIdx.x * TILE_THREADS + t; i < zero_hi; i += gridDim.x * TILE_THREADS)
+        T.bcnt[i] = 0;
     if (*abort_flag) return; // stable by now: its writers completed
     const uint32_t n = T.tile_n[tile], base = T.bbase[tile];
     const uint64_t gi = (uint64_t)tile * TILE_MAX;
     if (overlapping) {
-        for (uint32_t i = t; i < n; i += 256) dst[i] = base + i;
+        for (uint32_t i = t; i < n; i += TILE_THREADS) dst[i] = base + i;
     } else {
-        for (uint32_t i = t; i < TILE_MAX; i += 256) ac[i] = i < n ? T.accf[gi + i] : 0;
+        for (uint32_t i = t; i < TILE_MAX; i += TILE_THREADS) ac[i] = i < n ? T.accf[gi + i] : 0;
         __syncthreads();
-        // thread t owns the 4 occurrences [4 t, 4 t + 4)
-        const uint32_t mine = __popc(*(const uint32_t *)&ac[t * 4]);
-        uint32_t excl = 0;
+        // thread t owns the occurrences [t * TILE_PER_THREAD, (t + 1) * TILE_PER_THREAD)
+        uint32_t mine = 0, excl = 0;
+        _Pragma("unroll") for (uint32_t w = 0; w < TILE_PER_THREAD / 4; w++)
+            mine += __popc(*(const uint32_t *)&ac[t * TILE_PER_THREAD + 4 * w]);
         scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
         uint32_t d = base + excl;
-        for (uint32_t q = t * 4; q < t * 4 + 4; q++) dst[q] = ac[q] ? d++ : DST_NONE;
+        for (uint32_t q = t * TILE_PER_THREAD; q < (t + 1) * TILE_PER_THREAD; q++) dst[q] = ac[q] ? d++ : DST_NONE;
     }
     __syncthreads();
-    for (uint32_t i = t; i < n; i += 256) {
+    for (uint32_t i = t; i < n; i += TILE_THREADS) {
         const uint32_t d = dst[i];
         if (d == DST_NONE) continue;
-        const uint32_t pid = T.tpids[gi + i];
+        const uint4 v = T.trecs[gi + i];
         uint64_t s, e;
-        span_of(A, key_mode, T.tkeys[gi + i], pid, &s, &e);
-        out[d].pattern = pid; out[d].start = s; out[d].end = e;
+        span_of(rank_bits, key_mode, v, &s, &e);
+        out[d].pattern = v.z; out[d].start = s; out[d].end = e;
     }
 }
 
@@ -1263,15 +1282,16 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const int ov = overlapping ? 1 : 0;
     const uint32_t tiles = tile1 - tile0;
     if (tiles) {
-        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0, abort_flag);
-        hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0,
-                           abort_flag);
+        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, A.max_len, key_mode,
+                           ov, T, tile0, abort_flag);
+        hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
+                           tile0, abort_flag);
     }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, tile0, tile1, first ? 1 : 0, hit_counts,
                        hit_grid, hit_cap, summary, abort_flag, last ? next_flag : nullptr);
     if (tiles)
-        hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(256), 0, st, A, key_mode, ov, T, tile0, 0u,
-                           last ? T.n_buckets + 1 : 0u, out, abort_flag);
+        hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
+                           tile0, 0u, last ? T.n_buckets + 1 : 0u, out, abort_flag);
     return hipGetLastError();
 }
 

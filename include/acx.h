@@ -124,7 +124,9 @@ typedef struct acx_host_tables {
     const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
     const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} words */
     const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi,
-                                     state | OWN<<30 | KIDS<<31 (0xFFFFFFFF = empty), 0} */
+                                     state | OWN<<30 | MORE<<31 (0xFFFFFFFF = empty; MORE: another
+                                     prefix with this home slot sits further along the probe
+                                     sequence), pattern id or 0x80000000 | candidate list} */
     uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2          */
     uint32_t filter_entries_log2, prefix_table_log2;
     double filter_density;        /* fraction of X bits set                            */

@@ -111,6 +111,17 @@ def test_prefilter_tables_have_every_pattern_prefix():
             sid = st & ID_MASK
             assert h.level_start[q2] <= sid < h.level_start[q2 + 1]
             assert bool(st & FLAG_OWN) == (len(p) == q2 or any(len(o) == q2 and o == p[:q2] for o in pats))
+        # MORE (bit 31 of word 2) is set on a home slot iff some prefix hashing there lives elsewhere
+        tab = np.asarray(h.prefix_table)
+        used = np.nonzero(tab[:, 2] != 0xFFFFFFFF)[0]
+        displaced_homes = set()
+        for e in used:
+            gram = (int(tab[e, 1]) << 32 | int(tab[e, 0])).to_bytes(8, "little")[:q2]
+            home = capi.prefix_slot(gram, lg)
+            if home != e:
+                displaced_homes.add(home)
+        for e in used:
+            assert bool(int(tab[e, 2]) >> 31) == (int(e) in displaced_homes)
         assert 0 < h.t.filter_density <= 2 * len(pats) / (32 << 14)
         h.close()
 
