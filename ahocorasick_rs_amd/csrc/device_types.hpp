@@ -62,8 +62,8 @@ struct Segments {
 // *abort_flag and the host redoes the call in region mode.
 constexpr uint32_t BUCKET_SLOTS = 32;  // occurrence slots per bucket
 constexpr uint32_t BUCKET_BITS = 12;   // bucket = 4 KiB of stream position
-constexpr uint32_t TILE_BUCKETS = 32;  // buckets per workgroup of the tile kernels (K2b)
-constexpr uint32_t TILE_MAX = 512;     // occurrences per tile (held in LDS)
+constexpr uint32_t TILE_BUCKETS = 64;  // buckets per workgroup of the tile kernels (K2b)
+constexpr uint32_t TILE_MAX = 1024;    // occurrences per tile (held in LDS)
 struct Sink {
     uint4 *recs;            // region_cap * quads uint4 per region
     uint32_t *bucket_cnt;   // slot mode: per-bucket arrival counters

@@ -988,11 +988,11 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // depends only on the number of buckets (known to the host), never on the number of
 // occurrences (known only to the device), so the whole post stage is queued behind the
 // scan without a host round trip.  A workgroup owns a tile of TILE_BUCKETS consecutive
-// buckets (128 KiB of stream position); its occurrences (at most TILE_MAX, else the
+// buckets (256 KiB of stream position); its occurrences (at most TILE_MAX, else the
 // abort flag -> region mode + radix sort) are staged in LDS so that the per-bucket serial
 // work runs at LDS latency and every global access is coalesced.  These kernels are
 // latency chains (a few dependent HBM round trips per tile), so the workgroups are small
-// (one wave, 8 KiB of LDS): all tiles of a GiB are resident at once.
+// (two waves, 16 KiB of LDS).
 //   k_tile_sort     gather the slots, per-bucket insertion sort, sync-point flag of
 //                   every occurrence
 //   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point;
@@ -1000,7 +1000,7 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 //   k_tile_scan     exclusive scan of the tile counts, totals (one workgroup)
 //   k_tile_write    compaction into the final (pattern, start, end) records
 constexpr uint32_t DST_NONE = 0xFFFFFFFFu;
-constexpr uint32_t TILE_THREADS = 64;
+constexpr uint32_t TILE_THREADS = 128;
 constexpr uint32_t TILE_PER_THREAD = TILE_MAX / TILE_THREADS; // k_tile_write
 static_assert(TILE_BUCKETS <= 64, "one wave owns the buckets of a tile");
 static_assert(TILE_THREADS % TILE_BUCKETS == 0 && TILE_PER_THREAD % 4 == 0, "tile geometry");
