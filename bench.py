@@ -11,9 +11,10 @@ Metric (BASELINE.json): haystack GB/s (+ % of the HBM roofline), 10k-pattern DFA
           data-path collective; RCCL all-gather of the per-shard match counts only.
 
 A "step" is one complete pass of the hot path over the rank's resident batch: scan kernel
-(K1) -> compaction -> radix sort -> match-kind resolution -> final (pattern, start, end)
-u64 triples in HBM (+ the count all-gather for N > 1).  Inputs are resident in HBM before
-the timed region; nothing is cached between steps.
+(K1b prefilter) -> verification (k_walk_hits) -> tile kernels (sort, match-kind resolution,
+scan, write) -> final (pattern, start, end) u64 triples in HBM, their count on the host
+(+ the count all-gather for N > 1).  Inputs are resident in HBM before the timed region;
+nothing is cached between steps.
 
 One JSON line on rank 0; `roofline` is for the dominant kernel (K1) from HIP events recorded
 on the library's stream inside the timed region; `cpu_baseline` is the oracle's C DFA loop
