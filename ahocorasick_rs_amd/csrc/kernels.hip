@@ -515,7 +515,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     // call, or everything).  `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
     // stream and are never candidates.  Stream position = index - lead.
     __shared__ __attribute__((aligned(16))) K1bLds L;
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    // the wave index is wave-uniform: say so, and the tile index, its byte offset, the
+    // interior test and most of the prefetch address arithmetic move from VALU to SALU
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
     if (threadIdx.x == 0) L.count = 0;
     const BlockSink K = block_sink(GK, &L.count, 2); // sink of prefix hits (two quads per record)
@@ -580,18 +582,30 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint64_t last_block = total16 - 16;
     u32x4 nxt0, nxt1, nxt2, nxt3;
     uint2 nxtL;
+#define K1B_LOAD16(DST, PTR) DST = (ablate & 16) ? *(const u32x4 *)(PTR) : load16_stream(PTR); /* 16: plain loads */
 #define K1B_ISSUE_ROW(DST, TILE, R)                                                              \
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
         const uint8_t *ptr_ = hay + (off_ < last_block ? off_ : last_block);                     \
-        DST = (ablate & 16) ? *(const u32x4 *)ptr_ : load16_stream(ptr_); /* 16: plain loads */  \
+        K1B_LOAD16(DST, ptr_)                                                                    \
     }
+    // The tile index is wave-uniform (SGPRs): a tile that lies wholly inside the stream -- all
+    // but the last one -- is addressed as scalar base + lane * 16 + immediate row offset, no
+    // VALU address arithmetic; both branches issue the same five loads.
 #define K1B_ISSUE_TILE(TILE)                                                                     \
-    K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2)       \
-    K1B_ISSUE_ROW(nxt3, TILE, 3)                                                                 \
     {                                                                                            \
-        uint64_t off_ = ((TILE) + 1) * tile_bytes;                                               \
-        nxtL = *(const uint2 *)(hay + (off_ < last_block ? off_ : last_block));                  \
+        const uint64_t tb_ = (TILE) * tile_bytes;                                                \
+        if (tb_ + tile_bytes <= last_block) {                                                    \
+            const uint8_t *tp_ = hay + tb_ + lane * 16;                                          \
+            K1B_LOAD16(nxt0, tp_) K1B_LOAD16(nxt1, tp_ + 1024) K1B_LOAD16(nxt2, tp_ + 2048)      \
+            K1B_LOAD16(nxt3, tp_ + 3072)                                                         \
+            nxtL = *(const uint2 *)(hay + tb_ + tile_bytes);                                     \
+        } else {                                                                                 \
+            K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2) \
+            K1B_ISSUE_ROW(nxt3, TILE, 3)                                                         \
+            uint64_t off_ = tb_ + tile_bytes;                                                    \
+            nxtL = *(const uint2 *)(hay + (off_ < last_block ? off_ : last_block));              \
+        }                                                                                        \
     }
     K1B_ISSUE_TILE(gw)
 
@@ -723,6 +737,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     __syncthreads();
     if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = L.count;
 #undef K1B_ISSUE_ROW
+#undef K1B_LOAD16
 #undef K1B_ISSUE_TILE
 #undef K1B_HIT_PUSH
 #undef K1B_ROW
