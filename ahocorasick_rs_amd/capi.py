@@ -327,6 +327,10 @@ class Automaton:
         _check(lib().acx_automaton_info(self._h, ctypes.byref(i)))
         return i
 
+    @property
+    def max_pattern_len(self) -> int:
+        return int(self.info.max_pattern_len)
+
     def set_kernel(self, kernel: int) -> None:
         _check(lib().acx_set_kernel(self._h, kernel))
 

@@ -1,10 +1,14 @@
-"""Multi-GPU batches: one process per GPU, haystacks sharded by index.
+"""Multi-GPU: one process per GPU.
 
-The hot path shards naturally (independent haystacks), so there is NO data-path
-collective: every rank scans its own contiguous range of haystacks with its own
-replica of the automaton.  The only exchange is C1 of SURVEY.md §2: an
-all-gather of the per-rank match counts (world x 8 bytes, latency-bound over
-xGMI), from which every rank derives the global output offsets of its matches.
+Batches (cfg3): haystacks sharded by index.  The hot path shards naturally (independent
+haystacks), so there is NO data-path collective: every rank scans its own contiguous range
+of haystacks with its own replica of the automaton.  The only exchange is C1 of SURVEY.md §2:
+an all-gather of the per-rank match counts (world x 8 bytes, latency-bound over xGMI), from
+which every rank derives the global output offsets of its matches.
+
+One large haystack (second row): byte ranges with an overlap of
+max_pattern_len - 1 bytes; the only exchange is the greedy's carry -- where the previous
+rank's last match ends -- as an all-gather of one integer per rank (find_single_sharded).
 
 Works with any torch.distributed backend: `nccl` (= RCCL on ROCm) on GPUs,
 `gloo` in the CPU tests.
@@ -67,3 +71,110 @@ def find_batch_sharded(automaton, haystacks: Sequence[bytes], overlapping: bool 
     rank_counts, off, total = gather_match_counts(len(matches), group=group)
     return {"lo": lo, "hi": hi, "matches": matches, "counts": counts,
             "rank_counts": rank_counts, "global_offset": off, "global_total": total}
+
+
+# ---------------------------------------------------------------------------
+# one large haystack cut into byte ranges
+# ---------------------------------------------------------------------------
+def _shift(matches, by: int):
+    if by and len(matches):
+        matches = matches.copy()
+        matches["start"] += by
+        matches["end"] += by
+    return matches
+
+
+def _local_overlapping(automaton, hay, lo: int, hi: int, m: int):
+    """All occurrences that END in (lo, hi] (rank 0: in (0, hi]); global offsets.  An occurrence
+    that ends in the range starts at most m = max_pattern_len - 1 bytes before it."""
+    w = max(0, lo - m)
+    got = _shift(automaton.find(hay[w:hi], overlapping=True), w)
+    return got[got["end"] > lo] if lo > 0 else got
+
+
+def _local_greedy(automaton, hay, carry: int, hi: int, m: int, last: bool):
+    """The non-overlapping matches that START in [carry, hi), global offsets, given that the
+    global iteration resumes at `carry` (the end of the last match that starts before this
+    range, or the range's own start).  A match that starts before hi ends at most m bytes
+    after it, and no occurrence the truncated window hides can beat one that it shows."""
+    n = len(hay)
+    got = _shift(automaton.find(hay[carry:n if last else min(n, hi + m)], overlapping=False), carry)
+    return got if last else got[got["start"] < hi]
+
+
+def _carry_out(matches, hi: int, carry_in: int) -> int:
+    """Where the global iteration stands when it leaves a range that ends at hi."""
+    return max(hi, carry_in, int(matches["end"][-1]) if len(matches) else 0)
+
+
+def simulate_single_sharded(automaton, haystack, world: int, overlapping: bool = False):
+    """What find_single_sharded returns on every rank of a `world`-rank job, computed
+    sequentially in one process (tests, single-GPU validation).  List of per-rank match arrays;
+    their concatenation equals automaton.find(haystack, overlapping)."""
+    hay = memoryview(haystack).cast("B")
+    m = max(int(automaton.max_pattern_len) - 1, 0)
+    out, carry = [], 0
+    for rank in range(world):
+        lo, hi = shard_range(len(hay), rank, world)
+        if overlapping:
+            out.append(_local_overlapping(automaton, hay, lo, hi, m))
+            continue
+        carry = max(carry, lo)
+        got = _local_greedy(automaton, hay, carry, hi, m, rank == world - 1)
+        out.append(got)
+        carry = _carry_out(got, hi, carry)
+    return out
+
+
+def find_single_sharded(automaton, haystack, overlapping: bool = False, group=None):
+    """This rank's part of automaton.find(haystack, overlapping) when ONE haystack (every rank
+    passes the same bytes-like object) is cut into `world` contiguous byte ranges.
+
+    overlapping: a rank reports the occurrences that END in its range (window = range plus
+    max_pattern_len - 1 bytes to the left); no exchange beyond the counts.
+    non-overlapping (any match kind): a rank reports the matches that START in its range.  The
+    only coupling is the carry: a match of the previous rank that ends inside this range moves
+    the point the iteration resumes at.  Every rank first scans speculatively from its range
+    start; the carries are all-gathered (one integer per rank); a rank whose true carry
+    differs rescans from it; repeat until nothing changes (one round unless a match straddles
+    a cut, at most `world` rounds).  Offsets are global byte offsets.
+
+    `automaton`: find(bytes-like, overlapping=) -> structured array (pattern, start, end) and
+    max_pattern_len, e.g. ahocorasick_rs_amd.capi.Automaton.
+    Returns dict(lo, hi, matches, rank_counts, global_offset, global_total, rounds)."""
+    import torch
+    import torch.distributed as dist
+    hay = memoryview(haystack).cast("B")
+    on = dist.is_initialized()
+    rank = dist.get_rank(group) if on else 0
+    world = dist.get_world_size(group) if on else 1
+    lo, hi = shard_range(len(hay), rank, world)
+    m = max(int(automaton.max_pattern_len) - 1, 0)
+    rounds = 0
+    if overlapping:
+        got = _local_overlapping(automaton, hay, lo, hi, m)
+    else:
+        device = None
+        if on:
+            device = torch.device("cuda", torch.cuda.current_device()) \
+                if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        carry, last = lo, rank == world - 1
+        got = _local_greedy(automaton, hay, carry, hi, m, last)
+        while on and world > 1:
+            rounds += 1
+            mine = torch.tensor([_carry_out(got, hi, carry)], dtype=torch.int64, device=device)
+            every = torch.zeros(world, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(every, mine, group=group)
+            outs = [int(x) for x in every.cpu().tolist()]
+            want = lo if rank == 0 else max(lo, outs[rank - 1])
+            changed = want != carry
+            if changed:
+                carry = want
+                got = _local_greedy(automaton, hay, carry, hi, m, last)
+            flag = torch.tensor([1 if changed else 0], dtype=torch.int64, device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
+            if int(flag.item()) == 0:
+                break
+    rank_counts, off, total = gather_match_counts(len(got), group=group)
+    return {"lo": lo, "hi": hi, "matches": got, "rank_counts": rank_counts,
+            "global_offset": off, "global_total": total, "rounds": rounds}

@@ -101,3 +101,101 @@ def test_shard_range_properties():
     assert D.exclusive_offsets([3, 0, 5]) == [0, 3, 3]
     with pytest.raises(ValueError):
         D.shard_range(10, 2, 2)
+
+
+# ---------------------------------------------------------------------------
+# ONE haystack cut into byte ranges (second row)
+# ---------------------------------------------------------------------------
+MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
+
+
+class _OracleSingle:
+    """find() / max_pattern_len with the product's (capi.Automaton) signature, from the oracle."""
+
+    def __init__(self, pats, mk):
+        from oracle_lib import KIND_DFA, Oracle
+        self.o = Oracle(pats, mk, KIND_DFA)
+        self.max_pattern_len = max(len(p) for p in pats)
+        self.calls = 0
+
+    def find(self, hay, overlapping=False, codepoints=False):
+        self.calls += 1
+        raw = self.o.find_raw(bytes(hay), overlapping)
+        out = np.empty(len(raw), dtype=MATCH_DTYPE)
+        out["pattern"], out["start"], out["end"] = raw[:, 0], raw[:, 1], raw[:, 2]
+        return out
+
+
+def _load_distributed():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "acx_distributed", os.path.join(os.path.dirname(HERE), "ahocorasick_rs_amd", "distributed.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    return D
+
+
+def _single_case(mk):
+    """Patterns that overlap one another heavily + a haystack whose matches straddle every cut
+    of a 2- and 3-way split (so the carry exchange has to do real work)."""
+    sys.path.insert(0, HERE)
+    import gen
+    pats = [b"abab", b"bab", b"ababab", b"cc", b"ccc", b"abcabcabcabc"] + gen.gen_patterns(40, 2, 6, b"abc", 31)
+    hay = bytearray(gen.gen_uniform(6000, b"abcx", 32).tobytes())
+    for cut in (2000, 3000, 4000):
+        hay[cut - 7:cut + 7] = b"abababababcccc"
+    return pats, bytes(hay)
+
+
+def _worker_single(rank, world, port, mk, overlapping, ret):
+    sys.path.insert(0, HERE)
+    import torch.distributed as dist
+    D = _load_distributed()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    pats, hay = _single_case(mk)
+    a = _OracleSingle(pats, mk)
+    res = D.find_single_sharded(a, hay, overlapping=overlapping)
+    m = res["matches"]
+    ret[rank] = (res["lo"], res["hi"], np.stack([m["pattern"], m["start"], m["end"]], 1).tolist(),
+                 res["rank_counts"], res["global_offset"], res["global_total"], res["rounds"], a.calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("mk,overlapping", [(0, False), (0, True), (1, False), (2, False)])
+def test_single_haystack_sharded_equals_whole(world, mk, overlapping):
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_single, args=(world, port, mk, overlapping, ret), nprocs=world, join=True)
+    pats, hay = _single_case(mk)
+    from oracle_lib import KIND_DFA, Oracle
+    whole = Oracle(pats, mk, KIND_DFA).find_raw(hay, overlapping).tolist()
+    cat = sum((ret[r][2] for r in range(world)), [])
+    assert cat == whole
+    counts = [len(ret[r][2]) for r in range(world)]
+    for r in range(world):
+        assert ret[r][3] == counts and ret[r][4] == sum(counts[:r]) and ret[r][5] == len(whole)
+        if not overlapping:
+            assert 1 <= ret[r][6] <= world  # carry rounds
+    # the same answer from the sequential simulation (what the GPU tests use on one device)
+    D = _load_distributed()
+    sim = D.simulate_single_sharded(_OracleSingle(pats, mk), hay, world, overlapping)
+    assert [np.stack([m["pattern"], m["start"], m["end"]], 1).tolist() for m in sim] == \
+        [ret[r][2] for r in range(world)]
+
+
+def test_single_haystack_ranges_shorter_than_a_pattern():
+    # a match that swallows whole ranges: the carry passes through ranks that report nothing
+    D = _load_distributed()
+    pats = [b"abcdefghijklmnop", b"gh", b"p"]
+    hay = b"xxabcdefghijklmnopxx"
+    from oracle_lib import KIND_DFA, Oracle
+    for mk in (0, 1, 2):
+        for ov in ([False, True] if mk == 0 else [False]):
+            whole = Oracle(pats, mk, KIND_DFA).find_raw(hay, ov).tolist()
+            for world in (1, 2, 5, 7):
+                sim = D.simulate_single_sharded(_OracleSingle(pats, mk), hay, world, ov)
+                cat = sum((np.stack([m["pattern"], m["start"], m["end"]], 1).tolist() for m in sim), [])
+                assert cat == whole, (mk, ov, world)

@@ -135,3 +135,23 @@ def test_baseline_size_1gib_bit_exact():
     for (p, s, e) in got[:: max(1, len(got) // 2000)]:
         assert host[int(s):int(e)].tobytes() == pats[int(p)]
     a.close()
+
+
+@pytest.mark.parametrize("mk", [0, 1, 2])
+def test_single_haystack_cut_into_rank_ranges(mk):
+    """distributed.simulate_single_sharded == every rank of find_single_sharded, run on one
+    device: the ranges' matches concatenate to the whole haystack's, for every match kind."""
+    from ahocorasick_rs_amd import distributed as D
+    pats = gen.gen_patterns(2000, 3, 9, gen.AZ, 41) + [b"abab", b"bab", b"ababab"]
+    hay = bytearray(gen.gen_textlike(1 << 20, 42, pats).tobytes())
+    for cut in range(1 << 17, 1 << 20, 1 << 17):  # matches straddling the cuts of an 8-way split
+        hay[cut - 5:cut + 5] = b"ababababab"
+    hay = bytes(hay)
+    a = capi.Automaton(pats, mk)
+    for ov in ([False, True] if mk == 0 else [False]):
+        whole = cols(a.find(hay, overlapping=ov))
+        for world in (2, 8):
+            parts = D.simulate_single_sharded(a, hay, world, overlapping=ov)
+            got = np.concatenate([cols(p) for p in parts])
+            assert np.array_equal(got, whole), (mk, ov, world)
+    a.close()
