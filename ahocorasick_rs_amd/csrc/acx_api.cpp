@@ -205,7 +205,7 @@ int ensure_common(acx_automaton *a) {
         HIPCHK(hipMalloc((void **)&w.summary, 64));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
-        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 1024 * acx_automaton::MAX_CHUNKS));
+        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024 * acx_automaton::MAX_CHUNKS));
         HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
         w.sparse_dirty = true;
     }
@@ -357,7 +357,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
         const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
                                        : dfa_walk_grid(a->dev, len, a->n_cus);
-        const uint32_t grid = pre ? walk_hits_grid(scan_grid) : scan_grid; // emitting workgroups
+        const uint32_t hit_grid = pre ? prefilter_hit_regions(scan_grid) : 0; // hit regions of one K1b launch
+        const uint32_t grid = pre ? walk_hits_grid(hit_grid) : scan_grid;    // emitting workgroups
         const int rank_bits = (int)a->dev.rank_bits;
         const uint32_t bshift = (uint32_t)rank_bits + BUCKET_BITS;
         const uint64_t nb = (len >> BUCKET_BITS) + 2; // buckets of 4 KiB of stream position
@@ -373,7 +374,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             // the other kernels only get on the CUs when a K1b workgroup retires.
             static const int chunk_env = std::getenv("ACX_CHUNKS") ? std::atoi(std::getenv("ACX_CHUNKS")) : 1;
             const int chunks = sparse && pre ? std::max(1, std::min(chunk_env, (int)acx_automaton::MAX_CHUNKS)) : 1;
-            const uint64_t hit_regions = (uint64_t)scan_grid * chunks; // every chunk has its own hit regions
+            const uint64_t hit_regions = (uint64_t)hit_grid * chunks; // every chunk has its own hit regions
             const uint64_t hit_cap = pre ? w.hit_total / hit_regions : 0;
             Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode, nullptr, nullptr};
             if (sparse) {
@@ -425,8 +426,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                         const bool last = c == chunks - 1;
                         if (t1 == t0 && !last) continue;
                         Sink Hc = H;
-                        Hc.recs = w.hrecs + (uint64_t)c * scan_grid * hit_cap * 2;
-                        Hc.block_counts = w.hit_counts + (uint64_t)c * scan_grid;
+                        Hc.recs = w.hrecs + (uint64_t)c * hit_grid * hit_cap * 2;
+                        Hc.block_counts = w.hit_counts + (uint64_t)c * hit_grid;
                         hipError_t e = launch_prefilter(a->dev, a->d_dev, G, Hc, d_hay, len, scan_grid, t0, t1, st);
                         if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
                         if (last && a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
@@ -434,12 +435,11 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                             HIPCHK_R(hipEventRecord(a->chunk_ev[c], st));
                             HIPCHK_R(hipStreamWaitEvent(ps, a->chunk_ev[c], 0));
                         }
-                        HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, Hc, scan_grid, std::max(1u, walk_hits_grid(1) / (uint32_t)chunks), K,
-                                                  d_hay, len, ps));
+                        HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, Hc, hit_grid, 0, K, d_hay, len, ps));
                         const uint32_t tile1 = last ? T.n_tiles
                                                     : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
                         HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, tile0, std::max(tile0, tile1), first,
-                                           last, Hc.block_counts, scan_grid, hit_cap, w.final, w.summary, abort_flag,
+                                           last, Hc.block_counts, hit_grid, hit_cap, w.final, w.summary, abort_flag,
                                            next_flag, ps));
                         tile0 = std::max(tile0, tile1);
                         first = false;
@@ -478,8 +478,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                                  a->max_lds, st);
             if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
             if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, scan_grid, 0, K, d_hay, len, st));
-            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, pre ? w.hit_counts : nullptr, scan_grid,
+            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, hit_grid, 0, K, d_hay, len, st));
+            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, pre ? w.hit_counts : nullptr, hit_grid,
                                   hit_cap, w.summary, w.region_off, st));
             HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
             HIPCHK_R(hipStreamSynchronize(st));

@@ -66,19 +66,18 @@ ACX_HD static inline uint32_t filter_entry(uint32_t H) { return H >> (32 - FILTE
 ACX_HD static inline uint32_t filter_sig(uint32_t W, uint32_t b) {
     return (1u << (b & 31)) | (1u << (W & 31));
 }
-// 32-bit hash of a Q2-gram (little-endian in a u64, masked to Q2 bytes)
+// 32-bit hash of a Q2-gram (little-endian in a u64, masked to Q2 bytes): two multiplicative
+// hashes xor-ed; the table index is taken from the TOP bits (prefix_slot), where a
+// multiplicative hash is well mixed.  (K1b evaluates this for every level-1 survivor.)
 ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
-    uint32_t h = (uint32_t)gram * 0x85EBCA6Bu + (uint32_t)(gram >> 32) * 0xC2B2AE35u;
-    h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 13;
-    return h;
+    return ((uint32_t)gram * 0x9E3779B1u) ^ ((uint32_t)(gram >> 32) * 0x85EBCA6Bu);
 }
 // prefix-table entry, word 2: empty marker / "more prefixes with this home slot further along"
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PREFIX_MORE = 0x80000000u;
 // slot of a Q2-gram in the prefix table (2^log2 entries)
 ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
-    uint32_t m = (h2 ^ (h2 >> 7)) * 0x9E3779B1u;
-    return log2 ? m >> (32 - log2) : 0;
+    return log2 ? h2 >> (32 - log2) : 0;
 }
 static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     uint64_t g = 0;

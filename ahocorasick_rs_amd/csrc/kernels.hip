@@ -472,7 +472,7 @@ __device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments
     }
 }
 
-constexpr uint32_t K_WALK_SPLIT = 16; // workgroups per hit region of an unchunked call
+constexpr uint32_t K_WALK_SPLIT = 1; // workgroups per hit region (a region = one K1b wave's hits)
 
 // One thread per prefix hit of K1b.  Hits live in the per-workgroup regions of
 // the scan's sink (H); occurrences go to the occurrence sink (GK).
@@ -519,8 +519,12 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     // interior test and most of the prefetch address arithmetic move from VALU to SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
-    if (threadIdx.x == 0) L.count = 0;
-    const BlockSink K = block_sink(GK, &L.count, 2); // sink of prefix hits (two quads per record)
+    // sink of prefix hits (two quads per record): every WAVE owns a region and keeps its cursor
+    // in an SGPR -- no atomic, no cross-lane traffic on the push path
+    const uint32_t region = blockIdx.x * 16 + wave;
+    uint4 *const hrec = GK.recs + (uint64_t)region * GK.region_cap * 2;
+    const uint32_t hcap = (uint32_t)(GK.region_cap < 0xFFFFFFFFull ? GK.region_cap : 0xFFFFFFFFull);
+    uint32_t hcur = 0;
     {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
@@ -552,25 +556,22 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     uint32_t offB = 0, offC = 0;
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
 
-    // hand the prefix hits (p, st) of the lanes with found == true to the sink:
-    // one LDS atomic per wave reserves the slots
+    // hand the prefix hits (p, st) of the lanes with found == true to the wave's region
 #define K1B_HIT_PUSH(FOUND, P, ST, W0, W1)                                                       \
     {                                                                                            \
         unsigned long long fm_ = __ballot(FOUND);                                                \
         if (fm_) {                                                                               \
-            uint32_t base_ = 0;                                                                  \
-            if (lane == (uint32_t)__builtin_ctzll(fm_)) base_ = atomicAdd(K.lcount, (uint32_t)__popcll(fm_)); \
-            base_ = __shfl(base_, __builtin_ctzll(fm_));                                         \
             if (FOUND) {                                                                         \
-                uint32_t slot_ = base_ + __builtin_amdgcn_mbcnt_hi(                              \
-                                             (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
-                if (slot_ < K.region_cap) {                                                      \
+                uint32_t slot_ = hcur + __builtin_amdgcn_mbcnt_hi(                               \
+                                            (uint32_t)(fm_ >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
+                if (slot_ < hcap) {                                                              \
                     uint64_t p_ = (P), a_ = (W0), b_ = (W1);                                     \
-                    K.recs[2 * slot_] = make_uint4((uint32_t)p_, (uint32_t)(p_ >> 32), (ST), 0); \
-                    K.recs[2 * slot_ + 1] = make_uint4((uint32_t)a_, (uint32_t)(a_ >> 32),       \
-                                                       (uint32_t)b_, (uint32_t)(b_ >> 32));      \
+                    hrec[2 * slot_] = make_uint4((uint32_t)p_, (uint32_t)(p_ >> 32), (ST), 0);   \
+                    hrec[2 * slot_ + 1] = make_uint4((uint32_t)a_, (uint32_t)(a_ >> 32),         \
+                                                     (uint32_t)b_, (uint32_t)(b_ >> 32));        \
                 }                                                                                \
             }                                                                                    \
+            hcur += (uint32_t)__popcll(fm_); /* keeps counting past the capacity */              \
         }                                                                                        \
     }
 
@@ -734,8 +735,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             __builtin_amdgcn_wave_barrier();
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = L.count;
+    if (lane == 0) GK.block_counts[region] = hcur;
 #undef K1B_ISSUE_ROW
 #undef K1B_LOAD16
 #undef K1B_ISSUE_TILE
@@ -764,7 +764,7 @@ static uint32_t ablation_flags() {
     return (uint32_t)v;
 }
 
-uint32_t walk_hits_grid(uint32_t hit_grid) { return hit_grid * K_WALK_SPLIT; }
+uint32_t walk_hits_grid(uint32_t hit_regions) { return hit_regions * K_WALK_SPLIT; }
 
 hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
@@ -774,6 +774,8 @@ hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const
                        split, occ, d_hay, len, ablation_flags());
     return hipGetLastError();
 }
+
+uint32_t prefilter_hit_regions(uint32_t grid) { return grid * 16; } // one per wave
 
 uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
     const uint64_t total = ((uintptr_t)d_hay & 15) + len;

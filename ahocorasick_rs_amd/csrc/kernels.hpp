@@ -19,8 +19,10 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
                            size_t max_lds, hipStream_t st);
 // K1b: LDS q-gram prefilter + anchored DFA verification.
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
-// scans the 4 KiB tiles [tile_begin, tile_end) of the stream (prefilter_tiles() in all)
+// scans the 4 KiB tiles [tile_begin, tile_end) of the stream (prefilter_tiles() in all);
+// the hit sink K needs prefilter_hit_regions(grid) regions (one per wave)
 uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len);
+uint32_t prefilter_hit_regions(uint32_t grid);
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                             uint64_t tile_begin, uint64_t tile_end, hipStream_t st);
@@ -31,9 +33,9 @@ hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t re
 hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
                         uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st);
 // K1b emits prefix hits (position, depth-Q2 state); this kernel walks them into
-// occurrences.  `hits` is K1b's sink (hit_grid regions), `occ` the occurrence
-// sink with walk_hits_grid(hit_grid) regions.
-uint32_t walk_hits_grid(uint32_t hit_grid);
+// occurrences.  `hits` is K1b's sink (hit_grid = prefilter_hit_regions() regions), `occ`
+// the occurrence sink with walk_hits_grid(hit_grid) regions.
+uint32_t walk_hits_grid(uint32_t hit_regions);
 hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
                             const uint8_t *d_hay, uint64_t len, hipStream_t st);
