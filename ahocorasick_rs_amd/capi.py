@@ -55,7 +55,8 @@ class HostTables(ctypes.Structure):
 class Profile(ctypes.Structure):
     _fields_ = [("scan_ms", ctypes.c_double), ("scan_launches", ctypes.c_uint64),
                 ("post_ms", ctypes.c_double), ("scan_bytes", ctypes.c_uint64),
-                ("raw_occurrences", ctypes.c_uint64), ("prefix_hits", ctypes.c_uint64)]
+                ("raw_occurrences", ctypes.c_uint64), ("prefix_hits", ctypes.c_uint64),
+                ("small_calls", ctypes.c_uint64)]
 
 
 def _preload_hip_runtime() -> None:

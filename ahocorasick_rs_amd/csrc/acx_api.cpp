@@ -105,7 +105,9 @@ struct Workspace {
                                       // hits, [4] matches written, [5] abort flag of the sparse path
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
-    uint64_t *h_pinned = nullptr;     // pinned host scratch (8 x u64)
+    uint64_t *h_pinned = nullptr;     // pinned host scratch (16 x u64; [8], [9] = result of K0)
+    uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
+    acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
     TileSpace T{};                    // sparse path (slot mode + tile kernels)
@@ -136,6 +138,7 @@ struct acx_automaton {
     std::mutex stage_mu; // guards the host staging buffers (taken before mu)
     Workspace ws;
     bool prof = false;
+    bool kernel_forced = false; // the scan kernel was chosen explicitly: K0 never takes a call
     int dense_hold = 0; // > 0: the output was too dense for the sparse path; calls left in region mode
     acx_profile_t profile{};
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
@@ -196,6 +199,8 @@ void free_ws(Workspace &w, int device) {
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
+    if (w.pin_hay) (void)hipHostFree(w.pin_hay);
+    if (w.pin_out) (void)hipHostFree(w.pin_out);
     w = Workspace();
 }
 
@@ -206,7 +211,7 @@ int ensure_common(acx_automaton *a) {
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024 * acx_automaton::MAX_CHUNKS));
-        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 64, hipHostMallocDefault));
+        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 128, hipHostMallocDefault));
         w.sparse_dirty = true;
     }
     return ACX_OK;
@@ -304,6 +309,29 @@ int bits_for(uint64_t x) { // number of bits needed to represent x
     return b;
 }
 
+// K0 takes the call when the haystack is small and nobody asked for a particular scan kernel
+bool small_ok(const acx_automaton *a, uint64_t len) {
+    static const bool off = std::getenv("ACX_NO_SMALL") != nullptr;
+    return !off && !a->kernel_forced && len > 0 && len <= SMALL_MAX_LEN && a->host.n_patterns > 0;
+}
+
+// One K0 launch + one sync.  hay / out: anything the device can address (HBM or pinned host);
+// out holds SMALL_MAX_OCC records.  *done = false: too many occurrences, use the general path.
+// Caller holds a->mu.
+int run_small(acx_automaton *a, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
+              acx_match_t *out, uint64_t *n_out, bool *done) {
+    *done = false;
+    int rc = ensure_common(a);
+    if (rc) return rc;
+    Workspace &w = a->ws;
+    const int key_mode = overlapping ? 0 : a->host.match_kind;
+    HIPCHK(launch_small(a->dev, hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
+                        w.h_pinned + 8, a->stream));
+    HIPCHK(hipStreamSynchronize(a->stream));
+    if (w.h_pinned[9] == 0) { *n_out = w.h_pinned[8]; *done = true; a->profile.small_calls++; }
+    return ACX_OK;
+}
+
 void add_scan_profile(acx_automaton *a, uint64_t len) {
     if (!a->prof) return;
     float ms = 0;
@@ -320,7 +348,7 @@ void add_scan_profile(acx_automaton *a, uint64_t len) {
 //   dense output:            scan emits into regions -> compact -> radix sort -> spans ->
 //                            resolve -> offsets -> write                      (two round trips)
 int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
-             int overlapping, int codepoints, acx_result **out) {
+             int overlapping, int codepoints, acx_result **out, bool allow_small = true) {
     *out = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
         static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
@@ -345,6 +373,15 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     if (segmented) {
         HIPCHK_R(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
         HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
+    }
+    if (allow_small && !segmented && small_ok(a, len)) { // small haystack: the whole call in one workgroup (K0)
+        HIPCHK_R(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));
+        bool done = false;
+        int rc = run_small(a, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
+        if (rc) return bail(rc);
+        if (done) { *out = r; return ACX_OK; }
+        g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
+        r->d_matches = nullptr;
     }
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     uint64_t n_final = 0;
@@ -716,10 +753,12 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     else
         a->kernel = prefilter_ok ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
     if (const char *envk = std::getenv("ACX_KERNEL")) {
-        if (!std::strcmp(envk, "dfa_walk")) a->kernel = ACX_KERNEL_DFA_WALK;
+        if (!std::strcmp(envk, "dfa_walk")) { a->kernel = ACX_KERNEL_DFA_WALK; a->kernel_forced = true; }
         else if (!std::strcmp(envk, "prefilter") && H.filter_q >= 1 &&
-                 a->max_lds >= prefilter_lds_bytes())
+                 a->max_lds >= prefilter_lds_bytes()) {
             a->kernel = ACX_KERNEL_PREFILTER;
+            a->kernel_forced = true;
+        }
     }
 #undef HIPCHK_A
     *out = a;
@@ -806,14 +845,16 @@ int acx_automaton_info(const acx_automaton_t *a, acx_info_t *out) {
 
 int acx_set_kernel(acx_automaton_t *a, int kernel) {
     if (!a) return fail(ACX_EINVAL, "null automaton");
-    if (kernel == ACX_KERNEL_DFA_WALK) { a->kernel = kernel; return ACX_OK; }
+    if (kernel == ACX_KERNEL_DFA_WALK) { a->kernel = kernel; a->kernel_forced = true; return ACX_OK; }
     if (kernel == ACX_KERNEL_PREFILTER) {
         if (a->host.filter_q == 0 || a->max_lds < prefilter_lds_bytes())
             return fail(ACX_EINVAL, "prefilter kernel unavailable for this automaton/device");
         a->kernel = kernel;
+        a->kernel_forced = true;
         return ACX_OK;
     }
     if (kernel == ACX_KERNEL_AUTO) {
+        a->kernel_forced = false;
         a->kernel = (a->host.filter_q >= 3 && a->max_lds >= prefilter_lds_bytes())
                         ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
         return ACX_OK;
@@ -874,12 +915,40 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     }
     acx_result_t *r = nullptr;
     int rc;
+    const bool try_small = small_ok(a, len);
+    if (try_small) {
+        // small haystack: copy it into pinned memory, ONE launch (K0 reads and writes pinned host
+        // memory in place), one sync -- no H2D / D2H copies at all
+        std::lock_guard<std::mutex> lk(a->stage_mu);
+        std::lock_guard<std::mutex> lock(a->mu);
+        HIPCHK(hipSetDevice(a->device));
+        Workspace &w = a->ws;
+        if (!w.pin_hay) {
+            HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_MAX_LEN + 16, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocDefault));
+        }
+        std::memcpy(w.pin_hay, hay, len);
+        uint64_t n = 0;
+        bool done = false;
+        rc = run_small(a, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done);
+        if (rc != ACX_OK) return rc;
+        if (done) {
+            if (n) {
+                acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
+                if (!m) return fail(ACX_ENOMEM, "out of memory");
+                std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
+                *out = m;
+            }
+            *n_out = n;
+            return ACX_OK;
+        }
+    }
     {
         // the staging buffer is shared by the host-memory entry points
         std::lock_guard<std::mutex> lk(a->stage_mu);
         rc = stage_host(a, hay, len, nullptr, 0);
         if (rc == ACX_OK)
-            rc = run_find(a, a->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r);
+            rc = run_find(a, a->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small);
     }
     if (rc != ACX_OK) return rc;
     uint64_t n = acx_result_count(r);

@@ -1313,6 +1313,150 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 }
 
 // ---------------------------------------------------------------------------
+// K0: the whole call in ONE workgroup, for small haystacks
+// ---------------------------------------------------------------------------
+// A short haystack is launch-latency bound: the general pipeline is ~10 dependent device
+// operations (45-60 us) however little there is to scan.  Up to SMALL_MAX_LEN bytes, one
+// workgroup does everything: stage the haystack in LDS, enumerate the occurrences by an
+// ANCHORED walk from every position (one thread per start: follow trie edges only -- a
+// transition that does not go one level deeper is a failure transition, BFS ids make that one
+// comparison -- and report the patterns that end on the way: 2-3 dependent loads per
+// position on text), rank-sort them by key in LDS, resolve the match kind, convert to code
+// points, write the final records.  `hay`, `out` and `res` may live in pinned host memory
+// (zero-copy): the host-memory entry point then costs one launch and one sync.
+// res[0] = matches written, res[1] = 0, or 1: too many occurrences, nothing written.
+__global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
+                                                 uint32_t len, int key_mode, int overlapping,
+                                                 int codepoints, acx_match_t *out, uint64_t *res) {
+    __shared__ __attribute__((aligned(16))) uint8_t sh[SMALL_MAX_LEN + 16];
+    __shared__ uint8_t cls[256];
+    __shared__ uint4 occ[SMALL_MAX_OCC]; // {key lo, key hi, pid, pattern length}
+    __shared__ uint16_t order[SMALL_MAX_OCC];
+    __shared__ uint8_t syn[SMALL_MAX_OCC], acc[SMALL_MAX_OCC];
+    __shared__ uint32_t cpre[1025]; // code points before every 16-byte slice
+    __shared__ uint32_t nocc;
+    using scan_t = rocprim::block_scan<uint32_t, 1024>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    const uint32_t t = threadIdx.x;
+    if (t == 0) nocc = 0;
+    if (t < 256) cls[t] = A.classes[t];
+    for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
+    __syncthreads();
+    // ---- all occurrences: anchored walk from every position
+    for (uint32_t pos = t; pos < len; pos += 1024) {
+        uint32_t s = 0;
+        for (uint32_t d = 0; pos + d < len;) {
+            const uint32_t e = A.table[((size_t)s << A.stride2) + cls[sh[pos + d]]];
+            const uint32_t id = e & ID_MASK;
+            d++;
+            if (id < A.level_start[d]) break; // shallower than d: a failure transition, not an edge
+            s = id;
+            if (!(e & FLAG_OWN)) continue;
+            const uint32_t one = A.own1[s];
+            uint32_t b = 0, en = 1;
+            if (one == OWN1_MANY) { b = A.own_off[s]; en = A.own_off[s + 1]; }
+            for (uint32_t k = b; k < en; k++) { // the patterns that are exactly hay[pos, pos + d)
+                const uint32_t pid = one == OWN1_MANY ? A.own_pid[k] : one;
+                const uint64_t key = key_mode == 0   ? ((uint64_t)(pos + d) << A.rank_bits) | A.rank[pid]
+                                     : key_mode == 1 ? ((uint64_t)pos << A.rank_bits) | pid
+                                                     : ((uint64_t)pos << A.rank_bits) | A.rank[pid];
+                const uint32_t slot = atomicAdd(&nocc, 1u);
+                if (slot < SMALL_MAX_OCC) occ[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, d);
+            }
+        }
+    }
+    __syncthreads();
+    const uint32_t n = nocc;
+    if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
+        if (t == 0) { res[0] = 0; res[1] = 1; }
+        return;
+    }
+    // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
+    for (uint32_t i = t; i < n; i += 1024) {
+        const uint64_t ki = ((uint64_t)occ[i].y << 32) | occ[i].x;
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) r += ((((uint64_t)occ[j].y << 32) | occ[j].x) < ki) ? 1u : 0u;
+        order[r] = (uint16_t)i;
+    }
+    __syncthreads();
+#define K0_SPAN(I, S, E)                                                                          \
+    {                                                                                             \
+        const uint4 v_ = occ[order[(I)]];                                                         \
+        const uint64_t x_ = ((((uint64_t)v_.y << 32) | v_.x) >> A.rank_bits);                     \
+        if (key_mode == 0) { E = x_; S = x_ - v_.w; } else { S = x_; E = x_ + v_.w; }             \
+    }
+    // ---- match kind: sync points, then every sync point walks its greedy chain
+    uint32_t mine = 0;
+    if (overlapping) {
+        mine = t < n ? 1u : 0u;
+    } else {
+        if (t < n) {
+            uint64_t s, e, mx = 0;
+            K0_SPAN(t, s, e)
+            (void)e;
+            for (uint32_t j = t; j > 0;) {
+                j--;
+                uint64_t sj, ej;
+                K0_SPAN(j, sj, ej)
+                mx = max(mx, ej);
+                // sorted by end: the previous end is the maximum; sorted by start: nothing that
+                // starts max_len or more before s can end beyond it
+                if (key_mode == 0 || sj + A.max_len <= s) break;
+            }
+            syn[t] = mx <= s ? 1 : 0;
+        }
+        __syncthreads();
+        if (t < n && syn[t]) {
+            uint64_t s, pos;
+            K0_SPAN(t, s, pos)
+            acc[t] = 1;
+            for (uint32_t j = t + 1; j < n && !syn[j]; j++) {
+                uint64_t sj, ej;
+                K0_SPAN(j, sj, ej)
+                const bool take = sj >= pos;
+                acc[j] = take;
+                if (take) pos = ej;
+            }
+        }
+        __syncthreads();
+        mine = t < n ? acc[t] : 0u;
+    }
+    // ---- byte offset -> code point index (src/lib.rs:73-88): lead bytes before the offset
+    if (codepoints) {
+        uint32_t leads = 0;
+        for (uint32_t i = t * 16; i < t * 16 + 16 && i < len; i++) leads += (sh[i] & 0xC0) != 0x80;
+        uint32_t before = 0;
+        scan_t().exclusive_scan(leads, before, 0u, scan_tmp);
+        cpre[t] = before;
+        if (t == 1023) cpre[1024] = before + leads;
+        __syncthreads();
+    }
+    uint32_t dst = 0;
+    scan_t().exclusive_scan(mine, dst, 0u, scan_tmp);
+    if (mine) {
+        const uint4 v = occ[order[t]];
+        uint64_t s, e;
+        K0_SPAN(t, s, e)
+        if (codepoints) {
+            uint32_t cs = cpre[s >> 4], ce = cpre[e >> 4];
+            for (uint32_t i = (uint32_t)s & ~15u; i < s; i++) cs += (sh[i] & 0xC0) != 0x80;
+            for (uint32_t i = (uint32_t)e & ~15u; i < e; i++) ce += (sh[i] & 0xC0) != 0x80;
+            s = cs; e = ce;
+        }
+        out[dst].pattern = v.z; out[dst].start = s; out[dst].end = e;
+    }
+    if (t == 1023) { res[0] = dst + mine; res[1] = 0; }
+#undef K0_SPAN
+}
+
+hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
+                        bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st) {
+    hipLaunchKernelGGL(k0_small, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,
+                       codepoints ? 1 : 0, out, res);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // K3: UTF-8 code-point indexes
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ uint32_t lead_bytes_in_word(uint32_t w) {

@@ -48,6 +48,12 @@ size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                             uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
                             uint64_t n, int end_bit, hipStream_t st);
+// K0: a whole call in one workgroup (haystacks of at most SMALL_MAX_LEN bytes, at most
+// SMALL_MAX_OCC occurrences, one haystack).  hay / out / res may be pinned host memory.
+// out: SMALL_MAX_OCC records; res[0] = matches written, res[1] != 0: too dense, nothing written.
+constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
+hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
+                        bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st);
 // sparse path (slot mode): tile kernels -- order within buckets, resolve the match kind,
 // compact into out[] (capacity n_tiles * TILE_MAX).  The launch geometry depends on the
 // number of buckets only, so no host round trip is needed before them.  A call may be cut

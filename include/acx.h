@@ -51,7 +51,10 @@ extern "C" {
 #define ACX_IMPL_CONTIGUOUS_NFA 1
 #define ACX_IMPL_DFA 2
 
-/* scan kernels (acx_info.kernel, acx_set_kernel) */
+/* scan kernels (acx_info.kernel, acx_set_kernel).  Haystacks of at most 16 KiB are
+ * answered by K0 -- one workgroup does the whole call (anchored walk from every position,
+ * sort, resolve, output; one launch) -- unless a scan kernel was chosen explicitly with
+ * acx_set_kernel / ACX_KERNEL or the output is too dense for it. */
 #define ACX_KERNEL_AUTO 0
 #define ACX_KERNEL_DFA_WALK 1   /* K1a: chunked DFA walk, hot rows in LDS      */
 #define ACX_KERNEL_PREFILTER 2  /* K1b: LDS q-gram prefilter + DFA verification */
@@ -88,6 +91,8 @@ typedef struct acx_profile {
     uint64_t scan_bytes;   /* haystack bytes scanned by those launches          */
     uint64_t raw_occurrences; /* occurrences emitted by K1 before resolution    */
     uint64_t prefix_hits;     /* K1b: prefix hits handed to the walk kernel      */
+    uint64_t small_calls;     /* calls answered by K0 (whole call in one workgroup;
+                                 counted whether or not profiling is enabled)     */
 } acx_profile_t;
 
 /* ---- process-wide ---- */

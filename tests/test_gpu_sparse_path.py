@@ -1,6 +1,7 @@
-"""GPU: the sparse output path (bucket slots + tile kernels) at its seams -- greedy chains
-that cross tile boundaries, bucket / tile overflow into the dense (region + radix sort) path,
-the hold-off after a dense call, and the chunked two-stream variant (ACX_CHUNKS)."""
+"""GPU: the seams between the execution paths -- the sparse output path (bucket slots + tile
+kernels): greedy chains that cross tile boundaries, bucket / tile overflow into the dense
+(region + radix sort) path, the hold-off after a dense call, the chunked two-stream variant
+(ACX_CHUNKS); and K0, the one-workgroup kernel that answers small haystacks."""
 import os
 import subprocess
 import sys
@@ -97,3 +98,82 @@ def test_textlike_10k_patterns_matches_oracle_on_both_paths():
         out = "/tmp/acx_sparse_path_%s.npy" % "_".join(env)
         subprocess.run([sys.executable, "-c", code, out], check=True, env={**os.environ, **env}, timeout=600)
         assert np.array_equal(np.load(out), want), env
+
+
+# ---------------------------------------------------------------------------
+# K0: small haystacks answered by one workgroup
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("mk", [0, 1, 2])
+def test_small_call_kernel_equals_general_pipeline_and_oracle(mk):
+    import random
+    rng = random.Random(900 + mk)
+    for trial in range(12):
+        alpha = rng.choice([b"ab", b"abcd", bytes(range(97, 123)), bytes(range(256))])
+        pats = [bytes(rng.choice(alpha) for _ in range(rng.randint(1, rng.choice([3, 8, 40]))))
+                for _ in range(rng.choice([1, 5, 60, 400]))]
+        pats += [pats[0]]  # a duplicate pattern: ties resolve to the lowest index
+        n = rng.choice([1, 2, 15, 16, 17, 255, 1000, 4097, 16383, 16384])
+        hay = bytearray(rng.choice(alpha) for _ in range(n))
+        for _ in range(rng.randint(0, 6)):  # plant whole patterns, also flush with both ends
+            p = rng.choice(pats)
+            if len(p) <= n:
+                at = rng.choice([0, n - len(p), rng.randint(0, n - len(p))])
+                hay[at:at + len(p)] = p
+        hay = bytes(hay)
+        auto = capi.Automaton(pats, mk)                                   # small haystack -> K0
+        forced = capi.Automaton(pats, mk, kernel=capi.KERNEL_DFA_WALK)    # explicit kernel: never K0
+        o = Oracle(pats, mk, KIND_DFA)
+        n_occ = len(Oracle(pats, 0, KIND_DFA).find_raw(hay, overlapping=True))  # what K0 has to hold
+        for ov in ([False, True] if mk == 0 else [False]):
+            want = o.find_raw(hay, overlapping=ov)
+            auto.profile_read(reset=True)
+            got = cols(auto.find(hay, overlapping=ov))
+            k0_calls = auto.profile_read().small_calls
+            assert np.array_equal(got, want), (mk, ov, trial)
+            assert np.array_equal(cols(forced.find(hay, overlapping=ov)), want), (mk, ov, trial)
+            assert forced.profile_read().small_calls == 0
+            assert k0_calls == (1 if n_occ <= 1024 else 0)  # dense output falls through to the pipeline
+        auto.close()
+        forced.close()
+
+
+def test_small_call_kernel_limits_and_device_entry():
+    pats = [b"a", b"aa", b"abc"]
+    a = capi.Automaton(pats, 0)
+    o = Oracle(pats, 0, KIND_DFA)
+    # 16 KiB is the last K0 size, 16 KiB + 1 the first size of the general pipeline
+    for n, small in ((16384, 1), (16385, 0)):
+        hay = ((b"x" * 40 + b"abc") * 400)[:n]
+        a.profile_read(reset=True)
+        assert np.array_equal(cols(a.find(hay)), o.find_raw(hay))
+        assert a.profile_read().small_calls == small
+    # more than 1024 occurrences: K0 gives up, the general pipeline answers
+    hay = b"a" * 3000
+    for ov in (False, True):
+        a.profile_read(reset=True)
+        assert np.array_equal(cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov))
+        assert a.profile_read().small_calls == 0
+    # device-resident haystack and result
+    hay = b"..abc..aa..a" * 100
+    buf = capi.DeviceBuffer(len(hay) + 3)
+    buf.upload(np.frombuffer(b"###" + hay, dtype=np.uint8))
+    a.profile_read(reset=True)
+    r = a.find_device(buf.ptr + 3, len(hay))  # unaligned device pointer
+    assert np.array_equal(cols(r.matches()), o.find_raw(hay))
+    assert a.profile_read().small_calls == 1
+    r.free()
+    a.close()
+
+
+def test_small_call_kernel_code_points():
+    ac = pytest.importorskip("ahocorasick_rs_amd")
+    pats = ["é", "☃", "🤦", "aé", "z☃z", "needle"]
+    hay = ("aé☃🤦z☃z" * 50 + "needle" + "é" * 7 + "🤦needle☃") * 3
+    assert len(hay.encode()) <= 16384
+    kinds = {0: ac.MatchKind.Standard, 1: ac.MatchKind.LeftmostFirst, 2: ac.MatchKind.LeftmostLongest}
+    for mk, kind in kinds.items():
+        a = ac.AhoCorasick(pats, matchkind=kind)
+        got = a.find_matches_as_indexes(hay)
+        assert got == Oracle([p.encode() for p in pats], mk, KIND_DFA).find_str(hay)
+        for pid, s, e in got:  # offsets are code-point indexes: slicing the str gives the pattern
+            assert hay[s:e] == pats[pid]
