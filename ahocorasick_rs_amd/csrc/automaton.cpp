@@ -249,8 +249,9 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             const uint8_t *pp = pb + A.offsets[i];
             uint32_t wx = (uint32_t)gram_of(pp + 1, g) & gmask; // p[1..1+g)
             uint32_t wy = (uint32_t)gram_of(pp, g) & gmask;     // p[0..g)
-            A.filterA[2 * filter_entry(filter_hash(wx))] |= filter_sig(wx, pp[0]);
-            A.filterA[2 * filter_entry(filter_hash(wy)) + 1] |= filter_sig(wy, pp[Q - 1]);
+            A.filterA[2 * filter_entry(filter_hash(wx))] |= filter_bit(pp[0]) | filter_bit(wx);
+            A.filterA[2 * filter_entry(filter_hash(wy)) + 1] |= filter_bit(pp[Q - 1]);
+            A.filterA[2 * filter_entry(filter_hash(wy))] |= filter_bit(wy);
         }
         uint64_t set = 0;
         for (uint32_t e = 0; e < (1u << FILTER_ENTRIES_LOG2); e++)

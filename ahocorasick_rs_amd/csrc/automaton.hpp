@@ -61,11 +61,14 @@ constexpr uint32_t HASH_K1 = 0x9E3779u; // 24-bit odd multiplier (v_mad_u32_u24)
 // 32-bit hash of a g-gram W (little-endian, masked to g bytes)
 ACX_HD static inline uint32_t filter_hash(uint32_t W) { return (W & 0xFFFFFFu) * HASH_K1 + W; }
 ACX_HD static inline uint32_t filter_entry(uint32_t H) { return H >> (32 - FILTER_ENTRIES_LOG2); }
-// the two signature bits of byte b with the (masked) gram W: the kernel shifts the
-// table word right by b and by W (the hardware uses the low 5 bits of each)
-ACX_HD static inline uint32_t filter_sig(uint32_t W, uint32_t b) {
-    return (1u << (b & 31)) | (1u << (W & 31));
-}
+// Signature bits of a table row {X, Y} selected by the hash of a gram W.  A pattern whose bytes
+// 1..g are W (it could start one position before the gram) sets bit (p[0] & 31) in X; a pattern
+// whose bytes 0..g-1 are W sets bit (p[Q-1] & 31) in Y; BOTH set bit (W & 31) in X -- the gate
+// the kernel shares between the two tests of a pair of positions:
+//     g = X >> W;   position j: (X >> byte_j) & g;   position j + 1: (Y >> byte_{j+Q}) & g
+// (the hardware uses the low 5 bits of a shift amount).  One gate instead of one per word costs
+// nothing in selectivity: Y gets sparser by what X gets denser.
+ACX_HD static inline uint32_t filter_bit(uint32_t v) { return 1u << (v & 31); }
 // 32-bit hash of a Q2-gram (little-endian in a u64, masked to Q2 bytes): two multiplicative
 // hashes xor-ed; the table index is taken from the TOP bits (prefix_slot), where a
 // multiplicative hash is well mixed.  (K1b evaluates this for every level-1 survivor.)

@@ -683,8 +683,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
                     /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */  \
                     const uint32_t bx_ = K1B_BYTE_REG(j);                                        \
                     const uint32_t by_ = K1B_BYTE_REG(j + Q);                                    \
-                    const uint32_t tx_ = (e_.x >> (bx_ & 31)) & (e_.x >> (W_ & 31));             \
-                    const uint32_t ty_ = (e_.y >> (by_ & 31)) & (e_.y >> (W_ & 31));             \
+                    const uint32_t g_ = e_.x >> (W_ & 31); /* the gate both tests share */       \
+                    const uint32_t tx_ = (e_.x >> (bx_ & 31)) & g_;                              \
+                    const uint32_t ty_ = (e_.y >> (by_ & 31)) & g_;                              \
                     m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */  \
                     m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */  \
                 }                                                                                \

@@ -127,7 +127,8 @@ typedef struct acx_host_tables {
     const uint32_t *level_start;  /* max_pattern_len + 2: first BFS id of each depth */
     const uint32_t *pattern_len;  /* n_patterns                                      */
     const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
-    const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} words */
+    const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} signature words
+                                     (bit layout: csrc/automaton.hpp, filter_bit)      */
     const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi,
                                      state | OWN<<30 | MORE<<31 (0xFFFFFFFF = empty; MORE: another
                                      prefix with this home slot sits further along the probe
