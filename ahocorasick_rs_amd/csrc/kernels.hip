@@ -635,9 +635,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     for (uint64_t tile = gw; tile < ntiles + 3 * nw; tile += nw) {
         // Everything loaded during the previous iteration (the tile prefetch and the
         // level-2 windows/slots) is consumed from here on.  Passing the tile through
-        // an empty asm makes the compiler wait for those loads HERE, before the next
-        // prefetch is issued, instead of with a vmcnt(0) in the middle of level 1
-        // that would also wait for the prefetch and serialise load and compute.
+        // an empty asm makes the compiler wait for those loads HERE, not with a vmcnt(0)
+        // somewhere in the middle of level 1.
         u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
         uint2 vL = nxtL;
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
@@ -675,7 +674,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         // ---- level 1 on this tile
         const uint64_t tbase = tile * tile_bytes;
         tbA = tbase;
-        K1B_ISSUE_TILE(tile + nw) // prefetch the wave's next tile
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
         // a register whose LOW byte is byte k of the lane's 24-byte view: an odd window,
         // a dword, or a dword shifted by 16 (only bits [4:0] are consumed)
@@ -729,6 +727,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
         K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
         K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+        // Prefetch of the wave's next tile, issued LATE: the compaction below, the level-2 phases
+        // at the top of the next iteration and the three other waves of the SIMD cover its
+        // latency.  Measured (K1b, T): issued before row 0: 310 us; after row 1: 299; after row 2:
+        // 293; here: 291; no prefetch at all (loads at the top of the tile's own iteration): 308.
+        // The kernel runs within 5 % of the streaming ceiling of the fabric, and five 16-byte
+        // loads per lane that sit in flight for a whole iteration are in the way of everything
+        // else in the memory pipeline.
+        K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
         uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
         while (true) {
