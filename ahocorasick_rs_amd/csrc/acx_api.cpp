@@ -440,8 +440,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                     if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
                     if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
                     HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, 0, T.n_tiles, true, true, nullptr,
-                                       0, 0, w.final, w.summary, abort_flag, next_flag, st));
-                    HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 56, hipMemcpyDeviceToHost, st));
+                                       0, 0, w.final, w.summary, abort_flag, next_flag, w.h_pinned, st));
                     HIPCHK_R(hipStreamSynchronize(st));
                 } else {
                     // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon
@@ -477,17 +476,16 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                                     : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
                         HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, tile0, std::max(tile0, tile1), first,
                                            last, Hc.block_counts, hit_grid, hit_cap, w.final, w.summary, abort_flag,
-                                           next_flag, ps));
+                                           next_flag, w.h_pinned, ps));
                         tile0 = std::max(tile0, tile1);
                         first = false;
                     }
-                    HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 56, hipMemcpyDeviceToHost, ps));
                     HIPCHK_R(hipStreamSynchronize(ps));
                     if (ps != st) HIPCHK_R(hipStreamSynchronize(st));
                 }
                 w.sparse_dirty = false; // the tile kernels left the counters and the next flag clean
                 add_scan_profile(a, len);
-                const bool aborted = *(uint32_t *)(w.h_pinned + 5 + (a->flag_idx ^ 1)) != 0;
+                const bool aborted = w.h_pinned[5] != 0;
                 const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
                 if (aborted) { // the sparse path gave up
                     if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo

@@ -1226,11 +1226,14 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_resolve(uint32_t rank_bit
 // One workgroup, for the tiles [tile0, tile1) of one chunk of the call (chunks run in order):
 // bbase = exclusive scan of btot continuing the previous chunk's; summary[0] = occurrences,
 // summary[4] = reported matches, summary[2] / [3] = prefix hits kept / largest hit region, all
-// accumulated over the chunks.  The last chunk clears the abort flag the NEXT call will use.
+// accumulated over the chunks.  The last chunk clears the abort flag the NEXT call will use and
+// publishes {[0] occurrences, [2] hits, [3] largest hit region, [4] matches, [5] aborted} to
+// host_out (pinned host memory).
 __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0, uint32_t tile1, int first,
                                                     const uint64_t *hit_counts, uint32_t hit_grid,
                                                     uint64_t hit_cap, uint64_t *summary,
-                                                    const uint32_t *abort_flag, uint32_t *next_flag) {
+                                                    const uint32_t *abort_flag, uint32_t *next_flag,
+                                                    uint64_t *host_out) {
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     __shared__ uint64_t red[3][16];
@@ -1268,12 +1271,17 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0,
     }
     if ((t & 63) == 0) { red[0][t >> 6] = hsum; red[1][t >> 6] = hmax; red[2][t >> 6] = nsum; }
     __syncthreads();
-    if (t == 1023) summary[4] = excl;
+    if (t == 1023) {
+        summary[4] = excl;
+        if (host_out) host_out[4] = excl;
+    }
     if (t == 0) {
         uint64_t a = h_before, b = hmax_before, c = n_before;
         for (int i = 0; i < 16; i++) { a += red[0][i]; b = max(b, red[1][i]); c += red[2][i]; }
         summary[2] = a; summary[3] = b; summary[0] = c;
         if (next_flag) *next_flag = 0;
+        // last chunk: the totals go straight to pinned host memory (no copy operation)
+        if (host_out) { host_out[0] = c; host_out[2] = a; host_out[3] = b; host_out[5] = stop ? 1 : 0; }
     }
 }
 
@@ -1325,7 +1333,7 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits,
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
                      uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
                      uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
-                     uint32_t *abort_flag, uint32_t *next_flag, hipStream_t st) {
+                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t tiles = tile1 - tile0;
     if (tiles) {
@@ -1335,7 +1343,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                            tile0, abort_flag);
     }
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, tile0, tile1, first ? 1 : 0, hit_counts,
-                       hit_grid, hit_cap, summary, abort_flag, last ? next_flag : nullptr);
+                       hit_grid, hit_cap, summary, abort_flag, last ? next_flag : nullptr,
+                       last ? host_out : nullptr);
     if (tiles)
         hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
                            tile0, 0u, last ? T.n_buckets + 1 : 0u, out, abort_flag);
