@@ -1540,28 +1540,41 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
                                    rocprim::plus<uint64_t>(), st);
 }
 
-// code-point index of byte offset x = number of non-continuation bytes in [0, x)
-__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay,
-                                                  const uint64_t *blockpre, uint64_t x) {
-    uint64_t blk = x >> 10;
-    uint64_t c = blockpre[blk];
-    for (uint64_t k = blk << 10; k < x; k++) c += (hay[k] & 0xC0) != 0x80;
+// non-continuation (lead) bytes in [p, end): bytes up to an 8-byte boundary, then words
+__device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const uint8_t *end) {
+    uint64_t c = 0;
+    while (p < end && ((uintptr_t)p & 7)) { c += (*p & 0xC0) != 0x80; p++; }
+    for (; p + 8 <= end; p += 8) {
+        const uint64_t w = *(const uint64_t *)p;
+        c += 8 - __popcll(w & 0x8080808080808080ull & ((~w) << 1)); // continuation: bit7 = 1, bit6 = 0
+    }
+    for (; p < end; p++) c += (*p & 0xC0) != 0x80;
     return c;
 }
 
+// code-point index of byte offset x = number of non-continuation bytes in [0, x)
+__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay,
+                                                  const uint64_t *blockpre, uint64_t x) {
+    const uint64_t blk = x >> 10;
+    return blockpre[blk] + lead_bytes_between(hay + (blk << 10), hay + x);
+}
+
+// one thread per match: the start from its 1 KiB block's prefix, the end from the start
 __global__ void k_to_code_points(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
                                  acx_match_t *m, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= 2 * n) return;
-    uint64_t *field = (i & 1) ? &m[i >> 1].end : &m[i >> 1].start;
-    *field = code_point_of(hay, blockpre, *field);
+    if (i >= n) return;
+    const uint64_t s = m[i].start, e = m[i].end;
+    const uint64_t cs = code_point_of(hay, blockpre, s);
+    m[i].start = cs;
+    m[i].end = cs + lead_bytes_between(hay + s, hay + e);
 }
 
 hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre,
                           acx_match_t *m, uint64_t n, hipStream_t st) {
     (void)len;
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(k_to_code_points, dim3((uint32_t)((2 * n + 255) / 256)), dim3(256), 0, st,
+    hipLaunchKernelGGL(k_to_code_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
                        d_hay, blockpre, m, n);
     return hipGetLastError();
 }
@@ -1580,9 +1593,9 @@ __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t
     else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; base = G.offsets[h]; }
     (void)len;
     if (codepoints) {
-        uint64_t cb = code_point_of(hay, blockpre, base);
-        m[i].start = code_point_of(hay, blockpre, s) - cb;
-        m[i].end = code_point_of(hay, blockpre, e) - cb;
+        const uint64_t cs = code_point_of(hay, blockpre, s) - code_point_of(hay, blockpre, base);
+        m[i].start = cs;
+        m[i].end = cs + lead_bytes_between(hay + s, hay + e);
     } else {
         m[i].start = s - base;
         m[i].end = e - base;
