@@ -386,6 +386,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     uint64_t n_final = 0;
     bool pending = segmented; // work queued on the stream that nobody waited for yet
+    bool localized = false;   // batch: offsets are already local and the counts taken
     if (len > 0 && a->host.n_patterns > 0) {
         int rc = ensure_common(a);
         if (rc) return bail(rc);
@@ -434,13 +435,15 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (a->flag_idx ^ 1));
                 a->flag_idx ^= 1;
                 Sink K{nullptr, T.bcnt, w.block_counts, 0, bshift, key_mode, T.slots, abort_flag};
+                // batch with byte offsets: the write kernel localises and counts per haystack itself
+                uint64_t *seg_counts = segmented && !codepoints ? r->d_counts : nullptr;
                 if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
                 if (!pre) {
                     hipError_t e = launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid, a->max_lds, st);
                     if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
                     if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
                     HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, 0, T.n_tiles, true, true, nullptr,
-                                       0, 0, w.final, w.summary, abort_flag, next_flag, w.h_pinned, st));
+                                       0, 0, w.final, w.summary, abort_flag, next_flag, w.h_pinned, G, seg_counts, st));
                     HIPCHK_R(hipStreamSynchronize(st));
                 } else {
                     // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon
@@ -476,7 +479,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                                                     : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
                         HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, tile0, std::max(tile0, tile1), first,
                                            last, Hc.block_counts, hit_grid, hit_cap, w.final, w.summary, abort_flag,
-                                           next_flag, w.h_pinned, ps));
+                                           next_flag, w.h_pinned, G, seg_counts, ps));
                         tile0 = std::max(tile0, tile1);
                         first = false;
                     }
@@ -488,6 +491,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 const bool aborted = w.h_pinned[5] != 0;
                 const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
                 if (aborted) { // the sparse path gave up
+                    if (seg_counts) // (a chunked call may already have counted the matches of its first chunks)
+                        HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
                     if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo
                         rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64));
                         if (rc) return bail(rc);
@@ -501,6 +506,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 n_final = w.h_pinned[4];
                 r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
                 w.final = nullptr;
+                localized = seg_counts != nullptr;
+                if (localized) pending = false; // the stream has drained, counts included
                 break;
             }
             // ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
@@ -568,7 +575,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
         }
         if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += pre ? w.h_pinned[2] : 0; }
         r->n = n_final;
-        if (n_final && (codepoints || segmented)) {
+        if (n_final && (codepoints || (segmented && !localized))) {
             if (codepoints) {
                 uint64_t nb1 = (len + 1023) / 1024 + 1;
                 if ((rc = ensure_blocks(a, nb1)) != ACX_OK) return bail(rc);

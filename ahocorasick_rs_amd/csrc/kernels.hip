@@ -1286,10 +1286,14 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0,
 }
 
 // zero_lo..zero_hi: the arrival counters this launch leaves clean for the next call
+// seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
+// their haystack and the per-haystack counts are taken here -- one atomic per run of matches
+// of the same haystack inside the tile instead of a separate pass with one atomic per match.
 __global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, int overlapping,
                                                              TileSpace T, uint32_t tile0, uint32_t zero_lo,
                                                              uint32_t zero_hi, acx_match_t *out,
-                                                             const uint32_t *abort_flag) {
+                                                             const uint32_t *abort_flag, Segments G,
+                                                             uint64_t *seg_counts) {
     __shared__ __attribute__((aligned(16))) uint8_t ac[TILE_MAX];
     __shared__ uint32_t dst[TILE_MAX];
     using scan_t = rocprim::block_scan<uint32_t, TILE_THREADS>;
@@ -1314,13 +1318,32 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits,
         for (uint32_t q = t * TILE_PER_THREAD; q < (t + 1) * TILE_PER_THREAD; q++) dst[q] = ac[q] ? d++ : DST_NONE;
     }
     __syncthreads();
+    __shared__ uint32_t hs[TILE_MAX]; // haystack index of the tile's reported matches, in output order
     for (uint32_t i = t; i < n; i += TILE_THREADS) {
         const uint32_t d = dst[i];
         if (d == DST_NONE) continue;
         const uint4 v = T.trecs[gi + i];
         uint64_t s, e;
         span_of(rank_bits, key_mode, v, &s, &e);
+        if (seg_counts) {
+            uint64_t h, hbase;
+            if (G.uniform_len) { h = s / G.uniform_len; hbase = h * G.uniform_len; }
+            else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; hbase = G.offsets[h]; }
+            s -= hbase; e -= hbase;
+            hs[d - base] = (uint32_t)h;
+        }
         out[d].pattern = v.z; out[d].start = s; out[d].end = e;
+    }
+    if (seg_counts) {
+        __syncthreads();
+        const uint32_t total = T.btot[tile];
+        for (uint32_t c = t; c < total; c += TILE_THREADS) {
+            const uint32_t h = hs[c];
+            if (c > 0 && hs[c - 1] == h) continue; // not the head of its run
+            uint32_t run = 1;
+            while (c + run < total && hs[c + run] == h) run++;
+            atomicAdd((unsigned long long *)&seg_counts[h], (unsigned long long)run);
+        }
     }
 }
 
@@ -1333,7 +1356,8 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits,
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
                      uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
                      uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
-                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, hipStream_t st) {
+                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, const Segments &G,
+                     uint64_t *seg_counts, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t tiles = tile1 - tile0;
     if (tiles) {
@@ -1347,7 +1371,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                        last ? host_out : nullptr);
     if (tiles)
         hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
-                           tile0, 0u, last ? T.n_buckets + 1 : 0u, out, abort_flag);
+                           tile0, 0u, last ? T.n_buckets + 1 : 0u, out, abort_flag, G, seg_counts);
     return hipGetLastError();
 }
 

@@ -62,11 +62,14 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // *abort_flag != 0 afterwards: the output did not fit the sparse path (or hits were dropped).
 // The last chunk leaves T.bcnt and *next_flag zeroed for the next call and publishes
 // {[0] occurrences, [2] hits, [3] largest hit region, [4] matches, [5] aborted} to host_out
-// (pinned host memory, read by the host after the stream has drained).
+// (pinned host memory, read by the host after the stream has drained).  seg_counts != null
+// (batch, byte offsets): offsets are made local to the match's haystack (G) and the
+// per-haystack counts are accumulated into seg_counts (zeroed by the caller).
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
                      uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
                      uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
-                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, hipStream_t st);
+                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, const Segments &G,
+                     uint64_t *seg_counts, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,
