@@ -150,22 +150,6 @@ __device__ __noinline__ void emit_state(const DevAutomaton *A, const BlockSink K
     }
 }
 
-// only the patterns that end exactly at state s with depth(s) == length;
-// start / end are both known to the anchored walk
-__device__ __forceinline__ void emit_own_span(const DevAutomaton &A, const BlockSink &K, uint32_t s,
-                                              uint64_t start, uint64_t end) {
-    uint32_t one = A.own1[s];
-    uint32_t b = 0, e = 1;
-    if (one == OWN1_MANY) { b = A.own_off[s]; e = A.own_off[s + 1]; }
-    for (uint32_t k = b; k < e; k++) {
-        uint32_t pid = one == OWN1_MANY ? A.own_pid[k] : one;
-        uint64_t key = K.key_mode == 0   ? (end << A.rank_bits) | A.rank[pid]
-                       : K.key_mode == 1 ? (start << A.rank_bits) | pid
-                                         : (start << A.rank_bits) | A.rank[pid];
-        emit_key(K, key, pid, (uint32_t)(end - start));
-    }
-}
-
 // first index i in [0, n] with off[i] > x
 __device__ __forceinline__ uint64_t upper_bound_u64(const uint64_t *off, uint64_t n,
                                                     uint64_t x) {
@@ -380,8 +364,6 @@ constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane
 constexpr uint32_t K1B_HB = 40;     // prefix hits a wave collects in LDS before one burst store
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
-    uint32_t count;
-    uint32_t pad[3];
     uint16_t q1[16][K1B_Q1CAP];
     uint4 hb[16][K1B_HB][2];
 };
