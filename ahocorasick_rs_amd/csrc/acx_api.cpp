@@ -437,8 +437,8 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 Sink K{nullptr, T.bcnt, w.block_counts, 0, bshift, key_mode, T.slots, abort_flag};
                 // batch with byte offsets: the write kernel localises and counts per haystack itself
                 uint64_t *seg_counts = segmented && !codepoints ? r->d_counts : nullptr;
-                if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
                 if (!pre) {
+                    if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
                     hipError_t e = launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid, a->max_lds, st);
                     if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
                     if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
@@ -467,9 +467,11 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                         Sink Hc = H;
                         Hc.recs = w.hrecs + (uint64_t)c * hit_grid * hit_cap * 2;
                         Hc.block_counts = w.hit_counts + (uint64_t)c * hit_grid;
-                        hipError_t e = launch_prefilter(a->dev, a->d_dev, G, Hc, d_hay, len, scan_grid, t0, t1, st);
+                        // measurement: the event pair rides on the dispatch (first chunk's start, last chunk's stop)
+                        hipError_t e = launch_prefilter(a->dev, a->d_dev, G, Hc, d_hay, len, scan_grid, t0, t1, st,
+                                                        a->prof && c == 0 ? a->ev[0] : nullptr,
+                                                        a->prof && last ? a->ev[1] : nullptr);
                         if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
-                        if (last && a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
                         if (ps != st) {
                             HIPCHK_R(hipEventRecord(a->chunk_ev[c], st));
                             HIPCHK_R(hipStreamWaitEvent(ps, a->chunk_ev[c], 0));

@@ -27,6 +27,8 @@
 
 #include <rocprim/rocprim.hpp>
 
+#include <hip/hip_ext.h>
+
 #include "automaton.hpp"
 #include "kernels.hpp"
 
@@ -796,14 +798,17 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
 
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st) {
+                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st, hipEvent_t ev_start,
+                            hipEvent_t ev_stop) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
     uint32_t ab = ablation_flags();
+    // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
 #define ACX_K1B(Q)                                                                                    \
-    hipLaunchKernelGGL(k1b_prefilter<Q>, g, b, 0, st, A, Ad, G, K, base, len, lead, tile_begin, tile_end, ab)
+    hipExtLaunchKernelGGL(k1b_prefilter<Q>, g, b, 0, st, ev_start, ev_stop, 0, A, Ad, G, K, base, len, lead, \
+                          tile_begin, tile_end, ab)
     switch (A.filter_q) {
     case 1: ACX_K1B(1); break;
     case 2: ACX_K1B(2); break;

@@ -25,7 +25,8 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len);
 uint32_t prefilter_hit_regions(uint32_t grid);
 hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                             const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st);
+                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st,
+                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
 // sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
