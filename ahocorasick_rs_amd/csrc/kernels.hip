@@ -387,6 +387,21 @@ __device__ __forceinline__ uint64_t load_window(const uint8_t *__restrict__ stre
     return w;
 }
 
+// 16 bytes of the stream at position p (zero beyond the end): ONE unaligned 16-byte load when
+// they all exist (everywhere but in the last bytes of the stream)
+__device__ __forceinline__ void load_window16(const uint8_t *__restrict__ stream, uint64_t len, uint64_t p,
+                                              uint64_t *w0, uint64_t *w1) {
+    if (p + 16 <= len) {
+        u32x4 v;
+        __builtin_memcpy(&v, stream + p, 16);
+        *w0 = ((uint64_t)v.y << 32) | v.x;
+        *w1 = ((uint64_t)v.w << 32) | v.z;
+    } else {
+        *w0 = load_window(stream, len, p);
+        *w1 = load_window(stream, len, p + 8);
+    }
+}
+
 // A prefix hit handed to the walk kernel is (position, code), code = word 3 of
 // the prefix-table entry: the id of the only pattern with that prefix, or
 // HIT_LIST | index into blist ({count, pid, ...}); HIT_RETRY when the home
@@ -647,8 +662,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         if (q1c) {
             if (lane < q1c) {
                 offB = q1[lane];
-                winB = load_window(stream, len, tbA + offB - lead);
-                winB1 = load_window(stream, len, tbA + offB - lead + 8);
+                load_window16(stream, len, tbA + offB - lead, &winB, &winB1);
             }
         }
         nB = q1c; tbB = tbA; q1c = 0;
