@@ -138,6 +138,7 @@ struct acx_automaton {
     std::mutex stage_mu; // guards the host staging buffers (taken before mu)
     Workspace ws;
     bool prof = false;
+    bool post_pending = false;  // profiling: ev[2] of the last call has not been read yet
     bool kernel_forced = false; // the scan kernel was chosen explicitly: K0 never takes a call
     int dense_hold = 0; // > 0: the output was too dense for the sparse path; calls left in region mode
     acx_profile_t profile{};
@@ -332,6 +333,15 @@ int run_small(acx_automaton *a, const uint8_t *hay, uint64_t len, int overlappin
     return ACX_OK;
 }
 
+// post_ms of the previous profiled call: ev[1] (end of the scan) .. ev[2] (end of the call's device work)
+void settle_post_profile(acx_automaton *a) {
+    if (!a->post_pending) return;
+    a->post_pending = false;
+    float ms = 0;
+    if (hipEventSynchronize(a->ev[2]) == hipSuccess && hipEventElapsedTime(&ms, a->ev[1], a->ev[2]) == hipSuccess)
+        a->profile.post_ms += ms;
+}
+
 void add_scan_profile(acx_automaton *a, uint64_t len) {
     if (!a->prof) return;
     float ms = 0;
@@ -358,6 +368,7 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     if (len >= (1ull << 40)) return fail(ACX_ETOOBIG, "haystack stream of 2^40 bytes or more");
     std::lock_guard<std::mutex> lock(a->mu);
     HIPCHK(hipSetDevice(a->device));
+    settle_post_profile(a);
     hipStream_t st = a->stream;
     const bool segmented = G.uniform_len != 0 || G.offsets != nullptr;
     acx_result *r = new (std::nothrow) acx_result();
@@ -591,13 +602,9 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
                 HIPCHK_R(to_code_points(d_hay, len, w.blockpre, r->d_matches, n_final, st));
             pending = true;
         }
-        if (a->prof) {
+        if (a->prof) { // end of the post stage: read lazily (next call / acx_profile_read), no extra sync here
             HIPCHK_R(hipEventRecord(a->ev[2], st));
-            HIPCHK_R(hipStreamSynchronize(st));
-            pending = false;
-            float ms = 0;
-            HIPCHK_R(hipEventElapsedTime(&ms, a->ev[1], a->ev[2]));
-            a->profile.post_ms += ms;
+            a->post_pending = true;
         }
     }
     if (pending) HIPCHK_R(hipStreamSynchronize(st));
@@ -1024,6 +1031,7 @@ int acx_profile_enable(acx_automaton_t *a, int on) {
 int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset) {
     if (!a || !out) return fail(ACX_EINVAL, "null argument");
     std::lock_guard<std::mutex> lock(a->mu);
+    settle_post_profile(a);
     *out = a->profile;
     if (reset) a->profile = acx_profile_t{};
     return ACX_OK;
