@@ -351,12 +351,275 @@ void add_scan_profile(acx_automaton *a, uint64_t len) {
     a->profile.scan_bytes += len;
 }
 
-// The whole device pipeline.  d_hay: device pointer, len bytes.
+// ---------------------------------------------------------------------------
+// The device pipeline.  d_hay: device pointer, len bytes.
 //
+//   small haystack:          K0, the whole call in one workgroup                 one launch
 //   sparse output (default): scan (K1a, or K1b + walk) emits into bucket slots -> tile kernels
-//                            (sort, resolve, scan, write) -> final matches   ONE host round trip
+//                            (sort, resolve, scan, write) -> final matches       ONE host round trip
 //   dense output:            scan emits into regions -> compact -> radix sort -> spans ->
-//                            resolve -> offsets -> write                      (two round trips)
+//                            resolve -> offsets -> write                         (two round trips)
+// ---------------------------------------------------------------------------
+#define HIPCHK_RC(expr)                                  \
+    do {                                                 \
+        hipError_t e__ = (expr);                         \
+        if (e__ != hipSuccess) return hipfail(e__, #expr); \
+    } while (0)
+
+// what one call works on (all attempts of it)
+struct FindCall {
+    acx_automaton *a;
+    const uint8_t *d_hay;
+    uint64_t len;
+    const Segments &G;
+    bool overlapping, codepoints, segmented;
+    acx_result *r;
+    int key_mode;
+    bool pre;           // K1b + walk (else K1a)
+    uint32_t scan_grid; // workgroups of the scan kernel
+    uint32_t hit_grid;  // hit regions of one K1b launch
+    uint32_t grid;      // emitting workgroups (= occurrence regions in region mode)
+    uint32_t bshift;    // bucket = key >> bshift
+    uint64_t nb;        // buckets of 4 KiB of stream position
+    // results
+    uint64_t n_raw = 0, n_final = 0;
+    bool pending = false;   // work queued on the stream that nobody waited for yet
+    bool localized = false; // batch: offsets are already local and the counts taken
+};
+enum class Attempt { Done, Again, GoDense };
+
+// ---- sparse output: slot mode + tile kernels, ONE host round trip
+int attempt_sparse(FindCall &c, Attempt *what) {
+    acx_automaton *a = c.a;
+    Workspace &w = a->ws;
+    hipStream_t st = a->stream;
+    int rc = ensure_tiles(a, c.nb);
+    if (rc) return rc;
+    // Chunked variant (ACX_CHUNKS=n, experiments only): K1b in n launches, each chunk's walk +
+    // tile kernels on the post stream underneath the next chunk's scan.  Measured on MI355X: no
+    // gain -- K1b's 16 waves x 128 VGPRs per CU fill the register file, so the other kernels only
+    // get on the CUs when a K1b workgroup retires.
+    static const int chunk_env = std::getenv("ACX_CHUNKS") ? std::atoi(std::getenv("ACX_CHUNKS")) : 1;
+    const int chunks = c.pre ? std::max(1, std::min(chunk_env, (int)acx_automaton::MAX_CHUNKS)) : 1;
+    const uint64_t hit_regions = (uint64_t)c.hit_grid * chunks; // every chunk has its own hit regions
+    const uint64_t hit_cap = c.pre ? w.hit_total / hit_regions : 0;
+    const Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, c.key_mode, nullptr, nullptr};
+    const TileSpace &T = w.T;
+    const uint64_t out_cap = (uint64_t)T.n_tiles * TILE_MAX;
+    if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+    if (!w.final) {
+        HIPCHK_RC(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
+        w.final_cap = out_cap;
+    }
+    if (w.sparse_dirty) {
+        HIPCHK_RC(hipMemsetAsync(T.bcnt, 0, (c.nb + 1) * 4, st));
+        HIPCHK_RC(hipMemsetAsync(w.summary + 5, 0, 16, st));
+    }
+    w.sparse_dirty = true;
+    // two abort flags used in turn: this attempt's tile kernels clear the other one
+    uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + a->flag_idx);
+    uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (a->flag_idx ^ 1));
+    a->flag_idx ^= 1;
+    const Sink K{nullptr, T.bcnt, w.block_counts, 0, c.bshift, c.key_mode, T.slots, abort_flag};
+    // batch with byte offsets: the write kernel localises and counts per haystack itself
+    uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
+    if (!c.pre) {
+        if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[0], st));
+        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+        if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
+        HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, 0, T.n_tiles, true, true, nullptr, 0, 0,
+                            w.final, w.summary, abort_flag, next_flag, w.h_pinned, c.G, seg_counts, st));
+        HIPCHK_RC(hipStreamSynchronize(st));
+    } else {
+        // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon as its
+        // scan is done.  After the scan of K1b tiles [0, t1) every bucket below t1 - 1 is final (a key
+        // position never precedes the start of its occurrence), so the post stage trails by a tile.
+        const uint64_t k_tiles = prefilter_tiles(c.d_hay, c.len);
+        const uint64_t per = ((k_tiles + chunks - 1) / chunks + TILE_BUCKETS - 1) / TILE_BUCKETS * TILE_BUCKETS;
+        hipStream_t ps = chunks > 1 ? a->post_stream : st;
+        if (ps != st) {
+            HIPCHK_RC(hipEventRecord(a->post_ev, st)); // memsets above / earlier work on st
+            HIPCHK_RC(hipStreamWaitEvent(ps, a->post_ev, 0));
+        }
+        uint32_t tile0 = 0;
+        bool first = true;
+        for (int k = 0; k < chunks; k++) {
+            const uint64_t t0 = std::min<uint64_t>((uint64_t)k * per, k_tiles);
+            const uint64_t t1 = k == chunks - 1 ? k_tiles : std::min<uint64_t>(t0 + per, k_tiles);
+            const bool last = k == chunks - 1;
+            if (t1 == t0 && !last) continue;
+            Sink Hc = H;
+            Hc.recs = w.hrecs + (uint64_t)k * c.hit_grid * hit_cap * 2;
+            Hc.block_counts = w.hit_counts + (uint64_t)k * c.hit_grid;
+            // measurement: the event pair rides on the dispatch (first chunk's start, last chunk's stop)
+            HIPCHK_RC(launch_prefilter(a->dev, a->d_dev, c.G, Hc, c.d_hay, c.len, c.scan_grid, t0, t1, st,
+                                       a->prof && k == 0 ? a->ev[0] : nullptr,
+                                       a->prof && last ? a->ev[1] : nullptr));
+            if (ps != st) {
+                HIPCHK_RC(hipEventRecord(a->chunk_ev[k], st));
+                HIPCHK_RC(hipStreamWaitEvent(ps, a->chunk_ev[k], 0));
+            }
+            HIPCHK_RC(launch_walk_hits(a->dev, a->d_dev, c.G, Hc, c.hit_grid, 0, K, c.d_hay, c.len, ps));
+            const uint32_t tile1 = last ? T.n_tiles
+                                        : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
+            HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, tile0, std::max(tile0, tile1), first, last,
+                                Hc.block_counts, c.hit_grid, hit_cap, w.final, w.summary, abort_flag, next_flag,
+                                w.h_pinned, c.G, seg_counts, ps));
+            tile0 = std::max(tile0, tile1);
+            first = false;
+        }
+        HIPCHK_RC(hipStreamSynchronize(ps));
+        if (ps != st) HIPCHK_RC(hipStreamSynchronize(st));
+    }
+    w.sparse_dirty = false; // the tile kernels left the counters and the next flag clean
+    add_scan_profile(a, c.len);
+    const bool aborted = w.h_pinned[5] != 0;
+    const uint64_t hit_max = c.pre ? w.h_pinned[3] : 0;
+    if (aborted) { // the sparse path gave up
+        if (seg_counts) // (a chunked call may already have counted the matches of its first chunks)
+            HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
+        if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo
+            if ((rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
+            *what = Attempt::Again;
+        } else { // a bucket or a tile overflowed: dense output, use the region mode
+            a->dense_hold = 8;
+            *what = Attempt::GoDense;
+        }
+        return ACX_OK;
+    }
+    c.n_raw = w.h_pinned[0];
+    c.n_final = w.h_pinned[4];
+    c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
+    w.final = nullptr;
+    c.localized = seg_counts != nullptr;
+    if (c.localized) c.pending = false; // the stream has drained, counts included
+    *what = Attempt::Done;
+    return ACX_OK;
+}
+
+// ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
+int attempt_dense(FindCall &c, Attempt *what) {
+    acx_automaton *a = c.a;
+    Workspace &w = a->ws;
+    hipStream_t st = a->stream;
+    int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, c.len / 64));
+    if (rc) return rc;
+    const uint64_t hit_cap = c.pre ? w.hit_total / c.hit_grid : 0;
+    const uint64_t region_cap = w.cap / c.grid;
+    const Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, c.key_mode, nullptr, nullptr};
+    const Sink K{w.recs, nullptr, w.block_counts, region_cap, c.bshift, c.key_mode, nullptr, nullptr};
+    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[0], st));
+    HIPCHK_RC(c.pre ? launch_prefilter(a->dev, a->d_dev, c.G, H, c.d_hay, c.len, c.scan_grid, 0, ~0ull, st)
+                    : launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
+    if (c.pre) HIPCHK_RC(launch_walk_hits(a->dev, a->d_dev, c.G, H, c.hit_grid, 0, K, c.d_hay, c.len, st));
+    HIPCHK_RC(sink_summary(w.block_counts, c.grid, region_cap, c.pre ? w.hit_counts : nullptr, c.hit_grid, hit_cap,
+                           w.summary, w.region_off, st));
+    HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK_RC(hipStreamSynchronize(st));
+    add_scan_profile(a, c.len);
+    const uint64_t n_raw = w.h_pinned[0], region_max = w.h_pinned[1], hit_max = c.pre ? w.h_pinned[3] : 0;
+    if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
+        if (hit_max > hit_cap && (rc = ensure_hits(a, (uint64_t)c.hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK)
+            return rc;
+        // hits that overflowed were dropped, so the occurrence count is a lower bound
+        uint64_t want = (uint64_t)c.grid * (region_max + region_max / 8 + 64);
+        if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
+        if ((rc = ensure_occ_capacity(a, want)) != ACX_OK) return rc;
+        *what = Attempt::Again;
+        return ACX_OK;
+    }
+    if (n_raw >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+    if (n_raw > 8 * c.nb) a->dense_hold = 8;
+    else if (a->dense_hold > 0) a->dense_hold--;
+    c.n_raw = n_raw;
+    *what = Attempt::Done;
+    if (n_raw == 0) return ACX_OK;
+    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
+    HIPCHK_RC(sink_compact(w.recs, w.region_off, c.grid, region_cap, w.keys[1], w.pids[1], st));
+    const int end_bit = std::min(64, (int)a->dev.rank_bits + bits_for(c.len));
+    HIPCHK_RC(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1], w.pids[0], n_raw, end_bit, st));
+    HIPCHK_RC(make_spans(a->dev, c.key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
+    if (c.overlapping) {
+        c.n_final = n_raw;
+    } else {
+        // Standard: sorted by end, so the running max of the ends IS the array of ends
+        const uint64_t *M = w.E;
+        if (c.key_mode != 0) {
+            HIPCHK_RC(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
+            M = w.M;
+        }
+        HIPCHK_RC(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
+        HIPCHK_RC(resolve_greedy(w.S, w.E, M, w.flags, n_raw, st));
+        HIPCHK_RC(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
+        HIPCHK_RC(hipMemcpyAsync(w.h_pinned + 6, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK_RC(hipStreamSynchronize(st));
+        c.n_final = *(uint32_t *)(w.h_pinned + 6);
+    }
+    HIPCHK_RC(g_bufs.get((void **)&c.r->d_matches, std::max<uint64_t>(c.n_final, 1) * sizeof(acx_match_t),
+                         a->device));
+    HIPCHK_RC(write_matches(w.pids[0], w.S, w.E, c.overlapping ? nullptr : w.flags, c.overlapping ? nullptr : w.idx,
+                            c.r->d_matches, n_raw, st));
+    c.pending = true;
+    return ACX_OK;
+}
+
+// everything after the matches exist: code points (str API), local offsets + counts (batches)
+int finish_matches(FindCall &c) {
+    acx_automaton *a = c.a;
+    Workspace &w = a->ws;
+    hipStream_t st = a->stream;
+    if (!c.n_final || !(c.codepoints || (c.segmented && !c.localized))) return ACX_OK;
+    if (c.codepoints) {
+        const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
+        int rc = ensure_blocks(a, nb1);
+        if (rc) return rc;
+        HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, st));
+        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
+    }
+    if (c.segmented)
+        HIPCHK_RC(localize(c.G, c.d_hay, c.len, w.blockpre, c.codepoints, c.r->d_matches, c.n_final, c.r->d_counts, st));
+    else
+        HIPCHK_RC(to_code_points(c.d_hay, c.len, w.blockpre, c.r->d_matches, c.n_final, st));
+    c.pending = true;
+    return ACX_OK;
+}
+
+// the general pipeline on an allocated result; caller holds a->mu
+int run_pipeline(FindCall &c) {
+    acx_automaton *a = c.a;
+    int rc = ensure_common(a);
+    if (rc) return rc;
+    c.pre = a->kernel == ACX_KERNEL_PREFILTER;
+    // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
+    c.scan_grid = c.pre ? prefilter_grid(c.d_hay, c.len, a->n_cus) : dfa_walk_grid(a->dev, c.len, a->n_cus);
+    c.hit_grid = c.pre ? prefilter_hit_regions(c.scan_grid) : 0;
+    c.grid = c.pre ? walk_hits_grid(c.hit_grid) : c.scan_grid;
+    c.bshift = a->dev.rank_bits + BUCKET_BITS;
+    c.nb = (c.len >> BUCKET_BITS) + 2;
+    static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
+    bool sparse = a->dense_hold == 0 && !no_bucket_env && c.nb < (1ull << 31);
+    if (c.pre && (rc = ensure_hits(a, std::max<uint64_t>(1u << 16, c.len / 64))) != ACX_OK) return rc;
+    for (int attempt = 0;; attempt++) {
+        if (attempt == 5) return fail(ACX_EDEVICE, "occurrence buffer overflow persisted");
+        Attempt what = Attempt::Done;
+        if ((rc = sparse ? attempt_sparse(c, &what) : attempt_dense(c, &what)) != ACX_OK) return rc;
+        if (what == Attempt::GoDense) sparse = false;
+        if (what == Attempt::Done) break;
+    }
+    if (a->prof) {
+        a->profile.raw_occurrences += c.n_raw;
+        a->profile.prefix_hits += c.pre ? a->ws.h_pinned[2] : 0;
+    }
+    c.r->n = c.n_final;
+    if ((rc = finish_matches(c)) != ACX_OK) return rc;
+    if (a->prof) { // end of the post stage: read lazily (next call / acx_profile_read), no extra sync here
+        HIPCHK_RC(hipEventRecord(a->ev[2], a->stream));
+        a->post_pending = true;
+    }
+    return ACX_OK;
+}
+
 int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
              int overlapping, int codepoints, acx_result **out, bool allow_small = true) {
     *out = nullptr;
@@ -375,243 +638,35 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
     if (!r) return fail(ACX_ENOMEM, "out of memory");
     r->device = a->device;
     r->n_hay = segmented ? G.n_hay : 0;
-    auto bail = [&](int code) { acx_free_result(r); return code; };
-#define HIPCHK_R(expr)                                         \
-    do {                                                       \
-        hipError_t e__ = (expr);                               \
-        if (e__ != hipSuccess) return bail(hipfail(e__, #expr)); \
-    } while (0)
-    if (segmented) {
-        HIPCHK_R(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
-        HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
-    }
-    if (allow_small && !segmented && small_ok(a, len)) { // small haystack: the whole call in one workgroup (K0)
-        HIPCHK_R(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));
-        bool done = false;
-        int rc = run_small(a, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
-        if (rc) return bail(rc);
-        if (done) { *out = r; return ACX_OK; }
-        g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
-        r->d_matches = nullptr;
-    }
-    const int key_mode = overlapping ? 0 : a->host.match_kind;
-    uint64_t n_final = 0;
-    bool pending = segmented; // work queued on the stream that nobody waited for yet
-    bool localized = false;   // batch: offsets are already local and the counts taken
-    if (len > 0 && a->host.n_patterns > 0) {
-        int rc = ensure_common(a);
-        if (rc) return bail(rc);
-        Workspace &w = a->ws;
-        const bool pre = a->kernel == ACX_KERNEL_PREFILTER;
-        // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
-        const uint32_t scan_grid = pre ? prefilter_grid(d_hay, len, a->n_cus)
-                                       : dfa_walk_grid(a->dev, len, a->n_cus);
-        const uint32_t hit_grid = pre ? prefilter_hit_regions(scan_grid) : 0; // hit regions of one K1b launch
-        const uint32_t grid = pre ? walk_hits_grid(hit_grid) : scan_grid;    // emitting workgroups
-        const int rank_bits = (int)a->dev.rank_bits;
-        const uint32_t bshift = (uint32_t)rank_bits + BUCKET_BITS;
-        const uint64_t nb = (len >> BUCKET_BITS) + 2; // buckets of 4 KiB of stream position
-        static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
-        bool sparse = a->dense_hold == 0 && !no_bucket_env && nb < (1ull << 31);
-        if (pre && (rc = ensure_hits(a, std::max<uint64_t>(1u << 16, len / 64))) != ACX_OK) return bail(rc);
-        uint64_t n_raw = 0;
-        for (int attempt = 0;; attempt++) {
-            if (attempt == 5) return bail(fail(ACX_EDEVICE, "occurrence buffer overflow persisted"));
-            // Chunked sparse path (ACX_CHUNKS=n, experiments only): K1b in n launches, each chunk's
-            // walk + tile kernels on the post stream underneath the next chunk's scan.  Measured
-            // on MI355X: no gain -- K1b's 16 waves x 128 VGPRs per CU fill the register file, so
-            // the other kernels only get on the CUs when a K1b workgroup retires.
-            static const int chunk_env = std::getenv("ACX_CHUNKS") ? std::atoi(std::getenv("ACX_CHUNKS")) : 1;
-            const int chunks = sparse && pre ? std::max(1, std::min(chunk_env, (int)acx_automaton::MAX_CHUNKS)) : 1;
-            const uint64_t hit_regions = (uint64_t)hit_grid * chunks; // every chunk has its own hit regions
-            const uint64_t hit_cap = pre ? w.hit_total / hit_regions : 0;
-            Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, key_mode, nullptr, nullptr};
-            if (sparse) {
-                // ---- sparse output: slot mode + tile kernels, ONE host round trip
-                if ((rc = ensure_tiles(a, nb)) != ACX_OK) return bail(rc);
-                const TileSpace &T = w.T;
-                const uint64_t out_cap = (uint64_t)T.n_tiles * TILE_MAX;
-                if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
-                if (!w.final) {
-                    HIPCHK_R(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
-                    w.final_cap = out_cap;
-                }
-                if (w.sparse_dirty) {
-                    HIPCHK_R(hipMemsetAsync(T.bcnt, 0, (nb + 1) * 4, st));
-                    HIPCHK_R(hipMemsetAsync(w.summary + 5, 0, 16, st));
-                }
-                w.sparse_dirty = true;
-                // two abort flags used in turn: this attempt's tile kernels clear the other one
-                uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + a->flag_idx);
-                uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (a->flag_idx ^ 1));
-                a->flag_idx ^= 1;
-                Sink K{nullptr, T.bcnt, w.block_counts, 0, bshift, key_mode, T.slots, abort_flag};
-                // batch with byte offsets: the write kernel localises and counts per haystack itself
-                uint64_t *seg_counts = segmented && !codepoints ? r->d_counts : nullptr;
-                if (!pre) {
-                    if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
-                    hipError_t e = launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid, a->max_lds, st);
-                    if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
-                    if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-                    HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, 0, T.n_tiles, true, true, nullptr,
-                                       0, 0, w.final, w.summary, abort_flag, next_flag, w.h_pinned, G, seg_counts, st));
-                    HIPCHK_R(hipStreamSynchronize(st));
-                } else {
-                    // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon
-                    // as its scan is done, i.e. underneath the scan of the next chunk.  After the
-                    // scan of K1b tiles [0, t1) every bucket below t1 - 1 is final (a key position
-                    // never precedes the start of its occurrence), so the post stage trails by a tile.
-                    const uint64_t k_tiles = prefilter_tiles(d_hay, len);
-                    const uint64_t per = ((k_tiles + chunks - 1) / chunks + TILE_BUCKETS - 1) / TILE_BUCKETS * TILE_BUCKETS;
-                    hipStream_t ps = chunks > 1 ? a->post_stream : st;
-                    if (ps != st) {
-                        HIPCHK_R(hipEventRecord(a->post_ev, st)); // memsets above / earlier work on st
-                        HIPCHK_R(hipStreamWaitEvent(ps, a->post_ev, 0));
-                    }
-                    uint32_t tile0 = 0;
-                    bool first = true;
-                    for (int c = 0; c < chunks; c++) {
-                        const uint64_t t0 = std::min<uint64_t>((uint64_t)c * per, k_tiles);
-                        const uint64_t t1 = c == chunks - 1 ? k_tiles : std::min<uint64_t>(t0 + per, k_tiles);
-                        const bool last = c == chunks - 1;
-                        if (t1 == t0 && !last) continue;
-                        Sink Hc = H;
-                        Hc.recs = w.hrecs + (uint64_t)c * hit_grid * hit_cap * 2;
-                        Hc.block_counts = w.hit_counts + (uint64_t)c * hit_grid;
-                        // measurement: the event pair rides on the dispatch (first chunk's start, last chunk's stop)
-                        hipError_t e = launch_prefilter(a->dev, a->d_dev, G, Hc, d_hay, len, scan_grid, t0, t1, st,
-                                                        a->prof && c == 0 ? a->ev[0] : nullptr,
-                                                        a->prof && last ? a->ev[1] : nullptr);
-                        if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
-                        if (ps != st) {
-                            HIPCHK_R(hipEventRecord(a->chunk_ev[c], st));
-                            HIPCHK_R(hipStreamWaitEvent(ps, a->chunk_ev[c], 0));
-                        }
-                        HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, Hc, hit_grid, 0, K, d_hay, len, ps));
-                        const uint32_t tile1 = last ? T.n_tiles
-                                                    : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
-                        HIPCHK_R(tile_post(a->dev, key_mode, overlapping != 0, T, tile0, std::max(tile0, tile1), first,
-                                           last, Hc.block_counts, hit_grid, hit_cap, w.final, w.summary, abort_flag,
-                                           next_flag, w.h_pinned, G, seg_counts, ps));
-                        tile0 = std::max(tile0, tile1);
-                        first = false;
-                    }
-                    HIPCHK_R(hipStreamSynchronize(ps));
-                    if (ps != st) HIPCHK_R(hipStreamSynchronize(st));
-                }
-                w.sparse_dirty = false; // the tile kernels left the counters and the next flag clean
-                add_scan_profile(a, len);
-                const bool aborted = w.h_pinned[5] != 0;
-                const uint64_t hit_max = pre ? w.h_pinned[3] : 0;
-                if (aborted) { // the sparse path gave up
-                    if (seg_counts) // (a chunked call may already have counted the matches of its first chunks)
-                        HIPCHK_R(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
-                    if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo
-                        rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64));
-                        if (rc) return bail(rc);
-                    } else { // a bucket or a tile overflowed: dense output, use the region mode
-                        sparse = false;
-                        a->dense_hold = 8;
-                    }
-                    continue;
-                }
-                n_raw = w.h_pinned[0];
-                n_final = w.h_pinned[4];
-                r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
-                w.final = nullptr;
-                localized = seg_counts != nullptr;
-                if (localized) pending = false; // the stream has drained, counts included
-                break;
-            }
-            // ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
-            if ((rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, len / 64))) != ACX_OK) return bail(rc);
-            const uint64_t region_cap = w.cap / grid;
-            Sink K{w.recs, nullptr, w.block_counts, region_cap, bshift, key_mode, nullptr, nullptr};
-            if (a->prof) HIPCHK_R(hipEventRecord(a->ev[0], st));
-            hipError_t e = pre ? launch_prefilter(a->dev, a->d_dev, G, H, d_hay, len, scan_grid, 0, ~0ull, st)
-                               : launch_dfa_walk(a->dev, a->d_dev, G, K, d_hay, len, scan_grid,
-                                                 a->max_lds, st);
-            if (e != hipSuccess) return bail(hipfail(e, "scan kernel launch"));
-            if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-            if (pre) HIPCHK_R(launch_walk_hits(a->dev, a->d_dev, G, H, hit_grid, 0, K, d_hay, len, st));
-            HIPCHK_R(sink_summary(w.block_counts, grid, region_cap, pre ? w.hit_counts : nullptr, hit_grid,
-                                  hit_cap, w.summary, w.region_off, st));
-            HIPCHK_R(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
-            HIPCHK_R(hipStreamSynchronize(st));
-            add_scan_profile(a, len);
-            n_raw = w.h_pinned[0];
-            const uint64_t region_max = w.h_pinned[1], hit_max = pre ? w.h_pinned[3] : 0;
-            if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
-                if (hit_max > hit_cap) {
-                    rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64));
-                    if (rc) return bail(rc);
-                }
-                // hits that overflowed were dropped, so the occurrence count is a lower bound
-                uint64_t want = (uint64_t)grid * (region_max + region_max / 8 + 64);
-                if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
-                if ((rc = ensure_occ_capacity(a, want)) != ACX_OK) return bail(rc);
-                continue;
-            }
-            if (n_raw >= (1ull << 32) - 2) return bail(fail(ACX_ETOOBIG, "more than 2^32 occurrences"));
-            if (n_raw > 8 * nb) a->dense_hold = 8;
-            else if (a->dense_hold > 0) a->dense_hold--;
-            if (n_raw > 0) {
-                if (a->prof) HIPCHK_R(hipEventRecord(a->ev[1], st));
-                HIPCHK_R(sink_compact(w.recs, w.region_off, grid, region_cap, w.keys[1], w.pids[1], st));
-                int end_bit = std::min(64, rank_bits + bits_for(len));
-                HIPCHK_R(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1], w.pids[0],
-                                          n_raw, end_bit, st));
-                HIPCHK_R(make_spans(a->dev, key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
-                if (overlapping) {
-                    n_final = n_raw;
-                } else {
-                    // Standard: sorted by end, so the running max of the ends IS the array of ends
-                    const uint64_t *M = w.E;
-                    if (key_mode != 0) {
-                        HIPCHK_R(prefix_max(w.temp, w.temp_bytes, w.E, w.M, n_raw, st));
-                        M = w.M;
-                    }
-                    HIPCHK_R(hipMemsetAsync(w.flags + n_raw, 0, 4, st));
-                    HIPCHK_R(resolve_greedy(w.S, w.E, M, w.flags, n_raw, st));
-                    HIPCHK_R(flag_offsets(w.temp, w.temp_bytes, w.flags, w.idx, n_raw, st));
-                    HIPCHK_R(hipMemcpyAsync(w.h_pinned + 6, w.idx + n_raw, 4, hipMemcpyDeviceToHost, st));
-                    HIPCHK_R(hipStreamSynchronize(st));
-                    n_final = *(uint32_t *)(w.h_pinned + 6);
-                }
-                HIPCHK_R(g_bufs.get((void **)&r->d_matches,
-                                    std::max<uint64_t>(n_final, 1) * sizeof(acx_match_t), a->device));
-                HIPCHK_R(write_matches(w.pids[0], w.S, w.E, overlapping ? nullptr : w.flags,
-                                       overlapping ? nullptr : w.idx, r->d_matches, n_raw, st));
-                pending = true;
-            }
-            break;
+    FindCall c{a, d_hay, len, G, overlapping != 0, codepoints != 0, segmented, r,
+               overlapping ? 0 : a->host.match_kind};
+    auto body = [&]() -> int {
+        if (segmented) {
+            HIPCHK_RC(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
+            HIPCHK_RC(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
+            c.pending = true;
         }
-        if (a->prof) { a->profile.raw_occurrences += n_raw; a->profile.prefix_hits += pre ? w.h_pinned[2] : 0; }
-        r->n = n_final;
-        if (n_final && (codepoints || (segmented && !localized))) {
-            if (codepoints) {
-                uint64_t nb1 = (len + 1023) / 1024 + 1;
-                if ((rc = ensure_blocks(a, nb1)) != ACX_OK) return bail(rc);
-                HIPCHK_R(count_lead_bytes(d_hay, len, w.blockcnt, st));
-                HIPCHK_R(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
-            }
-            if (segmented)
-                HIPCHK_R(localize(G, d_hay, len, w.blockpre, codepoints, r->d_matches, n_final,
-                                  r->d_counts, st));
-            else
-                HIPCHK_R(to_code_points(d_hay, len, w.blockpre, r->d_matches, n_final, st));
-            pending = true;
+        if (allow_small && !segmented && small_ok(a, len)) { // small haystack: the whole call in one workgroup (K0)
+            HIPCHK_RC(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));
+            bool done = false;
+            int rc = run_small(a, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
+            if (rc || done) return rc;
+            g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
+            r->d_matches = nullptr;
         }
-        if (a->prof) { // end of the post stage: read lazily (next call / acx_profile_read), no extra sync here
-            HIPCHK_R(hipEventRecord(a->ev[2], st));
-            a->post_pending = true;
+        if (len > 0 && a->host.n_patterns > 0) {
+            int rc = run_pipeline(c);
+            if (rc) return rc;
         }
-    }
-    if (pending) HIPCHK_R(hipStreamSynchronize(st));
-#undef HIPCHK_R
+        if (c.pending) HIPCHK_RC(hipStreamSynchronize(st));
+        return ACX_OK;
+    };
+    const int rc = body();
+    if (rc != ACX_OK) { acx_free_result(r); return rc; }
     *out = r;
     return ACX_OK;
 }
+#undef HIPCHK_RC
 
 int stage_host(acx_automaton *a, const uint8_t *hay, uint64_t len, const uint64_t *offsets,
                uint64_t n_off) {
