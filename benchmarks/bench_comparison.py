@@ -23,34 +23,16 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
-def names_like(n=4244, seed=6):
-    """Stand-in for the reference's names.txt: n lower-case patterns of
-    5-12 letters, ~5 % deliberate duplicates."""
-    import gen
-    pats = [p.decode() for p in gen.gen_patterns(n, 5, 12, gen.AZ, seed)]
-    for i in range(0, n, 20):
-        pats[i] = pats[(i * 7 + 3) % n]
-    return pats
-
-
 def datasets(names_file):
+    import gen
     short_p = ["abc", "hello", "world", "aardvark", "fish", "what", "arbitrarymonkey", "birds", "host7", "host76"]
     short_h = ["arbitrarymonkey says hello to fish host76, 0.123 my friend, but why??? {}".format(i)
                for i in range(10_000)]
     if names_file and os.path.exists(names_file):
         long_p = [l.strip().lower() for l in open(names_file) if len(l.strip()) > 4]
     else:
-        long_p = names_like()
-    filler = ("it was the habit of {} to walk the length of the harbour wall before the boats came in, counting "
-              "the gulls on the breakwater and the nets laid out to dry, and nobody in the town thought it strange. "
-              "the keeper of the light kept a ledger of the weather, the tides and the vessels sighted, written in a "
-              "small careful hand, and on most days the entries were short. when the wind backed to the north the "
-              "whole street smelled of tar and salt, the shutters were fastened early, and the children were sent "
-              "to bring the washing in before the rain. entry number {} records nothing else of note.")
-    long_h = []
-    for i in range(100_000):
-        name = long_p[i % len(long_p)] if i % 90 == 0 else "notaperson"
-        long_h.append(filler.format(name, i))
+        long_p = gen.names_like()  # seeded stand-in
+    long_h = gen.names_lines(long_p, 100_000, every=90)
     return {"short": (short_p, short_h), "long": (long_p, long_h)}
 
 

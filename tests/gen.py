@@ -126,3 +126,67 @@ def gen_unicode_textlike(nchars: int, seed: int, patterns: Sequence[str] = (),
             o = b * plant_every + rng.next() % (plant_every - len(p))
             chars[o:o + len(p)] = list(p)
     return "".join(chars)
+
+
+# ---------------------------------------------------------------------------
+# cfg1 shape: the reference's benchmark uses a list of first names filtered by
+# `len > 4` and lower-cased (/root/reference/benchmarks/test_comparison.py:16-18: 4 244
+# patterns, 221 of them duplicates) over ~600-character prose lines with a name slot.  That
+# file does not travel to the GPU box, so the tests use a seeded stand-in of the same shape.
+# ---------------------------------------------------------------------------
+def names_like(n: int = 4244, seed: int = 6) -> List[str]:
+    """n lower-case patterns of 5-12 letters, every 20th one a copy of another (~5 %
+    deliberate duplicates: the duplicate tie-break -- lowest pattern index -- is exercised)."""
+    pats = [p.decode() for p in gen_patterns(n, 5, 12, AZ, seed)]
+    for i in range(0, n, 20):
+        pats[i] = pats[(i * 7 + 3) % n]
+    return pats
+
+
+NAMES_FILLER = (
+    "it was the habit of {} to walk the length of the harbour wall before the boats came in, counting "
+    "the gulls on the breakwater and the nets laid out to dry, and nobody in the town thought it strange. "
+    "the keeper of the light kept a ledger of the weather, the tides and the vessels sighted, written in a "
+    "small careful hand, and on most days the entries were short. when the wind backed to the north the "
+    "whole street smelled of tar and salt, the shutters were fastened early, and the children were sent "
+    "to bring the washing in before the rain. entry number {} records nothing else of note.")
+
+
+def names_lines(patterns: Sequence[str], n_lines: int, every: int = 90) -> List[str]:
+    """The reference's `make_haystacks_long` shape (benchmarks/test_comparison.py:22-31): one
+    line in `every` carries a pattern, the others the word 'notaperson'."""
+    return [NAMES_FILLER.format(patterns[i % len(patterns)] if i % every == 0 else "notaperson", i)
+            for i in range(n_lines)]
+
+
+def names_haystack(patterns: Sequence[str], nbytes: int = 1_000_000, every: int = 3) -> bytes:
+    """cfg1 haystack: the lines joined by newlines, cut at exactly `nbytes` ASCII bytes.  A name
+    every third line keeps ~500 matches per MB, duplicates among them."""
+    n_lines = nbytes // (len(NAMES_FILLER) + 4) + 2
+    s = "\n".join(names_lines(patterns, n_lines, every)).encode("ascii")
+    assert len(s) >= nbytes
+    return s[:nbytes]
+
+
+def nested_patterns(n: int = 10000, seed: int = 21) -> List[bytes]:
+    """Pattern set for the large golden fixtures: ~5 % duplicates (names_like) and, for every
+    fifth pattern, a proper prefix / suffix / infix of another one -- so that the match kinds
+    disagree (Standard reports the piece that ends first, LeftmostFirst the lower index,
+    LeftmostLongest the longer) and overlapping searches report nested occurrences."""
+    pats = [p.encode() for p in names_like(n, seed)]
+    rng = SplitMix64(seed ^ 0xABCD)
+    for i in range(2, n, 5):
+        src = pats[rng.next() % n]
+        L = 2 + rng.next() % (len(src) - 1)       # 2 .. len(src)
+        o = rng.next() % (len(src) - L + 1)
+        pats[i] = src[o:o + L]
+    return pats
+
+
+def large_case_inputs(case: dict):
+    """(patterns, haystack bytes) of an entry of tests/golden/kinds_large.json."""
+    g, n, pseed = case["generator"], case["n_patterns"], case["pattern_seed"]
+    pats = nested_patterns(n, pseed) if g == "nested" else [p.encode() for p in names_like(n, pseed)]
+    hay = gen_textlike(case["haystack_bytes"], case["haystack_seed"], pats,
+                       plant_every=case["plant_every"]).tobytes()
+    return pats, hay

@@ -13,6 +13,12 @@ Cargo.lock:6-7).  Nothing here is needed on the GPU box; the JSON files are.
   ll_crate_large.json     same at 10k-pattern scale: seeds + SHA-256 + count
   lf_re.json              LeftmostFirst results produced by Python `re`
                           alternation (independent engine)
+  kinds_large.json        10k-pattern sets WITH duplicates and nested patterns over
+                          256-512 KB haystacks, every search mode: Standard and
+                          overlapping from the brute-force spec (tests/spec.py),
+                          LeftmostFirst from `re` alternation (and the spec, which must
+                          agree), LeftmostLongest from the spec; seeds + SHA-256 of the
+                          canonical (pattern,start,end) u64 stream + count + head
 
 usage: python tests/golden/make_golden.py
 """
@@ -137,14 +143,17 @@ def make_ll_small():
 
 def make_ll_large():
     out = []
-    for (npat, nchars, pseed, hseed) in [(10000, 200_000, 5, 55), (2000, 100_000, 6, 66),
-                                         (150, 50_000, 7, 77)]:
-        pats = uniq(gen.gen_patterns(npat, 5, 12, gen.AZ_UNI, pseed))
-        hay = gen.gen_unicode_textlike(nchars, hseed, pats)
+    for (npat, nchars, pseed, hseed, plant, lo) in [(10000, 200_000, 5, 55, 512, 5), (2000, 100_000, 6, 66, 512, 5),
+                                                    (150, 50_000, 7, 77, 512, 5),
+                                                    # denser: a planted pattern every 48 characters, short
+                                                    # patterns (2-9 characters: nested occurrences)
+                                                    (10000, 300_000, 8, 88, 48, 2)]:
+        pats = uniq(gen.gen_patterns(npat, lo, lo + 7, gen.AZ_UNI, pseed))
+        hay = gen.gen_unicode_textlike(nchars, hseed, pats, plant_every=plant)
         exp = crate_ll(pats, hay)
-        out.append({"n_patterns_requested": npat, "n_unique": len(pats), "lo": 5, "hi": 12,
+        out.append({"n_patterns_requested": npat, "n_unique": len(pats), "lo": lo, "hi": lo + 7,
                     "alphabet": "AZ_UNI", "pattern_seed": pseed, "nchars": nchars,
-                    "haystack_seed": hseed, "count": len(exp),
+                    "haystack_seed": hseed, "plant_every": plant, "count": len(exp),
                     "sha256": gen.canonical_sha256(exp), "head": exp[:16]})
         print("ll large", npat, "->", len(exp), "matches")
     return out
@@ -173,8 +182,40 @@ def make_lf():
     return cases
 
 
+# ---------------------------------------------------------------- large, all kinds
+LARGE_CASES = [
+    # (generator, n_patterns, pattern seed, haystack bytes, haystack seed, plant_every)
+    ("nested", 10000, 21, 256 * 1024, 31, 128),   # dense: 2-byte pieces, nested, ~9 % duplicates
+    ("names", 10000, 22, 512 * 1024, 32, 256),    # sparse: 5-12 letters, ~5 % duplicates
+    ("names", 4244, 6, 1_000_000, 33, 512),       # the cfg1 pattern set
+]
+
+
+def make_kinds_large():
+    import spec
+    out = []
+    for (g, n, pseed, nbytes, hseed, plant) in LARGE_CASES:
+        pats, hay = gen.large_case_inputs({"generator": g, "n_patterns": n, "pattern_seed": pseed,
+                                           "haystack_bytes": nbytes, "haystack_seed": hseed,
+                                           "plant_every": plant})
+        res = {}
+        for name, kind, ov in (("standard", "std", False), ("overlapping", "std", True),
+                               ("leftmost_first", "lf", False), ("leftmost_longest", "ll", False)):
+            m = [list(x) for x in spec.spec(pats, hay, kind, overlapping=ov)]
+            if name == "leftmost_first":  # independent engine; must agree with the spec
+                via_re = re_lf([p.decode() for p in pats], hay.decode())
+                assert via_re == m, "re alternation and the spec disagree"
+            res[name] = {"count": len(m), "sha256": gen.canonical_sha256(m), "head": m[:16]}
+            print("kinds large", g, n, name, len(m))
+        out.append({"generator": g, "n_patterns": n, "pattern_seed": pseed, "haystack_bytes": nbytes,
+                    "haystack_seed": hseed, "plant_every": plant,
+                    "n_duplicates": len(pats) - len(set(pats)), "results": res})
+    return out
+
+
 if __name__ == "__main__":
     dump("reference_vectors.json", REFERENCE)
     dump("ll_crate.json", make_ll_small())
     dump("ll_crate_large.json", make_ll_large())
     dump("lf_re.json", make_lf())
+    dump("kinds_large.json", make_kinds_large())

@@ -268,7 +268,8 @@ def test_golden_leftmost_longest_large_genuine_crate():
     for c in load("ll_crate_large.json"):
         pats = list(dict.fromkeys(gen.gen_patterns(c["n_patterns_requested"], c["lo"], c["hi"],
                                                    gen.AZ_UNI, c["pattern_seed"])))
-        hay = gen.gen_unicode_textlike(c["nchars"], c["haystack_seed"], pats)
+        hay = gen.gen_unicode_textlike(c["nchars"], c["haystack_seed"], pats,
+                                       plant_every=c.get("plant_every", 512))
         got = AhoCorasick(pats, matchkind=MatchKind.LeftmostLongest).find_matches_as_indexes(hay)
         assert len(got) == c["count"]
         assert [list(m) for m in got[:16]] == c["head"]
@@ -280,3 +281,22 @@ def test_golden_leftmost_first_re():
         a = AhoCorasick(c["patterns"], matchkind=MatchKind.LeftmostFirst)
         got = [list(m) for m in a.find_matches_as_indexes(c["haystack"])]
         assert got == c["expected"], (c["patterns"], c["haystack"])
+
+
+@pytest.mark.parametrize("implementation", [None, Implementation.DFA, Implementation.NoncontiguousNFA])
+@pytest.mark.parametrize("case", load("kinds_large.json"),
+                         ids=lambda c: f'{c["generator"]}{c["n_patterns"]}')
+def test_golden_large_pattern_sets_all_kinds(case, implementation):
+    """kinds_large.json through the HIP path (both scan kernels via the implementation hint):
+    10k patterns with duplicates / nested pieces, every search mode, SHA-256 of the stream."""
+    import gen
+    pats, hay = gen.large_case_inputs(case)
+    modes = [("standard", 0, False), ("overlapping", 0, True), ("leftmost_first", 1, False),
+             ("leftmost_longest", 2, False)]
+    for name, mk, ov in modes:
+        want = case["results"][name]
+        b = BytesAhoCorasick(pats, matchkind=KINDS[mk], implementation=implementation)
+        got = b.find_matches_as_indexes(hay, overlapping=ov)
+        assert len(got) == want["count"], name
+        assert [list(m) for m in got[:16]] == want["head"], name
+        assert gen.canonical_sha256(got) == want["sha256"], name

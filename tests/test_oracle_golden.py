@@ -59,11 +59,33 @@ def test_leftmost_longest_large_vs_genuine_crate():
         pats = list(dict.fromkeys(gen.gen_patterns(c["n_patterns_requested"], c["lo"], c["hi"],
                                                    gen.AZ_UNI, c["pattern_seed"])))
         assert len(pats) == c["n_unique"]
-        hay = gen.gen_unicode_textlike(c["nchars"], c["haystack_seed"], pats)
+        hay = gen.gen_unicode_textlike(c["nchars"], c["haystack_seed"], pats,
+                                       plant_every=c.get("plant_every", 512))
         got = Oracle([p.encode() for p in pats], 2, KIND_DFA).find_str(hay)
         assert len(got) == c["count"]
         assert [list(m) for m in got[:16]] == c["head"]
         assert gen.canonical_sha256(got) == c["sha256"]
+
+
+LARGE_MODES = [("standard", 0, False), ("overlapping", 0, True), ("leftmost_first", 1, False),
+               ("leftmost_longest", 2, False)]
+
+
+@pytest.mark.parametrize("kind", [KIND_NFA, KIND_DFA])
+@pytest.mark.parametrize("case", load("kinds_large.json"),
+                         ids=lambda c: f'{c["generator"]}{c["n_patterns"]}')
+def test_large_pattern_sets_all_kinds(case, kind):
+    """10k-pattern sets with duplicates and nested patterns: Standard / overlapping (brute-force
+    spec), LeftmostFirst (`re` alternation), LeftmostLongest (spec) -- SHA-256 of the canonical
+    stream.  Pins the duplicate tie-break (lowest index) at scale."""
+    pats, hay = gen.large_case_inputs(case)
+    assert len(pats) - len(set(pats)) == case["n_duplicates"] > 0
+    for name, mk, ov in LARGE_MODES:
+        want = case["results"][name]
+        got = Oracle(pats, mk, kind).find(hay, overlapping=ov)
+        assert len(got) == want["count"], name
+        assert [list(m) for m in got[:16]] == want["head"], name
+        assert gen.canonical_sha256(got) == want["sha256"], name
 
 
 @pytest.mark.parametrize("kind", [KIND_NFA, KIND_DFA])
