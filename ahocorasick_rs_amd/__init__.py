@@ -9,11 +9,12 @@ deprecated MATCHKIND_* aliases, served by a C++ CPython extension
 There is NO CPU matching path: importing needs the built extension, and every
 search needs a HIP device (RuntimeError otherwise).
 """
-from . import capi as _capi
-
-# one HIP runtime per process: if torch is present let it load its bundled runtime first
-_capi._preload_hip_runtime()
-
+# Importing this package needs neither numpy nor torch (the reference's needs neither): the
+# ctypes view of the C ABI (`ahocorasick_rs_amd.capi`, numpy-based, used by bench.py and the
+# device-pointer workflows) is imported on first attribute access only.  One process holds ONE
+# HIP runtime: torch wheels bundle a libamdhip64 with the same SONAME as /opt/rocm's, and
+# whichever is loaded first serves both -- code that hands torch device pointers to this
+# library should `import torch` first (bench.py and the tests do).
 try:
     from .ahocorasick_rs import (  # noqa: E402
         AhoCorasick,
@@ -42,3 +43,10 @@ __all__ = [
     "MATCHKIND_LEFTMOST_FIRST",
     "MATCHKIND_LEFTMOST_LONGEST",
 ]
+
+
+def __getattr__(name):  # lazy submodules: capi (ctypes + numpy), distributed (torch.distributed)
+    if name in ("capi", "distributed"):
+        import importlib
+        return importlib.import_module("." + name, __name__)
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")

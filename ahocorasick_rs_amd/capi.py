@@ -60,11 +60,11 @@ class Profile(ctypes.Structure):
 
 
 def _preload_hip_runtime() -> None:
-    # One process must hold ONE HIP runtime.  PyTorch wheels bundle their own
-    # libamdhip64 (same SONAME as /opt/rocm's); if torch is importable, let it
-    # load first so that libacx_hip.so binds to the same runtime and device
-    # pointers of torch tensors are valid here.  Opt out with ACX_NO_TORCH=1.
-    if os.environ.get("ACX_NO_TORCH") == "1" or "torch" in sys.modules:
+    # One process holds ONE HIP runtime: PyTorch wheels bundle their own libamdhip64 with the
+    # same SONAME as /opt/rocm's, and whichever is loaded first serves both libraries.  Nothing
+    # is imported here unless asked for (ACX_PRELOAD_TORCH=1): a plain AhoCorasick user needs
+    # no torch, and a process that already imported torch already has its runtime loaded.
+    if os.environ.get("ACX_PRELOAD_TORCH") != "1" or "torch" in sys.modules:
         return
     try:
         import torch  # noqa: F401

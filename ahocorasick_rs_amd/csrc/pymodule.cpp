@@ -44,15 +44,10 @@ PyObject *enum_int(PyObject *self) {
 PyObject *enum_richcompare(PyObject *a, PyObject *b, int op) {
     if (op != Py_EQ && op != Py_NE) Py_RETURN_NOTIMPLEMENTED;
     int eq;
-    if (Py_TYPE(a) == Py_TYPE(b)) {
-        eq = reinterpret_cast<EnumObject *>(a)->value == reinterpret_cast<EnumObject *>(b)->value;
-    } else if (PyLong_Check(b)) { // PyO3 simple enums also compare equal to their discriminant
-        long v = PyLong_AsLong(b);
-        if (v == -1 && PyErr_Occurred()) { PyErr_Clear(); Py_RETURN_NOTIMPLEMENTED; }
-        eq = v == reinterpret_cast<EnumObject *>(a)->value;
-    } else {
-        Py_RETURN_NOTIMPLEMENTED;
-    }
+    // pyclass(eq) without eq_int (src/lib.rs:93, 113): only members of the same enum compare
+    // equal; `MatchKind.Standard == 0` is False
+    if (Py_TYPE(a) != Py_TYPE(b)) Py_RETURN_NOTIMPLEMENTED;
+    eq = reinterpret_cast<EnumObject *>(a)->value == reinterpret_cast<EnumObject *>(b)->value;
     if ((op == Py_EQ) == (eq != 0)) Py_RETURN_TRUE;
     Py_RETURN_FALSE;
 }
@@ -104,6 +99,18 @@ PyObject *raise_acx(int rc) {
     return nullptr;
 }
 
+// `overlapping: bool` / `store_patterns: Option<bool>` (src/lib.rs:135, 229, 253, 422): PyO3
+// extracts a real bool and raises TypeError for anything else
+bool parse_bool(PyObject *o, const char *name, int *out) {
+    if (!PyBool_Check(o)) {
+        PyErr_Format(PyExc_TypeError, "argument '%s': '%.100s' object cannot be converted to 'PyBool'", name,
+                     Py_TYPE(o)->tp_name);
+        return false;
+    }
+    *out = o == Py_True;
+    return true;
+}
+
 bool parse_matchkind(PyObject *o, int *out) {
     if (!o) { *out = ACX_MATCH_STANDARD; return true; }
     if (Py_TYPE(o) != MatchKindType) {
@@ -135,7 +142,11 @@ bool get_bytes_view(PyObject *obj, Py_buffer *view) {
         PyErr_SetString(PyExc_TypeError, "Only one-dimensional sequences are supported");
         return false;
     }
-    if (view->itemsize != 1) {
+    // PyBuffer::<u8>::get (src/lib.rs:286) accepts unsigned one-byte items only: format "B"
+    // (absent = "B"), optionally behind a byte-order character; 'b', 'c', '?' are rejected
+    const char *fmt = view->format;
+    if (fmt && (*fmt == '@' || *fmt == '=' || *fmt == '<' || *fmt == '>' || *fmt == '!')) fmt++;
+    if (view->itemsize != 1 || (fmt && !(fmt[0] == 'B' && fmt[1] == 0))) {
         PyBuffer_Release(view);
         PyErr_SetString(PyExc_BufferError, "buffer contents are not compatible with u8");
         return false;
@@ -269,10 +280,7 @@ PyObject *ac_new(PyTypeObject *type, PyObject *args, PyObject *kwargs) {
     int mk, impl;
     if (!parse_matchkind(mk_o, &mk) || !parse_implementation(impl_o, &impl)) return nullptr;
     int store = -1; // None -> heuristic
-    if (store_o != Py_None) {
-        store = PyObject_IsTrue(store_o);
-        if (store < 0) return nullptr;
-    }
+    if (store_o != Py_None && !parse_bool(store_o, "store_patterns", &store)) return nullptr;
     PyObject *iter = PyObject_GetIter(patterns); // non-iterable -> TypeError (tests/test_ac.py:79-80)
     if (!iter) return nullptr;
     PyObject *kept = PyList_New(0);
@@ -335,7 +343,9 @@ bool parse_find_args(PyObject *args, PyObject *kwargs, const char *fmt, PyObject
                      int *overlapping) {
     static const char *kw[] = {"haystack", "overlapping", nullptr};
     *overlapping = 0;
-    return PyArg_ParseTupleAndKeywords(args, kwargs, fmt, const_cast<char **>(kw), hay, overlapping) != 0;
+    PyObject *ov = nullptr;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, fmt, const_cast<char **>(kw), hay, &ov)) return false;
+    return !ov || parse_bool(ov, "overlapping", overlapping);
 }
 
 bool str_view(PyObject *hay, const char **s, Py_ssize_t *len) {
@@ -352,7 +362,7 @@ bool str_view(PyObject *hay, const char **s, Py_ssize_t *len) {
 PyObject *ac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
     AcObject *self = reinterpret_cast<AcObject *>(self_);
     PyObject *hay; int overlapping;
-    if (!parse_find_args(args, kwargs, "O|p:find_matches_as_indexes", &hay, &overlapping)) return nullptr;
+    if (!parse_find_args(args, kwargs, "O|O:find_matches_as_indexes", &hay, &overlapping)) return nullptr;
     const char *s; Py_ssize_t len;
     if (!str_view(hay, &s, &len)) return nullptr;
     // ASCII haystack: byte offset == code-point index, skip the device fix-up
@@ -370,7 +380,7 @@ PyObject *ac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
 PyObject *ac_find_strings(PyObject *self_, PyObject *args, PyObject *kwargs) {
     AcObject *self = reinterpret_cast<AcObject *>(self_);
     PyObject *hay; int overlapping;
-    if (!parse_find_args(args, kwargs, "O|p:find_matches_as_strings", &hay, &overlapping)) return nullptr;
+    if (!parse_find_args(args, kwargs, "O|O:find_matches_as_strings", &hay, &overlapping)) return nullptr;
     const char *s; Py_ssize_t len;
     if (!str_view(hay, &s, &len)) return nullptr;
     acx_match_t *m = nullptr; uint64_t n = 0;
@@ -395,10 +405,11 @@ PyObject *ac_find_strings(PyObject *self_, PyObject *args, PyObject *kwargs) {
 
 PyObject *ac_find_batch(PyObject *self_, PyObject *args, PyObject *kwargs) {
     static const char *kw[] = {"haystacks", "overlapping", nullptr};
-    PyObject *hs; int overlapping = 0;
-    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|p:find_matches_as_indexes_batch",
-                                     const_cast<char **>(kw), &hs, &overlapping))
+    PyObject *hs, *ov = nullptr; int overlapping = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|O:find_matches_as_indexes_batch",
+                                     const_cast<char **>(kw), &hs, &ov))
         return nullptr;
+    if (ov && !parse_bool(ov, "overlapping", &overlapping)) return nullptr;
     return find_batch_impl(reinterpret_cast<AcObject *>(self_)->ac, hs, overlapping, true);
 }
 
@@ -497,7 +508,7 @@ PyObject *bac_new(PyTypeObject *type, PyObject *args, PyObject *kwargs) {
 PyObject *bac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
     BacObject *self = reinterpret_cast<BacObject *>(self_);
     PyObject *hay; int overlapping;
-    if (!parse_find_args(args, kwargs, "O|p:find_matches_as_indexes", &hay, &overlapping)) return nullptr;
+    if (!parse_find_args(args, kwargs, "O|O:find_matches_as_indexes", &hay, &overlapping)) return nullptr;
     Py_buffer v;
     if (!get_bytes_view(hay, &v)) return nullptr;
     acx_match_t *m = nullptr; uint64_t n = 0;
@@ -511,10 +522,11 @@ PyObject *bac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
 
 PyObject *bac_find_batch(PyObject *self_, PyObject *args, PyObject *kwargs) {
     static const char *kw[] = {"haystacks", "overlapping", nullptr};
-    PyObject *hs; int overlapping = 0;
-    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|p:find_matches_as_indexes_batch",
-                                     const_cast<char **>(kw), &hs, &overlapping))
+    PyObject *hs, *ov = nullptr; int overlapping = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|O:find_matches_as_indexes_batch",
+                                     const_cast<char **>(kw), &hs, &ov))
         return nullptr;
+    if (ov && !parse_bool(ov, "overlapping", &overlapping)) return nullptr;
     return find_batch_impl(reinterpret_cast<BacObject *>(self_)->ac, hs, overlapping, false);
 }
 

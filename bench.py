@@ -7,24 +7,39 @@ Metric (BASELINE.json): haystack GB/s (+ % of the HBM roofline), 10k-pattern DFA
           ONE 1 GiB text-like synthetic haystack (seed 11, one pattern planted per KiB),
           MatchKind.Standard, non-overlapping, byte offsets (BytesAhoCorasick path).
   N > 1   cfg3: the same automaton on every GPU; a batch of 8 KiB haystacks cut from one
-          global SplitMix64 stream, 131 072 haystacks (1 GiB) per GPU (weak scaling); no
-          data-path collective; RCCL all-gather of the per-shard match counts only.
+          global SplitMix64 stream (seed 13, offset by rank), 131 072 haystacks (1 GiB) per GPU
+          (weak scaling); no data-path collective; RCCL all-gather of the per-shard match
+          counts only.  `python bench.py --gpus N` launches its own N ranks (one per GPU,
+          torch.distributed.run, rendezvous on 127.0.0.1) when it is not already running under
+          a launcher (RANK unset); under `python -m torch.distributed.run ... bench.py --gpus N`
+          it is one of the ranks.  Fewer than N devices: non-zero exit, no line.
+  --config cfg2|cfg3|cfg4|cfg4b|cfg5 selects another BASELINE.json configuration at N = 1 (same JSON
+          shape, `config.workload` names it): cfg4 = 100 000 patterns a-z, overlapping, uniform
+          haystack; cfg4b = the byte-alphabet variant; cfg5 = 10 000 patterns over a-z + 2/3/4-byte
+          characters, LeftmostLongest, UTF-8 haystack, code-point indexes (the str API's path).
+  --host  the host-memory entry point (acx_find: host bytes in -> host match array out, the
+          only shape the reference's API has): a separate, labelled metric, never `value` of
+          the device-resident metric.
 
-A "step" is one complete pass of the hot path over the rank's resident batch: scan kernel
-(K1b prefilter) -> verification (k_walk_hits) -> tile kernels (sort, match-kind resolution,
-scan, write) -> final (pattern, start, end) u64 triples in HBM, their count on the host
-(+ the count all-gather for N > 1).  Inputs are resident in HBM before the timed region;
-nothing is cached between steps.
+A "step" is one complete pass of the hot path over the rank's resident batch: scan kernel ->
+verification / ordering / match-kind resolution -> final (pattern, start, end) u64 triples in
+HBM, their count on the host (+ the count all-gather for N > 1).  Inputs are resident in HBM
+before the timed region; nothing is cached between steps.
 
-One JSON line on rank 0; `roofline` is for the dominant kernel (K1) from HIP events recorded
-on the library's stream inside the timed region; `cpu_baseline` is the oracle's C DFA loop
-(a port of the reference's algorithm, 1 core) on the same haystack, timed on rank 0 at N = 1.
+One JSON line on rank 0; `roofline` is for the dominant kernel (K1) from HIP events recorded on
+the library's stream inside the timed region; `cpu_baseline` is the reference's algorithm on
+the host cores of this box (rank 0, N = 1): a genuine `ahocorasick_rs` wheel if one is
+importable, else the oracle's C restatement -- 1 core and all cores, 3 warm-ups, median of 7.
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -37,21 +52,131 @@ HBM_PEAK_GBPS = 8000.0  # MI355X spec, /opt/skills/guides/MI355X_MICROARCH.md
 GIB = 1 << 30
 
 
-def main() -> None:
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5"], default="auto",
+                    help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U"], default="T",
-                    help="T text-like (headline), U iid-uniform a-z")
+                    help="cfg2 haystack: T text-like (headline), U iid-uniform a-z")
     ap.add_argument("--kernel", choices=["auto", "dfa_walk", "prefilter"], default="auto")
     ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
-                    help="auto: cfg2 single haystack at N=1, cfg3 batch of 8 KiB haystacks at N>1")
+                    help="(kept for round-1 scripts) batch == --config cfg3")
+    ap.add_argument("--host", action="store_true",
+                    help="time the host-memory entry point (acx_find) instead: separate metric")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-bytes", type=int, default=GIB)
-    args = ap.parse_args()
+    ap.add_argument("--cpu-sample-bytes", type=int, default=256 << 20,
+                    help="prefix of the haystack the 1-core CPU leg scans per run")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launcher / collective plumbing only: gloo on CPU, no device work (tests)")
+    return ap.parse_args(argv)
 
+
+# ---------------------------------------------------------------------------
+# launcher: `python bench.py --gpus N` spawns its own ranks
+# ---------------------------------------------------------------------------
+def free_port() -> int:
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args) -> int:
+    if not args.dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            print(f"bench.py: --gpus {args.gpus} but only {have} HIP device(s) are visible", file=sys.stderr)
+            return 2
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this driver (RCCL needs it)
+    env["ACX_BENCH_SELF_LAUNCHED"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+# ---------------------------------------------------------------------------
+# workloads
+# ---------------------------------------------------------------------------
+def resolve_config(args, world: int) -> str:
+    if args.config != "auto":
+        return args.config
+    if args.workload == "batch":
+        return "cfg3"
+    if args.workload == "single":
+        return "cfg2"
+    return "cfg3" if world > 1 else "cfg2"
+
+
+def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
+    """-> dict(ac, hay (device tensor), nbytes, find kwargs, description, patterns, match_kind,
+    overlapping)."""
+    nbytes = args.bytes
+    kern = {"auto": None, "dfa_walk": capi.KERNEL_DFA_WALK, "prefilter": capi.KERNEL_PREFILTER}[args.kernel]
+    w = {"cfg": cfg, "overlapping": False, "codepoints": False, "n_hay": 0, "uniform_len": 0}
+    if cfg in ("cfg2", "cfg3"):
+        pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+        w["mk"], impl = capi.MATCH_STANDARD, capi.IMPL_DFA
+    elif cfg in ("cfg4", "cfg4b"):
+        pats = gen.gen_patterns(100000, 5, 12, gen.AZ if cfg == "cfg4" else gen.ALL_BYTES, 3 if cfg == "cfg4" else 4)
+        w["mk"], impl, w["overlapping"] = capi.MATCH_STANDARD, capi.IMPL_AUTO, True
+    else:  # cfg5
+        spats = list(dict.fromkeys(gen.gen_patterns(10000, 5, 12, gen.AZ_UNI, 5)))
+        pats = [p.encode() for p in spats]
+        w["mk"], impl, w["codepoints"] = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO, True
+    ac = capi.Automaton(pats, w["mk"], impl, kernel=kern)
+    w.update(ac=ac, patterns=pats)
+    if cfg == "cfg5":
+        # ~1.13 bytes per character at 5 % non-ASCII: generate enough characters, cut at a
+        # character boundary at or below --bytes
+        host = gen.gen_unicode_textlike_bytes(int(nbytes / 1.12) + 1024, 56, spats,
+                                              threads=min(32, os.cpu_count() or 1))
+        cut = min(nbytes, len(host))
+        while cut < len(host) and (host[cut] & 0xC0) == 0x80:
+            cut -= 1
+        nbytes = cut
+        hay = torch.from_numpy(host[:cut]).to(dev)
+        w["desc"] = (f"cfg5: 10k patterns over a-z + e-acute/snowman/facepalm (2/3/4-byte), seed 5, MatchKind."
+                     f"LeftmostLongest, {nbytes / GIB:.3f} GiB UTF-8 text-like str haystack (~5 % non-ASCII, "
+                     "seed 56), code-point indexes (AhoCorasick str path)")
+    else:
+        hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        if cfg == "cfg2":
+            kind, seed = (1, 11) if args.dist == "T" else (0, 12)
+            ac.generate(hay.data_ptr(), nbytes, kind, seed)
+            w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
+                         f"{nbytes / GIB:g} GiB "
+                         f"{'text-like (T, seed 11)' if args.dist == 'T' else 'uniform a-z (U, seed 12)'}"
+                         " bytes haystack, MatchKind.Standard, non-overlapping")
+        elif cfg == "cfg3":
+            if nbytes % 8192:
+                raise SystemExit("--bytes must be a multiple of 8192 for cfg3")
+            ac.generate(hay.data_ptr(), nbytes, 1, 13, stream_offset=rank * nbytes)
+            w["uniform_len"], w["n_hay"] = 8192, nbytes // 8192
+            w["desc"] = ("cfg3: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, batch of "
+                         f"{nbytes // 8192} x 8 KiB haystacks per GPU from one SplitMix64 stream (seed 13, "
+                         "offset by rank), MatchKind.Standard, sharded by haystack, RCCL all-gather of match counts")
+        elif cfg == "cfg4":
+            ac.generate(hay.data_ptr(), nbytes, 0, 12)
+            w["desc"] = (f"cfg4: 100k patterns a-z len 5-12 (seed 3), implementation=None, overlapping=True, one "
+                         f"{nbytes / GIB:g} GiB uniform a-z haystack (seed 12)")
+        else:
+            host = gen.gen_uniform(nbytes, gen.ALL_BYTES, 12)
+            hay = torch.from_numpy(host).to(dev)
+            w["desc"] = (f"cfg4b: 100k patterns over all byte values len 5-12 (seed 4), implementation=None, "
+                         f"overlapping=True, one {nbytes / GIB:g} GiB uniform-bytes haystack (seed 12)")
+    w.update(hay=hay, nbytes=nbytes)
+    return w
+
+
+# ---------------------------------------------------------------------------
+def run(args) -> None:
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -60,83 +185,94 @@ def main() -> None:
 
     import numpy as np
     import torch
-    import gen
-    from ahocorasick_rs_amd import capi
-
-    if not torch.cuda.is_available() or capi.device_count() < 1:
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    capi.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1 or "RANK" in os.environ:  # launched by torch.distributed.run: one rank per GPU over RCCL
-        import torch.distributed as dist
-        dist.init_process_group(backend="nccl", device_id=dev)
-
-    # ---- automaton (cfg2 / cfg3)
-    patterns = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
-    impl = capi.IMPL_DFA
-    kern = {"auto": None, "dfa_walk": capi.KERNEL_DFA_WALK,
-            "prefilter": capi.KERNEL_PREFILTER}[args.kernel]
-    ac = capi.Automaton(patterns, capi.MATCH_STANDARD, impl, kernel=kern)
-    info = ac.info
-
-    # ---- synthetic haystack, generated in HBM by the library (bit-exact twin of tests/gen.py)
-    nbytes = args.bytes
-    hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
-    kind, seed = (1, 11) if args.dist == "T" else (0, 12)
-    if world > 1 or args.workload == "batch":
-        seed = 13  # cfg3: ONE global stream cut into 8 KiB haystacks, sharded by rank
-    torch.cuda.synchronize()
-    ac.generate(hay.data_ptr(), nbytes, kind, seed, stream_offset=rank * nbytes)
-    batch = world > 1 if args.workload == "auto" else args.workload == "batch"
-    uniform_len = 8192 if batch else 0
-    n_hay = nbytes // uniform_len if batch else 0
-    if batch and nbytes % uniform_len:
-        raise SystemExit("--bytes must be a multiple of 8192 for the batch workload")
+    if args.dry_run:
+        dev = torch.device("cpu")
+        if "RANK" in os.environ:
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+        w = {"cfg": resolve_config(args, world), "nbytes": args.bytes, "desc": "dry run: no device work"}
+    else:
+        import gen
+        from ahocorasick_rs_amd import capi
+        if not torch.cuda.is_available() or capi.device_count() < 1:
+            raise SystemExit("bench.py needs a HIP device (there is no CPU fallback)")
+        if torch.cuda.device_count() < world:
+            raise SystemExit(f"{world} ranks but only {torch.cuda.device_count()} HIP device(s)")
+        torch.cuda.set_device(local_rank)
+        capi.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        if world > 1 or "RANK" in os.environ:  # one rank per GPU over RCCL
+            import torch.distributed as dist
+            dist.init_process_group(backend="nccl", device_id=dev)
+        w = build_workload(resolve_config(args, world), args, rank, capi, gen, torch, dev)
+    world_observed = dist.get_world_size() if dist is not None else 1
+    cfg, nbytes = w["cfg"], w["nbytes"]
 
     counts_local = torch.zeros(1, dtype=torch.int64, device=dev)
     counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
+    last = {}
 
     def step() -> int:
-        r = ac.find_device(hay.data_ptr(), nbytes, n_hay=n_hay, uniform_len=uniform_len)
-        n = r.count
+        if args.dry_run:
+            n = 1000 + rank
+        elif args.host:
+            m = w["ac"].find(w["host_hay"], overlapping=w["overlapping"], codepoints=w["codepoints"])
+            n = len(m)
+            last["matches"] = m
+        else:
+            r = w["ac"].find_device(w["hay"].data_ptr(), nbytes, n_hay=w["n_hay"], uniform_len=w["uniform_len"],
+                                    overlapping=w["overlapping"], codepoints=w["codepoints"])
+            n = r.count
+            if last.get("keep"):
+                last["matches"] = r.matches()
+            r.free()
         if dist is not None:  # C1: per-shard match counts -> global output offsets
             counts_local.fill_(n)
             dist.all_gather_into_tensor(counts_all, counts_local)
-        r.free()
         return n
 
+    if args.host and not args.dry_run:
+        w["host_hay"] = w["hay"].cpu().numpy()  # pageable host memory, what a Python caller holds
+
+    def sync():
+        if not args.dry_run:
+            torch.cuda.synchronize()
+
+    n_matches = 0
     for _ in range(args.warmup):
         n_matches = step()
-    ac.profile_enable(True)
-    ac.profile_read(reset=True)
+    if not args.dry_run:
+        w["ac"].profile_enable(True)
+        w["ac"].profile_read(reset=True)
     if dist is not None:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         n_matches = step()
-    torch.cuda.synchronize()
+    sync()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    prof = ac.profile_read(reset=True)
-    ac.profile_enable(False)
+    prof = None
+    if not args.dry_run:
+        prof = w["ac"].profile_read(reset=True)
+        w["ac"].profile_enable(False)
 
     total_matches = n_matches
+    per_rank = [nbytes * args.steps / elapsed / 1e9]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(every, t)
+        per_rank = [nbytes * args.steps / float(x) / 1e9 for x in every.cpu().tolist()]
+        elapsed = float(every.max().item())  # MAX over ranks
         total_matches = int(counts_all.sum().item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = world * nbytes * args.steps / elapsed / 1e9
-        scan_ms = prof.scan_ms / max(prof.scan_launches, 1)
-        algo_bytes = nbytes + 24 * n_matches  # 1 B read / haystack byte + 24 B / match
-        achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
         out = {
             "metric": "haystack GB/s, 10k-pattern DFA",
             "value": round(value, 2),
@@ -150,86 +286,223 @@ def main() -> None:
             "vs_baseline": None,
             "dtype": "u8",
             "data": "synthetic",
-            "config": {
-                "workload": ("cfg3: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, batch of "
-                             f"{n_hay} x 8 KiB haystacks per GPU from one SplitMix64 stream (seed 13), "
-                             "MatchKind.Standard, sharded by haystack, RCCL all-gather of match counts")
-                if batch else
-                ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
-                 f"{nbytes / GIB:g} GiB {'text-like (T, seed 11)' if args.dist == 'T' else 'uniform a-z (U, seed 12)'}"
-                 " bytes haystack, MatchKind.Standard, non-overlapping"),
-                "bytes_per_gpu": nbytes,
-                "n_patterns": len(patterns),
-                "n_states": int(info.n_states),
-                "dfa_table_bytes": int(info.table_bytes),
-                "scan_kernel": capi.KERNEL_NAMES[info.kernel],
-                "matches_per_gpu_step": int(n_matches),
-                "matches_total": int(total_matches),
+            "config": {"workload": w["desc"], "bytes_per_gpu": nbytes,
+                       "world_size_observed": world_observed,
+                       "launcher": "self (torch.distributed.run)" if os.environ.get("ACX_BENCH_SELF_LAUNCHED")
+                       else ("torch.distributed.run" if "RANK" in os.environ else "none"),
+                       "per_rank_gbps": [round(x, 2) for x in per_rank],
+                       "matches_per_gpu_step": int(n_matches), "matches_total": int(total_matches)},
+        }
+        if cfg not in ("cfg2", "cfg3"):
+            out["metric"] = f"haystack GB/s, {cfg} (not the headline metric)"
+        if args.host:
+            out["metric"] = ("host-memory entry point GB/s (acx_find: pageable host bytes in -> host match array "
+                             f"out, PCIe-inclusive), {cfg}")
+        if args.dry_run:
+            out["metric"] = "dry run (launcher / collective plumbing only)"
+            out["data"] = "none"
+        else:
+            info = w["ac"].info
+            scan_ms = prof.scan_ms / max(prof.scan_launches, 1)
+            algo_bytes = nbytes + 24 * n_matches  # 1 B read / haystack byte + 24 B / match
+            achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+            kname = "k1b_prefilter" if info.kernel == capi.KERNEL_PREFILTER else "k1a_dfa_walk"
+            traffic, traffic_src = measured_traffic(kname, nbytes, args.dist, cfg)
+            out["config"].update({
+                "n_patterns": len(w["patterns"]), "n_states": int(info.n_states),
+                "dfa_table_bytes": int(info.table_bytes), "scan_kernel": capi.KERNEL_NAMES[info.kernel],
                 "raw_occurrences_per_step": int(prof.raw_occurrences // max(prof.scan_launches, 1)),
                 "prefix_hits_per_step": int(prof.prefix_hits // max(prof.scan_launches, 1)),
                 "percent_of_hbm_roofline": round(100.0 * value / (HBM_PEAK_GBPS * world), 2),
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": "k1b_prefilter" if info.kernel == capi.KERNEL_PREFILTER else "k1a_dfa_walk",
-                "achieved": round(achieved, 2),
-                "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                "traffic": measured_traffic(info, nbytes, args.dist, batch),
-                "kernel_ms": round(scan_ms, 4),
+            })
+            out["roofline"] = {
+                "bound": "hbm", "kernel": kname, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "traffic_source": traffic_src, "kernel_ms": round(scan_ms, 4),
                 "algorithmic_bytes": int(algo_bytes),
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(patterns, hay, min(args.cpu_sample_bytes, nbytes), n_matches, nbytes)
+            }
+            if world == 1 and not args.no_cpu_baseline:
+                last["keep"] = True
+                step()  # one more pass, keeping the match stream for the SHA-256 comparison
+                out["cpu_baseline"] = cpu_baseline(w, last.get("matches"), args.cpu_sample_bytes)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def measured_traffic(info, nbytes, dist_name, batch):
+def measured_traffic(kernel: str, nbytes: int, dist_name: str, cfg: str):
     """HBM bytes per launch of the dominant kernel from the PMC passes of the SAME command
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction; produced by
-    tools/collect_profiles.sh and committed under profiles/).  null when no measurement of this
+    tools/collect_profiles.sh and committed under profiles/).  NOT measured in this run: the
+    second value names the file the number comes from; (None, None) when no measurement of this
     exact configuration is on file."""
     try:
-        best = None
+        best = (None, None)
         for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
             f = os.path.join(ROOT, "profiles", d, "pmc_traffic.json")
             if os.path.exists(f):
                 t = json.load(open(f))
-                kern = "k1b_prefilter" if info.kernel == 2 else "k1a_dfa_walk"
-                if (t.get("kernel") == kern and t.get("workload_bytes") == nbytes
-                        and t.get("dist") == dist_name and not batch):
-                    best = int(t["traffic_bytes"])
+                if (t.get("kernel") == kernel and t.get("workload_bytes") == nbytes
+                        and t.get("dist") == dist_name and t.get("config", "cfg2") == cfg):
+                    best = (int(t["traffic_bytes"]), os.path.relpath(f, ROOT))
         return best
     except Exception:
-        return None
+        return (None, None)
 
 
-def cpu_baseline(patterns, hay_t, sample_bytes, gpu_matches, nbytes):
-    """The oracle's dense-DFA loop (C port of the reference's algorithm: class map, one
-    dependent u32 load per byte, special-state range check), one core, on a prefix of the
-    very same haystack.  A reported baseline, not the target."""
+# ---------------------------------------------------------------------------
+# CPU baseline (BASELINE.md §2)
+# ---------------------------------------------------------------------------
+def probe_genuine_wheel():
+    """A genuine `ahocorasick_rs` (the Rust wheel) importable from OUTSIDE this repository?
+    The repository ships its own package of that name (marked __acx_amd__): search with the
+    repository's directories off sys.path and refuse anything that carries the marker."""
+    import importlib
+    import importlib.util
+    saved_path, saved_mods = list(sys.path), {k: v for k, v in sys.modules.items() if k.startswith("ahocorasick_rs")}
     try:
-        from oracle_lib import KIND_DFA, Oracle
-        host = hay_t[:sample_bytes].cpu().numpy()
-        o = Oracle(patterns, 0, KIND_DFA)
-        o.count(host[: 1 << 24])  # warm-up
+        sys.path[:] = [p for p in sys.path if p not in ("", ".") and os.path.abspath(p) != ROOT
+                       and not os.path.abspath(p).startswith(ROOT + os.sep)]
+        for k in list(saved_mods):
+            if not k.startswith("ahocorasick_rs_amd"):
+                sys.modules.pop(k, None)
+        spec = importlib.util.find_spec("ahocorasick_rs")
+        if spec is None or (spec.origin and os.path.abspath(spec.origin).startswith(ROOT + os.sep)):
+            return None
+        mod = importlib.import_module("ahocorasick_rs")
+        return None if getattr(mod, "__acx_amd__", False) else mod
+    except Exception:
+        return None
+    finally:
+        sys.path[:] = saved_path
+        for k in [k for k in sys.modules if k.startswith("ahocorasick_rs") and not k.startswith("ahocorasick_rs_amd")]:
+            sys.modules.pop(k, None)
+        sys.modules.update(saved_mods)
+
+
+def sha256_stream(arr) -> str:
+    """SHA-256 of the canonical (pattern:u64, start:u64, end:u64) little-endian stream."""
+    import numpy as np
+    a = np.ascontiguousarray(arr, dtype="<u8").reshape(-1, 3)
+    return hashlib.sha256(a.tobytes()).hexdigest()
+
+
+def median_time(fn, warm=3, runs=7):
+    for _ in range(warm):
+        fn()
+    ts = []
+    for _ in range(runs):
         t0 = time.perf_counter()
-        n = o.count(host)
-        dt = time.perf_counter() - t0
-        res = {"value": round(sample_bytes / dt / 1e9, 4), "unit": "GB/s", "cores": 1,
-               "kind": "port",
-               "sample": f"first {sample_bytes / GIB:g} GiB of the same haystack, 1 pass, "
-                         f"{dt:.1f} s, {n} matches"}
-        if sample_bytes == nbytes:
-            res["matches_equal_gpu"] = bool(n == gpu_matches)
+        fn()
+        ts.append(time.perf_counter() - t0)
+    return statistics.median(ts), ts
+
+
+def oracle_all_cores(o, host, max_len, threads, overlapping):
+    """The whole stream, exactly, with `threads` host threads (ctypes releases the GIL): ranges
+    of the haystack with max_len - 1 bytes of overlap.  Overlapping searches: a range reports
+    the occurrences that end in it.  Non-overlapping: a range reports the matches that start in
+    it, scanned speculatively from its own start; a sequential pass then follows the carry (the
+    end of the previous range's last match) and rescans the rare range whose carry differs."""
+    import numpy as np
+    from concurrent.futures import ThreadPoolExecutor
+    n, m = len(host), max(max_len - 1, 0)
+    cuts = [n * i // threads for i in range(threads + 1)]
+
+    def pin(i):
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            os.sched_setaffinity(0, {cpus[i % len(cpus)]})
+        except Exception:
+            pass
+
+    def scan(i, carry=None):
+        lo, hi = cuts[i], cuts[i + 1]
+        pin(i)
+        if overlapping:
+            w0 = max(0, lo - m)
+            r = o.find_raw(host[w0:hi], overlapping=True)
+            r[:, 1:] += w0
+            return r[r[:, 2] > lo] if lo > 0 else r
+        c = lo if carry is None else carry
+        if c >= hi and i < threads - 1:
+            return np.zeros((0, 3), np.uint64)
+        r = o.find_raw(host[c:n if i == threads - 1 else min(n, hi + m)])
+        r[:, 1:] += c
+        return r if i == threads - 1 else r[r[:, 1] < hi]
+
+    with ThreadPoolExecutor(threads) as ex:
+        parts = list(ex.map(scan, range(threads)))
+    if not overlapping:
+        carry = 0
+        for i in range(threads):
+            lo, hi = cuts[i], cuts[i + 1]
+            want = max(carry, lo)
+            if want != lo:
+                parts[i] = scan(i, want)
+            carry = max(hi, want, int(parts[i][-1, 2]) if len(parts[i]) else 0)
+    return np.concatenate(parts) if parts else np.zeros((0, 3), np.uint64)
+
+
+def cpu_baseline(w, gpu_matches, sample_bytes):
+    """The reference's algorithm on this box's host cores, on the very same haystack bytes.
+    Ladder: a genuine `ahocorasick_rs` wheel if importable; else the oracle's C
+    restatement (class map, one dependent u32 load per byte, special-state range check).
+    1 core on a bounded prefix and all cores on the whole haystack; 3 warm-ups, median of 7;
+    SHA-256 of the (u64,u64,u64) stream compared with the GPU's."""
+    import numpy as np
+    try:
+        host = w["hay"].cpu().numpy()
+        nbytes = len(host)
+        mk, ov = w["mk"], w["overlapping"]
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        sample = host[: min(sample_bytes, nbytes)]
+        gpu_sha = None
+        if gpu_matches is not None and not w["codepoints"]:
+            gpu_sha = sha256_stream(np.stack([gpu_matches["pattern"], gpu_matches["start"], gpu_matches["end"]], 1))
+        wheel = probe_genuine_wheel()
+        if wheel is not None:
+            kinds = [wheel.MatchKind.Standard, wheel.MatchKind.LeftmostFirst, wheel.MatchKind.LeftmostLongest]
+            a = wheel.BytesAhoCorasick(w["patterns"], matchkind=kinds[mk],
+                                       implementation=wheel.Implementation.DFA if w["cfg"] in ("cfg2", "cfg3") else None)
+            buf = sample.tobytes()
+            med, ts = median_time(lambda: a.find_matches_as_indexes(buf, overlapping=ov))
+            full = a.find_matches_as_indexes(host.tobytes(), overlapping=ov)
+            sha = sha256_stream(np.array(full, dtype=np.uint64).reshape(-1, 3))
+            return {"value": round(len(sample) / med / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "reference",
+                    "sample": f"genuine ahocorasick_rs wheel, first {len(sample) / GIB:g} GiB of the same haystack, "
+                              f"3 warm-ups, median of 7 ({min(ts):.3f}-{max(ts):.3f} s)",
+                    "host_cores_available": ncpu, "sha256_equal_gpu": None if gpu_sha is None else sha == gpu_sha}
+        from oracle_lib import KIND_DFA, Oracle
+        o = Oracle(w["patterns"], mk, KIND_DFA)
+        max_len = max(len(p) for p in w["patterns"])
+        one = (lambda: o.find_raw(sample, overlapping=True)) if ov else (lambda: o.count(sample))
+        med1, ts1 = median_time(one)
+        threads = max(1, min(ncpu, 64))
+        medn, tsn = median_time(lambda: oracle_all_cores(o, host, max_len, threads, ov), warm=1, runs=3)
+        full = oracle_all_cores(o, host, max_len, threads, ov)
+        res = {"value": round(len(sample) / med1 / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+               "sample": f"CPU restatement of the reference algorithm (not the Rust binary): oracle DFA loop, first "
+                         f"{len(sample) / GIB:g} GiB of the same haystack, 3 warm-ups, median of 7 "
+                         f"({min(ts1):.3f}-{max(ts1):.3f} s)",
+               "all_cores": {"value": round(nbytes / medn / 1e9, 4), "unit": "GB/s", "cores": threads,
+                             "sample": f"whole {nbytes / GIB:g} GiB haystack in {threads} ranges with "
+                                       f"{max_len - 1} bytes of overlap, threads pinned, 1 warm-up, median of 3 "
+                                       f"({min(tsn):.3f}-{max(tsn):.3f} s)"},
+               "host_cores_available": ncpu, "matches": int(len(full))}
+        if gpu_sha is not None:
+            res["sha256_equal_gpu"] = sha256_stream(full) == gpu_sha
         return res
     except Exception as e:  # the baseline must never take the GPU number down with it
-        return {"value": None, "unit": "GB/s", "cores": 1, "kind": "port", "sample": f"failed: {e}"}
+        return {"value": None, "unit": "GB/s", "cores": 1, "kind": "port", "sample": f"failed: {e!r}"}
+
+
+def main() -> None:
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
+    run(args)
 
 
 if __name__ == "__main__":

@@ -190,3 +190,61 @@ def large_case_inputs(case: dict):
     hay = gen_textlike(case["haystack_bytes"], case["haystack_seed"], pats,
                        plant_every=case["plant_every"]).tobytes()
     return pats, hay
+
+
+def gen_unicode_textlike_bytes(nchars: int, seed: int, patterns: Sequence[str] = (),
+                               plant_every: int = 512, chunk_chars: int = 1 << 22,
+                               threads: int = 1) -> np.ndarray:
+    """UTF-8 bytes of gen_unicode_textlike(nchars, seed, patterns, plant_every), vectorised
+    (SplitMix64 is counter based: character k uses output k, block b of the planting uses
+    outputs nchars + 2 b + 1 and nchars + 2 b + 2), generated in chunks so that a 1 GiB cfg5
+    haystack needs a few hundred MB of scratch.  Bit-exact twin of the scalar generator."""
+    assert chunk_chars % plant_every == 0
+    # code points: 32, a-z, and the three non-ASCII characters
+    extra_cp = np.array([ord(c) for c in UNI_EXTRA], dtype=np.uint32)
+    pat_cp = [np.array([ord(c) for c in p], dtype=np.uint32) for p in patterns]
+
+    def one_chunk(c0):
+        n = min(chunk_chars, nchars - c0)
+        z = stream_np(seed, n, start=c0 + 1)
+        r = (z & np.uint64(0xFF)).astype(np.uint32)
+        hi = (z >> np.uint64(8))
+        cp = (97 + (hi % np.uint64(26))).astype(np.uint32)
+        cp = np.where(r < 56, extra_cp[(hi % np.uint64(3)).astype(np.int64)], cp)
+        cp = np.where(r < 43, np.uint32(32), cp)
+        if len(patterns):
+            b0, b1 = c0 // plant_every, min((c0 + n) // plant_every, nchars // plant_every)
+            if b1 > b0:
+                zz = stream_np(seed, 2 * (b1 - b0), start=nchars + 2 * b0 + 1)
+                for b in range(b0, b1):
+                    p = pat_cp[int(zz[2 * (b - b0)] % np.uint64(len(patterns)))]
+                    o = b * plant_every + int(zz[2 * (b - b0) + 1] % np.uint64(plant_every - len(p))) - c0
+                    cp[o:o + len(p)] = p
+        # UTF-8 encode: 1-4 bytes per code point
+        nb = 1 + (cp >= 0x80).astype(np.int64) + (cp >= 0x800) + (cp >= 0x10000)
+        off = np.cumsum(nb) - nb
+        buf = np.zeros(int(off[-1] + nb[-1]) if n else 0, dtype=np.uint8)
+        m1 = nb == 1
+        buf[off[m1]] = cp[m1]
+        m2 = nb == 2
+        buf[off[m2]] = 0xC0 | (cp[m2] >> 6)
+        buf[off[m2] + 1] = 0x80 | (cp[m2] & 0x3F)
+        m3 = nb == 3
+        buf[off[m3]] = 0xE0 | (cp[m3] >> 12)
+        buf[off[m3] + 1] = 0x80 | ((cp[m3] >> 6) & 0x3F)
+        buf[off[m3] + 2] = 0x80 | (cp[m3] & 0x3F)
+        m4 = nb == 4
+        buf[off[m4]] = 0xF0 | (cp[m4] >> 18)
+        buf[off[m4] + 1] = 0x80 | ((cp[m4] >> 12) & 0x3F)
+        buf[off[m4] + 2] = 0x80 | ((cp[m4] >> 6) & 0x3F)
+        buf[off[m4] + 3] = 0x80 | (cp[m4] & 0x3F)
+        return buf
+
+    starts = list(range(0, nchars, chunk_chars))
+    if threads > 1 and len(starts) > 1:  # numpy releases the GIL inside its loops
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(threads) as ex:
+            out = list(ex.map(one_chunk, starts))
+    else:
+        out = [one_chunk(c0) for c0 in starts]
+    return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)

@@ -16,10 +16,10 @@ from hypothesis import strategies as st
 from spec import spec
 
 pytestmark = pytest.mark.gpu
-ac = pytest.importorskip("ahocorasick_rs_amd")
-from ahocorasick_rs_amd import (AhoCorasick, BytesAhoCorasick, Implementation,  # noqa: E402
-                                MatchKind, MATCHKIND_LEFTMOST_FIRST,
-                                MATCHKIND_LEFTMOST_LONGEST, MATCHKIND_STANDARD)
+ac = pytest.importorskip("ahocorasick_rs")  # the drop-in name (alias of ahocorasick_rs_amd)
+from ahocorasick_rs import (AhoCorasick, BytesAhoCorasick, Implementation,  # noqa: E402
+                            MatchKind, MATCHKIND_LEFTMOST_FIRST,
+                            MATCHKIND_LEFTMOST_LONGEST, MATCHKIND_STANDARD)
 
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 IMPLS = [None, Implementation.NoncontiguousNFA, Implementation.ContiguousNFA, Implementation.DFA]
@@ -129,6 +129,60 @@ def test_haystack_type_errors():
     with pytest.raises(TypeError) as e:
         b.find_matches_as_indexes(memoryview(b"abcdef")[::2])
     assert "contiguous" in str(e.value)
+
+
+def test_argument_types_follow_pyo3():
+    """`overlapping: bool` (src/lib.rs:229, 253, 422) takes a real bool; the buffer must hold
+    unsigned bytes (PyBuffer::<u8>::get, src/lib.rs:286)."""
+    import array
+    a, b = AhoCorasick(["x"]), BytesAhoCorasick([b"x"])
+    for bad in (1, 0, "yes", None):
+        with pytest.raises(TypeError):
+            a.find_matches_as_indexes("x", overlapping=bad)
+        with pytest.raises(TypeError):
+            a.find_matches_as_strings("x", overlapping=bad)
+        with pytest.raises(TypeError):
+            b.find_matches_as_indexes(b"x", overlapping=bad)
+    assert a.find_matches_as_indexes("x", True) == [(0, 0, 1)] == b.find_matches_as_indexes(b"x", overlapping=True)
+    with pytest.raises(BufferError):
+        b.find_matches_as_indexes(array.array("b", [120]))
+    assert b.find_matches_as_indexes(array.array("B", [120])) == [(0, 0, 1)]
+
+
+def test_concurrent_searches_from_threads():
+    """The reference releases the GIL around matching and lets threads search ONE automaton
+    concurrently (src/lib.rs:238, 261, 433; module gil_used = false, :438).  N threads on one
+    object and N threads on N objects return exactly what a single thread returns."""
+    import threading
+    import gen
+    from oracle_lib import KIND_DFA, Oracle
+    pats = gen.gen_patterns(3000, 4, 10, gen.AZ, 71)
+    hays = [gen.gen_textlike(n, 72 + i, pats, plant_every=256).tobytes()
+            for i, n in enumerate([300, 5000, 70_000, 1 << 20, 3 << 20, 17, 0, 40_000])]
+    o = Oracle(pats, 0, KIND_DFA)
+    want = [o.find(h) for h in hays]
+    want_ov = [o.find(h, overlapping=True) for h in hays]
+    shared = BytesAhoCorasick(pats)
+    own = [BytesAhoCorasick(pats) for _ in range(4)]
+    errors = []
+
+    def worker(t, automaton):
+        try:
+            for rep in range(6):
+                for k in range(len(hays)):
+                    i = (k + t + rep) % len(hays)
+                    if automaton.find_matches_as_indexes(hays[i]) != want[i]:
+                        errors.append(("non-overlapping", t, i))
+                    if automaton.find_matches_as_indexes(hays[i], overlapping=True) != want_ov[i]:
+                        errors.append(("overlapping", t, i))
+        except Exception as e:  # noqa: BLE001
+            errors.append(repr(e))
+
+    for automata in ([shared] * 8, own):
+        ts = [threading.Thread(target=worker, args=(t, a)) for t, a in enumerate(automata)]
+        [t.start() for t in ts]
+        [t.join() for t in ts]
+        assert not errors, errors[:5]
 
 
 # ---------------------------------------------------------------- bytes API

@@ -136,8 +136,27 @@ def test_compile_errors():
     h.close()
 
 
-def test_extension_api_surface_and_validation():
-    ac = pytest.importorskip("ahocorasick_rs_amd")
+def test_drop_in_package_name():
+    """`import ahocorasick_rs` -- the reference's package name and its native-submodule layout
+    (/root/reference/pysrc/ahocorasick_rs/__init__.py:2-7, src/lib.rs:438-445) -- resolves to
+    this build; importing it pulls in neither numpy nor torch (the reference needs neither)."""
+    import subprocess
+    import sys
+    code = ("import sys, ahocorasick_rs, ahocorasick_rs.ahocorasick_rs as native, ahocorasick_rs_amd as amd;"
+            "assert ahocorasick_rs.AhoCorasick is native.AhoCorasick is amd.AhoCorasick;"
+            "assert ahocorasick_rs.MatchKind.Standard is amd.MatchKind.Standard;"
+            "assert ahocorasick_rs.MATCHKIND_LEFTMOST_LONGEST is amd.MatchKind.LeftmostLongest;"
+            "assert set(ahocorasick_rs.__all__) == set(amd.__all__);"
+            "assert 'numpy' not in sys.modules and 'torch' not in sys.modules, 'heavy import';"
+            "import ahocorasick_rs_amd.capi; assert 'numpy' in sys.modules and 'torch' not in sys.modules")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+@pytest.mark.parametrize("name", ["ahocorasick_rs", "ahocorasick_rs_amd"])
+def test_extension_api_surface_and_validation(name):
+    ac = pytest.importorskip(name)
     assert ac.MATCHKIND_STANDARD == ac.MatchKind.Standard
     assert ac.MATCHKIND_LEFTMOST_FIRST == ac.MatchKind.LeftmostFirst
     assert ac.MATCHKIND_LEFTMOST_LONGEST == ac.MatchKind.LeftmostLongest
@@ -168,6 +187,18 @@ def test_extension_api_surface_and_validation():
         ac.AhoCorasick(["a"], matchkind="standard")
     with pytest.raises(TypeError):
         ac.AhoCorasick(["a"], implementation=2)
+    # pyclass(eq) without eq_int (src/lib.rs:93, 113): an enum member is not equal to its discriminant
+    assert ac.MatchKind.Standard != 0 and ac.Implementation.DFA != 2 and not (ac.MatchKind.LeftmostFirst == 1)
+    assert ac.MatchKind.Standard != ac.Implementation.NoncontiguousNFA
+    # `store_patterns: Option<bool>` takes a real bool (src/lib.rs:135)
+    for bad in (1, 0, "yes"):
+        with pytest.raises(TypeError):
+            ac.AhoCorasick(["a"], store_patterns=bad)
+    # PyBuffer::<u8>::get (src/lib.rs:286): unsigned one-byte items only
+    import array
+    for bad in (array.array("b", [1, 2]), array.array("H", [1, 2])):
+        with pytest.raises(BufferError):
+            ac.BytesAhoCorasick([bad])
 
 
 @pytest.mark.skipif(os.path.exists("/dev/kfd"), reason="a GPU is present")
