@@ -13,6 +13,7 @@ from __future__ import annotations
 import ctypes
 import os
 import sys
+import weakref
 from typing import List, Optional, Sequence, Tuple
 
 import numpy as np
@@ -47,9 +48,11 @@ class HostTables(ctypes.Structure):
                 ("dlink", ctypes.c_void_p), ("level_start", ctypes.c_void_p),
                 ("pattern_len", ctypes.c_void_p), ("rank", ctypes.c_void_p),
                 ("filter_xy", ctypes.c_void_p), ("prefix_table", ctypes.c_void_p),
+                ("prefix_lists", ctypes.c_void_p),
                 ("filter_q", ctypes.c_uint32), ("filter_q2", ctypes.c_uint32),
                 ("filter_entries_log2", ctypes.c_uint32), ("prefix_table_log2", ctypes.c_uint32),
-                ("filter_density", ctypes.c_double)]
+                ("filter_density", ctypes.c_double),
+                ("n_prefix_keys", ctypes.c_uint32), ("n_prefix_lists", ctypes.c_uint32)]
 
 
 class Profile(ctypes.Structure):
@@ -84,7 +87,7 @@ def lib() -> ctypes.CDLL:
             f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
             " (hipcc --offload-arch=gfx950).  There is no CPU fallback.")
     _preload_hip_runtime()
-    L = ctypes.CDLL(_SO, mode=ctypes.RTLD_GLOBAL)
+    L = ctypes.CDLL(os.environ.get("ACX_LIB", _SO), mode=ctypes.RTLD_GLOBAL)  # ACX_LIB: experiments with variant builds
     vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     L.acx_version.restype = i32
     L.acx_last_error.restype = ctypes.c_char_p
@@ -99,7 +102,7 @@ def lib() -> ctypes.CDLL:
     L.acx_host_tables.argtypes = [vp, ctypes.POINTER(HostTables)]
     L.acx_filter_hash.argtypes = [ctypes.c_uint32]
     L.acx_filter_hash.restype = ctypes.c_uint32
-    L.acx_prefix_slot.argtypes = [u64, ctypes.c_uint32]
+    L.acx_prefix_slot.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32]
     L.acx_prefix_slot.restype = ctypes.c_uint32
     L.acx_free_host.argtypes = [vp]
     L.acx_free_host.restype = None
@@ -203,6 +206,7 @@ class HostAutomaton:
                               np.uint32).reshape(-1, 2)
         self.prefix_table = view(t.prefix_table, (4 << int(t.prefix_table_log2)) if t.filter_q else 0,
                                  np.uint32).reshape(-1, 4)
+        self.prefix_lists = view(t.prefix_lists, int(t.n_prefix_lists), np.uint32)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -222,8 +226,8 @@ def filter_hash(gram: bytes) -> int:
 
 
 def prefix_slot(gram: bytes, log2: int) -> int:
-    """home slot of a Q2-byte gram in the level-2 prefix table."""
-    return int(lib().acx_prefix_slot(int.from_bytes(gram[:8], "little"), log2))
+    """home slot of a key (the first len(gram) <= 8 bytes of a pattern) in the prefix table."""
+    return int(lib().acx_prefix_slot(int.from_bytes(gram[:8], "little"), len(gram[:8]), log2))
 
 
 class DeviceBuffer:
@@ -298,6 +302,17 @@ class DeviceResult:
             pass
 
 
+def _take_matches(ptr: Optional[int], n: int) -> np.ndarray:
+    """The library-owned host array of an acx_find* call as a numpy structured array, without a
+    copy (a large result sits in pinned host memory): acx_free_matches runs when the array and
+    every view of it are gone."""
+    if not n:
+        return np.empty(0, dtype=MATCH_DTYPE)
+    buf = (ctypes.c_uint8 * (n * 24)).from_address(ptr)
+    weakref.finalize(buf, lib().acx_free_matches, ptr)
+    return np.frombuffer(buf, dtype=MATCH_DTYPE)
+
+
 class Automaton:
     """acx_automaton_t: compiled patterns + device tables."""
 
@@ -343,11 +358,7 @@ class Automaton:
         _check(lib().acx_find(self._h, a.ctypes.data if a.size else None, a.size,
                               int(overlapping), int(codepoints), ctypes.byref(out),
                               ctypes.byref(n)))
-        res = np.empty(n.value, dtype=MATCH_DTYPE)
-        if n.value:
-            ctypes.memmove(res.ctypes.data, out.value, n.value * 24)
-            lib().acx_free_matches(out.value)
-        return res
+        return _take_matches(out.value, n.value)
 
     def find_tuples(self, hay, overlapping: bool = False,
                     codepoints: bool = False) -> List[Tuple[int, int, int]]:
@@ -361,11 +372,7 @@ class Automaton:
         _check(lib().acx_find_batch(self._h, blob.ctypes.data, off.ctypes.data, len(haystacks),
                                     int(overlapping), int(codepoints), ctypes.byref(out),
                                     ctypes.byref(n), counts.ctypes.data))
-        res = np.empty(n.value, dtype=MATCH_DTYPE)
-        if n.value:
-            ctypes.memmove(res.ctypes.data, out.value, n.value * 24)
-            lib().acx_free_matches(out.value)
-        return res, counts
+        return _take_matches(out.value, n.value), counts
 
     # ---- device-resident entry point
     def find_device(self, d_ptr: int, nbytes: int, *, d_offsets: int = 0, n_hay: int = 0,

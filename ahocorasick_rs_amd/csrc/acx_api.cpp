@@ -1,16 +1,30 @@
 // acx_api.cpp -- implementation of the C ABI declared in include/acx.h.
 // Host orchestration of the device pipeline (kernels.hip).  There is no CPU
 // matching path here: without a HIP device every find call fails (ACX_EDEVICE).
+//
+// Concurrency (reference: methods take a shared PyRef and release the GIL, the module is
+// gil_used = false -- /root/reference/src/lib.rs:238, 261, 433, 438): a handle owns a small pool of
+// *contexts* (stream + workspace + pinned scratch); every call leases one, so calls from different
+// threads on ONE automaton run side by side on different streams instead of queueing on a lock.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
 #include <string>
+#include <thread>
+#include <unordered_map>
 #include <vector>
+
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
 
 #include "../../include/acx.h"
 #include "automaton.hpp"
@@ -36,18 +50,94 @@ int hipfail(hipError_t e, const char *what) {
         if (e__ != hipSuccess) return hipfail(e__, #expr); \
     } while (0)
 
-// Small process-wide cache of device buffers for results, so that a find call
-// does not pay hipMalloc/hipFree (each tens of microseconds and a device sync).
+inline void cpu_relax() {
+#if defined(__x86_64__)
+    _mm_pause();
+#endif
+}
+
+// makes `dev` the calling thread's HIP device for a scope and restores the previous one
+struct DeviceScope {
+    int prev = -1;
+    bool changed = false;
+    explicit DeviceScope(int dev) {
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != dev) changed = hipSetDevice(dev) == hipSuccess;
+    }
+    ~DeviceScope() {
+        if (changed && prev >= 0) (void)hipSetDevice(prev);
+    }
+};
+
+// ---------------------------------------------------------------------------
+// process-wide pools
+// ---------------------------------------------------------------------------
+// events that mark "this result's device work is done"
+struct EventPool {
+    std::mutex mu;
+    std::vector<std::pair<int, hipEvent_t>> free_list;
+    hipEvent_t get(int dev) {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            for (size_t i = 0; i < free_list.size(); i++)
+                if (free_list[i].first == dev) {
+                    hipEvent_t e = free_list[i].second;
+                    free_list.erase(free_list.begin() + i);
+                    return e;
+                }
+        }
+        hipEvent_t e = nullptr;
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
+        return e;
+    }
+    void put(int dev, hipEvent_t e) {
+        if (!e) return;
+        std::lock_guard<std::mutex> lk(mu);
+        if (free_list.size() >= 64) { (void)hipEventDestroy(e); return; }
+        free_list.push_back({dev, e});
+    }
+};
+EventPool g_events;
+
+// Small cache of device buffers for results, so that a find call does not pay
+// hipMalloc/hipFree (each tens of microseconds and a device sync).  A buffer may come back
+// while the kernel that fills it is still running (the call returned as soon as the totals
+// were known): it waits in `deferred` until its event has fired.
 struct BufCache {
     struct Ent { void *p; size_t bytes; int dev; };
+    struct Deferred { void *p; int dev; hipEvent_t ev; };
     std::mutex mu;
     std::vector<Ent> free_list;
+    std::vector<Deferred> deferred;
+    std::unordered_map<void *, Ent> live; // every buffer handed out by get()
     size_t cached = 0;
-    static constexpr size_t MAX_CACHED = (size_t)2 << 30;
+    static constexpr size_t MAX_CACHED = (size_t)4 << 30;
+
+    void release_locked(void *p, int dev) {
+        auto it = live.find(p);
+        const size_t bytes = it == live.end() ? 0 : it->second.bytes;
+        if (!bytes || cached + bytes > MAX_CACHED || free_list.size() >= 24) {
+            if (it != live.end()) live.erase(it);
+            DeviceScope ds(dev);
+            (void)hipFree(p);
+            return;
+        }
+        free_list.push_back({p, bytes, dev});
+        cached += bytes;
+    }
+    void sweep_locked() {
+        for (size_t i = 0; i < deferred.size();) {
+            if (hipEventQuery(deferred[i].ev) == hipErrorNotReady) { i++; continue; }
+            g_events.put(deferred[i].dev, deferred[i].ev);
+            release_locked(deferred[i].p, deferred[i].dev);
+            deferred.erase(deferred.begin() + i);
+        }
+    }
     hipError_t get(void **out, size_t bytes, int dev) {
         bytes = std::max<size_t>((bytes + 255) / 256 * 256, 256);
         {
             std::lock_guard<std::mutex> lk(mu);
+            if (!deferred.empty()) sweep_locked();
             int best = -1;
             for (int i = 0; i < (int)free_list.size(); i++)
                 if (free_list[i].dev == dev && free_list[i].bytes >= bytes &&
@@ -64,31 +154,136 @@ struct BufCache {
         // round up so that slightly larger requests can reuse the buffer later
         size_t alloc = bytes + bytes / 4;
         alloc = (alloc + 4095) / 4096 * 4096;
+        DeviceScope ds(dev);
         hipError_t e = hipMalloc(out, alloc);
         if (e == hipSuccess) {
             std::lock_guard<std::mutex> lk(mu);
-            sizes.push_back({*out, alloc, dev});
+            live[*out] = {*out, alloc, dev};
         }
         return e;
     }
-    void put(void *p, int dev) {
-        if (!p) return;
+    // ev != null: work that writes the buffer may still be running; ev fires when it is done
+    // (ownership of the event passes to the cache)
+    void put(void *p, int dev, hipEvent_t ev = nullptr) {
+        if (!p) { g_events.put(dev, ev); return; }
         std::lock_guard<std::mutex> lk(mu);
-        size_t bytes = 0;
-        for (auto &e : sizes) if (e.p == p) { bytes = e.bytes; break; }
-        if (!bytes || cached + bytes > MAX_CACHED || free_list.size() >= 16) {
-            for (size_t i = 0; i < sizes.size(); i++) if (sizes[i].p == p) { sizes.erase(sizes.begin() + i); break; }
-            (void)hipSetDevice(dev);
-            (void)hipFree(p);
-            return;
+        if (ev) {
+            if (hipEventQuery(ev) == hipErrorNotReady) { deferred.push_back({p, dev, ev}); return; }
+            g_events.put(dev, ev);
         }
-        free_list.push_back({p, bytes, dev});
-        cached += bytes;
+        release_locked(p, dev);
     }
-    std::vector<Ent> sizes; // every live buffer handed out by get()
 };
 BufCache g_bufs;
 
+// Pinned host buffers handed to callers as acx_find results (the D2H copy lands in them and
+// the caller reads them in place: no second copy).  acx_free_matches() gives them back.
+struct PinnedResults {
+    struct Ent { void *p; size_t bytes; bool used; };
+    std::mutex mu;
+    std::vector<Ent> all;
+    size_t total = 0;
+    static constexpr size_t MAX_TOTAL = (size_t)2 << 30;
+    void *get(size_t bytes) {
+        std::lock_guard<std::mutex> lk(mu);
+        int best = -1;
+        for (int i = 0; i < (int)all.size(); i++)
+            if (!all[i].used && all[i].bytes >= bytes && (best < 0 || all[i].bytes < all[best].bytes)) best = i;
+        if (best >= 0) { all[best].used = true; return all[best].p; }
+        size_t alloc = std::max<size_t>(bytes + bytes / 4, 1 << 20);
+        if (total + alloc > MAX_TOTAL) { // drop idle buffers, then give up (the caller falls back to malloc)
+            for (size_t i = 0; i < all.size();)
+                if (!all[i].used) { (void)hipHostFree(all[i].p); total -= all[i].bytes; all.erase(all.begin() + i); }
+                else i++;
+            if (total + alloc > MAX_TOTAL) return nullptr;
+        }
+        void *p = nullptr;
+        if (hipHostMalloc(&p, alloc, hipHostMallocDefault) != hipSuccess) return nullptr;
+        all.push_back({p, alloc, true});
+        total += alloc;
+        return p;
+    }
+    bool put(void *p) { // false: not one of ours
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &e : all)
+            if (e.p == p) { e.used = false; return true; }
+        return false;
+    }
+};
+PinnedResults g_pinned_results;
+
+// Host threads that copy a caller's pageable bytes into pinned staging chunks (one thread moves
+// ~10 GB/s; the PCIe link wants ~55): created on the first large host-memory call.
+class CopyPool {
+public:
+    static CopyPool &get() {
+        static CopyPool p;
+        return p;
+    }
+    int threads() const { return (int)workers_.size() + 1; }
+    // memcpy(dst, src, n) by all threads; returns when done.  One job at a time.
+    void copy(void *dst, const void *src, size_t n) {
+        const int T = threads();
+        if (n < (1u << 20) || T == 1) { std::memcpy(dst, src, n); return; }
+        std::lock_guard<std::mutex> job(job_mu_);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            dst_ = (uint8_t *)dst; src_ = (const uint8_t *)src; n_ = n;
+            pending_ = T - 1;
+            gen_++;
+        }
+        cv_.notify_all();
+        slice(0, T);
+        std::unique_lock<std::mutex> lk(mu_);
+        done_cv_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+private:
+    CopyPool() {
+        int T = (int)std::thread::hardware_concurrency() / 2;
+        if (const char *e = std::getenv("ACX_COPY_THREADS")) T = std::atoi(e);
+        T = std::max(1, std::min(T, 16));
+        for (int i = 1; i < T; i++) workers_.emplace_back([this, i, T] { run(i, T); });
+    }
+    ~CopyPool() {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            stop_ = true;
+        }
+        cv_.notify_all();
+        for (auto &t : workers_) t.join();
+    }
+    void slice(int i, int T) {
+        const size_t per = ((n_ + T - 1) / T + 4095) & ~(size_t)4095;
+        const size_t lo = std::min(n_, per * i), hi = std::min(n_, per * (i + 1));
+        if (hi > lo) std::memcpy(dst_ + lo, src_ + lo, hi - lo);
+    }
+    void run(int i, int T) {
+        uint64_t seen = 0;
+        for (;;) {
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || gen_ != seen; });
+                if (stop_) return;
+                seen = gen_;
+            }
+            slice(i, T);
+            std::lock_guard<std::mutex> lk(mu_);
+            if (--pending_ == 0) done_cv_.notify_one();
+        }
+    }
+    std::vector<std::thread> workers_;
+    std::mutex mu_, job_mu_;
+    std::condition_variable cv_, done_cv_;
+    uint8_t *dst_ = nullptr;
+    const uint8_t *src_ = nullptr;
+    size_t n_ = 0;
+    int pending_ = 0;
+    uint64_t gen_ = 0;
+    bool stop_ = false;
+};
+
+// ---------------------------------------------------------------------------
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -98,27 +293,44 @@ struct Workspace {
     void *temp = nullptr;
     size_t temp_bytes = 0;
     uint4 *recs = nullptr;            // occurrence sink: cap records of 16 B in per-workgroup regions
-    uint4 *hrecs = nullptr;           // K1b prefix-hit sink: hit_total records of 32 B
+    uint4 *hrecs = nullptr;           // dense path, K1b prefix-hit sink: hit_total records of 32 B
     uint64_t hit_total = 0;
-    uint64_t *hit_counts = nullptr;   // device: one per K1b workgroup
+    uint64_t *hit_counts = nullptr;   // device: one per K1b wave
     uint64_t *summary = nullptr;      // device: [0] occurrences kept, [1] max per region, [2..3] same for
-                                      // hits, [4] matches written, [5] abort flag of the sparse path
+                                      // hits, [4] matches written, [5..6] abort flags of the sparse path
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
-    uint64_t *h_pinned = nullptr;     // pinned host scratch (16 x u64; [8], [9] = result of K0)
+    uint64_t *h_pinned = nullptr;     // pinned host scratch (16 x u64; [8], [9] = result of K0; [7] = seq)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr;
     uint64_t block_cap = 0;
-    TileSpace T{};                    // sparse path (slot mode + tile kernels)
-    uint64_t tile_buckets = 0;        // buckets T is allocated for
-    bool sparse_dirty = true;         // T.bcnt / the abort flag are not known to be zero
+    TileSpace T{};                    // sparse path (hit slots + tile kernels)
+    uint64_t tile_cap = 0;            // tiles T is allocated for
+    bool flags_dirty = true;          // the abort flags are not known to be zero
     acx_match_t *final = nullptr;     // sparse path: output buffer the next call writes into
     uint64_t final_cap = 0;
-    uint8_t *hay = nullptr; // staging buffer of the host-memory entry points
+    uint8_t *hay = nullptr;           // device staging buffer of the host-memory entry points
     uint64_t hay_cap = 0;
     uint64_t *offsets = nullptr;
     uint64_t offsets_cap = 0;
+    // pipelined host -> device staging: ring of pinned chunks
+    static constexpr int RING = 3;
+    uint8_t *pin_chunk[RING] = {nullptr, nullptr, nullptr};
+    hipEvent_t chunk_ev[RING] = {nullptr, nullptr, nullptr};
+    size_t chunk_bytes = 0;
+};
+
+// everything one in-flight call needs
+struct Ctx {
+    hipStream_t stream = nullptr, copy_stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; // profiling: scan start / stop, end of the call
+    hipEvent_t copy_done = nullptr;                 // staging: the last chunk has landed
+    Workspace ws;
+    bool post_pending = false; // profiling: ev[2] of the last call has not been read yet
+    int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
+    int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
+    uint64_t seq = 0;          // sequence number the scan kernel publishes to h_pinned[7]
 };
 
 } // namespace
@@ -126,7 +338,6 @@ struct Workspace {
 struct acx_automaton {
     Automaton host;
     int device = 0;
-    hipStream_t stream = nullptr;
     DevAutomaton dev{};
     const DevAutomaton *d_dev = nullptr; // the same struct, resident in HBM
     std::vector<void *> allocs;
@@ -134,22 +345,17 @@ struct acx_automaton {
     int n_cus = 1;
     size_t max_lds = 65536;
     uint64_t table_bytes = 0;
-    std::mutex mu;       // guards the workspace + device pipeline
-    std::mutex stage_mu; // guards the host staging buffers (taken before mu)
-    Workspace ws;
-    bool prof = false;
-    bool post_pending = false;  // profiling: ev[2] of the last call has not been read yet
     bool kernel_forced = false; // the scan kernel was chosen explicitly: K0 never takes a call
-    int dense_hold = 0; // > 0: the output was too dense for the sparse path; calls left in region mode
+    bool sparse_ok = true;      // tile_lookback(max_len) <= MAX_LOOKBACK
+    // contexts
+    std::mutex pool_mu;
+    std::condition_variable pool_cv;
+    std::vector<Ctx *> ctxs, idle;
+    int max_ctx = 4;
+    // profiling (accumulated over the contexts)
+    std::mutex prof_mu;
+    std::atomic<bool> prof{false};
     acx_profile_t profile{};
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
-    // pipelined sparse path: the scan of chunk c + 1 (stream) overlaps the verification and
-    // tile kernels of chunk c (post_stream); chunk_ev[c] = scan of chunk c done
-    static constexpr int MAX_CHUNKS = 8;
-    hipStream_t post_stream = nullptr;
-    hipEvent_t chunk_ev[MAX_CHUNKS] = {};
-    hipEvent_t post_ev = nullptr; // the post stream caught up (start of a call)
-    int flag_idx = 0;             // which of the two abort flags the next sparse attempt uses
 };
 
 struct acx_host_automaton {
@@ -162,30 +368,39 @@ struct acx_result {
     uint64_t n = 0;
     uint64_t *d_counts = nullptr;
     uint64_t n_hay = 0;
+    hipEvent_t done = nullptr; // non-null: device work that fills the buffers may still be running
 };
 
 namespace {
 
+// the result's buffers are complete after this
+int result_wait(const acx_result *r) {
+    if (r && r->done) {
+        DeviceScope ds(r->device);
+        HIPCHK(hipEventSynchronize(r->done));
+    }
+    return ACX_OK;
+}
+
 template <typename T>
-int upload(acx_automaton *a, const T *src, size_t count, const T **dst) {
+int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T **dst) {
     size_t bytes = std::max<size_t>(count * sizeof(T), 16);
     bytes = (bytes + 15) / 16 * 16;
     void *d = nullptr;
     HIPCHK(hipMalloc(&d, bytes));
     a->allocs.push_back(d);
-    HIPCHK(hipMemsetAsync(d, 0, bytes, a->stream));
-    if (count) HIPCHK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, a->stream));
+    HIPCHK(hipMemsetAsync(d, 0, bytes, st));
+    if (count) HIPCHK(hipMemcpyAsync(d, src, count * sizeof(T), hipMemcpyHostToDevice, st));
     *dst = (const T *)d;
     return ACX_OK;
 }
 
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
-    (void)hipFree(T.slots); (void)hipFree(T.bcnt); (void)hipFree(T.trecs);
-    (void)hipFree(T.syncf); (void)hipFree(T.accf); (void)hipFree(T.tile_n); (void)hipFree(T.btot);
-    (void)hipFree(T.bbase);
+    (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs);
+    (void)hipFree(T.gocc); (void)hipFree(T.btot); (void)hipFree(T.bbase);
     T = TileSpace{};
-    w.tile_buckets = 0;
+    w.tile_cap = 0;
 }
 
 void free_ws(Workspace &w, int device) {
@@ -196,31 +411,87 @@ void free_ws(Workspace &w, int device) {
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     free_tiles(w);
     g_bufs.put(w.final, device);
-
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
     if (w.pin_hay) (void)hipHostFree(w.pin_hay);
     if (w.pin_out) (void)hipHostFree(w.pin_out);
+    for (int i = 0; i < Workspace::RING; i++) {
+        if (w.pin_chunk[i]) (void)hipHostFree(w.pin_chunk[i]);
+        if (w.chunk_ev[i]) (void)hipEventDestroy(w.chunk_ev[i]);
+    }
     w = Workspace();
 }
 
-int ensure_common(acx_automaton *a) {
-    Workspace &w = a->ws;
+void destroy_ctx(Ctx *c, int device) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    free_ws(c->ws, device);
+    for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
+    if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+Ctx *create_ctx() { // the automaton's device is current
+    Ctx *c = new (std::nothrow) Ctx();
+    if (!c) return nullptr;
+    bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
+    for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) == hipSuccess;
+    if (!ok) { destroy_ctx(c, 0); return nullptr; }
+    return c;
+}
+
+// a context of the automaton for the duration of one call (and the automaton's device as the
+// calling thread's current device)
+struct Lease {
+    acx_automaton *a;
+    Ctx *c = nullptr;
+    DeviceScope dev;
+    explicit Lease(acx_automaton *a_) : a(a_), dev(a_->device) {
+        std::unique_lock<std::mutex> lk(a->pool_mu);
+        for (;;) {
+            if (!a->idle.empty()) { c = a->idle.back(); a->idle.pop_back(); return; }
+            if ((int)a->ctxs.size() < a->max_ctx) {
+                c = create_ctx();
+                if (c) { a->ctxs.push_back(c); return; }
+                if (a->ctxs.empty()) return; // nothing to wait for: the caller reports the failure
+            }
+            a->pool_cv.wait(lk);
+        }
+    }
+    ~Lease() {
+        if (!c) return;
+        {
+            std::lock_guard<std::mutex> lk(a->pool_mu);
+            a->idle.push_back(c);
+        }
+        a->pool_cv.notify_one();
+    }
+};
+
+int ensure_common(Ctx *c) {
+    Workspace &w = c->ws;
     if (!w.summary) {
         HIPCHK(hipMalloc((void **)&w.summary, 64));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
-        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024 * acx_automaton::MAX_CHUNKS));
-        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 128, hipHostMallocDefault));
-        w.sparse_dirty = true;
+        HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
+        // polled by the host while kernels still run: system-coherent
+        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 128, hipHostMallocCoherent));
+        std::memset(w.h_pinned, 0, 128);
+        w.flags_dirty = true;
     }
     return ACX_OK;
 }
 
-// prefix-hit sink of K1b
-int ensure_hits(acx_automaton *a, uint64_t want) {
-    Workspace &w = a->ws;
+// dense path: prefix-hit sink of K1b
+int ensure_hits(Ctx *c, uint64_t want) {
+    Workspace &w = c->ws;
     if (want <= w.hit_total) return ACX_OK;
     (void)hipFree(w.hrecs); w.hrecs = nullptr; w.hit_total = 0;
     HIPCHK(hipMalloc((void **)&w.hrecs, want * 32));
@@ -229,8 +500,8 @@ int ensure_hits(acx_automaton *a, uint64_t want) {
 }
 
 // dense path: occurrence regions + everything the radix sort / resolve pipeline needs
-int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
-    Workspace &w = a->ws;
+int ensure_occ_capacity(Ctx *c, uint64_t want) {
+    Workspace &w = c->ws;
     if (want <= w.cap) return ACX_OK;
     uint64_t cap = std::max<uint64_t>(want, 1u << 16);
     for (int i = 0; i < 2; i++) {
@@ -259,43 +530,40 @@ int ensure_occ_capacity(acx_automaton *a, uint64_t want) {
     return ACX_OK;
 }
 
-// sparse path: slots and tile arrays for nb buckets
-int ensure_tiles(acx_automaton *a, uint64_t nb) {
-    Workspace &w = a->ws;
+// sparse path: hit slots for `tiles` tiles of index space, group arrays.  One bucket beyond the
+// last tile exists (an occurrence may END exactly at the end of the last tile).
+int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
+    Workspace &w = c->ws;
     TileSpace &T = w.T;
-    const uint64_t tiles = (nb + TILE_BUCKETS - 1) / TILE_BUCKETS;
-    if (nb > w.tile_buckets) {
+    const uint64_t groups = (tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
+    if (tiles > w.tile_cap) {
         free_tiles(w);
         if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
-        const uint64_t ents = tiles * TILE_MAX;
-        HIPCHK(hipMalloc((void **)&T.slots, nb * BUCKET_SLOTS * 16));
-        HIPCHK(hipMalloc((void **)&T.bcnt, (nb + 1) * 4));
-        HIPCHK(hipMalloc((void **)&T.trecs, ents * 16));
-        HIPCHK(hipMalloc((void **)&T.syncf, ents));
-        HIPCHK(hipMalloc((void **)&T.accf, ents));
-        HIPCHK(hipMalloc((void **)&T.tile_n, tiles * 4));
-        HIPCHK(hipMalloc((void **)&T.btot, tiles * 4));
-        HIPCHK(hipMalloc((void **)&T.bbase, tiles * 4));
-        w.tile_buckets = nb;
-        w.sparse_dirty = true;
+        const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
+        const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
+        HIPCHK(hipMalloc((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32));
+        HIPCHK(hipMalloc((void **)&T.hcnt, (cap_tiles + 1) * 4));
+        HIPCHK(hipMalloc((void **)&T.trecs, cap_groups * GROUP_MAX * 16));
+        HIPCHK(hipMalloc((void **)&T.gocc, cap_groups * 4));
+        HIPCHK(hipMalloc((void **)&T.btot, cap_groups * 4));
+        HIPCHK(hipMalloc((void **)&T.bbase, cap_groups * 4));
+        w.tile_cap = cap_tiles;
     }
-    T.n_buckets = (uint32_t)nb;
     T.n_tiles = (uint32_t)tiles;
+    T.n_groups = (uint32_t)groups;
     return ACX_OK;
 }
 
-int ensure_blocks(acx_automaton *a, uint64_t nblocks_plus1) {
-    Workspace &w = a->ws;
-    if (nblocks_plus1 <= w.block_cap) {
-        // the scan temp storage may need to cover this size too
-    } else {
+int ensure_blocks(Ctx *c, uint64_t nblocks_plus1) {
+    Workspace &w = c->ws;
+    if (nblocks_plus1 > w.block_cap) {
         (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
         w.blockcnt = w.blockpre = nullptr; w.block_cap = 0;
         HIPCHK(hipMalloc((void **)&w.blockcnt, nblocks_plus1 * 8));
         HIPCHK(hipMalloc((void **)&w.blockpre, nblocks_plus1 * 8));
         w.block_cap = nblocks_plus1;
     }
-    size_t need = scan_temp_bytes(nblocks_plus1) + 256;
+    size_t need = scan_temp_bytes(nblocks_plus1) + 256; // the scan temp storage must cover this size too
     if (need > w.temp_bytes) {
         (void)hipFree(w.temp); w.temp = nullptr;
         HIPCHK(hipMalloc(&w.temp, need));
@@ -318,46 +586,73 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 
 // One K0 launch + one sync.  hay / out: anything the device can address (HBM or pinned host);
 // out holds SMALL_MAX_OCC records.  *done = false: too many occurrences, use the general path.
-// Caller holds a->mu.
-int run_small(acx_automaton *a, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
+int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
               acx_match_t *out, uint64_t *n_out, bool *done) {
     *done = false;
-    int rc = ensure_common(a);
+    int rc = ensure_common(c);
     if (rc) return rc;
-    Workspace &w = a->ws;
+    Workspace &w = c->ws;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     HIPCHK(launch_small(a->dev, hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        w.h_pinned + 8, a->stream));
-    HIPCHK(hipStreamSynchronize(a->stream));
-    if (w.h_pinned[9] == 0) { *n_out = w.h_pinned[8]; *done = true; a->profile.small_calls++; }
+                        w.h_pinned + 8, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (w.h_pinned[9] == 0) {
+        *n_out = w.h_pinned[8];
+        *done = true;
+        std::lock_guard<std::mutex> lk(a->prof_mu);
+        a->profile.small_calls++;
+    }
     return ACX_OK;
 }
 
 // post_ms of the previous profiled call: ev[1] (end of the scan) .. ev[2] (end of the call's device work)
-void settle_post_profile(acx_automaton *a) {
-    if (!a->post_pending) return;
-    a->post_pending = false;
+void settle_post_profile(acx_automaton *a, Ctx *c) {
+    if (!c->post_pending) return;
+    c->post_pending = false;
     float ms = 0;
-    if (hipEventSynchronize(a->ev[2]) == hipSuccess && hipEventElapsedTime(&ms, a->ev[1], a->ev[2]) == hipSuccess)
+    if (hipEventSynchronize(c->ev[2]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(a->prof_mu);
         a->profile.post_ms += ms;
+    }
 }
 
-void add_scan_profile(acx_automaton *a, uint64_t len) {
+void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len) {
     if (!a->prof) return;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, a->ev[0], a->ev[1]) != hipSuccess) return;
+    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) != hipSuccess) return;
+    std::lock_guard<std::mutex> lk(a->prof_mu);
     a->profile.scan_ms += ms;
     a->profile.scan_launches++;
     a->profile.scan_bytes += len;
+}
+
+// Wait until the scan kernel has published sequence number `seq` to pinned host memory.  The
+// wake-up of a blocking stream synchronisation costs 10-20 us; polling the word the kernel
+// writes costs one PCIe round trip.  Falls back to the stream after a few milliseconds.
+int wait_published(Ctx *c, uint64_t seq) {
+    volatile uint64_t *p = c->ws.h_pinned;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; p[7] != seq; spins++) {
+        cpu_relax();
+        if ((spins & 1023) == 1023 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+            HIPCHK(hipStreamSynchronize(c->stream));
+            if (p[7] != seq) return fail(ACX_EDEVICE, "the scan kernel did not publish its totals");
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return ACX_OK;
 }
 
 // ---------------------------------------------------------------------------
 // The device pipeline.  d_hay: device pointer, len bytes.
 //
 //   small haystack:          K0, the whole call in one workgroup                 one launch
-//   sparse output (default): scan (K1a, or K1b + walk) emits into bucket slots -> tile kernels
-//                            (sort, resolve, scan, write) -> final matches       ONE host round trip
-//   dense output:            scan emits into regions -> compact -> radix sort -> spans ->
+//   sparse output (default): scan (K1b: prefix hits / K1a: occurrences) into per-tile hit slots ->
+//                            k_tile_main (verify, order, match kind) -> k_tile_scan -> k_tile_write;
+//                            the host returns as soon as the scan kernel has published the totals
+//   dense output:            scan emits into regions -> (walk) -> compact -> radix sort -> spans ->
 //                            resolve -> offsets -> write                         (two round trips)
 // ---------------------------------------------------------------------------
 #define HIPCHK_RC(expr)                                  \
@@ -369,130 +664,79 @@ void add_scan_profile(acx_automaton *a, uint64_t len) {
 // what one call works on (all attempts of it)
 struct FindCall {
     acx_automaton *a;
+    Ctx *c;
     const uint8_t *d_hay;
     uint64_t len;
     const Segments &G;
     bool overlapping, codepoints, segmented;
     acx_result *r;
     int key_mode;
-    bool pre;           // K1b + walk (else K1a)
+    bool pre;           // K1b (else K1a)
     uint32_t scan_grid; // workgroups of the scan kernel
-    uint32_t hit_grid;  // hit regions of one K1b launch
-    uint32_t grid;      // emitting workgroups (= occurrence regions in region mode)
-    uint32_t bshift;    // bucket = key >> bshift
-    uint64_t nb;        // buckets of 4 KiB of stream position
+    uint32_t lead;      // d_hay & 15: index = stream position + lead
+    uint64_t tiles;     // 4 KiB tiles of index space
     // results
-    uint64_t n_raw = 0, n_final = 0;
-    bool pending = false;   // work queued on the stream that nobody waited for yet
+    uint64_t n_raw = 0, n_final = 0, n_hits = 0;
+    bool queued = false;    // work queued on the stream that nobody waited for yet
     bool localized = false; // batch: offsets are already local and the counts taken
 };
-enum class Attempt { Done, Again, GoDense };
+enum class Attempt { Done, GoDense, Again };
 
-// ---- sparse output: slot mode + tile kernels, ONE host round trip
+// ---- sparse output: hit slots + tile kernels; returns when the totals are known
 int attempt_sparse(FindCall &c, Attempt *what) {
     acx_automaton *a = c.a;
-    Workspace &w = a->ws;
-    hipStream_t st = a->stream;
-    int rc = ensure_tiles(a, c.nb);
+    Ctx *x = c.c;
+    Workspace &w = x->ws;
+    hipStream_t st = x->stream;
+    int rc = ensure_tiles(a, x, c.tiles);
     if (rc) return rc;
-    // Chunked variant (ACX_CHUNKS=n, experiments only): K1b in n launches, each chunk's walk +
-    // tile kernels on the post stream underneath the next chunk's scan.  Measured on MI355X: no
-    // gain -- K1b's 16 waves x 128 VGPRs per CU fill the register file, so the other kernels only
-    // get on the CUs when a K1b workgroup retires.
-    static const int chunk_env = std::getenv("ACX_CHUNKS") ? std::atoi(std::getenv("ACX_CHUNKS")) : 1;
-    const int chunks = c.pre ? std::max(1, std::min(chunk_env, (int)acx_automaton::MAX_CHUNKS)) : 1;
-    const uint64_t hit_regions = (uint64_t)c.hit_grid * chunks; // every chunk has its own hit regions
-    const uint64_t hit_cap = c.pre ? w.hit_total / hit_regions : 0;
-    const Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, c.key_mode, nullptr, nullptr};
     const TileSpace &T = w.T;
-    const uint64_t out_cap = (uint64_t)T.n_tiles * TILE_MAX;
+    const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX;
     if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
     if (!w.final) {
         HIPCHK_RC(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
         w.final_cap = out_cap;
     }
-    if (w.sparse_dirty) {
-        HIPCHK_RC(hipMemsetAsync(T.bcnt, 0, (c.nb + 1) * 4, st));
-        HIPCHK_RC(hipMemsetAsync(w.summary + 5, 0, 16, st));
-    }
-    w.sparse_dirty = true;
-    // two abort flags used in turn: this attempt's tile kernels clear the other one
-    uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + a->flag_idx);
-    uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (a->flag_idx ^ 1));
-    a->flag_idx ^= 1;
-    const Sink K{nullptr, T.bcnt, w.block_counts, 0, c.bshift, c.key_mode, T.slots, abort_flag};
+    if (w.flags_dirty) HIPCHK_RC(hipMemsetAsync(w.summary + 5, 0, 16, st));
+    w.flags_dirty = true;
+    // two abort flags used in turn: this attempt's scan kernel clears the other one
+    uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + x->flag_idx);
+    uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (x->flag_idx ^ 1));
+    x->flag_idx ^= 1;
+    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
-    if (!c.pre) {
-        if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[0], st));
-        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
-        if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
-        HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, 0, T.n_tiles, true, true, nullptr, 0, 0,
-                            w.final, w.summary, abort_flag, next_flag, w.h_pinned, c.G, seg_counts, st));
-        HIPCHK_RC(hipStreamSynchronize(st));
+    const bool prof = a->prof;
+    if (c.pre) {
+        // measurement: the event pair rides on the dispatch
+        HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
+                                   prof ? x->ev[1] : nullptr));
     } else {
-        // K1b in chunks on `st`; each chunk's walk + tile kernels on the post stream as soon as its
-        // scan is done.  After the scan of K1b tiles [0, t1) every bucket below t1 - 1 is final (a key
-        // position never precedes the start of its occurrence), so the post stage trails by a tile.
-        const uint64_t k_tiles = prefilter_tiles(c.d_hay, c.len);
-        const uint64_t per = ((k_tiles + chunks - 1) / chunks + TILE_BUCKETS - 1) / TILE_BUCKETS * TILE_BUCKETS;
-        hipStream_t ps = chunks > 1 ? a->post_stream : st;
-        if (ps != st) {
-            HIPCHK_RC(hipEventRecord(a->post_ev, st)); // memsets above / earlier work on st
-            HIPCHK_RC(hipStreamWaitEvent(ps, a->post_ev, 0));
-        }
-        uint32_t tile0 = 0;
-        bool first = true;
-        for (int k = 0; k < chunks; k++) {
-            const uint64_t t0 = std::min<uint64_t>((uint64_t)k * per, k_tiles);
-            const uint64_t t1 = k == chunks - 1 ? k_tiles : std::min<uint64_t>(t0 + per, k_tiles);
-            const bool last = k == chunks - 1;
-            if (t1 == t0 && !last) continue;
-            Sink Hc = H;
-            Hc.recs = w.hrecs + (uint64_t)k * c.hit_grid * hit_cap * 2;
-            Hc.block_counts = w.hit_counts + (uint64_t)k * c.hit_grid;
-            // measurement: the event pair rides on the dispatch (first chunk's start, last chunk's stop)
-            HIPCHK_RC(launch_prefilter(a->dev, a->d_dev, c.G, Hc, c.d_hay, c.len, c.scan_grid, t0, t1, st,
-                                       a->prof && k == 0 ? a->ev[0] : nullptr,
-                                       a->prof && last ? a->ev[1] : nullptr));
-            if (ps != st) {
-                HIPCHK_RC(hipEventRecord(a->chunk_ev[k], st));
-                HIPCHK_RC(hipStreamWaitEvent(ps, a->chunk_ev[k], 0));
-            }
-            HIPCHK_RC(launch_walk_hits(a->dev, a->d_dev, c.G, Hc, c.hit_grid, 0, K, c.d_hay, c.len, ps));
-            const uint32_t tile1 = last ? T.n_tiles
-                                        : (uint32_t)std::min<uint64_t>((t1 - 1) / TILE_BUCKETS, T.n_tiles);
-            HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, tile0, std::max(tile0, tile1), first, last,
-                                Hc.block_counts, c.hit_grid, hit_cap, w.final, w.summary, abort_flag, next_flag,
-                                w.h_pinned, c.G, seg_counts, ps));
-            tile0 = std::max(tile0, tile1);
-            first = false;
-        }
-        HIPCHK_RC(hipStreamSynchronize(ps));
-        if (ps != st) HIPCHK_RC(hipStreamSynchronize(st));
+        HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
+        if (prof) HIPCHK_RC(hipEventRecord(x->ev[0], st));
+        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+        if (prof) HIPCHK_RC(hipEventRecord(x->ev[1], st));
     }
-    w.sparse_dirty = false; // the tile kernels left the counters and the next flag clean
-    add_scan_profile(a, c.len);
-    const bool aborted = w.h_pinned[5] != 0;
-    const uint64_t hit_max = c.pre ? w.h_pinned[3] : 0;
-    if (aborted) { // the sparse path gave up
-        if (seg_counts) // (a chunked call may already have counted the matches of its first chunks)
-            HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
-        if (hit_max > hit_cap) { // prefix hits were dropped: grow their sink, redo
-            if ((rc = ensure_hits(a, hit_regions * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
-            *what = Attempt::Again;
-        } else { // a bucket or a tile overflowed: dense output, use the region mode
-            a->dense_hold = 8;
-            *what = Attempt::GoDense;
-        }
+    const uint64_t seq = ++x->seq;
+    HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
+                        next_flag, w.h_pinned, seq, prof && c.pre, c.G, seg_counts, st));
+    if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
+    w.flags_dirty = false; // the scan kernel left the next flag clean
+    add_scan_profile(a, x, c.len);
+    if (w.h_pinned[5] != 0) { // the slots could not hold the output: dense path
+        HIPCHK_RC(hipStreamSynchronize(st));
+        if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
+        x->dense_hold = 8;
+        *what = Attempt::GoDense;
         return ACX_OK;
     }
     c.n_raw = w.h_pinned[0];
+    c.n_hits = w.h_pinned[2];
     c.n_final = w.h_pinned[4];
     c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
     w.final = nullptr;
     c.localized = seg_counts != nullptr;
-    if (c.localized) c.pending = false; // the stream has drained, counts included
+    c.queued = true; // k_tile_write is still running
     *what = Attempt::Done;
     return ACX_OK;
 }
@@ -500,43 +744,52 @@ int attempt_sparse(FindCall &c, Attempt *what) {
 // ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
 int attempt_dense(FindCall &c, Attempt *what) {
     acx_automaton *a = c.a;
-    Workspace &w = a->ws;
-    hipStream_t st = a->stream;
-    int rc = ensure_occ_capacity(a, std::max<uint64_t>(1u << 16, c.len / 64));
+    Ctx *x = c.c;
+    Workspace &w = x->ws;
+    hipStream_t st = x->stream;
+    int rc = ensure_occ_capacity(x, std::max<uint64_t>(1u << 16, c.len / 64));
     if (rc) return rc;
-    const uint64_t hit_cap = c.pre ? w.hit_total / c.hit_grid : 0;
-    const uint64_t region_cap = w.cap / c.grid;
-    const Sink H{w.hrecs, nullptr, w.hit_counts, hit_cap, 0, c.key_mode, nullptr, nullptr};
-    const Sink K{w.recs, nullptr, w.block_counts, region_cap, c.bshift, c.key_mode, nullptr, nullptr};
-    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[0], st));
-    HIPCHK_RC(c.pre ? launch_prefilter(a->dev, a->d_dev, c.G, H, c.d_hay, c.len, c.scan_grid, 0, ~0ull, st)
-                    : launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
-    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
-    if (c.pre) HIPCHK_RC(launch_walk_hits(a->dev, a->d_dev, c.G, H, c.hit_grid, 0, K, c.d_hay, c.len, st));
-    HIPCHK_RC(sink_summary(w.block_counts, c.grid, region_cap, c.pre ? w.hit_counts : nullptr, c.hit_grid, hit_cap,
+    if (c.pre && (rc = ensure_hits(x, std::max<uint64_t>(1u << 16, c.len / 64))) != ACX_OK) return rc;
+    const uint32_t hit_grid = c.pre ? prefilter_hit_regions(c.scan_grid) : 0;
+    const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : c.scan_grid; // occurrence regions
+    const uint64_t hit_cap = c.pre ? w.hit_total / hit_grid : 0;
+    const uint64_t region_cap = w.cap / grid;
+    const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead};
+    const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead};
+    const bool prof = a->prof;
+    if (c.pre) {
+        HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
+                                   prof ? x->ev[1] : nullptr));
+        HIPCHK_RC(launch_walk_hits(a->dev, c.G, H, hit_grid, K, grid, c.d_hay, c.len, st));
+    } else {
+        if (prof) HIPCHK_RC(hipEventRecord(x->ev[0], st));
+        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+        if (prof) HIPCHK_RC(hipEventRecord(x->ev[1], st));
+    }
+    HIPCHK_RC(sink_summary(w.block_counts, grid, region_cap, c.pre ? w.hit_counts : nullptr, hit_grid, hit_cap,
                            w.summary, w.region_off, st));
     HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
     HIPCHK_RC(hipStreamSynchronize(st));
-    add_scan_profile(a, c.len);
+    add_scan_profile(a, x, c.len);
     const uint64_t n_raw = w.h_pinned[0], region_max = w.h_pinned[1], hit_max = c.pre ? w.h_pinned[3] : 0;
     if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
-        if (hit_max > hit_cap && (rc = ensure_hits(a, (uint64_t)c.hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK)
+        if (hit_max > hit_cap && (rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK)
             return rc;
         // hits that overflowed were dropped, so the occurrence count is a lower bound
-        uint64_t want = (uint64_t)c.grid * (region_max + region_max / 8 + 64);
+        uint64_t want = (uint64_t)grid * (region_max + region_max / 8 + 64);
         if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
-        if ((rc = ensure_occ_capacity(a, want)) != ACX_OK) return rc;
+        if ((rc = ensure_occ_capacity(x, want)) != ACX_OK) return rc;
         *what = Attempt::Again;
         return ACX_OK;
     }
     if (n_raw >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
-    if (n_raw > 8 * c.nb) a->dense_hold = 8;
-    else if (a->dense_hold > 0) a->dense_hold--;
+    if (n_raw > 8 * c.tiles) x->dense_hold = 8;
+    else if (x->dense_hold > 0) x->dense_hold--;
     c.n_raw = n_raw;
+    c.n_hits = c.pre ? w.h_pinned[2] : 0;
     *what = Attempt::Done;
     if (n_raw == 0) return ACX_OK;
-    if (a->prof) HIPCHK_RC(hipEventRecord(a->ev[1], st));
-    HIPCHK_RC(sink_compact(w.recs, w.region_off, c.grid, region_cap, w.keys[1], w.pids[1], st));
+    HIPCHK_RC(sink_compact(w.recs, w.region_off, grid, region_cap, w.keys[1], w.pids[1], st));
     const int end_bit = std::min(64, (int)a->dev.rank_bits + bits_for(c.len));
     HIPCHK_RC(sort_occurrences(w.temp, w.temp_bytes, w.keys[1], w.keys[0], w.pids[1], w.pids[0], n_raw, end_bit, st));
     HIPCHK_RC(make_spans(a->dev, c.key_mode, w.keys[0], w.pids[0], w.S, w.E, n_raw, st));
@@ -560,19 +813,19 @@ int attempt_dense(FindCall &c, Attempt *what) {
                          a->device));
     HIPCHK_RC(write_matches(w.pids[0], w.S, w.E, c.overlapping ? nullptr : w.flags, c.overlapping ? nullptr : w.idx,
                             c.r->d_matches, n_raw, st));
-    c.pending = true;
+    c.queued = true;
     return ACX_OK;
 }
 
 // everything after the matches exist: code points (str API), local offsets + counts (batches)
 int finish_matches(FindCall &c) {
-    acx_automaton *a = c.a;
-    Workspace &w = a->ws;
-    hipStream_t st = a->stream;
+    Ctx *x = c.c;
+    Workspace &w = x->ws;
+    hipStream_t st = x->stream;
     if (!c.n_final || !(c.codepoints || (c.segmented && !c.localized))) return ACX_OK;
     if (c.codepoints) {
         const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
-        int rc = ensure_blocks(a, nb1);
+        int rc = ensure_blocks(x, nb1);
         if (rc) return rc;
         HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, st));
         HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
@@ -581,75 +834,73 @@ int finish_matches(FindCall &c) {
         HIPCHK_RC(localize(c.G, c.d_hay, c.len, w.blockpre, c.codepoints, c.r->d_matches, c.n_final, c.r->d_counts, st));
     else
         HIPCHK_RC(to_code_points(c.d_hay, c.len, w.blockpre, c.r->d_matches, c.n_final, st));
-    c.pending = true;
+    c.queued = true;
     return ACX_OK;
 }
 
-// the general pipeline on an allocated result; caller holds a->mu
+// the general pipeline on an allocated result
 int run_pipeline(FindCall &c) {
     acx_automaton *a = c.a;
-    int rc = ensure_common(a);
+    Ctx *x = c.c;
+    int rc = ensure_common(x);
     if (rc) return rc;
     c.pre = a->kernel == ACX_KERNEL_PREFILTER;
-    // K1b emits prefix hits; k_walk_hits turns them into occurrences.  K1a emits occurrences.
     c.scan_grid = c.pre ? prefilter_grid(c.d_hay, c.len, a->n_cus) : dfa_walk_grid(a->dev, c.len, a->n_cus);
-    c.hit_grid = c.pre ? prefilter_hit_regions(c.scan_grid) : 0;
-    c.grid = c.pre ? walk_hits_grid(c.hit_grid) : c.scan_grid;
-    c.bshift = a->dev.rank_bits + BUCKET_BITS;
-    c.nb = (c.len >> BUCKET_BITS) + 2;
-    static const bool no_bucket_env = std::getenv("ACX_NO_BUCKET") != nullptr; // profiling only
-    bool sparse = a->dense_hold == 0 && !no_bucket_env && c.nb < (1ull << 31);
-    if (c.pre && (rc = ensure_hits(a, std::max<uint64_t>(1u << 16, c.len / 64))) != ACX_OK) return rc;
+    c.lead = (uint32_t)((uintptr_t)c.d_hay & 15);
+    c.tiles = prefilter_tiles(c.d_hay, c.len);
+    static const bool no_sparse_env = std::getenv("ACX_NO_BUCKET") != nullptr; // tests / profiling: force the dense path
+    bool sparse = a->sparse_ok && x->dense_hold == 0 && !no_sparse_env && c.tiles < (1ull << 26);
     for (int attempt = 0;; attempt++) {
-        if (attempt == 5) return fail(ACX_EDEVICE, "occurrence buffer overflow persisted");
+        if (attempt == 6) return fail(ACX_EDEVICE, "occurrence buffer overflow persisted");
         Attempt what = Attempt::Done;
         if ((rc = sparse ? attempt_sparse(c, &what) : attempt_dense(c, &what)) != ACX_OK) return rc;
         if (what == Attempt::GoDense) sparse = false;
         if (what == Attempt::Done) break;
     }
     if (a->prof) {
+        std::lock_guard<std::mutex> lk(a->prof_mu);
         a->profile.raw_occurrences += c.n_raw;
-        a->profile.prefix_hits += c.pre ? a->ws.h_pinned[2] : 0;
+        a->profile.prefix_hits += c.n_hits;
     }
     c.r->n = c.n_final;
     if ((rc = finish_matches(c)) != ACX_OK) return rc;
     if (a->prof) { // end of the post stage: read lazily (next call / acx_profile_read), no extra sync here
-        HIPCHK_RC(hipEventRecord(a->ev[2], a->stream));
-        a->post_pending = true;
+        HIPCHK_RC(hipEventRecord(x->ev[2], x->stream));
+        x->post_pending = true;
     }
     return ACX_OK;
 }
 
-int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segments &G,
-             int overlapping, int codepoints, acx_result **out, bool allow_small = true) {
+// d_hay must stay valid until the result's device work is done (acx_result accessors wait for it)
+int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G,
+             int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait) {
     *out = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
         static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
         return fail(ACX_EOVERLAP, std::string("match kind ") + names[a->host.match_kind] +
                                       " does not support overlapping searches");
     }
-    if (len >= (1ull << 40)) return fail(ACX_ETOOBIG, "haystack stream of 2^40 bytes or more");
-    std::lock_guard<std::mutex> lock(a->mu);
-    HIPCHK(hipSetDevice(a->device));
-    settle_post_profile(a);
-    hipStream_t st = a->stream;
+    if (len >= (1ull << 38)) return fail(ACX_ETOOBIG, "haystack stream of 2^38 bytes or more");
+    if (!x) return fail(ACX_EDEVICE, "could not create a stream for the call");
+    settle_post_profile(a, x);
+    hipStream_t st = x->stream;
     const bool segmented = G.uniform_len != 0 || G.offsets != nullptr;
     acx_result *r = new (std::nothrow) acx_result();
     if (!r) return fail(ACX_ENOMEM, "out of memory");
     r->device = a->device;
     r->n_hay = segmented ? G.n_hay : 0;
-    FindCall c{a, d_hay, len, G, overlapping != 0, codepoints != 0, segmented, r,
+    FindCall c{a, x, d_hay, len, G, overlapping != 0, codepoints != 0, segmented, r,
                overlapping ? 0 : a->host.match_kind};
     auto body = [&]() -> int {
         if (segmented) {
             HIPCHK_RC(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
             HIPCHK_RC(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
-            c.pending = true;
+            c.queued = true;
         }
         if (allow_small && !segmented && small_ok(a, len)) { // small haystack: the whole call in one workgroup (K0)
             HIPCHK_RC(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));
             bool done = false;
-            int rc = run_small(a, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
+            int rc = run_small(a, x, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
             if (rc || done) return rc;
             g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
             r->d_matches = nullptr;
@@ -658,35 +909,117 @@ int run_find(acx_automaton *a, const uint8_t *d_hay, uint64_t len, const Segment
             int rc = run_pipeline(c);
             if (rc) return rc;
         }
-        if (c.pending) HIPCHK_RC(hipStreamSynchronize(st));
+        if (c.queued) {
+            // the totals are known; what is still running (the write kernel, the fix-ups) is fenced
+            // by an event the result's accessors wait for
+            if (wait) {
+                HIPCHK_RC(hipStreamSynchronize(st));
+            } else {
+                r->done = g_events.get(a->device);
+                if (!r->done) HIPCHK_RC(hipStreamSynchronize(st));
+                else HIPCHK_RC(hipEventRecord(r->done, st));
+            }
+        }
         return ACX_OK;
     };
     const int rc = body();
-    if (rc != ACX_OK) { acx_free_result(r); return rc; }
+    if (rc != ACX_OK) {
+        (void)hipStreamSynchronize(st);
+        acx_free_result(r);
+        return rc;
+    }
     *out = r;
     return ACX_OK;
 }
 #undef HIPCHK_RC
 
-int stage_host(acx_automaton *a, const uint8_t *hay, uint64_t len, const uint64_t *offsets,
+// ---------------------------------------------------------------------------
+// host memory -> device staging buffer
+// ---------------------------------------------------------------------------
+// Small inputs: one hipMemcpyAsync from the caller's (pageable) memory.  Large inputs: the
+// runtime's own pageable path moves 20-40 GB/s (one staging thread), so the bytes are copied by
+// several host threads into a ring of pinned chunks, each chunk DMA'd by its own asynchronous copy
+// while the threads fill the next one; the scan is queued behind the last chunk.
+constexpr uint64_t STAGE_DIRECT_MAX = 8ull << 20;
+
+int stage_host(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, const uint64_t *offsets,
                uint64_t n_off) {
-    Workspace &w = a->ws;
-    HIPCHK(hipSetDevice(a->device));
+    Workspace &w = c->ws;
+    hipStream_t st = c->stream;
+    (void)a;
     if (len > w.hay_cap) {
+        HIPCHK(hipStreamSynchronize(st));
         (void)hipFree(w.hay); w.hay = nullptr; w.hay_cap = 0;
         uint64_t cap = std::max<uint64_t>(len + len / 8, 4096);
         HIPCHK(hipMalloc((void **)&w.hay, cap));
         w.hay_cap = cap;
     }
-    if (len) HIPCHK(hipMemcpyAsync(w.hay, hay, len, hipMemcpyHostToDevice, a->stream));
     if (n_off) {
         if (n_off > w.offsets_cap) {
+            HIPCHK(hipStreamSynchronize(st));
             (void)hipFree(w.offsets); w.offsets = nullptr; w.offsets_cap = 0;
             HIPCHK(hipMalloc((void **)&w.offsets, n_off * 8));
             w.offsets_cap = n_off;
         }
-        HIPCHK(hipMemcpyAsync(w.offsets, offsets, n_off * 8, hipMemcpyHostToDevice, a->stream));
+        HIPCHK(hipMemcpyAsync(w.offsets, offsets, n_off * 8, hipMemcpyHostToDevice, st));
     }
+    static const int mode = std::getenv("ACX_STAGE") ? std::atoi(std::getenv("ACX_STAGE")) : 0;
+    if (len <= STAGE_DIRECT_MAX || mode == 1) { // 1: always the runtime's pageable copy (measurements)
+        if (len) HIPCHK(hipMemcpyAsync(w.hay, hay, len, hipMemcpyHostToDevice, st));
+        return ACX_OK;
+    }
+    if (mode == 2) { // measurements: pin the caller's pages for the call, one DMA
+        HIPCHK(hipHostRegister((void *)hay, len, hipHostRegisterDefault));
+        hipError_t e = hipMemcpyAsync(w.hay, hay, len, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        (void)hipHostUnregister((void *)hay);
+        if (e != hipSuccess) return hipfail(e, "registered host copy");
+        return ACX_OK;
+    }
+    static const size_t chunk = std::getenv("ACX_STAGE_CHUNK") ? (size_t)std::atoll(std::getenv("ACX_STAGE_CHUNK"))
+                                                                : ((size_t)16 << 20);
+    if (w.chunk_bytes != chunk) {
+        for (int i = 0; i < Workspace::RING; i++) {
+            if (w.pin_chunk[i]) { (void)hipHostFree(w.pin_chunk[i]); w.pin_chunk[i] = nullptr; }
+            HIPCHK(hipHostMalloc((void **)&w.pin_chunk[i], chunk, hipHostMallocDefault));
+            if (!w.chunk_ev[i]) HIPCHK(hipEventCreateWithFlags(&w.chunk_ev[i], hipEventDisableTiming));
+        }
+        w.chunk_bytes = chunk;
+    }
+    CopyPool &pool = CopyPool::get();
+    uint64_t k = 0;
+    for (uint64_t off = 0; off < len; off += chunk, k++) {
+        const int slot = (int)(k % Workspace::RING);
+        const size_t n = (size_t)std::min<uint64_t>(chunk, len - off);
+        if (k >= (uint64_t)Workspace::RING) HIPCHK(hipEventSynchronize(w.chunk_ev[slot])); // its last DMA has read it
+        pool.copy(w.pin_chunk[slot], hay + off, n);
+        HIPCHK(hipMemcpyAsync(w.hay + off, w.pin_chunk[slot], n, hipMemcpyHostToDevice, c->copy_stream));
+        HIPCHK(hipEventRecord(w.chunk_ev[slot], c->copy_stream));
+    }
+    HIPCHK(hipEventRecord(c->copy_done, c->copy_stream));
+    HIPCHK(hipStreamWaitEvent(st, c->copy_done, 0));
+    return ACX_OK;
+}
+
+// device result -> host array the caller owns (acx_free_matches).  Large results land in a pinned
+// buffer that is handed out as it is.
+int download_matches(const acx_result *r, acx_match_t **out, uint64_t *n_out) {
+    *out = nullptr;
+    const uint64_t n = r->n;
+    *n_out = n;
+    if (!n) return result_wait(r);
+    const size_t bytes = n * sizeof(acx_match_t);
+    acx_match_t *m = nullptr;
+    if (bytes >= (1u << 20)) m = (acx_match_t *)g_pinned_results.get(bytes);
+    const bool pinned = m != nullptr;
+    if (!m) m = (acx_match_t *)std::malloc(bytes);
+    if (!m) return fail(ACX_ENOMEM, "out of memory");
+    int rc = acx_result_copy(r, m);
+    if (rc != ACX_OK) {
+        if (pinned) g_pinned_results.put(m); else std::free(m);
+        return rc;
+    }
+    *out = m;
     return ACX_OK;
 }
 
@@ -748,13 +1081,14 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     int dev = g_device;
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
     a->device = dev;
+    if (const char *envc = std::getenv("ACX_MAX_CONCURRENCY")) a->max_ctx = std::max(1, std::min(16, std::atoi(envc)));
+    DeviceScope scope(dev);
     auto destroy = [&](int rc) { acx_free_automaton(a); return rc; };
 #define HIPCHK_A(expr)                                            \
     do {                                                          \
         hipError_t e__ = (expr);                                  \
         if (e__ != hipSuccess) return destroy(hipfail(e__, #expr)); \
     } while (0)
-    HIPCHK_A(hipSetDevice(dev));
     {
         int v = 0;
         HIPCHK_A(hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev));
@@ -765,11 +1099,11 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         a->max_lds = (size_t)std::max(std::max(l1, l2), 65536);
         if (a->max_lds > 160 * 1024) a->max_lds = 160 * 1024;
     }
-    HIPCHK_A(hipStreamCreateWithFlags(&a->stream, hipStreamNonBlocking));
-    for (auto &ev : a->ev) HIPCHK_A(hipEventCreate(&ev));
-    HIPCHK_A(hipStreamCreateWithFlags(&a->post_stream, hipStreamNonBlocking));
-    for (auto &ev : a->chunk_ev) HIPCHK_A(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    HIPCHK_A(hipEventCreateWithFlags(&a->post_ev, hipEventDisableTiming));
+    Ctx *c0 = create_ctx();
+    if (!c0) return destroy(fail(ACX_EDEVICE, "could not create a HIP stream"));
+    a->ctxs.push_back(c0);
+    a->idle.push_back(c0);
+    hipStream_t st = c0->stream;
 
     Automaton &H = a->host;
     DevAutomaton &D = a->dev;
@@ -787,7 +1121,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.hot_rows = hot_rows;
     int rc;
 #define UP(vec, field)                                                                   \
-    if ((rc = upload(a, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
+    if ((rc = upload(a, st, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
     UP(H.table, table)
     UP(hot16, hot16)
     UP(H.own_off, own_off)
@@ -802,19 +1136,20 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.blist, blist)
     {
         const uint32_t *pi = nullptr;
-        if ((rc = upload(a, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
+        if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
         D.pinfo = reinterpret_cast<const uint4 *>(pi);
     }
-    H.blob.resize(H.blob.size() + 16, 0); // the walk kernel compares 8 bytes at a time
+    H.blob.resize(H.blob.size() + 16, 0); // the verification compares 8 bytes at a time
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)
 #undef UP
-    if ((rc = upload(a, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
-    if ((rc = upload(a, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
-    HIPCHK_A(hipStreamSynchronize(a->stream));
+    if ((rc = upload(a, st, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
+    if ((rc = upload(a, st, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
+    HIPCHK_A(hipStreamSynchronize(st));
     a->table_bytes = H.table.size() * 4;
     // the big host copy of the table is no longer needed
     std::vector<uint32_t>().swap(H.table);
+    a->sparse_ok = tile_lookback(H.max_len) <= MAX_LOOKBACK;
     // kernel selection
     bool prefilter_ok = H.filter_q >= 3 && a->max_lds >= prefilter_lds_bytes();
     if (implementation == ACX_IMPL_NONCONTIGUOUS_NFA || implementation == ACX_IMPL_CONTIGUOUS_NFA)
@@ -868,28 +1203,27 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->pattern_len = A.plen.data(); out->rank = A.rank.data();
     out->filter_xy = A.filterA.data();
     out->prefix_table = A.ptab.data();
+    out->prefix_lists = A.blist.data();
     out->filter_q = A.filter_q; out->filter_q2 = A.filter_q2;
     out->filter_entries_log2 = FILTER_ENTRIES_LOG2; out->prefix_table_log2 = A.ptab_log2;
     out->filter_density = A.filter_density;
+    out->n_prefix_keys = A.n_prefix_keys;
+    out->n_prefix_lists = (uint32_t)A.blist.size();
     return ACX_OK;
 }
 
 uint32_t acx_filter_hash(uint32_t gram) { return filter_hash(gram); }
-uint32_t acx_prefix_slot(uint64_t gram, uint32_t log2) { return prefix_slot(gram_hash2(gram), log2); }
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t key_len, uint32_t log2) {
+    return prefix_slot(prefix_key_hash(gram, key_len), log2);
+}
 
 void acx_free_host(acx_host_automaton_t *h) { delete h; }
 
 void acx_free_automaton(acx_automaton_t *a) {
     if (!a) return;
-    (void)hipSetDevice(a->device);
-    if (a->stream) (void)hipStreamSynchronize(a->stream);
+    DeviceScope scope(a->device);
+    for (Ctx *c : a->ctxs) destroy_ctx(c, a->device);
     for (void *p : a->allocs) (void)hipFree(p);
-    free_ws(a->ws, a->device);
-    for (auto &ev : a->ev) if (ev) (void)hipEventDestroy(ev);
-    for (auto &ev : a->chunk_ev) if (ev) (void)hipEventDestroy(ev);
-    if (a->post_ev) (void)hipEventDestroy(a->post_ev);
-    if (a->post_stream) { (void)hipStreamSynchronize(a->post_stream); (void)hipStreamDestroy(a->post_stream); }
-    if (a->stream) (void)hipStreamDestroy(a->stream);
     delete a;
 }
 
@@ -943,32 +1277,52 @@ int acx_find_device(acx_automaton_t *a, const void *d_hay, uint64_t len, const u
     } else if (d_offsets) {
         G.offsets = d_offsets; G.n_hay = n_hay;
     }
-    return run_find(a, (const uint8_t *)d_hay, len, G, overlapping, codepoints, out);
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD)
+        return run_find(a, nullptr, nullptr, 0, G, overlapping, codepoints, out, true, true); // the error, no device state
+    Lease lease(a);
+    // returns when the totals are known; accessors of the result wait for the rest of its device work
+    return run_find(a, lease.c, (const uint8_t *)d_hay, len, G, overlapping, codepoints, out, true, false);
 }
 
 uint64_t acx_result_count(const acx_result_t *r) { return r ? r->n : 0; }
-const acx_match_t *acx_result_device_matches(const acx_result_t *r) { return r ? r->d_matches : nullptr; }
-const uint64_t *acx_result_device_counts(const acx_result_t *r) { return r ? r->d_counts : nullptr; }
+const acx_match_t *acx_result_device_matches(const acx_result_t *r) {
+    if (!r || result_wait(r) != ACX_OK) return nullptr;
+    return r->d_matches;
+}
+const uint64_t *acx_result_device_counts(const acx_result_t *r) {
+    if (!r || result_wait(r) != ACX_OK) return nullptr;
+    return r->d_counts;
+}
 
 int acx_result_copy(const acx_result_t *r, acx_match_t *host_out) {
     if (!r) return fail(ACX_EINVAL, "null result");
-    if (!r->n) return ACX_OK;
-    HIPCHK(hipSetDevice(r->device));
+    int rc = result_wait(r);
+    if (rc != ACX_OK || !r->n) return rc;
+    DeviceScope ds(r->device);
     HIPCHK(hipMemcpy(host_out, r->d_matches, r->n * sizeof(acx_match_t), hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 
 int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts) {
     if (!r) return fail(ACX_EINVAL, "null result");
-    if (!r->d_counts || !r->n_hay) return ACX_OK;
-    HIPCHK(hipSetDevice(r->device));
+    int rc = result_wait(r);
+    if (rc != ACX_OK || !r->d_counts || !r->n_hay) return rc;
+    DeviceScope ds(r->device);
     HIPCHK(hipMemcpy(host_counts, r->d_counts, r->n_hay * 8, hipMemcpyDeviceToHost));
     return ACX_OK;
 }
 
 void acx_free_result(acx_result_t *r) {
     if (!r) return;
-    g_bufs.put(r->d_matches, r->device);
+    // the buffers may still be written by the call's last kernels: the cache holds them back until
+    // the event has fired (one event guards both buffers: the second waits for it here)
+    if (r->done && r->d_counts) {
+        DeviceScope ds(r->device);
+        (void)hipEventSynchronize(r->done);
+        g_events.put(r->device, r->done);
+        r->done = nullptr;
+    }
+    g_bufs.put(r->d_matches, r->device, r->done);
     g_bufs.put(r->d_counts, r->device);
     delete r;
 }
@@ -978,20 +1332,18 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     if (!a || !out || !n_out) return fail(ACX_EINVAL, "null argument");
     *out = nullptr; *n_out = 0;
     if (len && !hay) return fail(ACX_EINVAL, "null haystack");
-    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
-        acx_result_t *dummy = nullptr; // produces the error message, touches no device state
-        return run_find(a, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &dummy);
-    }
     acx_result_t *r = nullptr;
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) // produces the error message, touches no device state
+        return run_find(a, nullptr, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, true, true);
+    Lease lease(a);
+    Ctx *c = lease.c;
+    if (!c) return fail(ACX_EDEVICE, "could not create a stream for the call");
     int rc;
     const bool try_small = small_ok(a, len);
     if (try_small) {
         // small haystack: copy it into pinned memory, ONE launch (K0 reads and writes pinned host
         // memory in place), one sync -- no H2D / D2H copies at all
-        std::lock_guard<std::mutex> lk(a->stage_mu);
-        std::lock_guard<std::mutex> lock(a->mu);
-        HIPCHK(hipSetDevice(a->device));
-        Workspace &w = a->ws;
+        Workspace &w = c->ws;
         if (!w.pin_hay) {
             HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_MAX_LEN + 16, hipHostMallocDefault));
             HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocDefault));
@@ -999,7 +1351,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
         std::memcpy(w.pin_hay, hay, len);
         uint64_t n = 0;
         bool done = false;
-        rc = run_small(a, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done);
+        rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done);
         if (rc != ACX_OK) return rc;
         if (done) {
             if (n) {
@@ -1012,28 +1364,19 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             return ACX_OK;
         }
     }
-    {
-        // the staging buffer is shared by the host-memory entry points
-        std::lock_guard<std::mutex> lk(a->stage_mu);
-        rc = stage_host(a, hay, len, nullptr, 0);
-        if (rc == ACX_OK)
-            rc = run_find(a, a->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small);
-    }
+    rc = stage_host(a, c, hay, len, nullptr, 0);
+    if (rc == ACX_OK)
+        rc = run_find(a, c, c->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false);
     if (rc != ACX_OK) return rc;
-    uint64_t n = acx_result_count(r);
-    if (n) {
-        acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
-        if (!m) { acx_free_result(r); return fail(ACX_ENOMEM, "out of memory"); }
-        rc = acx_result_copy(r, m);
-        if (rc != ACX_OK) { std::free(m); acx_free_result(r); return rc; }
-        *out = m;
-    }
-    *n_out = n;
+    rc = download_matches(r, out, n_out); // waits for the call's device work: the staging buffer is free again
     acx_free_result(r);
-    return ACX_OK;
+    return rc;
 }
 
-void acx_free_matches(acx_match_t *m) { std::free(m); }
+void acx_free_matches(acx_match_t *m) {
+    if (!m) return;
+    if (!g_pinned_results.put(m)) std::free(m);
+}
 
 int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offsets, uint64_t n_hay,
                    int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out,
@@ -1044,35 +1387,25 @@ int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offse
         if (offsets[i + 1] < offsets[i]) return fail(ACX_EINVAL, "offsets not monotone");
         if (counts) counts[i] = 0;
     }
-    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
-        acx_result_t *dummy = nullptr;
-        return run_find(a, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &dummy);
-    }
+    acx_result_t *r = nullptr;
+    if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD)
+        return run_find(a, nullptr, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, true, true);
     if (n_hay == 0) return ACX_OK;
     uint64_t base = offsets[0], len = offsets[n_hay] - base;
     std::vector<uint64_t> rel(n_hay + 1);
     for (uint64_t i = 0; i <= n_hay; i++) rel[i] = offsets[i] - base;
-    acx_result_t *r = nullptr;
-    int rc;
-    {
-        std::lock_guard<std::mutex> lk(a->stage_mu);
-        rc = stage_host(a, hay ? hay + base : nullptr, len, rel.data(), n_hay + 1);
-        if (rc == ACX_OK) {
-            Segments G{a->ws.offsets, n_hay, 0};
-            rc = run_find(a, a->ws.hay, len, G, overlapping, codepoints, &r);
-        }
+    Lease lease(a);
+    Ctx *c = lease.c;
+    if (!c) return fail(ACX_EDEVICE, "could not create a stream for the call");
+    int rc = stage_host(a, c, hay ? hay + base : nullptr, len, rel.data(), n_hay + 1);
+    if (rc == ACX_OK) {
+        Segments G{c->ws.offsets, n_hay, 0};
+        rc = run_find(a, c, c->ws.hay, len, G, overlapping, codepoints, &r, true, false);
     }
     if (rc != ACX_OK) return rc;
-    uint64_t n = acx_result_count(r);
-    if (n) {
-        acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
-        if (!m) { acx_free_result(r); return fail(ACX_ENOMEM, "out of memory"); }
-        rc = acx_result_copy(r, m);
-        if (rc != ACX_OK) { std::free(m); acx_free_result(r); return rc; }
-        *out = m;
-    }
+    rc = download_matches(r, out, n_out);
     if (counts && rc == ACX_OK) rc = acx_result_copy_counts(r, counts);
-    *n_out = n;
+    if (rc != ACX_OK && *out) { acx_free_matches(*out); *out = nullptr; *n_out = 0; }
     acx_free_result(r);
     return rc;
 }
@@ -1085,8 +1418,22 @@ int acx_profile_enable(acx_automaton_t *a, int on) {
 
 int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset) {
     if (!a || !out) return fail(ACX_EINVAL, "null argument");
-    std::lock_guard<std::mutex> lock(a->mu);
-    settle_post_profile(a);
+    {
+        // settle the post-stage time of every context that is not in use right now
+        DeviceScope scope(a->device);
+        std::vector<Ctx *> idle;
+        {
+            std::lock_guard<std::mutex> lk(a->pool_mu);
+            idle.swap(a->idle);
+        }
+        for (Ctx *c : idle) settle_post_profile(a, c);
+        {
+            std::lock_guard<std::mutex> lk(a->pool_mu);
+            a->idle.insert(a->idle.end(), idle.begin(), idle.end());
+        }
+        a->pool_cv.notify_all();
+    }
+    std::lock_guard<std::mutex> lk(a->prof_mu);
     *out = a->profile;
     if (reset) a->profile = acx_profile_t{};
     return ACX_OK;
@@ -1113,10 +1460,10 @@ int acx_generate_haystack(acx_automaton_t *a, void *d_dst, uint64_t len, int kin
     if (!a || (!d_dst && len)) return fail(ACX_EINVAL, "null argument");
     if (kind != 0 && kind != 1) return fail(ACX_EINVAL, "unknown haystack kind");
     if (kind == 1 && (stream_offset % 1024)) return fail(ACX_EINVAL, "stream_offset must be a multiple of 1024");
-    std::lock_guard<std::mutex> lock(a->mu);
-    HIPCHK(hipSetDevice(a->device));
-    HIPCHK(generate(a->dev, (uint8_t *)d_dst, len, kind, seed, stream_offset, a->stream));
-    HIPCHK(hipStreamSynchronize(a->stream));
+    Lease lease(a);
+    if (!lease.c) return fail(ACX_EDEVICE, "could not create a stream for the call");
+    HIPCHK(generate(a->dev, (uint8_t *)d_dst, len, kind, seed, stream_offset, lease.c->stream));
+    HIPCHK(hipStreamSynchronize(lease.c->stream));
     return ACX_OK;
 }
 

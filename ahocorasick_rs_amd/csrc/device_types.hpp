@@ -42,50 +42,53 @@ struct Segments {
     uint64_t uniform_len;    // > 0: every haystack has this length
 };
 
-// Sink of the scan kernels: 16-byte records in per-workgroup regions.
-//   occurrence record  {key lo, key hi, pid, pattern length}
-//   prefix-hit record  two quads: {pos lo, pos hi, code, 0} {16 haystack bytes at pos}
+// Output of the scan kernels.
+//   occurrence record  {key lo, key hi, pid, pattern length}                    (16 B)
+//   prefix-hit record  two quads: {pos lo, pos hi, code, aux} {16 haystack bytes at pos}
 // Occurrence keys:
 //   key_mode 0 (Standard / overlapping): key = end   << rank_bits | rank(pid)
 //   key_mode 1 (LeftmostFirst):          key = start << rank_bits | pid
 //   key_mode 2 (LeftmostLongest):        key = start << rank_bits | rank(pid)
 // (rank_bits = bits needed for n_patterns - 1.)  Sorting by key ascending yields
 // exactly the order each match kind consumes.
-// Region mode (dense output, prefix hits): slot allocation uses NO contended global
-// atomic (one HBM word saturates at ~88 atomics/us on MI355X): every workgroup owns the
-// region [blockIdx * region_cap, (blockIdx + 1) * region_cap) and hands out slots from
-// a counter in LDS; its final count goes to block_counts[blockIdx] (it keeps
-// counting past region_cap so that the host can size a retry exactly).
-// Slot mode (sparse output, slots != null): an occurrence goes straight to slot
-// `arrival rank` of its 4 KiB-of-position bucket (bucket_cnt is the rank counter: an
-// address is shared by the few occurrences of one bucket only); a full bucket sets
-// *abort_flag and the host redoes the call in region mode.
-constexpr uint32_t BUCKET_SLOTS = 32;  // occurrence slots per bucket
-constexpr uint32_t BUCKET_BITS = 12;   // bucket = 4 KiB of stream position
-constexpr uint32_t TILE_BUCKETS = 64;  // buckets per workgroup of the tile kernels (K2b)
-constexpr uint32_t TILE_MAX = 1024;    // occurrences per tile (held in LDS)
+//
+// Hit-slot mode (sparse output, the default): the stream is cut into 4 KiB *tiles* of the
+// 16-byte-aligned index space (index = stream position + lead, lead = address & 15).  Every
+// tile owns HIT_SLOTS hit records and a count.  K1b: the wave that scans a tile is the only
+// producer of its slots (no atomics, the count is a plain store).  K1a: verified occurrences
+// take arrival ranks with one global atomic on the tile's count (an address shared by the
+// handful of occurrences of one 4 KiB stretch only).  More hits than slots: *abort_flag, the
+// host redoes the call in region mode.
+// Region mode (dense output): no contended global atomic either (one HBM word saturates at
+// ~88 atomics/us on MI355X): every wave (K1b) / workgroup (walk kernels) owns the region
+// [i * region_cap, (i + 1) * region_cap) and keeps its cursor in a register / in LDS; its final
+// count goes to block_counts[i] (it keeps counting past region_cap so that the host can size a
+// retry exactly).
+constexpr uint32_t TILE_BITS = 12;    // tile = 4 KiB of index space
+constexpr uint32_t HIT_SLOTS = 32;    // hit records per tile
+constexpr uint32_t GROUP_TILES = 64;  // tiles per workgroup of k_tile_main (256 KiB)
+constexpr uint32_t GROUP_MAX = 1024;  // reported matches per group
+constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group
 struct Sink {
-    uint4 *recs;            // region_cap * quads uint4 per region
-    uint32_t *bucket_cnt;   // slot mode: per-bucket arrival counters
-    uint64_t *block_counts; // gridDim.x entries
+    uint4 *recs;            // region mode: region_cap * quads uint4 per region
+    uint64_t *block_counts; // region mode: one per region
     uint64_t region_cap;    // records per region
-    uint32_t bucket_shift;  // bucket = key >> bucket_shift
     int key_mode;
-    uint4 *slots;           // slot mode: n_buckets * BUCKET_SLOTS records {key lo, key hi, pid, len}
-    uint32_t *abort_flag;   // slot mode: set when the sparse path cannot hold the output
+    uint4 *hslots;          // hit-slot mode: n_tiles * HIT_SLOTS records of two quads
+    uint32_t *hcnt;         // hit-slot mode: hits of every tile
+    uint32_t *abort_flag;   // hit-slot mode: set when the slots cannot hold the output
+    uint32_t lead;          // index = stream position + lead
 };
 
-// Storage of the sparse path, sized by the number of buckets / tiles of the stream.
+// Storage of the sparse path, sized by the number of tiles / groups of the stream.
 struct TileSpace {
-    uint4 *slots;       // n_buckets * BUCKET_SLOTS (filled by the scan's emission)
-    uint32_t *bcnt;     // n_buckets + 1 arrival counters
-    uint4 *trecs;       // tiles * TILE_MAX: the occurrences of a tile, sorted {key lo, key hi, pid, len}
-    uint8_t *syncf;     // tiles * TILE_MAX: occurrence is a sync point of the greedy
-    uint8_t *accf;      // tiles * TILE_MAX: occurrence is reported
-    uint32_t *tile_n;   // occurrences of each tile
-    uint32_t *btot;     // reported occurrences of each tile
+    uint4 *hslots;      // n_tiles * HIT_SLOTS * 2
+    uint32_t *hcnt;     // n_tiles
+    uint4 *trecs;       // groups * GROUP_MAX: the REPORTED occurrences of a group, in order
+    uint32_t *gocc;     // occurrences seen by each group (statistics)
+    uint32_t *btot;     // reported occurrences of each group
     uint32_t *bbase;    // exclusive prefix of btot
-    uint32_t n_buckets, n_tiles;
+    uint32_t n_tiles, n_groups;
 };
 
 } // namespace acx

@@ -3,19 +3,24 @@
 // crate iterators drained at /root/reference/src/lib.rs:229-249 and 422-434
 // (`try_find_iter` / `try_find_overlapping_iter`, called at src/lib.rs:59, 53).
 //
-// Pipeline (all on the device, one stream):
-//   K1   scan        every occurrence (pattern, end) of every pattern -> sink
-//        K1a dfa_walk    one lane walks one chunk of the stream through the
-//                        dense DFA; class map + hot (shallow, BFS-first) rows
-//                        live in LDS, cold rows come from the HBM table
-//        K1b prefilter   position-parallel: coalesced 16-B loads, a q-gram
-//                        bitmap in LDS says whether a pattern can start here;
-//                        survivors are ballot-compacted into a per-wave LDS
-//                        queue and verified 64 at a time by an anchored walk
-//                        of the HBM DFA table
-//   K2   sort (rocPRIM radix sort on the 64-bit key) + resolve: applies the
-//        match kind (Standard / LeftmostFirst / LeftmostLongest, overlapping
-//        or not) exactly as the reference iterators would
+// Pipeline (all on the device, one stream; DESIGN.md §4):
+//   K1   scan
+//        K1b prefilter   position-parallel: coalesced 16-B loads, a q-gram signature table
+//                        in LDS says whether a pattern can start here; survivors are ballot-
+//                        compacted into a per-wave LDS queue and settled against the exact
+//                        prefix table (HBM, L2-resident).  Output: *prefix hits* in per-tile
+//                        hit slots (the wave that owns a 4 KiB tile is their only producer)
+//        K1a dfa_walk    one lane walks one chunk of the stream through the dense DFA; class
+//                        map + hot (shallow, BFS-first) rows live in LDS, cold rows come from
+//                        the HBM table.  Output: verified occurrences, same hit slots
+//   K2   k_tile_main     one workgroup per 64 tiles: verifies the hits against the pattern
+//                        bytes, orders the occurrences, applies the match kind (Standard /
+//                        LeftmostFirst / LeftmostLongest, overlapping or not) exactly as the
+//                        reference iterators would; k_tile_scan + k_tile_write compact them
+//                        into the final (pattern, start, end) records
+//        dense inputs    (more occurrences than the slots hold) take the region path: K1b ->
+//                        k_walk_hits -> rocPRIM radix sort on the 64-bit key -> k_resolve
+//   K0   small haystacks: the whole call in one workgroup
 //   K3   UTF-8 byte offset -> code-point index (get_byte_to_code_point,
 //        src/lib.rs:73-88) by per-KiB lead-byte counts + prefix sum
 //
@@ -24,6 +29,7 @@
 
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 
 #include <rocprim/rocprim.hpp>
 
@@ -45,77 +51,41 @@ __device__ __forceinline__ u32x4 load16_stream(const uint8_t *p) {
     return __builtin_nontemporal_load((const u32x4 *)p);
 }
 
-// per-workgroup view of the sink: region base + LDS slot counter
+// per-workgroup view of the occurrence sink
+//   region mode (dense output): region base + LDS slot counter
+//   hit-slot mode (sparse output, K1a): verified occurrences go to the hit slots of the tile
+//   their START lies in, as records k_tile_main takes without verification
 struct BlockSink {
     uint4 *recs;
-    uint32_t *bucket_cnt;
     uint32_t *lcount; // LDS
     uint64_t region_cap;
-    uint32_t bucket_shift;
     int key_mode;
-    uint4 *slots;
+    uint4 *hslots;
+    uint32_t *hcnt;
     uint32_t *abort_flag;
+    uint32_t lead;
 };
 
 __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount, uint32_t quads = 1) {
-    return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, K.bucket_cnt, lcount,
-                     K.region_cap, K.bucket_shift, K.key_mode, K.slots, K.abort_flag};
+    return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, lcount, K.region_cap, K.key_mode,
+                     K.hslots, K.hcnt, K.abort_flag, K.lead};
 }
 
-// slot mode: the occurrence with arrival rank r of its bucket
-__device__ __forceinline__ void store_slot(const BlockSink &K, uint32_t bucket, uint32_t r, uint64_t key,
-                                           uint32_t pid, uint32_t plen) {
-    if (r < BUCKET_SLOTS)
-        K.slots[(uint64_t)bucket * BUCKET_SLOTS + r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
-    else
-        *K.abort_flag = 1;
-}
-
-// store one occurrence (ONE 16-byte store).  Slot mode: take the occurrence's arrival
-// rank inside its bucket (one global atomic, the address is shared by the ~4 occurrences
-// of a 4 KiB stretch only) and store into that slot.  Region mode: next slot of the region.
+// region mode: store one occurrence (ONE 16-byte store) into the next slot of the region
 // (records carry the pattern's length so that nothing downstream has to gather it again)
 __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid, uint32_t plen) {
-    if (K.slots) {
-        const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
-        store_slot(K, bucket, atomicAdd(&K.bucket_cnt[bucket], 1u), key, pid, plen);
-        return;
-    }
     uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
     if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
 }
 
-// Wave-aggregated variant for code where many lanes emit together (walk kernel).
-// Slot mode: ONE global atomic per run of adjacent emitting lanes that fall into the
-// same bucket takes the bucket ranks (hits arrive grouped by 4 KiB tile, so a run is
-// typically a whole tile: device-scope atomics with return are the expensive part of
-// emission).  Region mode: one LDS atomic per wave reserves the slots.
+// Wave-aggregated variant for code where many lanes emit together (walk kernel): one LDS
+// atomic per wave reserves the slots.
 __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64_t key, uint32_t pid,
                                              uint32_t plen) {
     const unsigned long long fm = __ballot(ok);
     if (!fm) return;
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below_me = (1ull << lane) - 1;
-    if (K.slots) {
-        const uint32_t bucket = (uint32_t)(key >> K.bucket_shift);
-        // previous emitting lane and its bucket
-        const unsigned long long below = fm & below_me;
-        const uint32_t prev = below ? 63u - (uint32_t)__builtin_clzll(below) : 0u;
-        const uint32_t pb = __shfl(bucket, prev);
-        const bool head = ok && (!below || pb != bucket);
-        const unsigned long long hm = __ballot(head);
-        // my run = emitting lanes from my head lane up to (not including) the next head
-        const unsigned long long upto_me = below_me | (1ull << lane);
-        const uint32_t hl = 63u - (uint32_t)__builtin_clzll((hm & upto_me) | 1ull);
-        const unsigned long long above = hl >= 63 ? 0ull : (hm & ~((2ull << hl) - 1));
-        const unsigned long long run_end = above ? ((1ull << __builtin_ctzll(above)) - 1) : ~0ull;
-        const unsigned long long run = fm & run_end & ~((1ull << hl) - 1);
-        uint32_t base = 0;
-        if (head) base = atomicAdd(&K.bucket_cnt[bucket], (uint32_t)__popcll(run));
-        base = __shfl(base, hl);
-        if (ok) store_slot(K, bucket, base + (uint32_t)__popcll(run & below_me), key, pid, plen);
-        return;
-    }
     const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
     uint32_t sbase = 0;
     if (lane == leader) sbase = atomicAdd(K.lcount, (uint32_t)__popcll(fm));
@@ -126,6 +96,15 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
     }
 }
 
+// A prefix hit / occurrence record in the hit slots is two quads:
+//   {position lo, position hi, code, aux} {16 haystack bytes at the position}
+// code = the id of the only pattern with that prefix, or HIT_LIST | index into blist
+// ({count, pid, ...}); HIT_VERIFIED | pid: an occurrence found by the DFA walk (aux = pattern
+// length, no second quad) -- nothing left to verify.
+constexpr uint32_t HIT_LIST = 0x80000000u;
+constexpr uint32_t HIT_VERIFIED = 0x40000000u;
+constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
+
 // The emit paths are cold and out of line; they read the automaton through a
 // pointer to its device-resident copy so that the kernels never have to spill
 // their by-value kernel arguments to scratch for them.
@@ -133,6 +112,17 @@ __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink 
                                          uint64_t end) {
     uint64_t key;
     const uint32_t plen = A->plen[pid];
+    if (K.hslots) { // sparse output: arrival rank inside the tile of the occurrence's start
+        const uint64_t start = end - plen;
+        const uint64_t tile = (start + K.lead) >> TILE_BITS;
+        const uint32_t r = atomicAdd(&K.hcnt[tile], 1u);
+        if (r < HIT_SLOTS)
+            K.hslots[(tile * HIT_SLOTS + r) * 2] = make_uint4((uint32_t)start, (uint32_t)(start >> 32),
+                                                              HIT_VERIFIED | pid, plen);
+        else
+            *K.abort_flag = 1;
+        return;
+    }
     if (K.key_mode == 0) {
         key = (end << A->rank_bits) | A->rank[pid];
     } else {
@@ -285,7 +275,7 @@ __global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, const DevAu
         }
     }
     __syncthreads();
-    if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = *lcount;
+    if (threadIdx.x == 0 && GK.block_counts) GK.block_counts[blockIdx.x] = *lcount;
 }
 
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds) {
@@ -324,13 +314,18 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
     if (rows > cap_rows) rows = cap_rows;
     size_t lds = K1A_LDS_HEADER + (((size_t)rows << A.stride2) * 2 + 15) / 16 * 16;
     uint64_t blocks = grid;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)k1a_dfa_walk,
-                                           hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)max_lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    { // more than 64 KiB of dynamic LDS needs the attribute -- per DEVICE (the function is loaded per device)
+        static std::mutex mu;
+        static bool attr_set[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        std::lock_guard<std::mutex> lk(mu);
+        if (dev < 0 || dev >= 64 || !attr_set[dev]) {
+            hipError_t e = hipFuncSetAttribute((const void *)k1a_dfa_walk,
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+            if (e != hipSuccess) return e;
+            if (dev >= 0 && dev < 64) attr_set[dev] = true;
+        }
     }
     hipLaunchKernelGGL(k1a_dfa_walk, dim3((uint32_t)blocks), dim3(1024), lds, st, A, Ad, G, K,
                        d_hay, len, chunk, rows);
@@ -338,7 +333,7 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 }
 
 // ---------------------------------------------------------------------------
-// K1b: LDS prefix prefilter -> exact prefix table -> anchored DFA walk
+// K1b: LDS prefix prefilter -> exact prefix table
 // ---------------------------------------------------------------------------
 // Geometry: 1024-thread workgroups (16 waves), one per CU, persistent.  A wave
 // owns tiles of K1B_ROWS rows; one row = 64 lanes x 16 B = 1 KiB read by ONE
@@ -349,20 +344,25 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //   L1  {X,Y} signature table in LDS (128 KiB): positions j, j+1 share ONE
 //       ds_read_b64 addressed by the (Q-1)-gram at j+1 and test a two-bit
 //       signature each; ~8 VALU + 0.5 LDS reads per haystack byte.  Survivors
-//       (true Q-byte prefix hits + ~0.1 % collisions) are ballot-compacted into
+//       (true Q-byte prefix hits + ~0.4 % collisions) are ballot-compacted into
 //       the wave's queue Q1 (tile-relative u16 offsets).
-//   L2  exact probe of the depth-Q2 prefix table (HBM, L2-resident), software-
-//       pipelined over tiles so that no wave waits on it: tile t's survivors
-//       re-read their 8-byte window (phase A, tile t+1), fetch their home slot
-//       (phase B, t+2), compare (phase C, t+3).  Hits (position, depth-Q2 state)
-//       leave through the sink: the scan kernel never walks the DFA itself, so
-//       its waves never sit in the long dependent-load chains of a walk.
-//   L3  (separate kernel k_walk_hits, one thread per prefix hit): the few
-//       patterns that own that prefix are settled by comparing their remaining
-//       bytes with the haystack; matches go to the occurrence sink.
+//   L2  exact probe of the prefix table (HBM, L2-resident).  The 16-byte windows of a
+//       tile's survivors are requested right after its compaction -- while the lines are
+//       still in the XCD's L2 -- and consumed at the top of the wave's next iteration,
+//       together with the prefetched tile: hash, ONE 16-byte gather of the home slot,
+//       compare.  A home slot holding another key ends the search unless its MORE bit is
+//       set; a group of patterns that are all longer than the set-wide minimum is probed
+//       once more with its own (longer) key.  Those dependent gathers are waited for in
+//       place: the other three waves of the SIMD have a tile of level-1 work each to
+//       cover them.  A tile with more survivors than Q1 holds settles them in rounds.
+//   Output: prefix hits (position, candidate code, 16 haystack bytes).  Sparse mode
+//       (SLOTS): into the hit slots of the hit's tile -- the wave is their only producer,
+//       the count is a plain store; dense mode: appended to the wave's region.  The kernel
+//       never walks the DFA and never compares pattern tails (k_tile_main / k_walk_hits do).
 // All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
-constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors of one tile (1 per lane)
+static_assert(K1B_ROWS * 1024 == (1 << TILE_BITS), "a K1b tile is a tile of the hit slots");
+constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors settled per round (1 per lane)
 constexpr uint32_t K1B_HB = 40;     // prefix hits a wave collects in LDS before one burst store
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
@@ -402,129 +402,139 @@ __device__ __forceinline__ void load_window16(const uint8_t *__restrict__ stream
     }
 }
 
-// A prefix hit handed to the walk kernel is (position, code), code = word 3 of
-// the prefix-table entry: the id of the only pattern with that prefix, or
-// HIT_LIST | index into blist ({count, pid, ...}); HIT_RETRY when the home
-// slot held another gram (the walk kernel probes the table again first).
-constexpr uint32_t HIT_LIST = 0x80000000u;
-constexpr uint32_t HIT_RETRY = 0xFFFFFFFFu;
+__device__ __forceinline__ uint64_t low_bytes(uint64_t w, uint32_t n) { // the first n (1..8) bytes of w
+    return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1));
+}
 
-// L3: verify a prefix hit at stream position p: the first Q2 bytes are known to
-// match, so every candidate pattern is settled by comparing its remaining bytes
-// with the haystack -- independent loads, no dependent DFA walk.  Emits every
-// pattern that starts at p.
-__device__ __forceinline__ void verify_hit(const DevAutomaton &A, const Segments &G,
-                                           const BlockSink &K, const uint8_t *__restrict__ stream,
-                                           uint64_t len, uint64_t p, uint32_t code, uint64_t w0,
-                                           uint64_t w1, uint32_t ablate) {
-    // (w0, w1) = the 16 haystack bytes at p, carried with the hit by K1b so that short
-    // patterns are verified without touching the (by now cold) haystack again
-    const uint32_t q = A.filter_q2;
-    const uint64_t room = segment_end(G, len, p) - p;
-    if (room < q) return; // the prefix would straddle the end of its haystack
-    if (code == HIT_RETRY) {
-        if (ablate & 128) return; // profiling only: drop the hits that need a second probe
-        const uint64_t gram = q >= 8 ? w0 : (w0 & ((1ull << (8 * q)) - 1));
-        uint32_t idx = prefix_slot(gram_hash2(gram), A.ptab_log2);
-        const uint32_t mask = (1u << A.ptab_log2) - 1;
-        for (;;) {
-            const uint4 e = *(const uint4 *)(A.ptab + (size_t)idx * 4);
-            if (e.z == PREFIX_EMPTY) return;
-            if ((((uint64_t)e.y << 32) | e.x) == gram) { code = e.w; break; }
-            idx = (idx + 1) & mask;
-        }
-    }
-    const bool list = (code & HIT_LIST) != 0;
-    const uint32_t li = code & ~HIT_LIST;
-    const uint32_t n = list ? A.blist[li] : 1;
-    for (uint32_t k = 0; k < n; k++) {
-        const uint32_t pid = list ? A.blist[li + 1 + k] : code;
-        // ONE 16-byte load: rank, length (if < 255) and the 12 bytes after the first q
-        const uint4 pi = A.pinfo[pid];
-        const uint32_t rk = pi.x & 0xFFFFFFu;
-        uint32_t L = pi.x >> 24;
-        if (L == 255) L = A.plen[pid];
-        bool ok = L <= room;
-        if (ok && L > q) {
-            // haystack bytes q.. from the carried window (16 - q of them), pattern bytes from pinfo
-            const uint32_t have = 16 - q;                 // carried bytes beyond the prefix
-            const uint32_t need = L - q < 12 ? L - q : 12; // bytes checkable against pinfo
-            uint64_t h0 = q < 8 ? (q ? (w0 >> (8 * q)) | (w1 << (64 - 8 * q)) : w0) : (w1 >> (8 * (q - 8)));
-            uint64_t h1 = q < 8 ? (q ? (w1 >> (8 * q)) : w1) : 0;
-            uint64_t p0 = ((uint64_t)pi.z << 32) | pi.y, p1 = pi.w;
-            uint32_t n0 = need < have ? need : have;       // bytes compared from the carried window
-            uint64_t m0 = n0 >= 8 ? ~0ull : ((1ull << (8 * n0)) - 1);
-            uint64_t m1 = n0 > 8 ? ((1ull << (8 * (n0 - 8))) - 1) : 0;
-            ok = (((h0 ^ p0) & m0) | ((h1 ^ p1) & m1)) == 0;
-            // whatever lies beyond the carried window / pinfo (long patterns): compare in place
-            for (uint32_t d = q + n0; ok && d < L; d += 8) {
-                uint64_t a = load_window(stream, len, p + d);
-                uint64_t b;
-                __builtin_memcpy(&b, A.pat_blob + A.pat_off[pid] + d, 8); // pat_blob is padded by 16 bytes
-                uint32_t nbytes = L - d < 8 ? L - d : 8;
-                uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
-                ok = ((a ^ b) & m) == 0;
-            }
-        }
-        uint64_t key = K.key_mode == 0   ? ((p + L) << A.rank_bits) | rk
-                       : K.key_mode == 1 ? (p << A.rank_bits) | pid
-                                         : (p << A.rank_bits) | rk;
-        emit_key_agg(K, ok && !(ablate & 32), key, pid, L);
+// One key (a K-byte gram) in the prefix table: walks the probe sequence from the home slot.
+// Returns the entry's meta word (PREFIX_EMPTY: absent) and its code.
+__device__ __forceinline__ uint32_t ptab_find(const uint32_t *__restrict__ ptab, uint32_t log2, uint64_t gram,
+                                              uint32_t K, uint32_t *code) {
+    const uint32_t mask = (1u << log2) - 1;
+    uint32_t idx = prefix_slot(prefix_key_hash(gram, K), log2);
+    for (bool home = true;; home = false) {
+        const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
+        if (e.z == PREFIX_EMPTY) return PREFIX_EMPTY;
+        if ((((uint64_t)e.y << 32) | e.x) == gram && (e.z & 15u) == K) { *code = e.w; return e.z; }
+        if (home && !(e.z & PREFIX_MORE)) return PREFIX_EMPTY; // nothing that hashes here lives elsewhere
+        idx = (idx + 1) & mask;
     }
 }
 
-constexpr uint32_t K_WALK_SPLIT = 1; // workgroups per hit region (a region = one K1b wave's hits)
+// The candidate code of the patterns that agree with the window w0 on their group's key
+// (automaton.cpp: the set-wide Q2 bytes, then the group's own longer key), or HIT_NONE.
+__device__ __forceinline__ uint32_t prefix_code(const DevAutomaton &A, uint64_t w0) {
+    uint32_t code = HIT_NONE;
+    uint32_t meta = ptab_find(A.ptab, A.ptab_log2, low_bytes(w0, A.filter_q2), A.filter_q2, &code);
+    if (meta == PREFIX_EMPTY) return HIT_NONE;
+    const uint32_t N = (meta >> 4) & 15u;
+    if (N && ptab_find(A.ptab, A.ptab_log2, low_bytes(w0, N), N, &code) == PREFIX_EMPTY) return HIT_NONE;
+    return code;
+}
 
-// One thread per prefix hit of K1b.  Hits live in the per-workgroup regions of
-// the scan's sink (H); occurrences go to the occurrence sink (GK).
-__global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, const DevAutomaton *Ad,
-                                                   Segments G, Sink H, uint32_t h_grid, uint32_t split,
+// L3: does pattern `pid` occur at stream position p?  The first Q2 bytes are known to match
+// (the prefix table said so), the rest is compared with the haystack: ONE 16-byte load (pinfo:
+// rank, length and the 12 bytes after the first Q2) settles a pattern of up to Q2 + 12 bytes
+// against the window (w0, w1) = the 16 haystack bytes at p that travel with the hit -- independent
+// loads, no dependent DFA walk, no second touch of the (by now cold) haystack.  Returns the
+// pattern's length (0: no occurrence); *rk = its tie-break rank.  room = bytes from p to the end
+// of its haystack.
+__device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, const uint8_t *__restrict__ stream,
+                                                     uint64_t len, uint64_t p, uint32_t pid, uint64_t w0,
+                                                     uint64_t w1, uint64_t room, uint32_t *rk) {
+    const uint32_t q = A.filter_q2;
+    const uint4 pi = A.pinfo[pid];
+    *rk = pi.x & 0xFFFFFFu;
+    uint32_t L = pi.x >> 24;
+    if (L == 255) L = A.plen[pid];
+    bool ok = L <= room;
+    if (ok && L > q) {
+        // haystack bytes q.. from the carried window (16 - q of them), pattern bytes from pinfo
+        const uint32_t have = 16 - q;                  // carried bytes beyond the prefix
+        const uint32_t need = L - q < 12 ? L - q : 12; // bytes checkable against pinfo
+        uint64_t h0 = q < 8 ? (q ? (w0 >> (8 * q)) | (w1 << (64 - 8 * q)) : w0) : (w1 >> (8 * (q - 8)));
+        uint64_t h1 = q < 8 ? (q ? (w1 >> (8 * q)) : w1) : 0;
+        uint64_t p0 = ((uint64_t)pi.z << 32) | pi.y, p1 = pi.w;
+        uint32_t n0 = need < have ? need : have;       // bytes compared from the carried window
+        uint64_t m0 = n0 >= 8 ? ~0ull : ((1ull << (8 * n0)) - 1);
+        uint64_t m1 = n0 > 8 ? ((1ull << (8 * (n0 - 8))) - 1) : 0;
+        ok = (((h0 ^ p0) & m0) | ((h1 ^ p1) & m1)) == 0;
+        // whatever lies beyond the carried window / pinfo (long patterns): compare in place
+        for (uint32_t d = q + n0; ok && d < L; d += 8) {
+            uint64_t a = load_window(stream, len, p + d);
+            uint64_t b;
+            __builtin_memcpy(&b, A.pat_blob + A.pat_off[pid] + d, 8); // pat_blob is padded by 16 bytes
+            uint32_t nbytes = L - d < 8 ? L - d : 8;
+            uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
+            ok = ((a ^ b) & m) == 0;
+        }
+    }
+    return ok ? L : 0;
+}
+
+__device__ __forceinline__ uint64_t occurrence_key(int key_mode, uint32_t rank_bits, uint64_t p, uint32_t L,
+                                                   uint32_t pid, uint32_t rk) {
+    return key_mode == 0   ? ((p + L) << rank_bits) | rk
+           : key_mode == 1 ? (p << rank_bits) | pid
+                           : (p << rank_bits) | rk;
+}
+
+// Dense path: one thread per prefix hit of K1b (region mode).  Hits live in the per-wave regions
+// of the scan's sink (H); occurrences go to the occurrence sink (GK, one region per workgroup).
+__global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, Sink H, uint32_t h_grid,
                                                    Sink GK, const uint8_t *__restrict__ stream,
-                                                   uint64_t len, uint32_t ablate) {
+                                                   uint64_t len) {
     __shared__ uint32_t lcount;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
-    (void)Ad;
     const BlockSink K = block_sink(GK, &lcount);
-    // `split` workgroups share one hit region
-    for (uint32_t b = blockIdx.x / split; b < h_grid; b += gridDim.x / split) {
+    for (uint32_t b = blockIdx.x; b < h_grid; b += gridDim.x) {
         uint64_t n = H.block_counts[b];
-        if (n > H.region_cap) { // hits were dropped: the host grows the hit sink and redoes the call
-            n = H.region_cap;
-            if (GK.abort_flag && threadIdx.x == 0) *GK.abort_flag = 1;
-        }
+        if (n > H.region_cap) n = H.region_cap; // hits were dropped: the host sees the count and redoes the call
         const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
-        for (uint64_t i = (blockIdx.x % split) * 256 + threadIdx.x; i < n; i += split * 256) {
+        for (uint64_t i = threadIdx.x; i < n; i += 256) {
             const uint4 h = rec[2 * i], w = rec[2 * i + 1];
-            if (ablate & 64) { if (h.x == 0x12345678u && w.y == 77) emit_key(K, 1, 1, 1); continue; }
-            verify_hit(A, G, K, stream, len, ((uint64_t)h.y << 32) | h.x, h.z,
-                       ((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z, ablate);
+            const uint64_t p = ((uint64_t)h.y << 32) | h.x;
+            const uint64_t w0 = ((uint64_t)w.y << 32) | w.x, w1 = ((uint64_t)w.w << 32) | w.z;
+            const uint64_t room = segment_end(G, len, p) - p;
+            const bool list = (h.z & HIT_LIST) != 0;
+            const uint32_t li = h.z & ~HIT_LIST;
+            const uint32_t nc = list ? A.blist[li] : 1;
+            for (uint32_t k = 0; k < nc; k++) {
+                const uint32_t pid = list ? A.blist[li + 1 + k] : h.z;
+                uint32_t rk;
+                const uint32_t L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
+                emit_key_agg(K, L != 0, occurrence_key(K.key_mode, A.rank_bits, p, L, pid, rk), pid, L);
+            }
         }
     }
     __syncthreads();
     if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = lcount;
 }
 
-template <int Q>
-__global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevAutomaton *Ad,
-                                                      Segments G, Sink GK,
+// what K1b needs of the automaton (the full struct would sit in ~50 SGPRs for the whole kernel)
+struct K1bTables {
+    const uint32_t *filterA;
+    const uint32_t *ptab;
+    uint32_t ptab_log2, filter_q2, min_len;
+};
+
+template <int Q, bool SLOTS>
+__global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
-                                                      uint64_t len, uint64_t lead,
-                                                      uint64_t tile_begin, uint64_t tile_end,
-                                                      uint32_t ablate) {
-    // Scans the 4 KiB tiles [tile_begin, tile_end) of the stream (a chunk of a pipelined
-    // call, or everything).  `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real
-    // stream and are never candidates.  Stream position = index - lead.
+                                                      uint64_t len, uint64_t lead) {
+    // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real stream and are
+    // never candidates.  Stream position = index - lead.
     __shared__ __attribute__((aligned(16))) K1bLds L;
     // the wave index is wave-uniform: say so, and the tile index, its byte offset, the
     // interior test and most of the prefetch address arithmetic move from VALU to SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
-    // sink of prefix hits (two quads per record): every WAVE owns a region and keeps its cursor
-    // in an SGPR -- no atomic, no cross-lane traffic on the push path
+    // region mode: every WAVE owns a region of the hit sink and keeps its cursor in an SGPR --
+    // no atomic, no cross-lane traffic on the push path
     const uint32_t region = blockIdx.x * 16 + wave;
-    uint4 *const hrec = GK.recs + (uint64_t)region * GK.region_cap * 2;
-    const uint32_t hcap = (uint32_t)(GK.region_cap < 0xFFFFFFFFull ? GK.region_cap : 0xFFFFFFFFull);
+    uint4 *const hrec = SLOTS ? GK.hslots : GK.recs + (uint64_t)region * GK.region_cap * 2;
+    const uint32_t hcap = SLOTS ? 0u : (uint32_t)(GK.region_cap < 0xFFFFFFFFull ? GK.region_cap : 0xFFFFFFFFull);
     uint32_t hcur = 0;
     {
         const uint4 *src = (const uint4 *)A.filterA;
@@ -541,59 +551,90 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint64_t last_start = total >= A.min_len ? total - A.min_len : 0; // last index a pattern can start at
     const bool any_start = total >= lead + A.min_len;
     const uint64_t tile_bytes = (uint64_t)K1B_ROWS * 1024;
-    const uint64_t all_tiles = any_start ? (total + tile_bytes - 1) / tile_bytes : 0;
-    const uint64_t ntiles = all_tiles < tile_end ? all_tiles : tile_end;
-    const uint64_t gw = tile_begin + (uint64_t)blockIdx.x * 16 + wave;
+    const uint64_t ntiles = (total + tile_bytes - 1) / tile_bytes; // every tile gets its hit count
+    const uint64_t gw = (uint64_t)blockIdx.x * 16 + wave;
     const uint64_t nw = (uint64_t)gridDim.x * 16;
     const uint32_t q2len = A.filter_q2;
     const uint64_t q2mask = q2len >= 8 ? ~0ull : ((1ull << (8 * q2len)) - 1);
+    const uint32_t q2salt = q2len * 0x9E3779B1u; // prefix_key_hash(gram, q2len) = gram_hash2(gram) + q2salt
     const uint32_t ptab_log2 = A.ptab_log2;
     uint32_t q1c = 0; // wave-uniform queue fill
 
-    // ---- level-2 pipeline registers (tile-synchronous, one entry per lane)
-    uint32_t nB = 0, nC = 0;            // wave-uniform counts
-    uint64_t tbA = 0, tbB = 0, tbC = 0; // tile bases of the entries in Q1 / phase B / phase C
-    uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
-    uint32_t offB = 0, offC = 0;
-    uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
-
-    // Prefix hits (p, st) of the lanes with found == true go to the wave's region THROUGH an LDS
-    // buffer that is stored in bursts of up to K1B_HB records: on this architecture stores count
-    // in vmcnt like loads, so a store issued every iteration makes the `s_waitcnt vmcnt(0)` in
-    // front of the next tile wait for HBM write latency every iteration; a burst every ~7
-    // iterations does not, and its records are contiguous (measured: 1-2 % of the kernel).
+    // Prefix hits leave the wave THROUGH an LDS buffer that is stored in bursts of up to K1B_HB
+    // records: on this architecture stores count in vmcnt like loads, so a store issued every
+    // iteration makes the `s_waitcnt vmcnt(0)` in front of the next tile wait for HBM write latency
+    // every iteration; a burst every few iterations does not (measured: 1-2 % of the kernel).
+    // Word 3 of a record's first quad carries its destination slot (sparse mode).
     uint4 (*const hb)[2] = L.hb[wave];
     uint32_t hbn = 0; // wave-uniform fill of the buffer
-#define K1B_HIT_FLUSH                                                                            \
-    {                                                                                            \
-        if (lane < hbn) {                                                                        \
-            const uint32_t s_ = hcur + lane;                                                     \
-            if (s_ < hcap) { hrec[2 * s_] = hb[lane][0]; hrec[2 * s_ + 1] = hb[lane][1]; }       \
-        }                                                                                        \
-        hcur += hbn; /* keeps counting past the capacity */                                      \
-        hbn = 0;                                                                                 \
-    }
-#define K1B_HIT_PUSH(FOUND, P, ST, W0, W1)                                                       \
-    {                                                                                            \
-        unsigned long long fm_ = __ballot(FOUND);                                                \
-        if (fm_) {                                                                               \
-            const uint32_t np_ = (uint32_t)__popcll(fm_);                                        \
-            if (hbn + np_ > K1B_HB) K1B_HIT_FLUSH                                                \
-            const uint32_t rk_ = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm_ >> 32),                \
-                                                           __builtin_amdgcn_mbcnt_lo((uint32_t)fm_, 0)); \
-            const uint64_t p_ = (P), a_ = (W0), b_ = (W1);                                       \
-            const uint4 r0_ = make_uint4((uint32_t)p_, (uint32_t)(p_ >> 32), (ST), 0);           \
-            const uint4 r1_ = make_uint4((uint32_t)a_, (uint32_t)(a_ >> 32), (uint32_t)b_,       \
-                                         (uint32_t)(b_ >> 32));                                  \
-            if (np_ > K1B_HB) { /* more hits at once than the buffer holds: straight to HBM */   \
-                if ((FOUND) && hcur + rk_ < hcap) { hrec[2 * (hcur + rk_)] = r0_; hrec[2 * (hcur + rk_) + 1] = r1_; } \
-                hcur += np_;                                                                     \
-            } else {                                                                             \
-                if (FOUND) { hb[hbn + rk_][0] = r0_; hb[hbn + rk_][1] = r1_; }                   \
-                hbn += np_;                                                                      \
-            }                                                                                    \
-        }                                                                                        \
-    }
+    auto hit_flush = [&]() {
+        if (lane < hbn) {
+            uint4 r0 = hb[lane][0];
+            const uint4 r1 = hb[lane][1];
+            if (SLOTS) {
+                const uint32_t dst = r0.w;
+                r0.w = 0;
+                if (dst != 0xFFFFFFFFu) { hrec[2 * (uint64_t)dst] = r0; hrec[2 * (uint64_t)dst + 1] = r1; }
+            } else {
+                const uint32_t s = hcur + lane;
+                if (s < hcap) { hrec[2 * (uint64_t)s] = r0; hrec[2 * (uint64_t)s + 1] = r1; }
+            }
+        }
+        if (!SLOTS) hcur += hbn; // keeps counting past the capacity
+        hbn = 0;
+    };
+    // the lanes with found == true push (p, code, 16 window bytes); sparse mode: into the slots
+    // cnt, cnt + 1, ... of `tile` (cnt is wave-uniform and advanced)
+    auto hit_push = [&](bool found, uint64_t p, uint32_t code, uint64_t w0, uint64_t w1, uint64_t tile,
+                        uint32_t &cnt) {
+        const unsigned long long fm = __ballot(found);
+        if (!fm) return;
+        const uint32_t np = (uint32_t)__popcll(fm);
+        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+        uint32_t dst = 0;
+        bool keep = found;
+        if (SLOTS) {
+            const uint32_t slot = cnt + rk;
+            keep = found && slot < HIT_SLOTS;
+            if (found && !keep) *GK.abort_flag = 1; // more hits than the tile holds: dense input
+            dst = (uint32_t)tile * HIT_SLOTS + slot;
+            cnt += np;
+        }
+        // (sparse mode: a dropped hit still takes its place in the buffer; its slot word says "nowhere")
+        const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, keep ? dst : 0xFFFFFFFFu);
+        const uint4 r1 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+        if (np > K1B_HB) { // more hits at once than the buffer holds: straight to HBM
+            if (SLOTS) {
+                if (keep) { hrec[2 * (uint64_t)dst] = make_uint4(r0.x, r0.y, r0.z, 0); hrec[2 * (uint64_t)dst + 1] = r1; }
+            } else {
+                hit_flush();
+                if (found && hcur + rk < hcap) { hrec[2 * (uint64_t)(hcur + rk)] = r0; hrec[2 * (uint64_t)(hcur + rk) + 1] = r1; }
+                hcur += np;
+            }
+            return;
+        }
+        if (hbn + np > K1B_HB) hit_flush();
+        if (found) { hb[hbn + rk][0] = r0; hb[hbn + rk][1] = r1; }
+        hbn += np;
+    };
+    // level 2 for the lanes with act == true: window (w0, w1) at index tb + off
+    auto settle = [&](bool act, uint64_t tb, uint32_t off, uint64_t w0, uint64_t w1, uint64_t tile, uint32_t &cnt) {
+        const uint64_t gram = w0 & q2mask;
+        uint4 ent = make_uint4(0, 0, PREFIX_EMPTY, 0);
+        if (act) ent = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(gram) + q2salt, ptab_log2) * 4);
+        const bool same = (((uint64_t)ent.y << 32) | ent.x) == gram && (ent.z & 15u) == q2len;
+        uint32_t meta = ent.z, code = ent.w;
+        bool found = act && same;
+        // a home slot holding another key proves absence unless PREFIX_MORE is set (rare: walk on)
+        if (act && !same && ent.z != PREFIX_EMPTY && (ent.z & PREFIX_MORE)) {
+            meta = ptab_find(A.ptab, ptab_log2, gram, q2len, &code);
+            found = meta != PREFIX_EMPTY;
+        }
+        // every pattern of this group is longer than Q2: the group's own key decides
+        const uint32_t N = found ? (meta >> 4) & 15u : 0u;
+        if (N) found = ptab_find(A.ptab, ptab_log2, low_bytes(w0, N), N, &code) != PREFIX_EMPTY;
+        hit_push(found, tb + off - lead, code, w0, w1, tile, cnt);
+    };
 
     // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
     // the stream) so that exactly five loads are in flight per prefetch: garbage
@@ -603,12 +644,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     const uint64_t last_block = total16 - 16;
     u32x4 nxt0, nxt1, nxt2, nxt3;
     uint2 nxtL;
-#define K1B_LOAD16(DST, PTR) DST = (ablate & 16) ? *(const u32x4 *)(PTR) : load16_stream(PTR); /* 16: plain loads */
 #define K1B_ISSUE_ROW(DST, TILE, R)                                                              \
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
-        const uint8_t *ptr_ = hay + (off_ < last_block ? off_ : last_block);                     \
-        K1B_LOAD16(DST, ptr_)                                                                    \
+        DST = load16_stream(hay + (off_ < last_block ? off_ : last_block));                      \
     }
     // The tile index is wave-uniform (SGPRs): a tile that lies wholly inside the stream -- all
     // but the last one -- is addressed as scalar base + lane * 16 + immediate row offset, no
@@ -618,8 +657,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         const uint64_t tb_ = (TILE) * tile_bytes;                                                \
         if (tb_ + tile_bytes <= last_block) {                                                    \
             const uint8_t *tp_ = hay + tb_ + lane * 16;                                          \
-            K1B_LOAD16(nxt0, tp_) K1B_LOAD16(nxt1, tp_ + 1024) K1B_LOAD16(nxt2, tp_ + 2048)      \
-            K1B_LOAD16(nxt3, tp_ + 3072)                                                         \
+            nxt0 = load16_stream(tp_); nxt1 = load16_stream(tp_ + 1024);                         \
+            nxt2 = load16_stream(tp_ + 2048); nxt3 = load16_stream(tp_ + 3072);                  \
             nxtL = *(const uint2 *)(hay + tb_ + tile_bytes);                                     \
         } else {                                                                                 \
             K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2) \
@@ -630,48 +669,30 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
     }
     K1B_ISSUE_TILE(gw)
 
-    // three extra iterations drain the level-2 pipeline
-    for (uint64_t tile = gw; tile < ntiles + 3 * nw; tile += nw) {
-        // Everything loaded during the previous iteration (the tile prefetch and the
-        // level-2 windows/slots) is consumed from here on.  Passing the tile through
-        // an empty asm makes the compiler wait for those loads HERE, not with a vmcnt(0)
-        // somewhere in the middle of level 1.
+    // ---- level-2 state: the survivors of the wave's previous tile, windows in flight
+    bool haveP = false;            // wave-uniform
+    uint32_t nP = 0, cntP = 0;     // survivors in flight / hits of that tile so far (sparse mode)
+    uint64_t tileP = 0;
+    uint64_t wP0 = 0, wP1 = 0;
+    uint32_t offP = 0;
+
+    // one extra iteration settles the last tile's survivors
+    for (uint64_t tile = gw; tile < ntiles + nw; tile += nw) {
+        // Everything loaded during the previous iteration (the tile prefetch and the survivors'
+        // windows) is consumed from here on.  Passing the tile through an empty asm makes the
+        // compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
         u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
         uint2 vL = nxtL;
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
-        // ---- phase C: compare the slots fetched one tile ago with their grams
-        if (nC) {
-            bool act = lane < nC;
-            bool same = (((uint64_t)entC.y << 32) | entC.x) == (winC & q2mask);
-            // a home slot holding another gram proves absence unless PREFIX_MORE is set
-            bool found = act && entC.z != PREFIX_EMPTY && (same || (entC.z & PREFIX_MORE));
-            uint32_t st = same ? entC.w : HIT_RETRY;
-            if (!(ablate & 2)) K1B_HIT_PUSH(found, tbC + offC - lead, st, winC, winC1)
+        if (haveP) {
+            if (nP) settle(lane < nP, tileP * tile_bytes, offP, wP0, wP1, tileP, cntP);
+            if (SLOTS && lane == 0) GK.hcnt[tileP] = cntP < HIT_SLOTS ? cntP : HIT_SLOTS;
+            haveP = false;
         }
-        // ---- phase B: hash the windows fetched one tile ago, fetch their home slots
-        if (nB) {
-            if (lane < nB) {
-                uint32_t idx = prefix_slot(gram_hash2(winB & q2mask), ptab_log2);
-                entC = *(const uint4 *)(A.ptab + (size_t)idx * 4);
-            }
-            offC = offB; winC = winB; winC1 = winB1;
-        }
-        nC = nB; tbC = tbB;
-        // ---- phase A: fetch the 8-byte windows of the previous tile's survivors
-        if (ablate & 1) q1c = 0;
-        if (q1c) {
-            if (lane < q1c) {
-                offB = q1[lane];
-                load_window16(stream, len, tbA + offB - lead, &winB, &winB1);
-            }
-        }
-        nB = q1c; tbB = tbA; q1c = 0;
-        __builtin_amdgcn_wave_barrier();
         if (tile >= ntiles) continue;
 
         // ---- level 1 on this tile
         const uint64_t tbase = tile * tile_bytes;
-        tbA = tbase;
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
         // a register whose LOW byte is byte k of the lane's 24-byte view: an odd window,
         // a dword, or a dword shifted by 16 (only bits [4:0] are consumed)
@@ -691,30 +712,26 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             _Pragma("unroll") for (int j = 1; j < 20; j += 2)                                    \
                 w_[j] = __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3);         \
             uint32_t m_ = 0;                                                                     \
-            if (!(ablate & 4)) {                                                                 \
-                _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                              \
-                    const uint32_t W_ = w_[j + 1] & GMASK;                                       \
-                    const uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                            \
-                    const uint2 e_ = *(const uint2 *)((const uint8_t *)L.xy +                    \
-                        ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u))); \
-                    /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */  \
-                    const uint32_t bx_ = K1B_BYTE_REG(j);                                        \
-                    const uint32_t by_ = K1B_BYTE_REG(j + Q);                                    \
-                    const uint32_t g_ = e_.x >> (W_ & 31); /* the gate both tests share */       \
-                    const uint32_t tx_ = (e_.x >> (bx_ & 31)) & g_;                              \
-                    const uint32_t ty_ = (e_.y >> (by_ & 31)) & g_;                              \
-                    m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */  \
-                    m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */  \
-                }                                                                                \
-                m_ >>= 16;                                                                       \
-            } else {                                                                             \
-                m_ = (d_[0] ^ d_[1] ^ d_[2] ^ d_[3] ^ d_[4]) == 0x12345678u ? 1u : 0u;           \
+            _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
+                const uint32_t W_ = w_[j + 1] & GMASK;                                           \
+                const uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                                \
+                const uint2 e_ = *(const uint2 *)((const uint8_t *)L.xy +                        \
+                    ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u)));  \
+                /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */      \
+                const uint32_t bx_ = K1B_BYTE_REG(j);                                            \
+                const uint32_t by_ = K1B_BYTE_REG(j + Q);                                        \
+                const uint32_t g_ = e_.x >> (W_ & 31); /* the gate both tests share */           \
+                const uint32_t tx_ = (e_.x >> (bx_ & 31)) & g_;                                  \
+                const uint32_t ty_ = (e_.y >> (by_ & 31)) & g_;                                  \
+                m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */      \
+                m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */      \
             }                                                                                    \
-            if (!interior) {                                                                     \
+            m_ >>= 16;                                                                           \
+            if (!interior) { /* wave-uniform: a scalar branch */                                 \
                 const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
                 uint32_t keep_ = 0;                                                              \
                 _Pragma("unroll") for (int j = 0; j < 16; j++)                                   \
-                    if (p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j;              \
+                    if (any_start && p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j; \
                 m_ &= keep_;                                                                     \
             }                                                                                    \
             MROW = m_;                                                                           \
@@ -725,29 +742,26 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
         K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
         K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
         K1B_ROW(3, v3, vL.x, vL.y, mrow3)
-        // Prefetch of the wave's next tile, issued LATE: the compaction below, the level-2 phases
-        // at the top of the next iteration and the three other waves of the SIMD cover its
-        // latency.  Measured (K1b, T): issued before row 0: 310 us; after row 1: 299; after row 2:
-        // 293; here: 291; no prefetch at all (loads at the top of the tile's own iteration): 308.
-        // The kernel runs within 5 % of the streaming ceiling of the fabric, and five 16-byte
-        // loads per lane that sit in flight for a whole iteration are in the way of everything
-        // else in the memory pipeline.
+        // Prefetch of the wave's next tile, issued LATE: the compaction below, level 2 at the top
+        // of the next iteration and the three other waves of the SIMD cover its latency.  Measured
+        // (round 1, T): issued before row 0: 310 us; after row 1: 299; after row 2: 293; here: 291;
+        // no prefetch at all (loads at the top of the tile's own iteration): 308.
         K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
+        uint32_t cntT = 0; // sparse mode: hits of THIS tile already pushed (full rounds below)
         uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
         while (true) {
             unsigned long long act = __ballot((mlo | mhi) != 0);
             if (!act) break;
             uint32_t np = __popcll(act);
             if (q1c + np > K1B_Q1CAP) {
-                // queue pressure (dense survivors): hand everything in Q1 to the walk
-                // kernel unprobed (it probes the prefix table itself)
-                bool found = lane < q1c;
-                uint64_t p = found ? tbase + q1[lane] - lead : 0;
-                uint64_t a0 = found ? load_window(stream, len, p) : 0;
-                uint64_t a1 = found ? load_window(stream, len, p + 8) : 0;
-                K1B_HIT_PUSH(found, p, HIT_RETRY, a0, a1)
+                // dense survivors: settle what is queued now, windows fetched in place
+                uint32_t off = 0;
+                uint64_t a0 = 0, a1 = 0;
+                if (lane < q1c) { off = q1[lane]; load_window16(stream, len, tbase + off - lead, &a0, &a1); }
+                settle(lane < q1c, tbase, off, a0, a1, tile, cntT);
                 q1c = 0;
+                __builtin_amdgcn_wave_barrier();
             }
             if (mlo | mhi) {
                 uint32_t pos;
@@ -760,14 +774,20 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
             q1c += np;
             __builtin_amdgcn_wave_barrier();
         }
+        // ---- request the windows of the queued survivors now (their lines were streamed a few
+        // microseconds ago); they are settled at the top of the next iteration
+        nP = q1c; cntP = cntT; tileP = tile; haveP = true;
+        if (lane < q1c) {
+            offP = q1[lane];
+            load_window16(stream, len, tbase + offP - lead, &wP0, &wP1);
+        }
+        q1c = 0;
+        __builtin_amdgcn_wave_barrier();
     }
-    K1B_HIT_FLUSH
-    if (lane == 0) GK.block_counts[region] = hcur;
-#undef K1B_HIT_FLUSH
+    hit_flush();
+    if (!SLOTS && lane == 0) GK.block_counts[region] = hcur;
 #undef K1B_ISSUE_ROW
-#undef K1B_LOAD16
 #undef K1B_ISSUE_TILE
-#undef K1B_HIT_PUSH
 #undef K1B_ROW
 #undef K1B_BYTE_REG
 }
@@ -775,31 +795,18 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(DevAutomaton A, const DevA
 size_t prefilter_lds_bytes() { return sizeof(K1bLds); }
 
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
-    uint64_t lead = (uintptr_t)d_hay & 15;
-    uint64_t total = lead + len;
-    uint64_t ntiles = (total + (uint64_t)K1B_ROWS * 1024 - 1) / ((uint64_t)K1B_ROWS * 1024);
+    uint64_t ntiles = prefilter_tiles(d_hay, len);
     uint64_t blocks = (ntiles + 15) / 16;
     if (blocks > (uint64_t)n_cus) blocks = n_cus;
     return blocks ? (uint32_t)blocks : 1;
 }
 
-static uint32_t ablation_flags() {
-    static int v = -1;
-    if (v < 0) {
-        const char *e = std::getenv("ACX_ABLATE"); // profiling only: 1 = level 1 only, 2 = skip level 3, 4 = loads only
-        v = e ? std::atoi(e) : 0;
-    }
-    return (uint32_t)v;
-}
+uint32_t walk_hits_grid(uint32_t hit_regions) { return hit_regions < 4096 ? hit_regions : 4096; }
 
-uint32_t walk_hits_grid(uint32_t hit_regions) { return hit_regions * K_WALK_SPLIT; }
-
-hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
-                            const uint8_t *d_hay, uint64_t len, hipStream_t st) {
-    if (split == 0 || split > K_WALK_SPLIT) split = K_WALK_SPLIT;
-    hipLaunchKernelGGL(k_walk_hits, dim3(hit_grid * split), dim3(256), 0, st, A, Ad, G, hits, hit_grid,
-                       split, occ, d_hay, len, ablation_flags());
+hipError_t launch_walk_hits(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
+                            const Sink &occ, uint32_t occ_grid, const uint8_t *d_hay, uint64_t len,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(k_walk_hits, dim3(occ_grid), dim3(256), 0, st, A, G, hits, hit_grid, occ, d_hay, len);
     return hipGetLastError();
 }
 
@@ -810,19 +817,20 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
     return (total + (uint64_t)K1B_ROWS * 1024 - 1) / ((uint64_t)K1B_ROWS * 1024);
 }
 
-hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st, hipEvent_t ev_start,
-                            hipEvent_t ev_stop) {
+// K.hslots != null: sparse mode (hit slots + counts); else region mode (per-wave regions)
+hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
+                            uint32_t grid, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
-    uint32_t ab = ablation_flags();
+    const K1bTables T{A.filterA, A.ptab, A.ptab_log2, A.filter_q2, A.min_len};
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
-#define ACX_K1B(Q)                                                                                    \
-    hipExtLaunchKernelGGL(k1b_prefilter<Q>, g, b, 0, st, ev_start, ev_stop, 0, A, Ad, G, K, base, len, lead, \
-                          tile_begin, tile_end, ab)
+#define ACX_K1B(Q)                                                                                         \
+    if (K.hslots)                                                                                          \
+        hipExtLaunchKernelGGL((k1b_prefilter<Q, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
+    else                                                                                                   \
+        hipExtLaunchKernelGGL((k1b_prefilter<Q, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
     switch (A.filter_q) {
     case 1: ACX_K1B(1); break;
     case 2: ACX_K1B(2); break;
@@ -1029,301 +1037,277 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 }
 
 // ---------------------------------------------------------------------------
-// K2b: sparse path -- tile kernels over the bucket slots
+// K2: sparse path -- verification, order, match kind, compaction
 // ---------------------------------------------------------------------------
-// In slot mode the scan's emission has already grouped the occurrences by 4 KiB bucket
-// of their key position (Sink::slots).  The launch geometry of everything that follows
-// depends only on the number of buckets (known to the host), never on the number of
-// occurrences (known only to the device), so the whole post stage is queued behind the
-// scan without a host round trip.  A workgroup owns a tile of TILE_BUCKETS consecutive
-// buckets (256 KiB of stream position); its occurrences (at most TILE_MAX, else the
-// abort flag -> region mode + radix sort) are staged in LDS so that the per-bucket serial
-// work runs at LDS latency and every global access is coalesced.  These kernels are
-// latency chains (a few dependent HBM round trips per tile), so the workgroups are small
-// (two waves, 16 KiB of LDS).
-//   k_tile_sort     gather the slots, per-bucket insertion sort, sync-point flag of
-//                   every occurrence
-//   k_tile_resolve  greedy chains, re-derived per bucket from the nearest sync point;
-//                   reported count of the tile
-//   k_tile_scan     exclusive scan of the tile counts, totals (one workgroup)
-//   k_tile_write    compaction into the final (pattern, start, end) records
-constexpr uint32_t DST_NONE = 0xFFFFFFFFu;
-constexpr uint32_t TILE_THREADS = 128;
-constexpr uint32_t TILE_PER_THREAD = TILE_MAX / TILE_THREADS; // k_tile_write
-static_assert(TILE_BUCKETS <= 64, "one wave owns the buckets of a tile");
-static_assert(TILE_THREADS % TILE_BUCKETS == 0 && TILE_PER_THREAD % 4 == 0, "tile geometry");
+// The scan left its hits in per-tile slots (Sink / TileSpace in device_types.hpp).  The launch
+// geometry of everything that follows depends only on the number of tiles (known to the host),
+// never on the number of hits (known only to the device), so the whole post stage is queued
+// behind the scan without a host round trip.
+//   k_tile_main   one workgroup per GROUP of 64 tiles (256 KiB of index space): verifies the
+//                 hits of its tiles (+ `lookback` context tiles in front) against the pattern
+//                 bytes, drops the occurrences into LDS buckets of 4 KiB of KEY position,
+//                 orders every bucket, applies the match kind and writes the group's REPORTED
+//                 occurrences, in order, to its stretch of trecs
+//   k_tile_scan   exclusive scan of the group totals (one workgroup); totals to pinned host memory
+//   k_tile_write  final (pattern, start, end) records, coalesced through LDS
+//
+// Match kind without communication between groups.  Sorted by key, the non-overlapping greedy
+// accepts occurrence i iff start_i >= end of the last accepted one.  Occurrence i is a *sync
+// point* when every earlier occurrence ends at or before its start: it is accepted whatever
+// happened before, and the greedy from there on is independent of the past.  A group stages
+// the occurrences of its context tiles too; an occurrence whose start lies at or beyond
+// W = (first staged index + max_len - 1) has all the occurrences that could overlap it staged
+// (nothing that starts before the staged tiles reaches it), so its sync-point test over the
+// staged occurrences alone is exact ("certified").  Every output bucket re-derives the greedy
+// from the nearest certified sync point at or before it -- chains are 1-2 long unless matches pile
+// up.  If there is none (a chain of overlapping occurrences longer than the context: periodic
+// patterns on periodic text), or a bucket overflows, the group raises the abort flag and the
+// host redoes the call on the dense path, whose resolve is global.
+constexpr uint32_t MAIN_THREADS = 256;
+constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
+static_assert(GROUP_TILES == 64, "one wave owns the output buckets of a group");
+
+__device__ __forceinline__ uint64_t rec_key(const uint4 v) { return ((uint64_t)v.y << 32) | v.x; }
 
 // span of an occurrence record {key lo, key hi, pid, pattern length}
 __device__ __forceinline__ void span_of(uint32_t rank_bits, int key_mode, uint4 v, uint64_t *s, uint64_t *e) {
-    const uint64_t x = (((uint64_t)v.y << 32) | v.x) >> rank_bits;
+    const uint64_t x = rec_key(v) >> rank_bits;
     if (key_mode == 0) { *e = x; *s = x - v.w; }
     else { *s = x; *e = x + v.w; }
 }
 
-// bo[0 .. TILE_BUCKETS] = offsets of the tile's buckets inside the tile (wave 0; the caller syncs)
-__device__ __forceinline__ void tile_offsets(const TileSpace &T, uint32_t B0, uint32_t *bo) {
-    const uint32_t t = threadIdx.x;
+__global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+                                                            int overlapping, TileSpace T, uint32_t lookback,
+                                                            uint32_t lead, const uint8_t *__restrict__ stream,
+                                                            uint64_t len, uint32_t *abort_flag) {
+    __shared__ uint4 st[STAGE_BUCKETS][HIT_SLOTS]; // staged occurrences by bucket of key position
+    __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
+    __shared__ uint64_t bmax[STAGE_BUCKETS];       // largest end per bucket
+    __shared__ uint32_t hoff[STAGE_BUCKETS + 1];   // exclusive prefix of the tiles' hit counts
+    __shared__ uint8_t syn[STAGE_BUCKETS][HIT_SLOTS], acc[STAGE_BUCKETS][HIT_SLOTS];
+    __shared__ uint32_t fail, stop;
+    using scan_t = rocprim::block_scan<uint32_t, MAIN_THREADS>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    const uint32_t tile0 = g * GROUP_TILES;
+    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
+    const uint32_t lb = tile0 - first;                               // context tiles in front
+    const uint32_t nb = GROUP_TILES + lb;                            // staged buckets
+    // ---- hits of the staged tiles
+    uint32_t c = 0;
+    if (t < nb && first + t < T.n_tiles) {
+        c = T.hcnt[first + t];
+        c = c < HIT_SLOTS ? c : HIT_SLOTS; // overfull: the producer raised the abort flag
+    }
+    if (t < STAGE_BUCKETS) { bn[t] = 0; bmax[t] = 0; }
+    if (t == 0) { fail = 0; stop = *abort_flag; }
+    uint32_t off = 0, H = 0;
+    scan_t().exclusive_scan(c, off, 0u, H, scan_tmp);
+    if (t <= nb) hoff[t] = off;
+    __syncthreads();
+    if (stop) return;
+    // index space: index = stream position + lead; a tile / bucket is 4 KiB of it
+    const uint64_t idx_lo = (uint64_t)tile0 << TILE_BITS, idx_hi = idx_lo + ((uint64_t)GROUP_TILES << TILE_BITS);
+    // occurrences whose key index is below `complete` may have unseen company: not staged.
+    // occurrences that start at or beyond `wlow` can be certified as sync points
+    const uint64_t margin = A.max_len ? A.max_len - 1 : 0;
+    const uint64_t first_idx = (uint64_t)first << TILE_BITS;
+    const uint64_t complete = first == 0 ? 0 : first_idx + (key_mode == 0 ? margin : 0);
+    const uint64_t wlow = first == 0 ? 0 : first_idx + margin;
+    // ---- verify: one thread per hit
+    for (uint32_t h = t; h < H; h += MAIN_THREADS) {
+        uint32_t lo = 0, hi = nb; // tile j = the last one with hoff[j] <= h
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hoff[mid] <= h) lo = mid; else hi = mid;
+        }
+        const uint4 *rec = T.hslots + ((uint64_t)(first + lo) * HIT_SLOTS + (h - hoff[lo])) * 2;
+        const uint4 r0 = rec[0];
+        const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
+        uint64_t w0 = 0, w1 = 0, room = 0;
+        uint32_t nc = 1, li = 0;
+        const bool verified = (r0.z & HIT_VERIFIED) != 0 && !(r0.z & HIT_LIST);
+        const bool list = (r0.z & HIT_LIST) != 0;
+        if (!verified) {
+            const uint4 w = rec[1];
+            w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
+            room = segment_end(G, len, p) - p;
+            if (list) { li = r0.z & ~HIT_LIST; nc = A.blist[li]; }
+        }
+        for (uint32_t k = 0; k < nc; k++) {
+            uint32_t pid, L, rk;
+            if (verified) {
+                pid = r0.z & ~HIT_VERIFIED; L = r0.w;
+                rk = key_mode == 1 ? 0u : A.rank[pid];
+            } else {
+                pid = list ? A.blist[li + 1 + k] : r0.z;
+                L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
+                if (!L) continue;
+            }
+            const uint64_t key = occurrence_key(key_mode, A.rank_bits, p, L, pid, rk);
+            const uint64_t kidx = (key_mode == 0 ? p + L : p) + lead;
+            if (kidx < complete || kidx >= idx_hi) continue; // another group's (or nobody's) business
+            const uint32_t b = (uint32_t)((kidx >> TILE_BITS) - first);
+            const uint32_t r = atomicAdd(&bn[b], 1u);
+            if (r < HIT_SLOTS) st[b][r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
+            else fail = 1;
+        }
+    }
+    __syncthreads();
+    if (fail) { if (t == 0) *abort_flag = 1; return; }
+    // ---- order every bucket (keys are unique), largest end per bucket
+    if (t < nb) {
+        const uint32_t n = bn[t];
+        uint64_t mx = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint4 v = st[t][i];
+            const uint64_t kk = rec_key(v);
+            uint32_t j = i;
+            while (j > 0 && rec_key(st[t][j - 1]) > kk) { st[t][j] = st[t][j - 1]; j--; }
+            st[t][j] = v;
+            uint64_t s, e;
+            span_of(A.rank_bits, key_mode, v, &s, &e);
+            mx = max(mx, e);
+        }
+        bmax[t] = mx;
+    }
+    __syncthreads();
+    uint32_t cnt = 0; // reported occurrences of output bucket t (wave 0)
+    if (overlapping) {
+        if (t < GROUP_TILES) cnt = bn[lb + t];
+    } else {
+        // ---- certified sync points.  Only occurrences of the last (lookback + 1) buckets can end
+        // beyond the start of one in bucket t (an occurrence spans at most max_len - 1 bytes
+        // besides its key position, and lookback tiles are longer than that).
+        if (t < nb) {
+            uint64_t m = 0;
+            for (uint32_t b = t > lookback + 1 ? t - lookback - 1 : 0; b < t; b++) m = max(m, bmax[b]);
+            const uint32_t n = bn[t];
+            for (uint32_t i = 0; i < n; i++) {
+                uint64_t s, e;
+                span_of(A.rank_bits, key_mode, st[t][i], &s, &e);
+                syn[t][i] = (s + lead >= wlow && m <= s) ? 1 : 0;
+                m = max(m, e);
+            }
+        }
+        __syncthreads();
+        // ---- greedy chains: every output bucket from the nearest certified sync point
+        if (t < GROUP_TILES && bn[lb + t]) {
+            const uint32_t ob = lb + t;
+            int b = (int)ob, i = 0;
+            bool ok = true;
+            while (!syn[b][i]) { // walk back to a sync point
+                if (--i < 0) {
+                    do { b--; } while (b >= 0 && bn[b] == 0);
+                    if (b < 0) { ok = false; break; }
+                    i = (int)bn[b] - 1;
+                }
+            }
+            if (!ok) {
+                fail = 1; // the chain enters from beyond the context: dense path
+            } else {
+                uint64_t pos = 0;
+                for (;;) { // forward again, to the end of bucket ob
+                    uint64_t s, e;
+                    span_of(A.rank_bits, key_mode, st[b][i], &s, &e);
+                    const bool take = s >= pos;
+                    if (take) pos = e;
+                    if ((uint32_t)b == ob) { acc[b][i] = take; cnt += take; }
+                    if (++i >= (int)bn[b]) {
+                        if ((uint32_t)b == ob) break;
+                        do { b++; } while (bn[b] == 0); // ob is not empty: terminates there at the latest
+                        i = 0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        if (fail) { if (t == 0) *abort_flag = 1; return; }
+    }
+    // ---- compact the reported occurrences of the 64 output buckets into the group's stretch
     if (t < 64) {
-        uint32_t c = t < TILE_BUCKETS && B0 + t < T.n_buckets ? T.bcnt[B0 + t] : 0;
-        c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS; // overfull: the emitter raised the abort flag
-        uint32_t incl = c;
+        uint32_t incl = cnt, occ = bn[lb + t];
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o);
             if ((int)t >= o) incl += v;
         }
-        if (t < TILE_BUCKETS) bo[t + 1] = incl;
-        if (t == 0) bo[0] = 0;
+        const uint32_t total = __shfl(incl, 63);
+        for (int o = 32; o > 0; o >>= 1) occ += __shfl_down(occ, o);
+        if (total > GROUP_MAX) {
+            if (t == 0) *abort_flag = 1;
+        } else {
+            uint4 *dst = T.trecs + (uint64_t)g * GROUP_MAX + (incl - cnt);
+            const uint32_t n = bn[lb + t];
+            for (uint32_t i = 0, k = 0; i < n; i++)
+                if (overlapping || acc[lb + t][i]) dst[k++] = st[lb + t][i];
+        }
+        if (t == 0) { T.btot[g] = total > GROUP_MAX ? 0 : total; T.gocc[g] = occ; }
     }
 }
 
-// largest end among the (unsorted) occurrences of the buckets [b0, b1)
-__device__ __forceinline__ uint64_t raw_max_end(uint32_t rank_bits, int key_mode, const TileSpace &T,
-                                                uint32_t b0, uint32_t b1) {
-    uint64_t mx = 0;
-    for (uint32_t b = b0; b < b1; b++) {
-        uint32_t c = T.bcnt[b];
-        c = c < BUCKET_SLOTS ? c : BUCKET_SLOTS;
-        for (uint32_t r = 0; r < c; r++) {
-            uint64_t s, e;
-            span_of(rank_bits, key_mode, T.slots[(uint64_t)b * BUCKET_SLOTS + r], &s, &e);
-            mx = max(mx, e);
-        }
-    }
-    return mx;
-}
-
-// Occurrence i is a "sync point" when every earlier occurrence (in sorted order) ends at or
-// before its start: whatever the greedy did before, i is reported.
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_sort(uint32_t rank_bits, uint32_t max_len,
-                                                            int key_mode, int overlapping, TileSpace T,
-                                                            uint32_t tile0, uint32_t *abort_flag) {
-    __shared__ uint64_t k[TILE_MAX];
-    __shared__ uint2 pl[TILE_MAX]; // {pid, pattern length}
-    __shared__ uint32_t bo[TILE_BUCKETS + 1];
-    __shared__ uint32_t stop;
-    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x, B0 = tile * TILE_BUCKETS;
-    tile_offsets(T, B0, bo);
-    if (t == 0) stop = *abort_flag;
-    __syncthreads();
-    const uint32_t n = bo[TILE_BUCKETS];
-    if (stop) return;
-    if (n > TILE_MAX) { if (t == 0) *abort_flag = 1; return; }
-    if (t == 0) T.tile_n[tile] = n;
-    { // gather: TILE_THREADS / 64 threads per bucket
-        constexpr uint32_t TPB = TILE_THREADS / TILE_BUCKETS;
-        const uint32_t bq = t / TPB, a = bo[bq], c = bo[bq + 1] - a;
-        for (uint32_t r = t % TPB; r < c; r += TPB) {
-            const uint4 v = T.slots[(uint64_t)(B0 + bq) * BUCKET_SLOTS + r];
-            k[a + r] = ((uint64_t)v.y << 32) | v.x;
-            pl[a + r] = make_uint2(v.z, v.w);
-        }
-    }
-    __syncthreads();
-    if (t < TILE_BUCKETS) {
-        const uint32_t a = bo[t], e = bo[t + 1];
-        for (uint32_t i = a + 1; i < e; i++) {
-            const uint64_t kk = k[i];
-            const uint2 pp = pl[i];
-            uint32_t j = i;
-            while (j > a && k[j - 1] > kk) { k[j] = k[j - 1]; pl[j] = pl[j - 1]; j--; }
-            k[j] = kk; pl[j] = pp;
-        }
-    }
-    __syncthreads();
-    const uint64_t gi = (uint64_t)tile * TILE_MAX;
-    for (uint32_t i = t; i < n; i += TILE_THREADS) {
-        const uint64_t key = k[i];
-        const uint2 pp = pl[i];
-        T.trecs[gi + i] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pp.x, pp.y);
-        if (overlapping) continue;
-        const uint64_t x = key >> rank_bits;
-        const uint64_t s = key_mode == 0 ? x - pp.y : x;
-        uint64_t mx = 0; // largest end among the occurrences before i
-        if (key_mode == 0) { // sorted by end: the previous end is the maximum
-            if (i > 0) mx = k[i - 1] >> rank_bits;
-            else if ((s >> BUCKET_BITS) < B0) // anything before the tile that ends beyond s ends in these buckets
-                mx = raw_max_end(rank_bits, key_mode, T, (uint32_t)(s >> BUCKET_BITS), B0);
-        } else { // sorted by start: only occurrences that start within max_len of s can end beyond it
-            bool open = true;
-            for (uint32_t j = i; j > 0;) {
-                j--;
-                const uint64_t sj = k[j] >> rank_bits;
-                if (sj + max_len <= s) { open = false; break; }
-                mx = max(mx, sj + pl[j].y);
-            }
-            const uint64_t p0 = s > max_len ? s - max_len : 0;
-            if (open && (p0 >> BUCKET_BITS) < B0)
-                mx = max(mx, raw_max_end(rank_bits, key_mode, T, (uint32_t)(p0 >> BUCKET_BITS), B0));
-        }
-        T.syncf[gi + i] = mx <= s ? 1 : 0;
-    }
-}
-
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_resolve(uint32_t rank_bits, int key_mode,
-                                                               int overlapping, TileSpace T, uint32_t tile0,
-                                                               const uint32_t *abort_flag) {
-    __shared__ uint32_t rel[TILE_MAX]; // key position relative to the tile's first byte
-    __shared__ uint32_t len[TILE_MAX];
-    __shared__ uint8_t sy[TILE_MAX], ac[TILE_MAX];
-    __shared__ uint32_t bo[TILE_BUCKETS + 1];
-    __shared__ uint32_t stop;
-    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x, B0 = tile * TILE_BUCKETS;
-    tile_offsets(T, B0, bo);
-    if (t == 0) stop = *abort_flag;
-    __syncthreads();
-    if (stop) return;
-    const uint32_t n = bo[TILE_BUCKETS];
-    const uint64_t base = (uint64_t)B0 << BUCKET_BITS, gi = (uint64_t)tile * TILE_MAX;
-    uint32_t cnt = 0; // reported occurrences of bucket t (wave 0 only)
-    if (overlapping) {
-        if (t < TILE_BUCKETS) cnt = bo[t + 1] - bo[t];
-    } else {
-        for (uint32_t i = t; i < n; i += TILE_THREADS) {
-            const uint4 v = T.trecs[gi + i];
-            rel[i] = (uint32_t)(((((uint64_t)v.y << 32) | v.x) >> rank_bits) - base);
-            len[i] = v.w;
-            sy[i] = T.syncf[gi + i];
-        }
-        __syncthreads();
-        const uint32_t a = t < TILE_BUCKETS ? bo[t] : 0, e = t < TILE_BUCKETS ? bo[t + 1] : 0;
-        if (e > a) {
-            // re-derive the greedy chain from the nearest sync point at or before a
-            uint32_t j = a;
-            while (j > 0 && !sy[j]) j--;
-            uint64_t pos = 0; // end of the last reported match
-            if (!sy[j]) { // the chain enters the tile from before it: follow it in HBM (rare)
-                uint32_t tt = tile, q = 0;
-                for (;;) { // the first occurrence of the stream is a sync point: this terminates
-                    while (q == 0) q = T.tile_n[--tt];
-                    q--;
-                    if (T.syncf[(uint64_t)tt * TILE_MAX + q]) break;
-                }
-                for (; tt < tile; tt++, q = 0) {
-                    const uint32_t nn = T.tile_n[tt];
-                    for (; q < nn; q++) {
-                        uint64_t s, en;
-                        span_of(rank_bits, key_mode, T.trecs[(uint64_t)tt * TILE_MAX + q], &s, &en);
-                        if (s >= pos) pos = en;
-                    }
-                }
-            }
-            for (uint32_t q = j; q < e; q++) {
-                const uint64_t x = base + rel[q], l = len[q];
-                const uint64_t s = key_mode == 0 ? x - l : x, en = key_mode == 0 ? x : x + l;
-                const bool take = s >= pos;
-                if (take) pos = en;
-                if (q >= a) { ac[q] = take; cnt += take; }
-            }
-        }
-        __syncthreads();
-        for (uint32_t i = t; i < n; i += TILE_THREADS) T.accf[gi + i] = ac[i];
-    }
-    if (t < 64) {
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-        if (t == 0) T.btot[tile] = cnt;
-    }
-}
-
-// One workgroup, for the tiles [tile0, tile1) of one chunk of the call (chunks run in order):
-// bbase = exclusive scan of btot continuing the previous chunk's; summary[0] = occurrences,
-// summary[4] = reported matches, summary[2] / [3] = prefix hits kept / largest hit region, all
-// accumulated over the chunks.  The last chunk clears the abort flag the NEXT call will use and
-// publishes {[0] occurrences, [2] hits, [3] largest hit region, [4] matches, [5] aborted} to
-// host_out (pinned host memory).
-__global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, uint32_t tile0, uint32_t tile1, int first,
-                                                    const uint64_t *hit_counts, uint32_t hit_grid,
-                                                    uint64_t hit_cap, uint64_t *summary,
+// One workgroup: bbase = exclusive scan of btot; publishes {[0] occurrences, [2] prefix hits (only
+// when count_hits), [4] matches, [5] aborted, [7] seq} to host_out (pinned, system-coherent host
+// memory the host polls: seq is written last, behind a system-scope fence) and mirrors them
+// in `summary`; clears the abort flag the NEXT call will use.
+__global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits, uint64_t *summary,
                                                     const uint32_t *abort_flag, uint32_t *next_flag,
-                                                    uint64_t *host_out) {
+                                                    volatile uint64_t *host_out, uint64_t seq) {
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
-    __shared__ uint64_t red[3][16];
+    __shared__ uint64_t red[2][16];
     const uint32_t t = threadIdx.x;
     const bool stop = *abort_flag != 0; // stable: its writers completed
-    const uint64_t n_before = first ? 0 : summary[0], h_before = first ? 0 : summary[2],
-                   hmax_before = first ? 0 : summary[3];
-    const uint32_t base = first ? 0 : (uint32_t)summary[4];
-    uint64_t hsum = 0, hmax = 0, nsum = 0;
-    if (hit_counts)
-        for (uint32_t g = t; g < hit_grid; g += 1024) {
-            const uint64_t c = hit_counts[g];
-            hmax = max(hmax, c);
-            hsum += c < hit_cap ? c : hit_cap;
-        }
-    const uint32_t per = (tile1 - tile0 + 1023) / 1024, g0 = tile0 + t * per;
-    uint32_t mine = 0, excl = 0;
-    // (unrolled so that the loads of several tiles are in flight together)
+    uint64_t hsum = 0, nsum = 0;
+    if (count_hits)
+        for (uint32_t i = t; i < T.n_tiles; i += 1024) hsum += T.hcnt[i];
+    const uint32_t per = (T.n_groups + 1023) / 1024, g0 = t * per;
+    uint32_t mine = 0, excl = 0, total = 0;
+    // (unrolled so that the loads of several groups are in flight together)
     if (!stop)
-        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < tile1; g++) {
+        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < T.n_groups; g++) {
             mine += T.btot[g];
-            nsum += T.tile_n[g];
+            nsum += T.gocc[g];
         }
-    scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
-    excl += base;
+    scan_t().exclusive_scan(mine, excl, 0u, total, scan_tmp);
     if (!stop)
-        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < tile1; g++) {
+        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < T.n_groups; g++) {
             T.bbase[g] = excl;
             excl += T.btot[g];
         }
     for (int o = 32; o > 0; o >>= 1) {
         hsum += __shfl_down(hsum, o);
         nsum += __shfl_down(nsum, o);
-        hmax = max(hmax, __shfl_down(hmax, o));
     }
-    if ((t & 63) == 0) { red[0][t >> 6] = hsum; red[1][t >> 6] = hmax; red[2][t >> 6] = nsum; }
+    if ((t & 63) == 0) { red[0][t >> 6] = hsum; red[1][t >> 6] = nsum; }
     __syncthreads();
-    if (t == 1023) {
-        summary[4] = excl;
-        if (host_out) host_out[4] = excl;
-    }
     if (t == 0) {
-        uint64_t a = h_before, b = hmax_before, c = n_before;
-        for (int i = 0; i < 16; i++) { a += red[0][i]; b = max(b, red[1][i]); c += red[2][i]; }
-        summary[2] = a; summary[3] = b; summary[0] = c;
+        uint64_t a = 0, c = 0;
+        for (int i = 0; i < 16; i++) { a += red[0][i]; c += red[1][i]; }
+        summary[0] = c; summary[2] = a; summary[4] = total;
         if (next_flag) *next_flag = 0;
-        // last chunk: the totals go straight to pinned host memory (no copy operation)
-        if (host_out) { host_out[0] = c; host_out[2] = a; host_out[3] = b; host_out[5] = stop ? 1 : 0; }
+        host_out[0] = c; host_out[2] = a; host_out[4] = total; host_out[5] = stop ? 1 : 0;
+        __threadfence_system();
+        host_out[7] = seq;
     }
 }
 
-// zero_lo..zero_hi: the arrival counters this launch leaves clean for the next call
+// The group's reported occurrences -> final records.  A group's output is one contiguous stretch
+// of 24-byte records: it is assembled in LDS and written as a flat array of dwords (coalesced).
 // seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
 // their haystack and the per-haystack counts are taken here -- one atomic per run of matches
-// of the same haystack inside the tile instead of a separate pass with one atomic per match.
-__global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, int overlapping,
-                                                             TileSpace T, uint32_t tile0, uint32_t zero_lo,
-                                                             uint32_t zero_hi, acx_match_t *out,
-                                                             const uint32_t *abort_flag, Segments G,
-                                                             uint64_t *seg_counts) {
-    __shared__ __attribute__((aligned(16))) uint8_t ac[TILE_MAX];
-    __shared__ uint32_t dst[TILE_MAX];
-    using scan_t = rocprim::block_scan<uint32_t, TILE_THREADS>;
-    __shared__ typename scan_t::storage_type scan_tmp;
-    const uint32_t t = threadIdx.x, tile = tile0 + blockIdx.x;
-    for (uint32_t i = zero_lo + blockIdx.x * TILE_THREADS + t; i < zero_hi; i += gridDim.x * TILE_THREADS)
-        T.bcnt[i] = 0;
+// of the same haystack inside the group instead of a separate pass with one atomic per match.
+constexpr uint32_t WRITE_THREADS = 256;
+__global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, TileSpace T,
+                                                              acx_match_t *out, const uint32_t *abort_flag,
+                                                              Segments G, uint64_t *seg_counts) {
+    __shared__ uint32_t img[GROUP_MAX * 6];
+    __shared__ uint32_t hs[GROUP_MAX]; // haystack index of the group's matches, in output order
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
     if (*abort_flag) return; // stable by now: its writers completed
-    const uint32_t n = T.tile_n[tile], base = T.bbase[tile];
-    const uint64_t gi = (uint64_t)tile * TILE_MAX;
-    if (overlapping) {
-        for (uint32_t i = t; i < n; i += TILE_THREADS) dst[i] = base + i;
-    } else {
-        for (uint32_t i = t; i < TILE_MAX; i += TILE_THREADS) ac[i] = i < n ? T.accf[gi + i] : 0;
-        __syncthreads();
-        // thread t owns the occurrences [t * TILE_PER_THREAD, (t + 1) * TILE_PER_THREAD)
-        uint32_t mine = 0, excl = 0;
-        _Pragma("unroll") for (uint32_t w = 0; w < TILE_PER_THREAD / 4; w++)
-            mine += __popc(*(const uint32_t *)&ac[t * TILE_PER_THREAD + 4 * w]);
-        scan_t().exclusive_scan(mine, excl, 0u, scan_tmp);
-        uint32_t d = base + excl;
-        for (uint32_t q = t * TILE_PER_THREAD; q < (t + 1) * TILE_PER_THREAD; q++) dst[q] = ac[q] ? d++ : DST_NONE;
-    }
-    __syncthreads();
-    __shared__ uint32_t hs[TILE_MAX]; // haystack index of the tile's reported matches, in output order
-    for (uint32_t i = t; i < n; i += TILE_THREADS) {
-        const uint32_t d = dst[i];
-        if (d == DST_NONE) continue;
-        const uint4 v = T.trecs[gi + i];
+    const uint32_t n = T.btot[g], base = T.bbase[g];
+    const uint4 *src = T.trecs + (uint64_t)g * GROUP_MAX;
+    for (uint32_t i = t; i < n; i += WRITE_THREADS) {
+        const uint4 v = src[i];
         uint64_t s, e;
         span_of(rank_bits, key_mode, v, &s, &e);
         if (seg_counts) {
@@ -1331,48 +1315,47 @@ __global__ __launch_bounds__(TILE_THREADS) void k_tile_write(uint32_t rank_bits,
             if (G.uniform_len) { h = s / G.uniform_len; hbase = h * G.uniform_len; }
             else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; hbase = G.offsets[h]; }
             s -= hbase; e -= hbase;
-            hs[d - base] = (uint32_t)h;
+            hs[i] = (uint32_t)h;
         }
-        out[d].pattern = v.z; out[d].start = s; out[d].end = e;
+        uint32_t *d = img + i * 6;
+        d[0] = v.z; d[1] = 0; d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
     }
+    __syncthreads();
+    uint32_t *flat = (uint32_t *)(out + base);
+    for (uint32_t k = t; k < n * 6; k += WRITE_THREADS) flat[k] = img[k];
     if (seg_counts) {
-        __syncthreads();
-        const uint32_t total = T.btot[tile];
-        for (uint32_t c = t; c < total; c += TILE_THREADS) {
+        for (uint32_t c = t; c < n; c += WRITE_THREADS) {
             const uint32_t h = hs[c];
             if (c > 0 && hs[c - 1] == h) continue; // not the head of its run
             uint32_t run = 1;
-            while (c + run < total && hs[c + run] == h) run++;
+            while (c + run < n && hs[c + run] == h) run++;
             atomicAdd((unsigned long long *)&seg_counts[h], (unsigned long long)run);
         }
     }
 }
 
-// Sort (within buckets), resolve and compact the slotted occurrences of the tiles
-// [tile0, tile1) into out[] (capacity n_tiles * TILE_MAX suffices for a whole call).  Chunks of
-// one call come in tile order; `first` / `last` mark the ends.  summary[0] = occurrences,
-// [2] = prefix hits kept, [3] = largest hit region, [4] = matches written (accumulated over the
-// chunks); *abort_flag != 0: the output did not fit the sparse path (or hits were dropped) and
-// out[] / summary[0], [4] are meaningless.  The last chunk zeroes T.bcnt and *next_flag.
-hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
-                     uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
-                     uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
-                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, const Segments &G,
-                     uint64_t *seg_counts, hipStream_t st) {
+uint32_t tile_lookback(uint32_t max_len) {
+    // context tiles in front of a group: longer than the longest pattern by at least 2 KiB
+    const uint64_t need = (uint64_t)(max_len ? max_len - 1 : 0) + 2048;
+    return (uint32_t)((need + (1u << TILE_BITS) - 1) >> TILE_BITS);
+}
+
+// Verify, order, resolve and compact the hits of the whole call into out[] (capacity
+// n_groups * GROUP_MAX suffices).  *abort_flag != 0 afterwards (published as host_out[5]): the
+// output did not fit the sparse path and out[] / the totals are meaningless.
+hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
+                     const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
+                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
+                     bool count_hits, const Segments &G, uint64_t *seg_counts, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
-    const uint32_t tiles = tile1 - tile0;
-    if (tiles) {
-        hipLaunchKernelGGL(k_tile_sort, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, A.max_len, key_mode,
-                           ov, T, tile0, abort_flag);
-        hipLaunchKernelGGL(k_tile_resolve, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
-                           tile0, abort_flag);
-    }
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, tile0, tile1, first ? 1 : 0, hit_counts,
-                       hit_grid, hit_cap, summary, abort_flag, last ? next_flag : nullptr,
-                       last ? host_out : nullptr);
-    if (tiles)
-        hipLaunchKernelGGL(k_tile_write, dim3(tiles), dim3(TILE_THREADS), 0, st, A.rank_bits, key_mode, ov, T,
-                           tile0, 0u, last ? T.n_buckets + 1 : 0u, out, abort_flag, G, seg_counts);
+    const uint32_t lookback = tile_lookback(A.max_len);
+    if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
+    hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
+                       lead, d_hay, len, abort_flag);
+    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, count_hits ? 1 : 0, summary, abort_flag,
+                       next_flag, (volatile uint64_t *)host_out, seq);
+    hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, T, out,
+                       abort_flag, G, seg_counts);
     return hipGetLastError();
 }
 

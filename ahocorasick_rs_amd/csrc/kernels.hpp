@@ -10,41 +10,41 @@
 
 namespace acx {
 
-// ---- K1: scan kernels (emit every occurrence of every pattern into the sink)
-// K1a: chunked DFA walk, class map + hot rows in LDS.
+// ---- K1: scan kernels
+// K1a: chunked DFA walk, class map + hot rows in LDS.  Emits verified occurrences: into the hit
+// slots of the tile their start lies in (K.hslots != null; K.hcnt must be zero beforehand) or
+// into per-workgroup regions (dense path).
 uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus);
 // Ad: device-resident copy of A (read by the cold, out-of-line emit paths)
 hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st);
-// K1b: LDS q-gram prefilter + anchored DFA verification.
+// K1b: LDS q-gram prefilter + exact prefix table.  Emits prefix hits: into the hit slots of
+// their tile (K.hslots != null; every tile's count is written) or into per-wave regions
+// (prefilter_hit_regions(grid) of them, dense path).
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
-// scans the 4 KiB tiles [tile_begin, tile_end) of the stream (prefilter_tiles() in all);
-// the hit sink K needs prefilter_hit_regions(grid) regions (one per wave)
-uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len);
+uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len); // 4 KiB tiles of the aligned index space
 uint32_t prefilter_hit_regions(uint32_t grid);
-hipError_t launch_prefilter(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
-                            uint64_t tile_begin, uint64_t tile_end, hipStream_t st,
-                            hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr);
-// sink bookkeeping: summary[0] = total kept, summary[1] = max count of a region
+hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
+                            uint32_t grid, hipStream_t st, hipEvent_t ev_start = nullptr,
+                            hipEvent_t ev_stop = nullptr);
+// sink bookkeeping (dense path): summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
                         uint64_t *summary, uint64_t *offsets, hipStream_t st);
 hipError_t sink_compact(const uint4 *recs, const uint64_t *offsets, uint32_t grid,
                         uint64_t region_cap, uint64_t *keys_out, uint32_t *pids_out, hipStream_t st);
-// K1b emits prefix hits (position, depth-Q2 state); this kernel walks them into
-// occurrences.  `hits` is K1b's sink (hit_grid = prefilter_hit_regions() regions), `occ`
-// the occurrence sink with walk_hits_grid(hit_grid) regions.
+// dense path: K1b's prefix hits (per-wave regions, `hit_grid` of them) -> verified occurrences in
+// the occurrence sink (`occ_grid` = walk_hits_grid(hit_grid) regions, one per workgroup)
 uint32_t walk_hits_grid(uint32_t hit_regions);
-hipError_t launch_walk_hits(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
-                            const Sink &hits, uint32_t hit_grid, uint32_t split, const Sink &occ,
-                            const uint8_t *d_hay, uint64_t len, hipStream_t st);
-size_t prefilter_lds_bytes(); // dynamic LDS K1b needs (bitmap + class map + queues)
+hipError_t launch_walk_hits(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
+                            const Sink &occ, uint32_t occ_grid, const uint8_t *d_hay, uint64_t len,
+                            hipStream_t st);
+size_t prefilter_lds_bytes(); // static LDS of K1b
 // rows of the hot16 table K1a can stage for this automaton and LDS size
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds);
 
-// ---- post-processing (n = number of raw occurrences)
+// ---- post-processing
 size_t sort_temp_bytes(uint64_t n);
 hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_in,
                             uint64_t *keys_out, const uint32_t *pids_in, uint32_t *pids_out,
@@ -55,22 +55,21 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
                         bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st);
-// sparse path (slot mode): tile kernels -- order within buckets, resolve the match kind,
-// compact into out[] (capacity n_tiles * TILE_MAX).  The launch geometry depends on the
-// number of buckets only, so no host round trip is needed before them.  A call may be cut
-// into chunks of tiles [tile0, tile1) that arrive in order (first / last mark the ends).
-// summary[0] = occurrences, [2] = prefix hits kept, [3] = largest hit region, [4] = matches;
-// *abort_flag != 0 afterwards: the output did not fit the sparse path (or hits were dropped).
-// The last chunk leaves T.bcnt and *next_flag zeroed for the next call and publishes
-// {[0] occurrences, [2] hits, [3] largest hit region, [4] matches, [5] aborted} to host_out
-// (pinned host memory, read by the host after the stream has drained).  seg_counts != null
-// (batch, byte offsets): offsets are made local to the match's haystack (G) and the
-// per-haystack counts are accumulated into seg_counts (zeroed by the caller).
-hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T,
-                     uint32_t tile0, uint32_t tile1, bool first, bool last, const uint64_t *hit_counts,
-                     uint32_t hit_grid, uint64_t hit_cap, acx_match_t *out, uint64_t *summary,
-                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, const Segments &G,
-                     uint64_t *seg_counts, hipStream_t st);
+// sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_scan -> k_tile_write
+// (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
+// number of tiles only, so no host round trip is needed before them.  The scan kernel publishes
+// {[0] occurrences, [2] prefix hits (count_hits only), [4] matches, [5] aborted, [7] seq} to
+// host_out (pinned host memory; [7] = seq is written last, the host may poll it while the write
+// kernel still runs) and clears *next_flag for the next call.  Aborted: the output did not fit
+// the slots, out[] and the totals are meaningless.  seg_counts != null (batch, byte offsets):
+// offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
+// into seg_counts (zeroed by the caller).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
+// cannot take this path.
+uint32_t tile_lookback(uint32_t max_len);
+hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
+                     const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
+                     uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
+                     bool count_hits, const Segments &G, uint64_t *seg_counts, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,

@@ -129,26 +129,40 @@ typedef struct acx_host_tables {
     const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
     const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} signature words
                                      (bit layout: csrc/automaton.hpp, filter_bit)      */
-    const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi,
-                                     state | OWN<<30 | MORE<<31 (0xFFFFFFFF = empty; MORE: another
-                                     prefix with this home slot sits further along the probe
-                                     sequence), pattern id or 0x80000000 | candidate list} */
-    uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2          */
+    const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi, meta, code}:
+                                     meta = key length K | next key length N << 4 | MORE << 31
+                                     (0xFFFFFFFF = empty; MORE: another key with this home slot sits
+                                     further along the probe sequence).  N = 0: code = the only
+                                     pattern with this key, or 0x80000000 | index into prefix_lists;
+                                     N > K: every pattern that starts with these K bytes is longer --
+                                     probe again with the first N bytes (csrc/automaton.cpp)       */
+    const uint32_t *prefix_lists; /* {count, pattern id, ...} per key shared by several patterns   */
+    uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2 (first-level keys)   */
     uint32_t filter_entries_log2, prefix_table_log2;
     double filter_density;        /* fraction of X bits set                            */
+    uint32_t n_prefix_keys;       /* entries of prefix_table in use                    */
+    uint32_t n_prefix_lists;      /* u32 words of prefix_lists                         */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);
 int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
 uint32_t acx_filter_hash(uint32_t gram);   /* level-1 hash of a little-endian (Q-1)-gram   */
-uint32_t acx_prefix_slot(uint64_t gram, uint32_t log2); /* home slot of a Q2-gram       */
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t key_len, uint32_t log2); /* home slot of a key */
 void acx_free_host(acx_host_automaton_t *h);
+
+/* ---- concurrency: every function taking an acx_automaton_t may be called from several
+ * threads on ONE handle at the same time (the reference lets threads search one object
+ * concurrently: methods take a shared reference and release the GIL, src/lib.rs:238, 261,
+ * 433, 438).  Calls run side by side on separate HIP streams (up to ACX_MAX_CONCURRENCY,
+ * default 4, per handle); acx_free_automaton must not race with them. */
 
 /* ---- the hot path, host-memory form.  Replaces get_matches + collect:
  * src/lib.rs:42-68 with consumers 229-249 (str: codepoints = 1 applies the
  * get_byte_to_code_point fix-up of 73-88 on the device) and 422-434 (bytes).
  * `hay` is borrowed for the call.  `*out` is library-owned (acx_free_matches).
- * Order and content are bit-exact with the reference iterator. */
+ * Order and content are bit-exact with the reference iterator.
+ * Large haystacks are staged through pinned chunks by several host threads, each chunk's DMA
+ * under the next chunk's copy; large results are returned in pinned host memory. */
 int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len,
              int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out);
 void acx_free_matches(acx_match_t *m);
@@ -165,7 +179,11 @@ int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offse
 /* ---- device-resident form (what bench.py times).  d_hay is a device pointer
  * to `len` bytes on the automaton's device.  Batches: either d_offsets
  * (device, n_hay + 1 u64, ragged) or uniform_len > 0 (n_hay * uniform_len ==
- * len) or neither (one haystack).  Results stay in HBM inside *out. */
+ * len) or neither (one haystack).  Results stay in HBM inside *out.
+ * The call returns as soon as the number of matches is known (acx_result_count is valid
+ * at once); the kernels that write the records may still be running on the library's
+ * stream -- every accessor of the records waits for them, d_hay (and d_offsets) must stay
+ * valid until one of them or acx_free_result has returned. */
 int acx_find_device(acx_automaton_t *a, const void *d_hay, uint64_t len,
                     const uint64_t *d_offsets, uint64_t n_hay, uint64_t uniform_len,
                     int overlapping, int codepoints, acx_result_t **out);

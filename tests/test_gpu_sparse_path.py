@@ -1,7 +1,8 @@
-"""GPU: the seams between the execution paths -- the sparse output path (bucket slots + tile
-kernels): greedy chains that cross tile boundaries, bucket / tile overflow into the dense
-(region + radix sort) path, the hold-off after a dense call, the chunked two-stream variant
-(ACX_CHUNKS); and K0, the one-workgroup kernel that answers small haystacks."""
+"""GPU: the seams between the execution paths -- the sparse output path (per-tile hit slots +
+k_tile_main): greedy chains that cross tile and group boundaries, chains longer than a group's
+context, slot / bucket / group overflow into the dense (region + radix sort) path, the hold-off
+after a dense call, long patterns (context tiles), two-level prefix keys; and K0, the
+one-workgroup kernel that answers small haystacks."""
 import os
 import subprocess
 import sys
@@ -15,7 +16,7 @@ from oracle_lib import KIND_DFA, Oracle
 pytestmark = pytest.mark.gpu
 capi = pytest.importorskip("ahocorasick_rs_amd.capi")
 KERNELS = [capi.KERNEL_DFA_WALK, capi.KERNEL_PREFILTER]
-TILE = 64 * 4096  # bytes of stream position per tile (TILE_BUCKETS * 4 KiB)
+TILE = 64 * 4096  # bytes of index space per group of k_tile_main (GROUP_TILES * 4 KiB)
 
 
 def cols(a):
@@ -31,8 +32,8 @@ def check(a, o, hay, mk):
 @pytest.mark.parametrize("mk", [0, 1, 2])
 def test_chains_across_bucket_and_tile_boundaries(mk, kernel):
     # runs of mutually overlapping occurrences laid over every kind of boundary: the greedy
-    # chain of a tile then starts in the previous tile (lookback in k_tile_sort, chain
-    # re-derivation from HBM in k_tile_resolve)
+    # chain of a group then starts in its context tiles (k_tile_main re-derives it from the
+    # nearest certified sync point)
     pats = [b"ababab", b"babab", b"abab", b"bab", b"abababababab"]
     hay = bytearray(b"x" * (3 * TILE + 5000))
     run = b"ab" * 14  # 28 bytes, < 32 occurrences per bucket
@@ -94,10 +95,76 @@ def test_textlike_10k_patterns_matches_oracle_on_both_paths():
         "m = a.find(hay)\n"
         "np.save(sys.argv[1], np.stack([m['pattern'], m['start'], m['end']], 1))\n"
     ) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
-    for env in ({"ACX_CHUNKS": "3"}, {"ACX_NO_BUCKET": "1"}):
+    for env in ({"ACX_NO_BUCKET": "1"},):
         out = "/tmp/acx_sparse_path_%s.npy" % "_".join(env)
         subprocess.run([sys.executable, "-c", code, out], check=True, env={**os.environ, **env}, timeout=600)
         assert np.array_equal(np.load(out), want), env
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("mk", [0, 1, 2])
+def test_chain_longer_than_the_context_takes_the_dense_path(mk, kernel):
+    # a 256-byte pattern of period 128 on a periodic haystack: an occurrence every 128 bytes (32 per
+    # tile: the slots hold them), each overlapping the next, no sync point anywhere -- no group can
+    # certify where the greedy chain stands, the call is redone on the dense path
+    unit = bytes((i * 7 + 3) % 251 for i in range(128))
+    pats = [unit * 2, unit[5:60]]
+    hay = b"q" * 1000 + unit * 4200 + b"q" * 777
+    a = capi.Automaton(pats, mk, kernel=kernel)
+    o = Oracle(pats, mk, KIND_DFA)
+    check(a, o, hay, mk)
+    check(a, o, hay[3:], mk)
+    a.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+@pytest.mark.parametrize("maxlen", [2049, 2050, 4096, 6200, 14000, 20000])
+def test_long_patterns_use_more_context_tiles_or_the_dense_path(maxlen, kernel):
+    # the context in front of a group must be longer than the longest pattern: 1, 2, .. tiles;
+    # beyond MAX_LOOKBACK tiles the automaton stays on the dense path
+    rng = np.random.default_rng(maxlen)
+    long_p = rng.integers(97, 123, maxlen, dtype=np.uint8).tobytes()
+    pats = [long_p, long_p[100:140], b"needle", long_p[-9:]]
+    hay = bytearray(rng.integers(97, 123, 3 * TILE + 999, dtype=np.uint8).tobytes())
+    for at in (5, TILE - maxlen // 2, 2 * TILE - 3, 2 * TILE + 4096 - maxlen + 1, 3 * TILE - maxlen):
+        at = max(at, 0)
+        hay[at:at + maxlen] = long_p
+    hay[TILE + 50:TILE + 56] = b"needle"
+    hay = bytes(hay)
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk, kernel=kernel)
+        check(a, Oracle(pats, mk, KIND_DFA), hay, mk)
+        a.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS)
+def test_slot_bucket_and_group_overflow(kernel):
+    o_pats = [b"abcdefg", b"efg", b"g"]
+    a = capi.Automaton(o_pats, 0, kernel=kernel)
+    o = Oracle(o_pats, 0, KIND_DFA)
+    # (1) more than 32 prefix hits in one tile; (2) 32 hits or fewer per tile, but more than 32
+    # occurrences in one bucket of the END position (overlapping: three per hit); (3) no bucket
+    # above 32, but more than 1024 reported matches in one group
+    for step, span in ((7, 7 * 40), (300, 20 * 300), (160, TILE)):
+        hay = bytearray(b"." * (2 * TILE))
+        for p in range(TILE // 2, TILE // 2 + span, step):
+            hay[p:p + 7] = b"abcdefg"
+        check(a, o, bytes(hay), 0)
+    a.close()
+
+
+def test_two_level_prefix_keys_on_the_device():
+    # patterns of 5 bytes next to longer ones sharing 5..7 bytes, zero bytes inside the keys, duplicates
+    pats = [b"abcde", b"abcde\0", b"abcde\0\0\0", b"abcdefgh", b"abcdefgi", b"abcdefghij", b"abcdf\0x", b"abcdf\0y",
+            b"abcde", b"zzzzzzzzzzzz", "\U0001F926a-tail".encode(), "\U0001F926b-tail".encode(), b"xyzzy"]
+    rng = np.random.default_rng(5)
+    pieces = [bytes(p) for p in pats] + [b"abcd", b"abcdf\0", "\U0001F926".encode(), b"\0\0", b"abcdefg", b"zzzzzzz"]
+    hay = b"".join(pieces[i] + bytes(rng.integers(0, 3, rng.integers(0, 4), dtype=np.uint8)) for i in
+                   rng.integers(0, len(pieces), 40000))
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk, kernel=capi.KERNEL_PREFILTER)
+        check(a, Oracle(pats, mk, KIND_DFA), hay, mk)
+        a.close()
 
 
 # ---------------------------------------------------------------------------

@@ -82,16 +82,60 @@ def test_compiler_matches_survey_sizes():
     h.close()
 
 
+def ptab_find(h, lg, key: bytes):
+    """Python twin of the kernels' ptab_find: walks the probe sequence of `key` from its home
+    slot; -> (meta, code) or None.  A home slot holding another key ends the search unless its
+    MORE bit is set."""
+    gram, K = int.from_bytes(key, "little"), len(key)
+    idx, home = capi.prefix_slot(key, lg), True
+    while True:
+        lo, hi, meta, code = (int(x) for x in h.prefix_table[idx])
+        if meta == 0xFFFFFFFF:
+            return None
+        if (hi << 32 | lo) == gram and (meta & 15) == K:
+            return meta, code
+        if home and not (meta >> 31):
+            return None
+        home = False
+        idx = (idx + 1) & ((1 << lg) - 1)
+
+
+def prefix_candidates(h, lg, q2, window: bytes):
+    """Python twin of prefix_code + the candidate list: the pattern ids K1b hands on for a
+    haystack window (>= 8 bytes, zero padded)."""
+    got = ptab_find(h, lg, window[:q2])
+    if got is None:
+        return []
+    meta, code = got
+    n = (meta >> 4) & 15
+    if n:
+        assert n > q2
+        got = ptab_find(h, lg, window[:n])
+        if got is None:
+            return []
+        meta, code = got
+        assert (meta >> 4) & 15 == 0
+    if code & 0x80000000:
+        i = code & 0x7FFFFFFF
+        cnt = int(h.prefix_lists[i])
+        return [int(x) for x in h.prefix_lists[i + 1:i + 1 + cnt]]
+    return [code]
+
+
 def test_prefilter_tables_have_every_pattern_prefix():
+    uni = [p.encode() for p in dict.fromkeys(gen.gen_patterns(600, 5, 12, gen.AZ_UNI, 5))]
+    zeros = [b"abcde", b"abcde\0", b"abcde\0\0\0", b"abcdefgh", b"abcdefgi", b"abcdefghij", b"abcdf\0x", b"abcdf\0y",
+             b"abcde", b"zzzzzzzzzzzz"]
     for pats in ([b"a", b"bc"], [b"abc", b"zzzz"], gen.gen_patterns(500, 4, 9, gen.ALL_BYTES, 3),
-                 gen.gen_patterns(500, 6, 9, gen.AZ, 4), gen.gen_patterns(300, 9, 12, gen.AZ, 5)):
+                 gen.gen_patterns(500, 6, 9, gen.AZ, 4), gen.gen_patterns(300, 9, 12, gen.AZ, 5),
+                 [p.encode() for p in gen.names_like(800, 6)], uni, zeros):
         h = capi.HostAutomaton(pats)
         minlen = min(len(p) for p in pats)
         q, q2 = int(h.t.filter_q), int(h.t.filter_q2)
         assert (q, q2) == (min(5, minlen), min(8, minlen))
         g = q - 1
         lg = int(h.t.prefix_table_log2)
-        for p in pats:
+        for pid, p in enumerate(pats):
             # level 1: in the row of p[1..1+g): bit p[0] of X; in the row of p[0..g): bit p[q-1] of Y;
             # in both rows the gate bit (gram & 31) of X
             for gram, byte, col in ((p[1:1 + g], p[0], 0), (p[0:g], p[q - 1], 1)):
@@ -100,24 +144,33 @@ def test_prefilter_tables_have_every_pattern_prefix():
                 assert H == ((W & 0xFFFFFF) * 0x9E3779 + W) & 0xFFFFFFFF
                 assert int(h.filter_xy[H >> 18, col]) >> (byte & 31) & 1
                 assert int(h.filter_xy[H >> 18, 0]) >> (W & 31) & 1
-            # level 2: the Q2-byte prefix is in the open-addressing table, reachable from its home slot
-            gram = int.from_bytes(p[:q2], "little")
-            idx = capi.prefix_slot(p[:q2], lg)
-            while True:
-                lo, hi, st, _ = (int(x) for x in h.prefix_table[idx])
-                assert st != 0xFFFFFFFF, "pattern prefix missing from the prefix table"
-                if (hi << 32 | lo) == gram:
-                    break
-                idx = (idx + 1) & ((1 << lg) - 1)
-            sid = st & ID_MASK
-            assert h.level_start[q2] <= sid < h.level_start[q2 + 1]
-            assert bool(st & FLAG_OWN) == (len(p) == q2 or any(len(o) == q2 and o == p[:q2] for o in pats))
-        # MORE (bit 31 of word 2) is set on a home slot iff some prefix hashing there lives elsewhere
+            # level 2: a window that starts with the pattern resolves to a candidate list that holds
+            # it -- and every candidate agrees with the window on min(8, its own length) bytes of
+            # the group's key, in pattern-id order
+            for tail in (b"\0" * 16, b"\xff" * 16, b"abcdefgh12345678"):
+                cands = prefix_candidates(h, lg, q2, (p + tail)[:16])
+                assert pid in cands, (p, cands)
+                assert cands == sorted(cands)
+                klen = min(min(len(pats[c]) for c in cands), 8)
+                assert all(pats[c][:klen] == p[:klen] for c in cands)
+        # a window that agrees with no pattern on its group's key resolves to nothing
+        rng = random.Random(9)
+        for _ in range(300):
+            p = pats[rng.randrange(len(pats))]
+            w = bytearray((p + bytes(rng.randrange(256) for _ in range(16)))[:16])
+            w[rng.randrange(min(len(p), 8))] ^= 1 + rng.randrange(255)
+            for c in prefix_candidates(h, lg, q2, bytes(w)):
+                klen = min(len(pats[c]), 8)
+                group = [o for o in pats if o[:q2] == pats[c][:q2]]
+                assert bytes(w[:min(klen, min(min(len(o) for o in group), 8))]) == pats[c][:min(klen, min(min(len(o) for o in group), 8))]
+        # MORE (bit 31 of the meta word) is set on a home slot iff some key hashing there lives elsewhere
         tab = np.asarray(h.prefix_table)
         used = np.nonzero(tab[:, 2] != 0xFFFFFFFF)[0]
+        assert len(used) == int(h.t.n_prefix_keys) <= 0.3 * (1 << lg) + 1
         displaced_homes = set()
         for e in used:
-            gram = (int(tab[e, 1]) << 32 | int(tab[e, 0])).to_bytes(8, "little")[:q2]
+            K = int(tab[e, 2]) & 15
+            gram = (int(tab[e, 1]) << 32 | int(tab[e, 0])).to_bytes(8, "little")[:K]
             home = capi.prefix_slot(gram, lg)
             if home != e:
                 displaced_homes.add(home)
@@ -125,6 +178,20 @@ def test_prefilter_tables_have_every_pattern_prefix():
             assert bool(int(tab[e, 2]) >> 31) == (int(e) in displaced_homes)
         assert 0 < h.t.filter_density <= 3 * len(pats) / (32 << 14)
         h.close()
+
+
+def test_prefix_keys_extend_beyond_the_shortest_pattern():
+    """A set that mixes a 5-byte pattern with patterns starting with a 4-byte UTF-8 character: the
+    long ones are filed under 8 bytes, so the character followed by an arbitrary byte is NOT a hit."""
+    pats = ["xyzzy".encode()] + [("\U0001F926" + c + "tail").encode() for c in "abcdefghijklmnopqrstuvwxyz"]
+    h = capi.HostAutomaton(pats)
+    lg, q2 = int(h.t.prefix_table_log2), int(h.t.filter_q2)
+    assert q2 == 5
+    face = "\U0001F926".encode()
+    assert prefix_candidates(h, lg, q2, (face + b"a" + b"tail" + bytes(8))[:16]) == [1]
+    assert prefix_candidates(h, lg, q2, (face + b"a" + b"tXil" + bytes(8))[:16]) == []
+    assert prefix_candidates(h, lg, q2, (b"xyzzy" + bytes(11))) == [0]
+    h.close()
 
 
 def test_compile_errors():
