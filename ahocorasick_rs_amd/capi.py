@@ -225,9 +225,9 @@ def filter_hash(gram: bytes) -> int:
     return int(lib().acx_filter_hash(int.from_bytes(gram[:4], "little")))
 
 
-def prefix_slot(gram: bytes, log2: int) -> int:
-    """home slot of a key (the first len(gram) <= 8 bytes of a pattern) in the prefix table."""
-    return int(lib().acx_prefix_slot(int.from_bytes(gram[:8], "little"), len(gram[:8]), log2))
+def prefix_slot(gram: bytes, q2: int, log2: int) -> int:
+    """home slot of the prefix-table keys that start with the first q2 bytes of `gram`."""
+    return int(lib().acx_prefix_slot(int.from_bytes(gram[:q2], "little"), q2, log2))
 
 
 class DeviceBuffer:

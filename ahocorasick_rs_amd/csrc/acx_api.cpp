@@ -398,7 +398,7 @@ int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
     (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs);
-    (void)hipFree(T.gocc); (void)hipFree(T.btot); (void)hipFree(T.bbase);
+    (void)hipFree(T.gocc); (void)hipFree(T.ghits); (void)hipFree(T.btot); (void)hipFree(T.bbase);
     T = TileSpace{};
     w.tile_cap = 0;
 }
@@ -542,9 +542,10 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
         const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
         const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
         HIPCHK(hipMalloc((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32));
-        HIPCHK(hipMalloc((void **)&T.hcnt, (cap_tiles + 1) * 4));
+        HIPCHK(hipMalloc((void **)&T.hcnt, (cap_tiles + 16 * 1024 + 16) * 4)); // + one slot per K1b wave (layout slack)
         HIPCHK(hipMalloc((void **)&T.trecs, cap_groups * GROUP_MAX * 16));
         HIPCHK(hipMalloc((void **)&T.gocc, cap_groups * 4));
+        HIPCHK(hipMalloc((void **)&T.ghits, cap_groups * 4));
         HIPCHK(hipMalloc((void **)&T.btot, cap_groups * 4));
         HIPCHK(hipMalloc((void **)&T.bbase, cap_groups * 4));
         w.tile_cap = cap_tiles;
@@ -690,7 +691,10 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     hipStream_t st = x->stream;
     int rc = ensure_tiles(a, x, c.tiles);
     if (rc) return rc;
-    const TileSpace &T = w.T;
+    TileSpace &T = w.T;
+    // hit counts: contiguous per K1b wave (K1a: plain per-tile arrival counters)
+    T.cnt_nw = c.pre ? c.scan_grid * 16 : 1;
+    T.cnt_iters = c.pre ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
     const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX;
     if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
     if (!w.final) {
@@ -703,7 +707,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + x->flag_idx);
     uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (x->flag_idx ^ 1));
     x->flag_idx ^= 1;
-    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead};
+    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     const bool prof = a->prof;
@@ -754,8 +758,8 @@ int attempt_dense(FindCall &c, Attempt *what) {
     const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : c.scan_grid; // occurrence regions
     const uint64_t hit_cap = c.pre ? w.hit_total / hit_grid : 0;
     const uint64_t region_cap = w.cap / grid;
-    const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead};
-    const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead};
+    const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
+    const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
     const bool prof = a->prof;
     if (c.pre) {
         HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
@@ -864,7 +868,8 @@ int run_pipeline(FindCall &c) {
     }
     c.r->n = c.n_final;
     if ((rc = finish_matches(c)) != ACX_OK) return rc;
-    if (a->prof) { // end of the post stage: read lazily (next call / acx_profile_read), no extra sync here
+    static const bool prof_post = std::getenv("ACX_PROFILE_POST") != nullptr;
+    if (a->prof && prof_post) { // end of the post stage (costs the next call a wait for this one's last kernel)
         HIPCHK_RC(hipEventRecord(x->ev[2], x->stream));
         x->post_pending = true;
     }
@@ -1213,8 +1218,8 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
 }
 
 uint32_t acx_filter_hash(uint32_t gram) { return filter_hash(gram); }
-uint32_t acx_prefix_slot(uint64_t gram, uint32_t key_len, uint32_t log2) {
-    return prefix_slot(prefix_key_hash(gram, key_len), log2);
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2) {
+    return prefix_slot(prefix_home_hash(q2 >= 8 ? gram : (gram & ((1ull << (8 * q2)) - 1)), q2), log2);
 }
 
 void acx_free_host(acx_host_automaton_t *h) { delete h; }

@@ -258,27 +258,24 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             set += __builtin_popcount(A.filterA[2 * e]);
         A.filter_density = (double)set / (double)(32u << FILTER_ENTRIES_LOG2);
 
-        // ---- prefix table (K1b level 2): two levels of exact keys in ONE open-addressing table.
+        // ---- prefix table (K1b level 2): exact keys of VARIABLE length in one open-addressing table.
         // A *group* is the set of patterns that share their first Q2 bytes (Q2 = the set-wide
-        // minimum, at most 8).  Its first-level entry is keyed by those Q2 bytes.  If every
-        // pattern of the group is longer, the entry only says how many bytes to look at next:
-        // Lg = min over the group of min(len, 8); the group's patterns are then filed under
-        // their first Lg bytes (second-level entries).  So a haystack position becomes a prefix
-        // hit only if it agrees with some pattern on min(len, 8) bytes of the SHORTEST pattern
-        // of its group -- not merely on the set-wide minimum (a set that mixes "xyzzy" with
-        // patterns starting with a 4-byte UTF-8 character would otherwise turn every occurrence
-        // of that character into a hit).  Entry = {gram lo, gram hi, meta, code}:
-        //   meta = key length K | next length N << 4 | PREFIX_MORE, 0xFFFFFFFF = empty;
-        //   N = 0: `code` is the only pattern with this key, or HIT_LIST | index into blist;
-        //   N > K: probe again with the first N bytes.
-        const uint32_t S2 = A.stride;
-        (void)S2;
-        std::vector<uint64_t> g1(n);              // first-level gram of every pattern
+        // minimum, at most 8).  Its keys are the first Lg bytes of its patterns, Lg = min over the
+        // group of min(len, 8): a haystack position becomes a prefix hit only if it agrees with some
+        // pattern on min(len, 8) bytes of the SHORTEST pattern of its group -- not merely on the
+        // set-wide minimum (a set that mixes "xyzzy" with patterns starting with a 4-byte UTF-8
+        // character would otherwise turn every occurrence of that character into a hit).  A key is
+        // filed under the hash of its first Q2 bytes -- all the lookup knows before it has seen an
+        // entry -- so the keys of one group share a home slot and follow each other in the probe
+        // sequence; ONE gather settles a position whose group has a single key (the common case).
+        // Entry = {key lo, key hi, meta, code}: meta = key length K | PREFIX_MORE, 0xFFFFFFFF = empty;
+        // code = the only pattern with this key, or HIT_LIST | index into blist.
+        std::vector<uint64_t> g1(n);              // first Q2 bytes of every pattern
         for (uint64_t i = 0; i < n; i++) g1[i] = gram_of(pb + A.offsets[i], Q2);
         std::vector<uint32_t> by_g1(n);
         std::iota(by_g1.begin(), by_g1.end(), 0u);
         std::stable_sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] < g1[b]; });
-        struct Key { uint64_t gram; uint32_t K, N; std::vector<uint32_t> pids; };
+        struct Key { uint64_t gram; uint32_t K; std::vector<uint32_t> pids; };
         std::vector<Key> keys;
         for (size_t b = 0; b < n;) {
             size_t e = b;
@@ -287,34 +284,28 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                 Lg = std::min<uint32_t>(Lg, std::min<uint32_t>(A.plen[by_g1[e]], FILTER2_MAX_Q));
                 e++;
             }
-            if (Lg == Q2) { // some pattern of the group IS the Q2 bytes (or Q2 = 8): final
-                Key k{g1[by_g1[b]], Q2, 0, {}};
-                for (size_t j = b; j < e; j++) k.pids.push_back(by_g1[j]);
+            std::vector<uint32_t> sub(by_g1.begin() + b, by_g1.begin() + e);
+            std::stable_sort(sub.begin(), sub.end(), [&](uint32_t x, uint32_t y) {
+                return gram_of(pb + A.offsets[x], Lg) < gram_of(pb + A.offsets[y], Lg);
+            });
+            for (size_t j = 0; j < sub.size();) {
+                const uint64_t g2 = gram_of(pb + A.offsets[sub[j]], Lg);
+                Key k{g2, Lg, {}};
+                while (j < sub.size() && gram_of(pb + A.offsets[sub[j]], Lg) == g2) k.pids.push_back(sub[j++]);
                 keys.push_back(std::move(k));
-            } else {
-                keys.push_back(Key{g1[by_g1[b]], Q2, Lg, {}});
-                std::vector<uint32_t> sub(by_g1.begin() + b, by_g1.begin() + e);
-                std::stable_sort(sub.begin(), sub.end(), [&](uint32_t x, uint32_t y) {
-                    return gram_of(pb + A.offsets[x], Lg) < gram_of(pb + A.offsets[y], Lg);
-                });
-                for (size_t j = 0; j < sub.size();) {
-                    const uint64_t g2 = gram_of(pb + A.offsets[sub[j]], Lg);
-                    Key k{g2, Lg, 0, {}};
-                    while (j < sub.size() && gram_of(pb + A.offsets[sub[j]], Lg) == g2) k.pids.push_back(sub[j++]);
-                    keys.push_back(std::move(k));
-                }
             }
             b = e;
         }
         A.n_prefix_keys = (uint32_t)keys.size();
         uint32_t lg = 4;
-        // load <= 0.3.  Sparser would save dependent probes, but measured on MI355X a table beyond
+        // load <= 1/4.  Sparser would save dependent probes, but measured on MI355X a table beyond
         // ~1 MiB costs K1b more (its level-2 gathers start missing L2) than the probes gain.
-        while ((double)(1u << lg) * 0.3 < (double)keys.size()) lg++;
+        while ((1u << lg) < 4 * keys.size()) lg++;
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = PREFIX_EMPTY;
         const uint32_t pmask = (1u << lg) - 1;
+        const uint64_t q2mask = Q2 >= 8 ? ~0ull : ((1ull << (8 * Q2)) - 1);
         A.pinfo.assign((size_t)4 * n, 0);
         for (uint64_t i = 0; i < n; i++) {
             const uint8_t *pp = pb + A.offsets[i];
@@ -326,22 +317,20 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         }
         A.blist.clear();
         for (Key &k : keys) {
-            uint32_t code = 0;
-            if (k.N == 0) {
-                std::sort(k.pids.begin(), k.pids.end()); // pattern id order inside every list
-                if (k.pids.size() == 1) {
-                    code = k.pids[0];
-                } else {
-                    code = 0x80000000u | (uint32_t)A.blist.size();
-                    A.blist.push_back((uint32_t)k.pids.size());
-                    A.blist.insert(A.blist.end(), k.pids.begin(), k.pids.end());
-                }
+            uint32_t code;
+            std::sort(k.pids.begin(), k.pids.end()); // pattern id order inside every list
+            if (k.pids.size() == 1) {
+                code = k.pids[0];
+            } else {
+                code = 0x80000000u | (uint32_t)A.blist.size();
+                A.blist.push_back((uint32_t)k.pids.size());
+                A.blist.insert(A.blist.end(), k.pids.begin(), k.pids.end());
             }
-            uint32_t idx = prefix_slot(prefix_key_hash(k.gram, k.K), lg);
+            uint32_t idx = prefix_slot(prefix_home_hash(k.gram & q2mask, Q2), lg);
             while (A.ptab[4 * (size_t)idx + 2] != PREFIX_EMPTY) idx = (idx + 1) & pmask;
             uint32_t *en = &A.ptab[4 * (size_t)idx];
             en[0] = (uint32_t)k.gram; en[1] = (uint32_t)(k.gram >> 32);
-            en[2] = k.K | (k.N << 4);
+            en[2] = k.K;
             en[3] = code;
         }
         // PREFIX_MORE on a home slot: some key that hashes here lives further along the probe
@@ -349,7 +338,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (size_t e = 0; e < ((size_t)1 << lg); e++) {
             if (A.ptab[4 * e + 2] == PREFIX_EMPTY) continue;
             uint64_t gram = ((uint64_t)A.ptab[4 * e + 1] << 32) | A.ptab[4 * e];
-            uint32_t home = prefix_slot(prefix_key_hash(gram, A.ptab[4 * e + 2] & 15u), lg);
+            uint32_t home = prefix_slot(prefix_home_hash(gram & q2mask, Q2), lg);
             if (home != e) A.ptab[4 * (size_t)home + 2] |= PREFIX_MORE;
         }
     }

@@ -44,9 +44,9 @@ constexpr uint32_t OWN1_MANY = 0xFFFFFFFEu; // own1[s]: several do (duplicates):
 // the table with the g-gram at j+1; position j tests X with byte j, position
 // j+1 tests Y with byte j+Q.  A position survives when BOTH signature bits are
 // set: true Q-byte prefix hits plus ~0.1 % collisions.
-// Level 2 (HBM, L2-resident): exact open-addressing table keyed by pattern prefixes:
-// Q2 = min(8, shortest pattern) bytes, then -- per group of patterns sharing those -- the first
-// min(8, shortest pattern of the group) bytes.
+// Level 2 (HBM, L2-resident): exact open-addressing table of pattern prefixes of variable length:
+// per group of patterns sharing their first Q2 = min(8, shortest pattern) bytes, the first
+// min(8, shortest pattern of the group) bytes; hashed by the Q2 bytes.
 constexpr uint32_t FILTER_ENTRIES_LOG2 = 14;
 constexpr uint32_t FILTER_WORDS = 2u << FILTER_ENTRIES_LOG2; // u32 words of the X|Y table
 constexpr uint32_t FILTER_MAX_Q = 5;
@@ -76,14 +76,14 @@ ACX_HD static inline uint32_t filter_bit(uint32_t v) { return 1u << (v & 31); }
 ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
     return ((uint32_t)gram * 0x9E3779B1u) ^ ((uint32_t)(gram >> 32) * 0x85EBCA6Bu);
 }
-// prefix-table entry, word 2 (meta): key length K (bits 3:0) | next key length N (bits 7:4,
-// 0 = final entry: word 3 is the candidate code) | PREFIX_MORE ("more keys with this home slot
-// further along"); PREFIX_EMPTY marks a free slot
+// prefix-table entry, word 2 (meta): key length K (bits 3:0, 1..8) | PREFIX_MORE ("more keys
+// with this home slot further along"); PREFIX_EMPTY marks a free slot
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
 constexpr uint32_t PREFIX_MORE = 0x80000000u;
-// hash of a key (K-byte gram, little-endian in a u64): the key length is part of the key
-ACX_HD static inline uint32_t prefix_key_hash(uint64_t gram, uint32_t K) {
-    return gram_hash2(gram) + K * 0x9E3779B1u;
+// home-slot hash of a key: of its first Q2 bytes (little-endian in a u64, masked), the set-wide
+// minimum key length -- all a lookup knows before it has seen an entry
+ACX_HD static inline uint32_t prefix_home_hash(uint64_t gram_q2, uint32_t Q2) {
+    return gram_hash2(gram_q2) + Q2 * 0x9E3779B1u;
 }
 // slot of a Q2-gram in the prefix table (2^log2 entries)
 ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
@@ -116,10 +116,11 @@ struct Automaton {
     std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
     double filter_density = 0.0;       // fraction of X bits set
     // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:
-    //   {gram lo, gram hi, K | N << 4 | PREFIX_MORE (0xFFFFFFFF = empty),
-    //    N == 0: the only pattern with this key, or 0x80000000 | index into blist}
-    // two levels of keys: the Q2-byte prefix of a group of patterns, then (when every pattern of
-    // the group is longer) the first N = min over the group of min(len, 8) bytes (automaton.cpp)
+    //   {key lo, key hi, K | PREFIX_MORE (0xFFFFFFFF = empty),
+    //    the only pattern with this key, or 0x80000000 | index into blist}
+    // keys have variable length K: the first min(8, shortest pattern of the group) bytes of the
+    // patterns of a group (= the patterns sharing their first Q2 bytes), filed under the hash of
+    // those Q2 bytes (automaton.cpp)
     std::vector<uint32_t> blist;       // {count, pid, pid, ...} per key shared by several patterns
     uint32_t n_prefix_keys = 0;        // entries in use
     // per pattern, 4 u32: {rank | min(len, 255) << 24, the 12 bytes that follow its first Q2 bytes}

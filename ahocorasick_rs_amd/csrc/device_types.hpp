@@ -69,23 +69,33 @@ constexpr uint32_t HIT_SLOTS = 32;    // hit records per tile
 constexpr uint32_t GROUP_TILES = 64;  // tiles per workgroup of k_tile_main (256 KiB)
 constexpr uint32_t GROUP_MAX = 1024;  // reported matches per group
 constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group
+// Where a tile's hit count lives: the counts of the tiles ONE K1b wave scans (tile, tile + nw,
+// tile + 2 nw, ...) are contiguous, so that the wave writes them 16 at a time with one store
+// instead of one store per iteration (nw = waves of the launch, iters = tiles per wave; K1a,
+// whose counts are atomic arrival counters: nw = 1, the identity).
+__host__ __device__ inline uint64_t hcnt_index(uint64_t tile, uint32_t nw, uint32_t iters) {
+    return nw <= 1 ? tile : (tile % nw) * iters + tile / nw;
+}
 struct Sink {
     uint4 *recs;            // region mode: region_cap * quads uint4 per region
     uint64_t *block_counts; // region mode: one per region
     uint64_t region_cap;    // records per region
     int key_mode;
     uint4 *hslots;          // hit-slot mode: n_tiles * HIT_SLOTS records of two quads
-    uint32_t *hcnt;         // hit-slot mode: hits of every tile
+    uint32_t *hcnt;         // hit-slot mode: hits of every tile, at hcnt_index(tile, cnt_nw, cnt_iters)
     uint32_t *abort_flag;   // hit-slot mode: set when the slots cannot hold the output
     uint32_t lead;          // index = stream position + lead
+    uint32_t cnt_nw, cnt_iters;
 };
 
 // Storage of the sparse path, sized by the number of tiles / groups of the stream.
 struct TileSpace {
     uint4 *hslots;      // n_tiles * HIT_SLOTS * 2
-    uint32_t *hcnt;     // n_tiles
+    uint32_t *hcnt;     // n_tiles (+ slack), indexed by hcnt_index(tile, cnt_nw, cnt_iters)
+    uint32_t cnt_nw, cnt_iters;
     uint4 *trecs;       // groups * GROUP_MAX: the REPORTED occurrences of a group, in order
     uint32_t *gocc;     // occurrences seen by each group (statistics)
+    uint32_t *ghits;    // prefix hits of each group's own tiles (statistics)
     uint32_t *btot;     // reported occurrences of each group
     uint32_t *bbase;    // exclusive prefix of btot
     uint32_t n_tiles, n_groups;

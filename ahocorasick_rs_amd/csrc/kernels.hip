@@ -64,11 +64,12 @@ struct BlockSink {
     uint32_t *hcnt;
     uint32_t *abort_flag;
     uint32_t lead;
+    uint32_t cnt_nw, cnt_iters;
 };
 
 __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount, uint32_t quads = 1) {
     return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, lcount, K.region_cap, K.key_mode,
-                     K.hslots, K.hcnt, K.abort_flag, K.lead};
+                     K.hslots, K.hcnt, K.abort_flag, K.lead, K.cnt_nw, K.cnt_iters};
 }
 
 // region mode: store one occurrence (ONE 16-byte store) into the next slot of the region
@@ -99,11 +100,13 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
 // A prefix hit / occurrence record in the hit slots is two quads:
 //   {position lo, position hi, code, aux} {16 haystack bytes at the position}
 // code = the id of the only pattern with that prefix, or HIT_LIST | index into blist
-// ({count, pid, ...}); HIT_VERIFIED | pid: an occurrence found by the DFA walk (aux = pattern
-// length, no second quad) -- nothing left to verify.
+// ({count, pid, ...}); HIT_RETRY: the window has to be looked up in the prefix table first;
+// HIT_VERIFIED | pid: an occurrence found by the DFA walk (aux = pattern length, no second
+// quad) -- nothing left to verify.
 constexpr uint32_t HIT_LIST = 0x80000000u;
 constexpr uint32_t HIT_VERIFIED = 0x40000000u;
 constexpr uint32_t HIT_NONE = 0xFFFFFFFFu;
+constexpr uint32_t HIT_RETRY = 0xFFFFFFFEu; // K1b found another key in the home slot (MORE set): look the window up
 
 // The emit paths are cold and out of line; they read the automaton through a
 // pointer to its device-resident copy so that the kernels never have to spill
@@ -115,7 +118,7 @@ __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink 
     if (K.hslots) { // sparse output: arrival rank inside the tile of the occurrence's start
         const uint64_t start = end - plen;
         const uint64_t tile = (start + K.lead) >> TILE_BITS;
-        const uint32_t r = atomicAdd(&K.hcnt[tile], 1u);
+        const uint32_t r = atomicAdd(&K.hcnt[hcnt_index(tile, K.cnt_nw, K.cnt_iters)], 1u);
         if (r < HIT_SLOTS)
             K.hslots[(tile * HIT_SLOTS + r) * 2] = make_uint4((uint32_t)start, (uint32_t)(start >> 32),
                                                               HIT_VERIFIED | pid, plen);
@@ -346,15 +349,15 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //       signature each; ~8 VALU + 0.5 LDS reads per haystack byte.  Survivors
 //       (true Q-byte prefix hits + ~0.4 % collisions) are ballot-compacted into
 //       the wave's queue Q1 (tile-relative u16 offsets).
-//   L2  exact probe of the prefix table (HBM, L2-resident).  The 16-byte windows of a
-//       tile's survivors are requested right after its compaction -- while the lines are
-//       still in the XCD's L2 -- and consumed at the top of the wave's next iteration,
-//       together with the prefetched tile: hash, ONE 16-byte gather of the home slot,
-//       compare.  A home slot holding another key ends the search unless its MORE bit is
-//       set; a group of patterns that are all longer than the set-wide minimum is probed
-//       once more with its own (longer) key.  Those dependent gathers are waited for in
-//       place: the other three waves of the SIMD have a tile of level-1 work each to
-//       cover them.  A tile with more survivors than Q1 holds settles them in rounds.
+//   L2  exact probe of the prefix table (HBM, L2-resident; keys of variable length -- the
+//       first min(8, shortest pattern of the group) bytes -- filed under their first Q2
+//       bytes, automaton.cpp), software-pipelined over tiles so that no wave waits on it:
+//       tile t's survivors re-read their 16-byte window (stage A -> B, top of iteration
+//       t+1), fetch their home slot (B -> C, t+2), compare (C, t+3).  A home slot holding
+//       another key ends the search unless its MORE bit is set (then the hit travels as
+//       HIT_RETRY and k_tile_main / k_walk_hits look it up).  A tile with more survivors
+//       than Q1 holds (dense filters: 10^5 patterns) settles the surplus in place, in
+//       rounds of 64 (dependent gathers waited for -- the other waves cover them).
 //   Output: prefix hits (position, candidate code, 16 haystack bytes).  Sparse mode
 //       (SLOTS): into the hit slots of the hit's tile -- the wave is their only producer,
 //       the count is a plain store; dense mode: appended to the wave's region.  The kernel
@@ -368,6 +371,7 @@ struct K1bLds {
     uint32_t xy[FILTER_WORDS];
     uint16_t q1[16][K1B_Q1CAP];
     uint4 hb[16][K1B_HB][2];
+    uint32_t cb[16][16]; // sparse mode: hit counts of the wave's last tiles, stored 16 at a time
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
 
@@ -406,30 +410,26 @@ __device__ __forceinline__ uint64_t low_bytes(uint64_t w, uint32_t n) { // the f
     return n >= 8 ? w : (w & ((1ull << (8 * n)) - 1));
 }
 
-// One key (a K-byte gram) in the prefix table: walks the probe sequence from the home slot.
-// Returns the entry's meta word (PREFIX_EMPTY: absent) and its code.
-__device__ __forceinline__ uint32_t ptab_find(const uint32_t *__restrict__ ptab, uint32_t log2, uint64_t gram,
-                                              uint32_t K, uint32_t *code) {
-    const uint32_t mask = (1u << log2) - 1;
-    uint32_t idx = prefix_slot(prefix_key_hash(gram, K), log2);
-    for (bool home = true;; home = false) {
-        const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
-        if (e.z == PREFIX_EMPTY) return PREFIX_EMPTY;
-        if ((((uint64_t)e.y << 32) | e.x) == gram && (e.z & 15u) == K) { *code = e.w; return e.z; }
-        if (home && !(e.z & PREFIX_MORE)) return PREFIX_EMPTY; // nothing that hashes here lives elsewhere
-        idx = (idx + 1) & mask;
-    }
+// Does the window (8 haystack bytes, little-endian) start with the entry's key?  (e.z != PREFIX_EMPTY)
+__device__ __forceinline__ bool entry_matches(const uint4 e, uint64_t w0) {
+    const uint32_t sh = (64u - 8u * (e.z & 15u)) & 63u; // key length 1..8
+    return (((((uint64_t)e.y << 32) | e.x) ^ w0) << sh) == 0;
 }
 
-// The candidate code of the patterns that agree with the window w0 on their group's key
-// (automaton.cpp: the set-wide Q2 bytes, then the group's own longer key), or HIT_NONE.
-__device__ __forceinline__ uint32_t prefix_code(const DevAutomaton &A, uint64_t w0) {
-    uint32_t code = HIT_NONE;
-    uint32_t meta = ptab_find(A.ptab, A.ptab_log2, low_bytes(w0, A.filter_q2), A.filter_q2, &code);
-    if (meta == PREFIX_EMPTY) return HIT_NONE;
-    const uint32_t N = (meta >> 4) & 15u;
-    if (N && ptab_find(A.ptab, A.ptab_log2, low_bytes(w0, N), N, &code) == PREFIX_EMPTY) return HIT_NONE;
-    return code;
+// The candidate code of the patterns whose prefix-table key the window w0 starts with, or
+// HIT_NONE: walks the probe sequence from the home slot of the window's first Q2 bytes
+// (automaton.cpp: keys of variable length, filed under their first Q2 bytes).
+__device__ __forceinline__ uint32_t prefix_code(const uint32_t *__restrict__ ptab, uint32_t log2, uint32_t q2,
+                                                uint64_t w0) {
+    const uint32_t mask = (1u << log2) - 1;
+    uint32_t idx = prefix_slot(prefix_home_hash(low_bytes(w0, q2), q2), log2);
+    for (bool home = true;; home = false) {
+        const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
+        if (e.z == PREFIX_EMPTY) return HIT_NONE;
+        if (entry_matches(e, w0)) return e.w;
+        if (home && !(e.z & PREFIX_MORE)) return HIT_NONE; // nothing that hashes here lives elsewhere
+        idx = (idx + 1) & mask;
+    }
 }
 
 // L3: does pattern `pid` occur at stream position p?  The first Q2 bytes are known to match
@@ -497,11 +497,13 @@ __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, S
             const uint64_t p = ((uint64_t)h.y << 32) | h.x;
             const uint64_t w0 = ((uint64_t)w.y << 32) | w.x, w1 = ((uint64_t)w.w << 32) | w.z;
             const uint64_t room = segment_end(G, len, p) - p;
-            const bool list = (h.z & HIT_LIST) != 0;
-            const uint32_t li = h.z & ~HIT_LIST;
-            const uint32_t nc = list ? A.blist[li] : 1;
+            uint32_t code = h.z;
+            if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
+            const uint32_t li = code & ~HIT_LIST;
+            const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
             for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t pid = list ? A.blist[li + 1 + k] : h.z;
+                const uint32_t pid = list ? A.blist[li + 1 + k] : code;
                 uint32_t rk;
                 const uint32_t L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
                 emit_key_agg(K, L != 0, occurrence_key(K.key_mode, A.rank_bits, p, L, pid, rk), pid, L);
@@ -567,7 +569,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // Word 3 of a record's first quad carries its destination slot (sparse mode).
     uint4 (*const hb)[2] = L.hb[wave];
     uint32_t hbn = 0; // wave-uniform fill of the buffer
-    auto hit_flush = [&]() {
+    auto hit_flush = [&]() __attribute__((always_inline)) {
         if (lane < hbn) {
             uint4 r0 = hb[lane][0];
             const uint4 r1 = hb[lane][1];
@@ -584,11 +586,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         hbn = 0;
     };
     // the lanes with found == true push (p, code, 16 window bytes); sparse mode: into the slots
-    // cnt, cnt + 1, ... of `tile` (cnt is wave-uniform and advanced)
+    // cnt, cnt + 1, ... of `tile` (cnt is wave-uniform).  Returns the number of hits pushed.
     auto hit_push = [&](bool found, uint64_t p, uint32_t code, uint64_t w0, uint64_t w1, uint64_t tile,
-                        uint32_t &cnt) {
+                        uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
         const unsigned long long fm = __ballot(found);
-        if (!fm) return;
+        if (!fm) return 0;
         const uint32_t np = (uint32_t)__popcll(fm);
         const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
         uint32_t dst = 0;
@@ -598,7 +600,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             keep = found && slot < HIT_SLOTS;
             if (found && !keep) *GK.abort_flag = 1; // more hits than the tile holds: dense input
             dst = (uint32_t)tile * HIT_SLOTS + slot;
-            cnt += np;
         }
         // (sparse mode: a dropped hit still takes its place in the buffer; its slot word says "nowhere")
         const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, keep ? dst : 0xFFFFFFFFu);
@@ -611,29 +612,25 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 if (found && hcur + rk < hcap) { hrec[2 * (uint64_t)(hcur + rk)] = r0; hrec[2 * (uint64_t)(hcur + rk) + 1] = r1; }
                 hcur += np;
             }
-            return;
+            return np;
         }
         if (hbn + np > K1B_HB) hit_flush();
         if (found) { hb[hbn + rk][0] = r0; hb[hbn + rk][1] = r1; }
         hbn += np;
+        return np;
     };
-    // level 2 for the lanes with act == true: window (w0, w1) at index tb + off
-    auto settle = [&](bool act, uint64_t tb, uint32_t off, uint64_t w0, uint64_t w1, uint64_t tile, uint32_t &cnt) {
-        const uint64_t gram = w0 & q2mask;
-        uint4 ent = make_uint4(0, 0, PREFIX_EMPTY, 0);
-        if (act) ent = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(gram) + q2salt, ptab_log2) * 4);
-        const bool same = (((uint64_t)ent.y << 32) | ent.x) == gram && (ent.z & 15u) == q2len;
-        uint32_t meta = ent.z, code = ent.w;
-        bool found = act && same;
-        // a home slot holding another key proves absence unless PREFIX_MORE is set (rare: walk on)
-        if (act && !same && ent.z != PREFIX_EMPTY && (ent.z & PREFIX_MORE)) {
-            meta = ptab_find(A.ptab, ptab_log2, gram, q2len, &code);
-            found = meta != PREFIX_EMPTY;
+    // level 2 in place (dense tiles only): the queued survivors of `tile` are looked up with the
+    // dependent gathers waited for on the spot
+    auto settle_now = [&](uint32_t n, uint64_t tb, uint64_t tile, uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
+        const bool act = lane < n;
+        uint32_t off = 0, code = HIT_NONE;
+        uint64_t w0 = 0, w1 = 0;
+        if (act) {
+            off = q1[lane];
+            load_window16(stream, len, tb + off - lead, &w0, &w1);
+            code = prefix_code(A.ptab, ptab_log2, q2len, w0);
         }
-        // every pattern of this group is longer than Q2: the group's own key decides
-        const uint32_t N = found ? (meta >> 4) & 15u : 0u;
-        if (N) found = ptab_find(A.ptab, ptab_log2, low_bytes(w0, N), N, &code) != PREFIX_EMPTY;
-        hit_push(found, tb + off - lead, code, w0, w1, tile, cnt);
+        return hit_push(act && code != HIT_NONE, tb + off - lead, code, w0, w1, tile, cnt);
     };
 
     // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
@@ -644,10 +641,13 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     const uint64_t last_block = total16 - 16;
     u32x4 nxt0, nxt1, nxt2, nxt3;
     uint2 nxtL;
+    // PLAIN loads, not non-temporal ones: the survivors' windows are re-read one iteration later
+    // and should still be in the XCD's L2 (measured: nt tile loads cost the kernel 15-20 %).
+#define K1B_LOAD16(PTR) (*(const u32x4 *)(PTR))
 #define K1B_ISSUE_ROW(DST, TILE, R)                                                              \
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
-        DST = load16_stream(hay + (off_ < last_block ? off_ : last_block));                      \
+        DST = K1B_LOAD16(hay + (off_ < last_block ? off_ : last_block));                         \
     }
     // The tile index is wave-uniform (SGPRs): a tile that lies wholly inside the stream -- all
     // but the last one -- is addressed as scalar base + lane * 16 + immediate row offset, no
@@ -657,8 +657,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         const uint64_t tb_ = (TILE) * tile_bytes;                                                \
         if (tb_ + tile_bytes <= last_block) {                                                    \
             const uint8_t *tp_ = hay + tb_ + lane * 16;                                          \
-            nxt0 = load16_stream(tp_); nxt1 = load16_stream(tp_ + 1024);                         \
-            nxt2 = load16_stream(tp_ + 2048); nxt3 = load16_stream(tp_ + 3072);                  \
+            nxt0 = K1B_LOAD16(tp_); nxt1 = K1B_LOAD16(tp_ + 1024);                               \
+            nxt2 = K1B_LOAD16(tp_ + 2048); nxt3 = K1B_LOAD16(tp_ + 3072);                        \
             nxtL = *(const uint2 *)(hay + tb_ + tile_bytes);                                     \
         } else {                                                                                 \
             K1B_ISSUE_ROW(nxt0, TILE, 0) K1B_ISSUE_ROW(nxt1, TILE, 1) K1B_ISSUE_ROW(nxt2, TILE, 2) \
@@ -669,26 +669,66 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     }
     K1B_ISSUE_TILE(gw)
 
-    // ---- level-2 state: the survivors of the wave's previous tile, windows in flight
-    bool haveP = false;            // wave-uniform
-    uint32_t nP = 0, cntP = 0;     // survivors in flight / hits of that tile so far (sparse mode)
-    uint64_t tileP = 0;
-    uint64_t wP0 = 0, wP1 = 0;
-    uint32_t offP = 0;
+    // ---- level-2 pipeline (tile-synchronous, one entry per lane per stage): the survivors of
+    // tile t wait in Q1 (stage A) until the top of the wave's next iteration, where their windows
+    // are requested; one iteration later the windows are hashed and the home slots requested
+    // (stage B -> C); one iteration later the slots are compared (stage C).  No wave ever waits on
+    // these gathers: each has a whole tile of level-1 work to land.
+    // At the top of the iteration for `tile`, stage A holds tile - nw, B tile - 2 nw, C tile - 3 nw.
+    uint32_t cntA = 0, cntB = 0, cntC = 0;            // sparse mode: hits of that tile pushed so far
+    uint32_t nB = 0, nC = 0;                          // survivors in the stage
+    uint32_t kC = 0;                                  // tiles of this wave that have left stage C
+    uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
+    uint32_t offB = 0, offC = 0;
+    uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
 
-    // one extra iteration settles the last tile's survivors
-    for (uint64_t tile = gw; tile < ntiles + nw; tile += nw) {
-        // Everything loaded during the previous iteration (the tile prefetch and the survivors'
-        // windows) is consumed from here on.  Passing the tile through an empty asm makes the
-        // compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
+    // three extra iterations drain the pipeline
+    for (uint64_t tile = gw; tile < ntiles + 3 * nw; tile += nw) {
+        // Everything loaded during the previous iteration (the tile prefetch and the level-2
+        // windows / slots) is consumed from here on.  Passing the tile through an empty asm makes
+        // the compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
         u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
         uint2 vL = nxtL;
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
-        if (haveP) {
-            if (nP) settle(lane < nP, tileP * tile_bytes, offP, wP0, wP1, tileP, cntP);
-            if (SLOTS && lane == 0) GK.hcnt[tileP] = cntP < HIT_SLOTS ? cntP : HIT_SLOTS;
-            haveP = false;
+        // ---- stage C: compare the slots fetched one tile ago with their windows
+        if (tile >= gw + 3 * nw) {
+            const uint64_t tileC = tile - 3 * nw;
+            if (nC) {
+                const bool act = lane < nC && entC.z != PREFIX_EMPTY;
+                const bool same = entry_matches(entC, winC);
+                // a home slot holding another key proves absence unless PREFIX_MORE is set (then
+                // k_tile_main / k_walk_hits look the window up: no dependent gathers here)
+                const bool found = act && (same || (entC.z & PREFIX_MORE));
+                cntC += hit_push(found, tileC * tile_bytes + offC - lead, same ? entC.w : HIT_RETRY, winC, winC1,
+                                 tileC, cntC);
+            }
+            if (SLOTS) { // the tile's count: through LDS, 16 tiles of the wave per store
+                if (lane == 0) L.cb[wave][kC & 15] = cntC < HIT_SLOTS ? cntC : HIT_SLOTS;
+                if ((kC & 15) == 15) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kC - 15) + lane] = L.cb[wave][lane];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                kC++;
+            }
         }
+        // ---- stage B -> C: hash the windows fetched one tile ago, fetch their home slots
+        if (nB) {
+            if (lane < nB)
+                entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winB & q2mask) + q2salt, ptab_log2) * 4);
+            offC = offB; winC = winB; winC1 = winB1;
+        }
+        nC = nB; cntC = cntB;
+        // ---- stage A -> B: fetch the 16-byte windows of the previous tile's survivors
+        if (q1c) {
+            if (lane < q1c) {
+                offB = q1[lane];
+                load_window16(stream, len, (tile - nw) * tile_bytes + offB - lead, &winB, &winB1);
+            }
+        }
+        nB = q1c; cntB = cntA;
+        q1c = 0; cntA = 0;
+        __builtin_amdgcn_wave_barrier();
         if (tile >= ntiles) continue;
 
         // ---- level 1 on this tile
@@ -748,18 +788,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // no prefetch at all (loads at the top of the tile's own iteration): 308.
         K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
-        uint32_t cntT = 0; // sparse mode: hits of THIS tile already pushed (full rounds below)
+        cntA = 0; // sparse mode: hits of THIS tile pushed by the full rounds below
         uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
         while (true) {
             unsigned long long act = __ballot((mlo | mhi) != 0);
             if (!act) break;
             uint32_t np = __popcll(act);
-            if (q1c + np > K1B_Q1CAP) {
-                // dense survivors: settle what is queued now, windows fetched in place
-                uint32_t off = 0;
-                uint64_t a0 = 0, a1 = 0;
-                if (lane < q1c) { off = q1[lane]; load_window16(stream, len, tbase + off - lead, &a0, &a1); }
-                settle(lane < q1c, tbase, off, a0, a1, tile, cntT);
+            if (q1c + np > K1B_Q1CAP) { // dense survivors: settle what is queued now, in place
+                cntA += settle_now(q1c, tbase, tile, cntA);
                 q1c = 0;
                 __builtin_amdgcn_wave_barrier();
             }
@@ -774,18 +810,15 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             q1c += np;
             __builtin_amdgcn_wave_barrier();
         }
-        // ---- request the windows of the queued survivors now (their lines were streamed a few
-        // microseconds ago); they are settled at the top of the next iteration
-        nP = q1c; cntP = cntT; tileP = tile; haveP = true;
-        if (lane < q1c) {
-            offP = q1[lane];
-            load_window16(stream, len, tbase + offP - lead, &wP0, &wP1);
-        }
-        q1c = 0;
-        __builtin_amdgcn_wave_barrier();
+        // Q1 now holds this tile's (remaining) survivors: stage A
     }
     hit_flush();
+    if (SLOTS && (kC & 15)) { // the counts of the wave's last tiles
+        __builtin_amdgcn_wave_barrier();
+        if (lane < (kC & 15)) GK.hcnt[gw * GK.cnt_iters + (kC & ~15u) + lane] = L.cb[wave][lane];
+    }
     if (!SLOTS && lane == 0) GK.block_counts[region] = hcur;
+#undef K1B_LOAD16
 #undef K1B_ISSUE_ROW
 #undef K1B_ISSUE_TILE
 #undef K1B_ROW
@@ -1065,6 +1098,8 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // host redoes the call on the dense path, whose resolve is global.
 constexpr uint32_t MAIN_THREADS = 256;
 constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
+// occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
+constexpr uint32_t STAGE_SLOTS = 24;
 static_assert(GROUP_TILES == 64, "one wave owns the output buckets of a group");
 
 __device__ __forceinline__ uint64_t rec_key(const uint4 v) { return ((uint64_t)v.y << 32) | v.x; }
@@ -1080,11 +1115,13 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag) {
-    __shared__ uint4 st[STAGE_BUCKETS][HIT_SLOTS]; // staged occurrences by bucket of key position
+    // (rows padded to an odd number of quads: lane t works on row t, and a power-of-two row stride would
+    // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
+    __shared__ uint4 st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
     __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
     __shared__ uint64_t bmax[STAGE_BUCKETS];       // largest end per bucket
     __shared__ uint32_t hoff[STAGE_BUCKETS + 1];   // exclusive prefix of the tiles' hit counts
-    __shared__ uint8_t syn[STAGE_BUCKETS][HIT_SLOTS], acc[STAGE_BUCKETS][HIT_SLOTS];
+    __shared__ uint8_t syn[STAGE_BUCKETS][STAGE_SLOTS + 4], acc[STAGE_BUCKETS][STAGE_SLOTS + 4];
     __shared__ uint32_t fail, stop;
     using scan_t = rocprim::block_scan<uint32_t, MAIN_THREADS>;
     __shared__ typename scan_t::storage_type scan_tmp;
@@ -1096,7 +1133,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     // ---- hits of the staged tiles
     uint32_t c = 0;
     if (t < nb && first + t < T.n_tiles) {
-        c = T.hcnt[first + t];
+        c = T.hcnt[hcnt_index(first + t, T.cnt_nw, T.cnt_iters)];
         c = c < HIT_SLOTS ? c : HIT_SLOTS; // overfull: the producer raised the abort flag
     }
     if (t < STAGE_BUCKETS) { bn[t] = 0; bmax[t] = 0; }
@@ -1125,22 +1162,24 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
         const uint4 r0 = rec[0];
         const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
         uint64_t w0 = 0, w1 = 0, room = 0;
-        uint32_t nc = 1, li = 0;
-        const bool verified = (r0.z & HIT_VERIFIED) != 0 && !(r0.z & HIT_LIST);
-        const bool list = (r0.z & HIT_LIST) != 0;
+        uint32_t nc = 1, li = 0, code = r0.z;
+        const bool verified = code != HIT_RETRY && (code & HIT_VERIFIED) != 0;
+        bool list = false;
         if (!verified) {
             const uint4 w = rec[1];
             w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
             room = segment_end(G, len, p) - p;
-            if (list) { li = r0.z & ~HIT_LIST; nc = A.blist[li]; }
+            if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            if (code == HIT_NONE) nc = 0;
+            else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
         }
         for (uint32_t k = 0; k < nc; k++) {
             uint32_t pid, L, rk;
             if (verified) {
-                pid = r0.z & ~HIT_VERIFIED; L = r0.w;
+                pid = code & ~HIT_VERIFIED; L = r0.w;
                 rk = key_mode == 1 ? 0u : A.rank[pid];
             } else {
-                pid = list ? A.blist[li + 1 + k] : r0.z;
+                pid = list ? A.blist[li + 1 + k] : code;
                 L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
                 if (!L) continue;
             }
@@ -1149,7 +1188,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             if (kidx < complete || kidx >= idx_hi) continue; // another group's (or nobody's) business
             const uint32_t b = (uint32_t)((kidx >> TILE_BITS) - first);
             const uint32_t r = atomicAdd(&bn[b], 1u);
-            if (r < HIT_SLOTS) st[b][r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
+            if (r < STAGE_SLOTS) st[b][r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
             else fail = 1;
         }
     }
@@ -1241,7 +1280,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             for (uint32_t i = 0, k = 0; i < n; i++)
                 if (overlapping || acc[lb + t][i]) dst[k++] = st[lb + t][i];
         }
-        if (t == 0) { T.btot[g] = total > GROUP_MAX ? 0 : total; T.gocc[g] = occ; }
+        if (t == 0) { T.btot[g] = total > GROUP_MAX ? 0 : total; T.gocc[g] = occ; T.ghits[g] = hoff[nb] - hoff[lb]; }
     }
 }
 
@@ -1258,8 +1297,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
     const uint32_t t = threadIdx.x;
     const bool stop = *abort_flag != 0; // stable: its writers completed
     uint64_t hsum = 0, nsum = 0;
-    if (count_hits)
-        for (uint32_t i = t; i < T.n_tiles; i += 1024) hsum += T.hcnt[i];
+    (void)count_hits;
     const uint32_t per = (T.n_groups + 1023) / 1024, g0 = t * per;
     uint32_t mine = 0, excl = 0, total = 0;
     // (unrolled so that the loads of several groups are in flight together)
@@ -1267,6 +1305,7 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
         _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < T.n_groups; g++) {
             mine += T.btot[g];
             nsum += T.gocc[g];
+            hsum += T.ghits[g];
         }
     scan_t().exclusive_scan(mine, excl, 0u, total, scan_tmp);
     if (!stop)
@@ -1291,23 +1330,35 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
     }
 }
 
-// The group's reported occurrences -> final records.  A group's output is one contiguous stretch
-// of 24-byte records: it is assembled in LDS and written as a flat array of dwords (coalesced).
+// The groups' reported occurrences -> final records.  A workgroup takes WRITE_GROUPS consecutive
+// groups: their output is one contiguous stretch of 24-byte records, assembled in LDS and written as
+// a flat array of dwords (coalesced).
 // seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
 // their haystack and the per-haystack counts are taken here -- one atomic per run of matches
-// of the same haystack inside the group instead of a separate pass with one atomic per match.
-constexpr uint32_t WRITE_THREADS = 256;
+// of the same haystack inside the stretch instead of a separate pass with one atomic per match.
+constexpr uint32_t WRITE_THREADS = 256, WRITE_GROUPS = 1, WRITE_MAX = WRITE_GROUPS * GROUP_MAX;
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
                                                               Segments G, uint64_t *seg_counts) {
-    __shared__ uint32_t img[GROUP_MAX * 6];
-    __shared__ uint32_t hs[GROUP_MAX]; // haystack index of the group's matches, in output order
-    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    __shared__ uint32_t img[WRITE_MAX * 6];
+    __shared__ uint32_t hs[WRITE_MAX]; // haystack index of the matches, in output order
+    __shared__ uint32_t goff[WRITE_GROUPS + 1];
+    const uint32_t t = threadIdx.x, g0 = blockIdx.x * WRITE_GROUPS;
     if (*abort_flag) return; // stable by now: its writers completed
-    const uint32_t n = T.btot[g], base = T.bbase[g];
-    const uint4 *src = T.trecs + (uint64_t)g * GROUP_MAX;
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t k = 0; k < WRITE_GROUPS; k++) {
+            goff[k] = run;
+            if (g0 + k < T.n_groups) run += T.btot[g0 + k];
+        }
+        goff[WRITE_GROUPS] = run;
+    }
+    __syncthreads();
+    const uint32_t n = goff[WRITE_GROUPS], base = T.bbase[g0];
     for (uint32_t i = t; i < n; i += WRITE_THREADS) {
-        const uint4 v = src[i];
+        uint32_t k = 0;
+        while (i >= goff[k + 1]) k++;
+        const uint4 v = T.trecs[(uint64_t)(g0 + k) * GROUP_MAX + (i - goff[k])];
         uint64_t s, e;
         span_of(rank_bits, key_mode, v, &s, &e);
         if (seg_counts) {
@@ -1354,8 +1405,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                        lead, d_hay, len, abort_flag);
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, count_hits ? 1 : 0, summary, abort_flag,
                        next_flag, (volatile uint64_t *)host_out, seq);
-    hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, T, out,
-                       abort_flag, G, seg_counts);
+    hipLaunchKernelGGL(k_tile_write, dim3((T.n_groups + WRITE_GROUPS - 1) / WRITE_GROUPS), dim3(WRITE_THREADS), 0, st,
+                       A.rank_bits, key_mode, T, out, abort_flag, G, seg_counts);
     return hipGetLastError();
 }
 

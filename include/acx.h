@@ -87,7 +87,8 @@ typedef struct acx_info {
 typedef struct acx_profile {
     double scan_ms;        /* accumulated HIP-event time of the scan kernel (K1) */
     uint64_t scan_launches;
-    double post_ms;        /* sort + resolve + fix-up kernels                   */
+    double post_ms;        /* kernels after the scan (collected only when ACX_PROFILE_POST is
+                              set: it costs every call a wait for the previous one) */
     uint64_t scan_bytes;   /* haystack bytes scanned by those launches          */
     uint64_t raw_occurrences; /* occurrences emitted by K1 before resolution    */
     uint64_t prefix_hits;     /* K1b: prefix hits handed to the walk kernel      */
@@ -129,13 +130,14 @@ typedef struct acx_host_tables {
     const uint32_t *rank;         /* n_patterns: rank in (len desc, id asc)          */
     const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} signature words
                                      (bit layout: csrc/automaton.hpp, filter_bit)      */
-    const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {gram lo, gram hi, meta, code}:
-                                     meta = key length K | next key length N << 4 | MORE << 31
-                                     (0xFFFFFFFF = empty; MORE: another key with this home slot sits
-                                     further along the probe sequence).  N = 0: code = the only
-                                     pattern with this key, or 0x80000000 | index into prefix_lists;
-                                     N > K: every pattern that starts with these K bytes is longer --
-                                     probe again with the first N bytes (csrc/automaton.cpp)       */
+    const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {key lo, key hi, meta, code}:
+                                     meta = key length K (1..8) | MORE << 31 (0xFFFFFFFF = empty; MORE:
+                                     another key with this home slot sits further along the probe
+                                     sequence); code = the only pattern with this key, or
+                                     0x80000000 | index into prefix_lists.  A key = the first
+                                     min(8, shortest pattern of its group) bytes of a pattern, a group =
+                                     the patterns sharing their first filter_q2 bytes; keys are filed
+                                     under the hash of those filter_q2 bytes (csrc/automaton.cpp)     */
     const uint32_t *prefix_lists; /* {count, pattern id, ...} per key shared by several patterns   */
     uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2 (first-level keys)   */
     uint32_t filter_entries_log2, prefix_table_log2;
@@ -147,7 +149,8 @@ int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_pa
                      int match_kind, acx_host_automaton_t **out);
 int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
 uint32_t acx_filter_hash(uint32_t gram);   /* level-1 hash of a little-endian (Q-1)-gram   */
-uint32_t acx_prefix_slot(uint64_t gram, uint32_t key_len, uint32_t log2); /* home slot of a key */
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2); /* home slot of the keys that start with
+                                                                       the q2 low bytes of gram */
 void acx_free_host(acx_host_automaton_t *h);
 
 /* ---- concurrency: every function taking an acx_automaton_t may be called from several

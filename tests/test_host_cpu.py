@@ -82,39 +82,22 @@ def test_compiler_matches_survey_sizes():
     h.close()
 
 
-def ptab_find(h, lg, key: bytes):
-    """Python twin of the kernels' ptab_find: walks the probe sequence of `key` from its home
-    slot; -> (meta, code) or None.  A home slot holding another key ends the search unless its
-    MORE bit is set."""
-    gram, K = int.from_bytes(key, "little"), len(key)
-    idx, home = capi.prefix_slot(key, lg), True
+def prefix_candidates(h, lg, q2, window: bytes):
+    """Python twin of the kernels' prefix_code + candidate list: walks the probe sequence from the
+    home slot of window[:q2]; an entry matches when the window starts with its key (K bytes).  A
+    home slot holding another key ends the search unless its MORE bit is set.  -> pattern ids."""
+    idx, home = capi.prefix_slot(window, q2, lg), True
     while True:
         lo, hi, meta, code = (int(x) for x in h.prefix_table[idx])
         if meta == 0xFFFFFFFF:
-            return None
-        if (hi << 32 | lo) == gram and (meta & 15) == K:
-            return meta, code
+            return []
+        K = meta & 15
+        if (hi << 32 | lo) == int.from_bytes(window[:K], "little"):
+            break
         if home and not (meta >> 31):
-            return None
+            return []
         home = False
         idx = (idx + 1) & ((1 << lg) - 1)
-
-
-def prefix_candidates(h, lg, q2, window: bytes):
-    """Python twin of prefix_code + the candidate list: the pattern ids K1b hands on for a
-    haystack window (>= 8 bytes, zero padded)."""
-    got = ptab_find(h, lg, window[:q2])
-    if got is None:
-        return []
-    meta, code = got
-    n = (meta >> 4) & 15
-    if n:
-        assert n > q2
-        got = ptab_find(h, lg, window[:n])
-        if got is None:
-            return []
-        meta, code = got
-        assert (meta >> 4) & 15 == 0
     if code & 0x80000000:
         i = code & 0x7FFFFFFF
         cnt = int(h.prefix_lists[i])
@@ -166,12 +149,13 @@ def test_prefilter_tables_have_every_pattern_prefix():
         # MORE (bit 31 of the meta word) is set on a home slot iff some key hashing there lives elsewhere
         tab = np.asarray(h.prefix_table)
         used = np.nonzero(tab[:, 2] != 0xFFFFFFFF)[0]
-        assert len(used) == int(h.t.n_prefix_keys) <= 0.3 * (1 << lg) + 1
+        assert len(used) == int(h.t.n_prefix_keys) <= 0.25 * (1 << lg) + 1
         displaced_homes = set()
         for e in used:
             K = int(tab[e, 2]) & 15
+            assert q2 <= K <= 8
             gram = (int(tab[e, 1]) << 32 | int(tab[e, 0])).to_bytes(8, "little")[:K]
-            home = capi.prefix_slot(gram, lg)
+            home = capi.prefix_slot(gram, q2, lg)
             if home != e:
                 displaced_homes.add(home)
         for e in used:

@@ -1,0 +1,56 @@
+#!/bin/bash
+# round-2 GPU check: tests (fail fast, most basic first), then short benches.  Every command
+# bounded by `timeout`.  usage: tools/gpu_r2.sh [tests|bench|all]
+set -u
+export TMPDIR=/tmp
+OUT=/root/repo/gpurun_out/r2
+mkdir -p $OUT
+cd /root/repo
+WHAT=${1:-all}
+if [ "$WHAT" = tests ] || [ "$WHAT" = all ]; then
+  timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sparse_path.py tests/test_gpu_batch.py \
+      tests/test_gpu_cfg1.py tests/test_gpu_configs.py tests/test_api_gpu.py -x -q -m gpu > $OUT/pytest.log 2>&1
+  echo "pytest rc=$?"; tail -25 $OUT/pytest.log
+fi
+if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
+  for d in T U; do
+    timeout 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --dist $d > $OUT/bench_$d.json 2> $OUT/bench_$d.err
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_$d.json")); c = d["config"]; r = d["roofline"]
+    print("$d", d["value"], "GB/s", d["ms_per_step"], "ms/step K1", r["kernel_ms"], "ms frac", r["frac"], "matches", c["matches_total"], "hits", c["prefix_hits_per_step"], "occ", c["raw_occurrences_per_step"])
+except Exception as e:
+    print("$d failed", e); print(open("$OUT/bench_$d.err").read()[-1500:])
+PY
+  done
+fi
+if [ "$WHAT" = trace ] || [ "$WHAT" = all ]; then
+  cd /tmp
+  rm -rf $OUT/trace_T
+  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_T.log 2>&1
+  cd /root/repo
+  python tools/rocprof_summary.py $OUT/trace_T 2>/dev/null | head -14
+fi
+if [ "$WHAT" = pmc ]; then
+  cd /tmp
+  for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU" \
+             "SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VMEM GRBM_GUI_ACTIVE" \
+             "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    tag=$(echo $set | cut -d' ' -f1)
+    rm -rf $OUT/pmc_$tag
+    timeout 300 rocprofv3 --pmc $set --kernel-trace --output-format csv -d $OUT/pmc_$tag -o r -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/pmc_$tag.log 2>&1
+  done
+  cd /root/repo
+  python - <<PY
+import csv, collections, glob
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("$OUT/pmc_*/r_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("acx::", "")[:24]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, v in agg.items():
+    if k.startswith(("k1b", "k_tile", "k1a", "k_walk")):
+        print(k, {c: round(sum(x) / len(x)) for c, x in sorted(v.items())})
+PY
+fi
