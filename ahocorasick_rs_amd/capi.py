@@ -225,9 +225,14 @@ def filter_hash(gram: bytes) -> int:
     return int(lib().acx_filter_hash(int.from_bytes(gram[:4], "little")))
 
 
-def prefix_slot(gram: bytes, q2: int, log2: int) -> int:
-    """home slot of the prefix-table keys that start with the first q2 bytes of `gram`."""
-    return int(lib().acx_prefix_slot(int.from_bytes(gram[:q2], "little"), q2, log2))
+def prefix_hash(gram: bytes, salt: int) -> int:
+    """32-bit hash of the first `salt` bytes of `gram` (the slot is its top bits)."""
+    return int(lib().acx_prefix_slot(int.from_bytes(gram[:salt], "little"), salt, 32))
+
+
+def prefix_slot(gram: bytes, salt: int, log2: int) -> int:
+    """home slot of the first `salt` bytes of `gram` in the prefix table."""
+    return int(lib().acx_prefix_slot(int.from_bytes(gram[:salt], "little"), salt, log2))
 
 
 class DeviceBuffer:

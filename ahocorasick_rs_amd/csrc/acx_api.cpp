@@ -303,7 +303,8 @@ struct Workspace {
     uint64_t *h_pinned = nullptr;     // pinned host scratch (16 x u64; [8], [9] = result of K0; [7] = seq)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
-    uint64_t *blockcnt = nullptr, *blockpre = nullptr;
+    uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
+    uint8_t *blocksub = nullptr;                        // lead bytes per 64 bytes of a block
     uint64_t block_cap = 0;
     TileSpace T{};                    // sparse path (hit slots + tile kernels)
     uint64_t tile_cap = 0;            // tiles T is allocated for
@@ -411,7 +412,7 @@ void free_ws(Workspace &w, int device) {
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     free_tiles(w);
     g_bufs.put(w.final, device);
-    (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
+    (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre); (void)hipFree(w.blocksub);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
     if (w.pin_hay) (void)hipHostFree(w.pin_hay);
@@ -558,10 +559,11 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
 int ensure_blocks(Ctx *c, uint64_t nblocks_plus1) {
     Workspace &w = c->ws;
     if (nblocks_plus1 > w.block_cap) {
-        (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre);
-        w.blockcnt = w.blockpre = nullptr; w.block_cap = 0;
+        (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre); (void)hipFree(w.blocksub);
+        w.blockcnt = w.blockpre = nullptr; w.blocksub = nullptr; w.block_cap = 0;
         HIPCHK(hipMalloc((void **)&w.blockcnt, nblocks_plus1 * 8));
         HIPCHK(hipMalloc((void **)&w.blockpre, nblocks_plus1 * 8));
+        HIPCHK(hipMalloc((void **)&w.blocksub, nblocks_plus1 * 16));
         w.block_cap = nblocks_plus1;
     }
     size_t need = scan_temp_bytes(nblocks_plus1) + 256; // the scan temp storage must cover this size too
@@ -678,6 +680,7 @@ struct FindCall {
     uint64_t tiles;     // 4 KiB tiles of index space
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
+    bool leads_counted = false; // the scan has written the lead-byte counts of every 64 bytes (str API)
     bool queued = false;    // work queued on the stream that nobody waited for yet
     bool localized = false; // batch: offsets are already local and the counts taken
 };
@@ -712,9 +715,17 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     const bool prof = a->prof;
     if (c.pre) {
+        // str API: the scan counts the UTF-8 lead bytes on its way (aligned haystacks: the blocks of
+        // the code-point prefix are then the rows of the scan's tiles)
+        uint8_t *cp_sub = nullptr;
+        if (c.codepoints && c.lead == 0) {
+            if ((rc = ensure_blocks(x, 4 * c.tiles + 1)) != ACX_OK) return rc;
+            cp_sub = w.blocksub;
+        }
         // measurement: the event pair rides on the dispatch
         HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
-                                   prof ? x->ev[1] : nullptr));
+                                   prof ? x->ev[1] : nullptr, cp_sub));
+        c.leads_counted = cp_sub != nullptr;
     } else {
         HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
         if (prof) HIPCHK_RC(hipEventRecord(x->ev[0], st));
@@ -731,6 +742,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         HIPCHK_RC(hipStreamSynchronize(st));
         if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
         x->dense_hold = 8;
+        c.leads_counted = false;
         *what = Attempt::GoDense;
         return ACX_OK;
     }
@@ -829,15 +841,17 @@ int finish_matches(FindCall &c) {
     if (!c.n_final || !(c.codepoints || (c.segmented && !c.localized))) return ACX_OK;
     if (c.codepoints) {
         const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
-        int rc = ensure_blocks(x, nb1);
+        int rc = ensure_blocks(x, c.leads_counted ? std::max<uint64_t>(nb1, 4 * c.tiles + 1) : nb1);
         if (rc) return rc;
-        HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, st));
+        if (c.leads_counted) HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, st));
+        else HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, w.blocksub, st));
         HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
     }
     if (c.segmented)
-        HIPCHK_RC(localize(c.G, c.d_hay, c.len, w.blockpre, c.codepoints, c.r->d_matches, c.n_final, c.r->d_counts, st));
+        HIPCHK_RC(localize(c.G, c.d_hay, c.len, w.blockpre, w.blocksub, c.codepoints, c.r->d_matches, c.n_final,
+                           c.r->d_counts, st));
     else
-        HIPCHK_RC(to_code_points(c.d_hay, c.len, w.blockpre, c.r->d_matches, c.n_final, st));
+        HIPCHK_RC(to_code_points(c.d_hay, c.len, w.blockpre, w.blocksub, c.r->d_matches, c.n_final, st));
     c.queued = true;
     return ACX_OK;
 }

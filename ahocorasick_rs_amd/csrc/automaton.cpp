@@ -264,18 +264,20 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // group of min(len, 8): a haystack position becomes a prefix hit only if it agrees with some
         // pattern on min(len, 8) bytes of the SHORTEST pattern of its group -- not merely on the
         // set-wide minimum (a set that mixes "xyzzy" with patterns starting with a 4-byte UTF-8
-        // character would otherwise turn every occurrence of that character into a hit).  A key is
-        // filed under the hash of its first Q2 bytes -- all the lookup knows before it has seen an
-        // entry -- so the keys of one group share a home slot and follow each other in the probe
-        // sequence; ONE gather settles a position whose group has a single key (the common case).
-        // Entry = {key lo, key hi, meta, code}: meta = key length K | PREFIX_MORE, 0xFFFFFFFF = empty;
-        // code = the only pattern with this key, or HIT_LIST | index into blist.
+        // character would otherwise turn every occurrence of that character into a hit).
+        //   * a group with ONE key: the key is filed under the hash of its first Q2 bytes -- all the
+        //     lookup knows before it has seen an entry: ONE gather settles a position (the common case);
+        //   * a group with several keys: a REDIRECT entry {the Q2 bytes, next = Lg} is filed there
+        //     instead, and the keys under the hash of their own Lg bytes: two dependent gathers.
+        // Entry = {key lo, key hi, meta, code}: meta = key length K | next << 4 | filter of displaced keys << 8,
+        // 0xFFFFFFFF = empty; next = 0: code = the only pattern with this key, or HIT_LIST | index
+        // into blist; next = N > K: look the first N bytes up (salt N).
         std::vector<uint64_t> g1(n);              // first Q2 bytes of every pattern
         for (uint64_t i = 0; i < n; i++) g1[i] = gram_of(pb + A.offsets[i], Q2);
         std::vector<uint32_t> by_g1(n);
         std::iota(by_g1.begin(), by_g1.end(), 0u);
         std::stable_sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] < g1[b]; });
-        struct Key { uint64_t gram; uint32_t K; std::vector<uint32_t> pids; };
+        struct Key { uint64_t gram; uint32_t K, next, salt; std::vector<uint32_t> pids; };
         std::vector<Key> keys;
         for (size_t b = 0; b < n;) {
             size_t e = b;
@@ -288,11 +290,16 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             std::stable_sort(sub.begin(), sub.end(), [&](uint32_t x, uint32_t y) {
                 return gram_of(pb + A.offsets[x], Lg) < gram_of(pb + A.offsets[y], Lg);
             });
+            const size_t first_key = keys.size();
             for (size_t j = 0; j < sub.size();) {
                 const uint64_t g2 = gram_of(pb + A.offsets[sub[j]], Lg);
-                Key k{g2, Lg, {}};
+                Key k{g2, Lg, 0, Q2, {}};
                 while (j < sub.size() && gram_of(pb + A.offsets[sub[j]], Lg) == g2) k.pids.push_back(sub[j++]);
                 keys.push_back(std::move(k));
+            }
+            if (keys.size() - first_key > 1) { // several keys: redirect from the Q2 bytes to the keys' own hash
+                for (size_t k = first_key; k < keys.size(); k++) keys[k].salt = Lg;
+                keys.push_back(Key{g1[by_g1[b]], Q2, Lg, Q2, {}});
             }
             b = e;
         }
@@ -305,7 +312,6 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         A.ptab.assign((size_t)4 << lg, 0);
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = PREFIX_EMPTY;
         const uint32_t pmask = (1u << lg) - 1;
-        const uint64_t q2mask = Q2 >= 8 ? ~0ull : ((1ull << (8 * Q2)) - 1);
         A.pinfo.assign((size_t)4 * n, 0);
         for (uint64_t i = 0; i < n; i++) {
             const uint8_t *pp = pb + A.offsets[i];
@@ -316,30 +322,46 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             std::memcpy(&A.pinfo[4 * i + 1], tail, 12);
         }
         A.blist.clear();
+        auto hash_of = [&](uint64_t gram, uint32_t salt) { // salt = the number of key bytes hashed
+            const uint64_t m = salt >= 8 ? ~0ull : ((1ull << (8 * salt)) - 1);
+            return prefix_home_hash(gram & m, salt);
+        };
+        std::vector<uint32_t> hash_at((size_t)1 << lg, 0); // hash of the entry stored in each slot
+        // Redirect entries first: every haystack position that starts like ANY pattern of the group
+        // looks the entry up, so it must sit in its home slot (a displaced one would turn all of
+        // them into HIT_RETRY traffic); then the single keys of the other groups, then the keys
+        // behind the redirects.
+        std::stable_sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
+            auto cls = [&](const Key &k) { return k.next ? 0 : (k.salt == Q2 ? 1 : 2); };
+            return cls(a) < cls(b);
+        });
         for (Key &k : keys) {
-            uint32_t code;
-            std::sort(k.pids.begin(), k.pids.end()); // pattern id order inside every list
-            if (k.pids.size() == 1) {
-                code = k.pids[0];
-            } else {
-                code = 0x80000000u | (uint32_t)A.blist.size();
-                A.blist.push_back((uint32_t)k.pids.size());
-                A.blist.insert(A.blist.end(), k.pids.begin(), k.pids.end());
+            uint32_t code = 0;
+            if (k.next == 0) {
+                std::sort(k.pids.begin(), k.pids.end()); // pattern id order inside every list
+                if (k.pids.size() == 1) {
+                    code = k.pids[0];
+                } else {
+                    code = 0x80000000u | (uint32_t)A.blist.size();
+                    A.blist.push_back((uint32_t)k.pids.size());
+                    A.blist.insert(A.blist.end(), k.pids.begin(), k.pids.end());
+                }
             }
-            uint32_t idx = prefix_slot(prefix_home_hash(k.gram & q2mask, Q2), lg);
+            const uint32_t h = hash_of(k.gram, k.salt);
+            uint32_t idx = prefix_slot(h, lg);
             while (A.ptab[4 * (size_t)idx + 2] != PREFIX_EMPTY) idx = (idx + 1) & pmask;
             uint32_t *en = &A.ptab[4 * (size_t)idx];
             en[0] = (uint32_t)k.gram; en[1] = (uint32_t)(k.gram >> 32);
-            en[2] = k.K;
+            en[2] = k.K | (k.next << 4);
             en[3] = code;
+            hash_at[idx] = h;
         }
-        // PREFIX_MORE on a home slot: some key that hashes here lives further along the probe
-        // sequence.  Without it a home slot holding a different key proves absence (one probe).
+        // the filter of displaced keys on every home slot: without the lookup's own bit a home slot
+        // holding a different key proves absence (one probe)
         for (size_t e = 0; e < ((size_t)1 << lg); e++) {
             if (A.ptab[4 * e + 2] == PREFIX_EMPTY) continue;
-            uint64_t gram = ((uint64_t)A.ptab[4 * e + 1] << 32) | A.ptab[4 * e];
-            uint32_t home = prefix_slot(prefix_home_hash(gram & q2mask, Q2), lg);
-            if (home != e) A.ptab[4 * (size_t)home + 2] |= PREFIX_MORE;
+            const uint32_t hm = prefix_slot(hash_at[e], lg);
+            if (hm != e) A.ptab[4 * (size_t)hm + 2] |= prefix_more_bit(hash_at[e]);
         }
     }
     return std::string();

@@ -76,14 +76,18 @@ ACX_HD static inline uint32_t filter_bit(uint32_t v) { return 1u << (v & 31); }
 ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
     return ((uint32_t)gram * 0x9E3779B1u) ^ ((uint32_t)(gram >> 32) * 0x85EBCA6Bu);
 }
-// prefix-table entry, word 2 (meta): key length K (bits 3:0, 1..8) | PREFIX_MORE ("more keys
-// with this home slot further along"); PREFIX_EMPTY marks a free slot
+// prefix-table entry, word 2 (meta): key length K (bits 3:0, 1..8) | next << 4 (0: final entry;
+// N > K: redirect -- look the first N bytes up) | a 16-bit filter of the keys that have this slot
+// as their home but live further along the probe sequence (bits 23:8: bit prefix_more_bit(h) of
+// every such key's hash h); PREFIX_EMPTY marks a free slot.  A lookup that finds another key in
+// its home slot goes on only if its own bit is set -- otherwise the key is not in the table.
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
-constexpr uint32_t PREFIX_MORE = 0x80000000u;
-// home-slot hash of a key: of its first Q2 bytes (little-endian in a u64, masked), the set-wide
-// minimum key length -- all a lookup knows before it has seen an entry
-ACX_HD static inline uint32_t prefix_home_hash(uint64_t gram_q2, uint32_t Q2) {
-    return gram_hash2(gram_q2) + Q2 * 0x9E3779B1u;
+ACX_HD static inline uint32_t prefix_more_bit(uint32_t home_hash) { return 1u << (8 + ((home_hash >> 11) & 15u)); }
+// home-slot hash of the first `salt` bytes of a key (little-endian in a u64, masked): salt = Q2,
+// the set-wide minimum key length -- all a lookup knows before it has seen an entry -- or the
+// key length a redirect entry names
+ACX_HD static inline uint32_t prefix_home_hash(uint64_t gram, uint32_t salt) {
+    return gram_hash2(gram) + salt * 0x9E3779B1u;
 }
 // slot of a Q2-gram in the prefix table (2^log2 entries)
 ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
@@ -116,11 +120,11 @@ struct Automaton {
     std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
     double filter_density = 0.0;       // fraction of X bits set
     // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:
-    //   {key lo, key hi, K | PREFIX_MORE (0xFFFFFFFF = empty),
+    //   {key lo, key hi, K | next << 4 | filter of displaced keys << 8 (0xFFFFFFFF = empty),
     //    the only pattern with this key, or 0x80000000 | index into blist}
     // keys have variable length K: the first min(8, shortest pattern of the group) bytes of the
-    // patterns of a group (= the patterns sharing their first Q2 bytes), filed under the hash of
-    // those Q2 bytes (automaton.cpp)
+    // patterns of a group (= the patterns sharing their first Q2 bytes); a group's single key is
+    // filed under the hash of those Q2 bytes, several keys behind a redirect entry (automaton.cpp)
     std::vector<uint32_t> blist;       // {count, pid, pid, ...} per key shared by several patterns
     uint32_t n_prefix_keys = 0;        // entries in use
     // per pattern, 4 u32: {rank | min(len, 255) << 24, the 12 bytes that follow its first Q2 bytes}

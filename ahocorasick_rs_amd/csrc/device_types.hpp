@@ -65,7 +65,7 @@ struct Segments {
 // count goes to block_counts[i] (it keeps counting past region_cap so that the host can size a
 // retry exactly).
 constexpr uint32_t TILE_BITS = 12;    // tile = 4 KiB of index space
-constexpr uint32_t HIT_SLOTS = 32;    // hit records per tile
+constexpr uint32_t HIT_SLOTS = 64;    // hit records per tile (HBM is 288 GB: half a byte of workspace per haystack byte)
 constexpr uint32_t GROUP_TILES = 64;  // tiles per workgroup of k_tile_main (256 KiB)
 constexpr uint32_t GROUP_MAX = 1024;  // reported matches per group
 constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group

@@ -354,10 +354,12 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //       bytes, automaton.cpp), software-pipelined over tiles so that no wave waits on it:
 //       tile t's survivors re-read their 16-byte window (stage A -> B, top of iteration
 //       t+1), fetch their home slot (B -> C, t+2), compare (C, t+3).  A home slot holding
-//       another key ends the search unless its MORE bit is set (then the hit travels as
-//       HIT_RETRY and k_tile_main / k_walk_hits look it up).  A tile with more survivors
-//       than Q1 holds (dense filters: 10^5 patterns) settles the surplus in place, in
-//       rounds of 64 (dependent gathers waited for -- the other waves cover them).
+//       another key ends the search unless the slot's filter of displaced keys has the window's
+//       bit (then the hit travels as HIT_RETRY and k_tile_main / k_walk_hits look it up); a
+//       group with several keys answers with a redirect to the keys' own hash: those gathers
+//       are waited for in place (rare unless many patterns share their first Q2 bytes).  A tile with more survivors
+//       than Q1 holds (dense filters: 10^5 patterns) moves the pipeline on in the middle of
+//       its compaction, a batch of 64 at a time (three batches in flight).
 //   Output: prefix hits (position, candidate code, 16 haystack bytes).  Sparse mode
 //       (SLOTS): into the hit slots of the hit's tile -- the wave is their only producer,
 //       the count is a plain store; dense mode: appended to the wave's region.  The kernel
@@ -416,20 +418,35 @@ __device__ __forceinline__ bool entry_matches(const uint4 e, uint64_t w0) {
     return (((((uint64_t)e.y << 32) | e.x) ^ w0) << sh) == 0;
 }
 
-// The candidate code of the patterns whose prefix-table key the window w0 starts with, or
-// HIT_NONE: walks the probe sequence from the home slot of the window's first Q2 bytes
-// (automaton.cpp: keys of variable length, filed under their first Q2 bytes).
-__device__ __forceinline__ uint32_t prefix_code(const uint32_t *__restrict__ ptab, uint32_t log2, uint32_t q2,
-                                                uint64_t w0) {
+// One probe sequence of the prefix table, from the home slot of the window's first `salt` bytes:
+// the code of the first FINAL entry (next = 0) whose key the window w0 starts with, or HIT_NONE.
+// redirect != null (first-level walk): a matching REDIRECT entry ends the walk with *redirect = its
+// `next` (the key length to look up instead).
+__device__ __forceinline__ uint32_t prefix_walk(const uint32_t *__restrict__ ptab, uint32_t log2, uint32_t salt,
+                                                uint64_t w0, uint32_t *redirect) {
     const uint32_t mask = (1u << log2) - 1;
-    uint32_t idx = prefix_slot(prefix_home_hash(low_bytes(w0, q2), q2), log2);
+    const uint32_t h = prefix_home_hash(low_bytes(w0, salt), salt);
+    uint32_t idx = prefix_slot(h, log2);
     for (bool home = true;; home = false) {
         const uint4 e = *(const uint4 *)(ptab + (size_t)idx * 4);
         if (e.z == PREFIX_EMPTY) return HIT_NONE;
-        if (entry_matches(e, w0)) return e.w;
-        if (home && !(e.z & PREFIX_MORE)) return HIT_NONE; // nothing that hashes here lives elsewhere
+        if (entry_matches(e, w0)) {
+            const uint32_t next = (e.z >> 4) & 15u;
+            if (!next) return e.w;
+            if (redirect) { *redirect = next; return HIT_NONE; }
+        }
+        if (home && !(e.z & prefix_more_bit(h))) return HIT_NONE; // no key with this hash lives elsewhere
         idx = (idx + 1) & mask;
     }
+}
+
+// The candidate code of the patterns whose prefix-table key the window w0 starts with, or
+// HIT_NONE (automaton.cpp: a group's single key, or a redirect to the group's keys).
+__device__ __forceinline__ uint32_t prefix_code(const uint32_t *__restrict__ ptab, uint32_t log2, uint32_t q2,
+                                                uint64_t w0) {
+    uint32_t next = 0;
+    const uint32_t code = prefix_walk(ptab, log2, q2, w0, &next);
+    return next ? prefix_walk(ptab, log2, next, w0, nullptr) : code;
 }
 
 // L3: does pattern `pid` occur at stream position p?  The first Q2 bytes are known to match
@@ -514,14 +531,23 @@ __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, S
     if (threadIdx.x == 0) GK.block_counts[blockIdx.x] = lcount;
 }
 
+__device__ __forceinline__ uint32_t lead_bytes_in_word(uint32_t w) {
+    // continuation byte: bit7 = 1 and bit6 = 0
+    uint32_t cont = w & 0x80808080u & ((~w) << 1);
+    return 4 - __popc(cont);
+}
+
 // what K1b needs of the automaton (the full struct would sit in ~50 SGPRs for the whole kernel)
 struct K1bTables {
     const uint32_t *filterA;
     const uint32_t *ptab;
     uint32_t ptab_log2, filter_q2, min_len;
+    uint8_t *cp_sub; // CP: lead (non-continuation) bytes of every 64 bytes of the stream (K3's sub counts)
 };
 
-template <int Q, bool SLOTS>
+// CP (str API, sparse mode, lead == 0): the scan also counts the UTF-8 lead bytes of every 64-byte
+// stretch it streams (the code-point fix-up then needs no second pass over the haystack).
+template <int Q, bool SLOTS, bool CP>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
@@ -619,20 +645,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         hbn += np;
         return np;
     };
-    // level 2 in place (dense tiles only): the queued survivors of `tile` are looked up with the
-    // dependent gathers waited for on the spot
-    auto settle_now = [&](uint32_t n, uint64_t tb, uint64_t tile, uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
-        const bool act = lane < n;
-        uint32_t off = 0, code = HIT_NONE;
-        uint64_t w0 = 0, w1 = 0;
-        if (act) {
-            off = q1[lane];
-            load_window16(stream, len, tb + off - lead, &w0, &w1);
-            code = prefix_code(A.ptab, ptab_log2, q2len, w0);
-        }
-        return hit_push(act && code != HIT_NONE, tb + off - lead, code, w0, w1, tile, cnt);
-    };
-
     // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
     // the stream) so that exactly five loads are in flight per prefetch: garbage
     // read for out-of-range blocks only ever feeds positions that are masked off.
@@ -669,18 +681,76 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     }
     K1B_ISSUE_TILE(gw)
 
-    // ---- level-2 pipeline (tile-synchronous, one entry per lane per stage): the survivors of
-    // tile t wait in Q1 (stage A) until the top of the wave's next iteration, where their windows
-    // are requested; one iteration later the windows are hashed and the home slots requested
-    // (stage B -> C); one iteration later the slots are compared (stage C).  No wave ever waits on
-    // these gathers: each has a whole tile of level-1 work to land.
-    // At the top of the iteration for `tile`, stage A holds tile - nw, B tile - 2 nw, C tile - 3 nw.
-    uint32_t cntA = 0, cntB = 0, cntC = 0;            // sparse mode: hits of that tile pushed so far
-    uint32_t nB = 0, nC = 0;                          // survivors in the stage
-    uint32_t kC = 0;                                  // tiles of this wave that have left stage C
+    // ---- level-2 pipeline (one entry per lane per stage).  A *batch* is up to 64 survivors of one
+    // tile.  Q1 collects the survivors of the tile under compaction (stage A); advance() moves every
+    // batch one stage on: the windows of the batch in Q1 are requested (A -> B), the windows
+    // requested by the previous advance are hashed and their home slots requested (B -> C), the
+    // slots requested by the advance before are compared and the hits pushed (C).  It runs once at
+    // the top of every iteration, with the tile's remaining survivors (its LAST batch): each gather
+    // then has a whole tile of level-1 work to land in, no wave waits.  A tile with more survivors
+    // than Q1 holds (dense filters: 10^5 patterns, multi-byte prefixes) advances the pipeline in the
+    // middle of its compaction as often as it takes: three batches are in flight, one gather
+    // latency is waited for per advance.  Batches reach stage C in tile order, the batches of one
+    // tile back to back, so ONE running count (cntC) numbers a tile's hit slots.
+    uint32_t stB = 0, stC = 0;     // stage holds: 0 nothing, 1 a batch, 2 the last batch of its tile
+    uint32_t tileB = 0, tileC = 0; // the tile of the batch (tiles < 2^32: 16 TiB of haystack)
+    uint32_t nB = 0, nC = 0;       // survivors in the batch
+    uint32_t cntC = 0;             // sparse mode: hits of tileC pushed so far
+    uint32_t kC = 0;               // tiles of this wave that have left stage C
     uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
     uint32_t offB = 0, offC = 0;
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
+    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
+        // ---- stage C: compare the slots with their windows
+        if (stC) {
+            if (nC) {
+                const bool act = lane < nC && entC.z != PREFIX_EMPTY;
+                const bool same = act && entry_matches(entC, winC);
+                uint32_t code = entC.w;
+                // a group with several keys: its home slot redirects to the keys' own hash.  These
+                // dependent gathers are waited for in place (rare unless many patterns share their
+                // first Q2 bytes; the other waves of the SIMD cover them)
+                const uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
+                if (next) code = prefix_walk(A.ptab, ptab_log2, next, winC, nullptr);
+                // a home slot holding another key proves absence unless the slot's filter of
+                // displaced keys has the window's bit: then the hit travels as HIT_RETRY and
+                // k_tile_main / k_walk_hits look the window up (no dependent gathers here: walking
+                // the probe sequence in place was measured at +15 % of the kernel on the headline set)
+                const bool retry = act && !same && (entC.z & prefix_more_bit(gram_hash2(winC & q2mask) + q2salt));
+                cntC += hit_push((same && code != HIT_NONE) || retry, (uint64_t)tileC * tile_bytes + offC - lead,
+                                 same ? code : HIT_RETRY, winC, winC1, tileC, cntC);
+            }
+            if (stC == 2) { // the tile is complete
+                if (SLOTS) { // its count: through LDS, 16 tiles of the wave per store
+                    if (lane == 0) L.cb[wave][kC & 15] = cntC < HIT_SLOTS ? cntC : HIT_SLOTS;
+                    if ((kC & 15) == 15) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kC - 15) + lane] = L.cb[wave][lane];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    kC++;
+                }
+                cntC = 0;
+            }
+        }
+        // ---- stage B -> C: hash the windows, fetch their home slots
+        if (nB) {
+            if (lane < nB)
+                entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winB & q2mask) + q2salt, ptab_log2) * 4);
+            offC = offB; winC = winB; winC1 = winB1;
+        }
+        nC = nB; stC = stB; tileC = tileB;
+        // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
+        if (q1c) {
+            if (lane < q1c) {
+                offB = q1[lane];
+                load_window16(stream, len, (uint64_t)tileQ * tile_bytes + offB - lead, &winB, &winB1);
+            }
+        }
+        nB = q1c; stB = stQ; tileB = tileQ;
+        q1c = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
 
     // three extra iterations drain the pipeline
     for (uint64_t tile = gw; tile < ntiles + 3 * nw; tile += nw) {
@@ -690,45 +760,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
         uint2 vL = nxtL;
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
-        // ---- stage C: compare the slots fetched one tile ago with their windows
-        if (tile >= gw + 3 * nw) {
-            const uint64_t tileC = tile - 3 * nw;
-            if (nC) {
-                const bool act = lane < nC && entC.z != PREFIX_EMPTY;
-                const bool same = entry_matches(entC, winC);
-                // a home slot holding another key proves absence unless PREFIX_MORE is set (then
-                // k_tile_main / k_walk_hits look the window up: no dependent gathers here)
-                const bool found = act && (same || (entC.z & PREFIX_MORE));
-                cntC += hit_push(found, tileC * tile_bytes + offC - lead, same ? entC.w : HIT_RETRY, winC, winC1,
-                                 tileC, cntC);
-            }
-            if (SLOTS) { // the tile's count: through LDS, 16 tiles of the wave per store
-                if (lane == 0) L.cb[wave][kC & 15] = cntC < HIT_SLOTS ? cntC : HIT_SLOTS;
-                if ((kC & 15) == 15) {
-                    __builtin_amdgcn_wave_barrier();
-                    if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kC - 15) + lane] = L.cb[wave][lane];
-                    __builtin_amdgcn_wave_barrier();
-                }
-                kC++;
-            }
-        }
-        // ---- stage B -> C: hash the windows fetched one tile ago, fetch their home slots
-        if (nB) {
-            if (lane < nB)
-                entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winB & q2mask) + q2salt, ptab_log2) * 4);
-            offC = offB; winC = winB; winC1 = winB1;
-        }
-        nC = nB; cntC = cntB;
-        // ---- stage A -> B: fetch the 16-byte windows of the previous tile's survivors
-        if (q1c) {
-            if (lane < q1c) {
-                offB = q1[lane];
-                load_window16(stream, len, (tile - nw) * tile_bytes + offB - lead, &winB, &winB1);
-            }
-        }
-        nB = q1c; cntB = cntA;
-        q1c = 0; cntA = 0;
-        __builtin_amdgcn_wave_barrier();
+        // the previous tile's remaining survivors: its last batch (possibly empty)
+        advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
         if (tile >= ntiles) continue;
 
         // ---- level 1 on this tile
@@ -782,23 +815,39 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
         K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
         K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+        if (CP) { // lead bytes of the lane's 16 bytes of every row, summed over the 4 lanes of a 64-byte stretch
+#define K1B_LEADS(RI, VR)                                                                        \
+            {                                                                                    \
+                uint32_t c_ = lead_bytes_in_word(VR.x) + lead_bytes_in_word(VR.y) +              \
+                              lead_bytes_in_word(VR.z) + lead_bytes_in_word(VR.w);               \
+                if (!interior) { /* bytes beyond the end of the stream do not count */            \
+                    const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;              \
+                    if (p0_ + 16 > total) {                                                      \
+                        const uint32_t w_[4] = {VR.x, VR.y, VR.z, VR.w};                         \
+                        c_ = 0;                                                                  \
+                        for (uint32_t k_ = 0; k_ < 16; k_++)                                     \
+                            if (p0_ + k_ < total && ((w_[k_ >> 2] >> (8 * (k_ & 3))) & 0xC0) != 0x80) c_++; \
+                    }                                                                            \
+                }                                                                                \
+                c_ += __shfl_xor(c_, 1);                                                         \
+                c_ += __shfl_xor(c_, 2);                                                         \
+                if ((lane & 3) == 0) A.cp_sub[(tile * 4 + (RI)) * 16 + (lane >> 2)] = (uint8_t)c_; \
+            }
+            K1B_LEADS(0, v0) K1B_LEADS(1, v1) K1B_LEADS(2, v2) K1B_LEADS(3, v3)
+#undef K1B_LEADS
+        }
         // Prefetch of the wave's next tile, issued LATE: the compaction below, level 2 at the top
         // of the next iteration and the three other waves of the SIMD cover its latency.  Measured
         // (round 1, T): issued before row 0: 310 us; after row 1: 299; after row 2: 293; here: 291;
         // no prefetch at all (loads at the top of the tile's own iteration): 308.
         K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
-        cntA = 0; // sparse mode: hits of THIS tile pushed by the full rounds below
         uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
         while (true) {
             unsigned long long act = __ballot((mlo | mhi) != 0);
             if (!act) break;
             uint32_t np = __popcll(act);
-            if (q1c + np > K1B_Q1CAP) { // dense survivors: settle what is queued now, in place
-                cntA += settle_now(q1c, tbase, tile, cntA);
-                q1c = 0;
-                __builtin_amdgcn_wave_barrier();
-            }
+            if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u); // dense survivors: a full batch moves on now
             if (mlo | mhi) {
                 uint32_t pos;
                 if (mlo) { pos = __builtin_ctz(mlo); mlo &= mlo - 1; }
@@ -852,18 +901,22 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
 
 // K.hslots != null: sparse mode (hit slots + counts); else region mode (per-wave regions)
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
-                            uint32_t grid, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop) {
+                            uint32_t grid, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
+                            uint8_t *cp_sub) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
-    const K1bTables T{A.filterA, A.ptab, A.ptab_log2, A.filter_q2, A.min_len};
+    const K1bTables T{A.filterA, A.ptab, A.ptab_log2, A.filter_q2, A.min_len, cp_sub};
+    if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
 #define ACX_K1B(Q)                                                                                         \
-    if (K.hslots)                                                                                          \
-        hipExtLaunchKernelGGL((k1b_prefilter<Q, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
+    if (cp_sub)                                                                                            \
+        hipExtLaunchKernelGGL((k1b_prefilter<Q, true, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
+    else if (K.hslots)                                                                                     \
+        hipExtLaunchKernelGGL((k1b_prefilter<Q, true, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
     else                                                                                                   \
-        hipExtLaunchKernelGGL((k1b_prefilter<Q, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
+        hipExtLaunchKernelGGL((k1b_prefilter<Q, false, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
     switch (A.filter_q) {
     case 1: ACX_K1B(1); break;
     case 2: ACX_K1B(2); break;
@@ -1557,15 +1610,9 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // ---------------------------------------------------------------------------
 // K3: UTF-8 code-point indexes
 // ---------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t lead_bytes_in_word(uint32_t w) {
-    // continuation byte: bit7 = 1 and bit6 = 0
-    uint32_t cont = w & 0x80808080u & ((~w) << 1);
-    return 4 - __popc(cont);
-}
-
-// one wave per 1 KiB block
+// one wave per 1 KiB block: cnt[blk] = its lead bytes, sub[blk * 16 + q] = those of its q-th 64 bytes
 __global__ __launch_bounds__(256) void k_count_leads(const uint8_t *__restrict__ hay,
-                                                     uint64_t len, uint64_t *cnt,
+                                                     uint64_t len, uint64_t *cnt, uint8_t *sub,
                                                      uint64_t nblocks) {
     uint64_t blk = (uint64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
     uint32_t lane = threadIdx.x & 63;
@@ -1581,15 +1628,37 @@ __global__ __launch_bounds__(256) void k_count_leads(const uint8_t *__restrict__
         for (uint32_t k = 0; k < 16; k++)
             if (base + k < len && (hay[base + k] & 0xC0) != 0x80) c++;
     }
+    uint32_t q = c + __shfl_xor(c, 1);
+    q += __shfl_xor(q, 2); // the four lanes of a 64-byte stretch
+    if ((lane & 3) == 0) sub[blk * 16 + (lane >> 2)] = (uint8_t)q;
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if (lane == 0) cnt[blk] = c;
 }
 
-hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt, hipStream_t st) {
+hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt, uint8_t *sub, hipStream_t st) {
     uint64_t nblocks = (len + 1023) / 1024;
     uint64_t waves = nblocks + 1;
     hipLaunchKernelGGL(k_count_leads, dim3((uint32_t)((waves + 3) / 4)), dim3(256), 0, st, d_hay,
-                       len, cnt, nblocks);
+                       len, cnt, sub, nblocks);
+    return hipGetLastError();
+}
+
+// cnt[blk] = the sum of the block's 16 sub counts (blk < nblocks), cnt[nblocks] = 0: the block
+// totals when K1b has already counted the 64-byte stretches (no second pass over the haystack)
+__global__ void k_block_totals(const uint8_t *__restrict__ sub, uint64_t *cnt, uint64_t nblocks) {
+    const uint64_t blk = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (blk > nblocks) return;
+    uint32_t acc = 0;
+    if (blk < nblocks) {
+        const uint4 v = *(const uint4 *)(sub + blk * 16);
+        acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
+        acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+    }
+    cnt[blk] = acc;
+}
+
+hipError_t block_totals(const uint8_t *sub, uint64_t *cnt, uint64_t nblocks, hipStream_t st) {
+    hipLaunchKernelGGL(k_block_totals, dim3((uint32_t)((nblocks + 256) / 256)), dim3(256), 0, st, sub, cnt, nblocks);
     return hipGetLastError();
 }
 
@@ -1599,42 +1668,60 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
                                    rocprim::plus<uint64_t>(), st);
 }
 
-// non-continuation (lead) bytes in [p, end): bytes up to an 8-byte boundary, then words
+// non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
+// range masked off (an aligned word never leaves the page its first / last byte of the range is
+// in, so the words at the two ends are safe to read in full) -- no byte loops
 __device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const uint8_t *end) {
+    if (p >= end) return 0;
+    const uint64_t HI = 0x8080808080808080ull;
+    const uint8_t *q = (const uint8_t *)((uintptr_t)p & ~(uintptr_t)7);
+    uint64_t valid = ~0ull << (8 * ((uintptr_t)p & 7)); // bytes of the first word at or after p
     uint64_t c = 0;
-    while (p < end && ((uintptr_t)p & 7)) { c += (*p & 0xC0) != 0x80; p++; }
-    for (; p + 8 <= end; p += 8) {
-        const uint64_t w = *(const uint64_t *)p;
-        c += 8 - __popcll(w & 0x8080808080808080ull & ((~w) << 1)); // continuation: bit7 = 1, bit6 = 0
+    for (; q < end; q += 8, valid = ~0ull) {
+        if (end - q < 8) valid &= ~0ull >> (8 * (8 - (end - q))); // bytes of the last word before end
+        const uint64_t w = *(const uint64_t *)q;
+        const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
+        c += __popcll(valid & HI) - __popcll(cont & valid);
     }
-    for (; p < end; p++) c += (*p & 0xC0) != 0x80;
     return c;
 }
 
-// code-point index of byte offset x = number of non-continuation bytes in [0, x)
-__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay,
-                                                  const uint64_t *blockpre, uint64_t x) {
+// code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of
+// its 1 KiB block + the counts of the whole 64-byte stretches before it inside the block (ONE
+// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place
+__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
+                                                  const uint8_t *__restrict__ sub, uint64_t x) {
     const uint64_t blk = x >> 10;
-    return blockpre[blk] + lead_bytes_between(hay + (blk << 10), hay + x);
+    const uint32_t q = (uint32_t)(x & 1023) >> 6; // whole 64-byte stretches before x
+    const uint4 sv = *(const uint4 *)(sub + blk * 16);
+    const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; d++) {
+        const uint32_t nb = q > 4 * d ? (q - 4 * d < 4 ? q - 4 * d : 4) : 0;
+        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
+        acc = __builtin_amdgcn_sad_u8(w[d] & m, 0u, acc);
+    }
+    return blockpre[blk] + acc + lead_bytes_between(hay + (x & ~63ull), hay + x);
 }
 
 // one thread per match: the start from its 1 KiB block's prefix, the end from the start
 __global__ void k_to_code_points(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
-                                 acx_match_t *m, uint64_t n) {
+                                 const uint8_t *__restrict__ sub, acx_match_t *m, uint64_t n) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t s = m[i].start, e = m[i].end;
-    const uint64_t cs = code_point_of(hay, blockpre, s);
+    const uint64_t cs = code_point_of(hay, blockpre, sub, s);
     m[i].start = cs;
     m[i].end = cs + lead_bytes_between(hay + s, hay + e);
 }
 
-hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre,
+hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre, const uint8_t *sub,
                           acx_match_t *m, uint64_t n, hipStream_t st) {
     (void)len;
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_to_code_points, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st,
-                       d_hay, blockpre, m, n);
+                       d_hay, blockpre, sub, m, n);
     return hipGetLastError();
 }
 
@@ -1642,8 +1729,8 @@ hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *bl
 // batch: local offsets + per-haystack counts
 // ---------------------------------------------------------------------------
 __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t len,
-                           const uint64_t *blockpre, int codepoints, acx_match_t *m,
-                           uint64_t n, uint64_t *counts) {
+                           const uint64_t *blockpre, const uint8_t *__restrict__ sub, int codepoints,
+                           acx_match_t *m, uint64_t n, uint64_t *counts) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     uint64_t s = m[i].start, e = m[i].end;
@@ -1652,7 +1739,7 @@ __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t
     else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; base = G.offsets[h]; }
     (void)len;
     if (codepoints) {
-        const uint64_t cs = code_point_of(hay, blockpre, s) - code_point_of(hay, blockpre, base);
+        const uint64_t cs = code_point_of(hay, blockpre, sub, s) - code_point_of(hay, blockpre, sub, base);
         m[i].start = cs;
         m[i].end = cs + lead_bytes_between(hay + s, hay + e);
     } else {
@@ -1663,11 +1750,11 @@ __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t
 }
 
 hipError_t localize(const Segments &G, const uint8_t *d_hay, uint64_t len,
-                    const uint64_t *blockpre, int codepoints, acx_match_t *m, uint64_t n,
+                    const uint64_t *blockpre, const uint8_t *sub, int codepoints, acx_match_t *m, uint64_t n,
                     uint64_t *counts, hipStream_t st) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(k_localize, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, G, d_hay,
-                       len, blockpre, codepoints, m, n, counts);
+                       len, blockpre, sub, codepoints, m, n, counts);
     return hipGetLastError();
 }
 

@@ -25,9 +25,12 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
 uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len); // 4 KiB tiles of the aligned index space
 uint32_t prefilter_hit_regions(uint32_t grid);
+// cp_sub != null (sparse mode, 16-byte aligned d_hay only): the scan also writes the lead-byte
+// counts of every 64 bytes it streams (16 per 1 KiB block; 4 KiB-tile granularity: the array
+// holds 64 * prefilter_tiles() bytes) -- block_totals() then replaces count_lead_bytes()
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
                             uint32_t grid, hipStream_t st, hipEvent_t ev_start = nullptr,
-                            hipEvent_t ev_stop = nullptr);
+                            hipEvent_t ev_stop = nullptr, uint8_t *cp_sub = nullptr);
 // sink bookkeeping (dense path): summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,
@@ -90,19 +93,21 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
                          uint64_t n, hipStream_t st);
 
 // ---- UTF-8 code-point fix-up (reference: get_byte_to_code_point)
-// lead-byte count of every 1 KiB block -> cnt[nblocks + 1] (last = 0)
-hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt,
+// lead-byte count of every 1 KiB block -> cnt[nblocks + 1] (last = 0), of every 64 bytes of a
+// block -> sub[16 * nblocks]
+hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt, uint8_t *sub,
                             hipStream_t st);
+hipError_t block_totals(const uint8_t *sub, uint64_t *cnt, uint64_t nblocks, hipStream_t st);
 hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uint64_t *out,
                           uint64_t n, hipStream_t st);
-hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre,
+hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre, const uint8_t *sub,
                           acx_match_t *m, uint64_t n, hipStream_t st);
 
 // ---- batch: make offsets local to each haystack, count matches per haystack.
 // base_cp != nullptr: subtract the code-point index of the haystack start
 // (computed from blockpre) instead of the byte offset.
 hipError_t localize(const Segments &G, const uint8_t *d_hay, uint64_t len,
-                    const uint64_t *blockpre, int codepoints, acx_match_t *m, uint64_t n,
+                    const uint64_t *blockpre, const uint8_t *sub, int codepoints, acx_match_t *m, uint64_t n,
                     uint64_t *counts, hipStream_t st);
 
 // ---- synthetic haystacks

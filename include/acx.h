@@ -131,13 +131,14 @@ typedef struct acx_host_tables {
     const uint32_t *filter_xy;    /* K1b level 1: 2^filter_entries_log2 x {X, Y} signature words
                                      (bit layout: csrc/automaton.hpp, filter_bit)      */
     const uint32_t *prefix_table; /* K1b level 2: 2^prefix_table_log2 x {key lo, key hi, meta, code}:
-                                     meta = key length K (1..8) | MORE << 31 (0xFFFFFFFF = empty; MORE:
-                                     another key with this home slot sits further along the probe
-                                     sequence); code = the only pattern with this key, or
-                                     0x80000000 | index into prefix_lists.  A key = the first
-                                     min(8, shortest pattern of its group) bytes of a pattern, a group =
-                                     the patterns sharing their first filter_q2 bytes; keys are filed
-                                     under the hash of those filter_q2 bytes (csrc/automaton.cpp)     */
+                                     meta = key length K (1..8) | next << 4 | MORE << 8 (0xFFFFFFFF =
+                                     empty; MORE: 16-bit filter of the keys with this home slot that sit
+                                     further along the probe sequence: bit ((hash >> 11) & 15) of each).  next = 0: code = the only pattern with this key, or
+                                     0x80000000 | index into prefix_lists; next = N: redirect -- look the
+                                     first N bytes up.  A key = the first min(8, shortest pattern of its
+                                     group) bytes of a pattern, a group = the patterns sharing their
+                                     first filter_q2 bytes; a group's single key sits at the hash of those
+                                     bytes, several keys behind a redirect entry (csrc/automaton.cpp)   */
     const uint32_t *prefix_lists; /* {count, pattern id, ...} per key shared by several patterns   */
     uint32_t filter_q, filter_q2; /* prefix lengths used by level 1 / level 2 (first-level keys)   */
     uint32_t filter_entries_log2, prefix_table_log2;
@@ -149,8 +150,8 @@ int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_pa
                      int match_kind, acx_host_automaton_t **out);
 int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
 uint32_t acx_filter_hash(uint32_t gram);   /* level-1 hash of a little-endian (Q-1)-gram   */
-uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2); /* home slot of the keys that start with
-                                                                       the q2 low bytes of gram */
+uint32_t acx_prefix_slot(uint64_t gram, uint32_t salt, uint32_t log2); /* home slot of the `salt` low
+                                                                         bytes of gram */
 void acx_free_host(acx_host_automaton_t *h);
 
 /* ---- concurrency: every function taking an acx_automaton_t may be called from several

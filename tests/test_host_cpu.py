@@ -82,22 +82,39 @@ def test_compiler_matches_survey_sizes():
     h.close()
 
 
-def prefix_candidates(h, lg, q2, window: bytes):
-    """Python twin of the kernels' prefix_code + candidate list: walks the probe sequence from the
-    home slot of window[:q2]; an entry matches when the window starts with its key (K bytes).  A
-    home slot holding another key ends the search unless its MORE bit is set.  -> pattern ids."""
-    idx, home = capi.prefix_slot(window, q2, lg), True
+def prefix_walk(h, lg, salt, window: bytes, allow_redirect: bool):
+    """Python twin of the kernels' prefix_walk: one probe sequence from the home slot of
+    window[:salt]; an entry matches when the window starts with its key (K bytes).  A home slot
+    holding another key ends the search unless its MORE bit is set.  -> ("code", code),
+    ("redirect", N) or None."""
+    idx, home = capi.prefix_slot(window, salt, lg), True
+    mine = 1 << (8 + ((capi.prefix_hash(window, salt) >> 11) & 15))
     while True:
         lo, hi, meta, code = (int(x) for x in h.prefix_table[idx])
         if meta == 0xFFFFFFFF:
-            return []
-        K = meta & 15
+            return None
+        K, nxt = meta & 15, (meta >> 4) & 15
         if (hi << 32 | lo) == int.from_bytes(window[:K], "little"):
-            break
-        if home and not (meta >> 31):
-            return []
+            if not nxt:
+                return ("code", code)
+            if allow_redirect:
+                return ("redirect", nxt)
+        if home and not (meta & mine):
+            return None
         home = False
         idx = (idx + 1) & ((1 << lg) - 1)
+
+
+def prefix_candidates(h, lg, q2, window: bytes):
+    """Python twin of prefix_code + the candidate list: the pattern ids K1b hands on for a
+    haystack window (>= 8 bytes, zero padded)."""
+    got = prefix_walk(h, lg, q2, window, True)
+    if got and got[0] == "redirect":
+        assert got[1] > q2
+        got = prefix_walk(h, lg, got[1], window, False)
+    if not got:
+        return []
+    code = got[1]
     if code & 0x80000000:
         i = code & 0x7FFFFFFF
         cnt = int(h.prefix_lists[i])
@@ -146,20 +163,31 @@ def test_prefilter_tables_have_every_pattern_prefix():
                 klen = min(len(pats[c]), 8)
                 group = [o for o in pats if o[:q2] == pats[c][:q2]]
                 assert bytes(w[:min(klen, min(min(len(o) for o in group), 8))]) == pats[c][:min(klen, min(min(len(o) for o in group), 8))]
-        # MORE (bit 31 of the meta word) is set on a home slot iff some key hashing there lives elsewhere
+        # the MORE filter (bits 23:8 of the meta word) of a home slot holds exactly the bits of the keys
+        # that hash there and live elsewhere; redirect entries and single keys sit at the hash of
+        # their first Q2 bytes, the keys behind a redirect at the hash of their own bytes
         tab = np.asarray(h.prefix_table)
         used = np.nonzero(tab[:, 2] != 0xFFFFFFFF)[0]
         assert len(used) == int(h.t.n_prefix_keys) <= 0.25 * (1 << lg) + 1
-        displaced_homes = set()
+        keys_of = {}
+        for p_ in pats:
+            g_ = [o for o in pats if o[:q2] == p_[:q2]]
+            keys_of.setdefault(p_[:q2], set()).add(p_[:min(8, min(len(o) for o in g_))])
+        want_more = {}
         for e in used:
-            K = int(tab[e, 2]) & 15
+            K, nxt = int(tab[e, 2]) & 15, (int(tab[e, 2]) >> 4) & 15
             assert q2 <= K <= 8
             gram = (int(tab[e, 1]) << 32 | int(tab[e, 0])).to_bytes(8, "little")[:K]
-            home = capi.prefix_slot(gram, q2, lg)
+            multi = len(keys_of[gram[:q2]]) > 1
+            assert bool(nxt) == (multi and gram not in keys_of[gram[:q2]]) or (nxt and K == q2)
+            salt = q2 if (nxt or not multi) else K
+            home = capi.prefix_slot(gram, salt, lg)
             if home != e:
-                displaced_homes.add(home)
+                want_more[home] = want_more.get(home, 0) | 1 << (8 + ((capi.prefix_hash(gram, salt) >> 11) & 15))
+            if nxt:
+                assert home == e  # redirect entries are placed first: always in their home slot
         for e in used:
-            assert bool(int(tab[e, 2]) >> 31) == (int(e) in displaced_homes)
+            assert int(tab[e, 2]) & 0x00FFFF00 == want_more.get(int(e), 0)
         assert 0 < h.t.filter_density <= 3 * len(pats) / (32 << 14)
         h.close()
 

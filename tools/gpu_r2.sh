@@ -28,9 +28,11 @@ fi
 if [ "$WHAT" = trace ] || [ "$WHAT" = all ]; then
   cd /tmp
   rm -rf $OUT/trace_T
-  timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline > $OUT/trace_T.log 2>&1
+  TAG=${TRACE_TAG:-T}
+  rm -rf $OUT/trace_$TAG
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$TAG -o bench -- python /root/repo/bench.py --steps ${TRACE_STEPS:-10} --warmup 3 --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/trace_$TAG.log 2>&1
   cd /root/repo
-  python tools/rocprof_summary.py $OUT/trace_T 2>/dev/null | head -14
+  python tools/rocprof_summary.py $OUT/trace_$TAG 2>/dev/null | head -16
 fi
 if [ "$WHAT" = pmc ]; then
   cd /tmp
@@ -53,4 +55,17 @@ for k, v in agg.items():
     if k.startswith(("k1b", "k_tile", "k1a", "k_walk")):
         print(k, {c: round(sum(x) / len(x)) for c, x in sorted(v.items())})
 PY
+fi
+if [ "$WHAT" = cfgs ]; then
+  for cfg in cfg4 cfg4b cfg5 cfg3; do
+    timeout 600 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --config $cfg ${BENCH_ARGS:-} > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_$cfg.json")); c = d["config"]; r = d["roofline"]
+    print("$cfg", d["value"], "GB/s", d["ms_per_step"], "ms/step K1", r["kernel_ms"], "ms", r["kernel"], "matches", c["matches_total"], "hits", c["prefix_hits_per_step"], "occ", c["raw_occurrences_per_step"])
+except Exception as e:
+    print("$cfg failed", e); print(open("$OUT/bench_$cfg.err").read()[-1500:])
+PY
+  done
 fi
