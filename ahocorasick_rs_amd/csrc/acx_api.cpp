@@ -1129,6 +1129,10 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.n_patterns = H.n_patterns; D.n_states = H.n_states; D.stride2 = H.stride2;
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
     D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
+    {
+        static const char *big_env = std::getenv("ACX_FILTER_BIG"); // measurements: 0 / 1 force the choice
+        D.filter_big = big_env ? (uint32_t)std::atoi(big_env) : (H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
+    }
     D.rank_bits = (uint32_t)std::max(1, bits_for(H.n_patterns ? H.n_patterns - 1 : 0));
     // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile
     uint32_t hot_rows = dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024);
@@ -1138,11 +1142,40 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         hot16[i] = id < 0x3FFFu ? (uint16_t)(id | ((en >> 30) << 14)) : (uint16_t)0xFFFF;
     }
     D.hot_rows = hot_rows;
+    // K1a's compact table (automata of at most 65 535 states): see DevAutomaton::table16
+    std::vector<uint16_t> table16;
+    std::vector<uint32_t> walk_bfs;
+    D.n_classes = H.n_classes;
+    D.walk_plain = 0;
+    if (H.n_states <= 0xFFFF && H.n_patterns > 0) {
+        const uint32_t NS = H.n_states, NC = H.n_classes, S = H.stride;
+        std::vector<uint8_t> reports(NS, 0); // FLAG_OUT is a property of the TARGET state
+        for (size_t i = 0; i < (size_t)NS * S; i++)
+            if (H.table[i] & FLAG_OUT) reports[H.table[i] & ID_MASK] = 1;
+        std::vector<uint32_t> walk_of(NS);
+        walk_bfs.resize(NS);
+        uint32_t k = 0;
+        for (int pass = 0; pass < 2; pass++) {
+            for (uint32_t s = 0; s < NS; s++)
+                if (reports[s] == pass) { walk_of[s] = k; walk_bfs[k] = s; k++; }
+            if (pass == 0) D.walk_plain = k;
+        }
+        table16.assign((size_t)NS * NC + 8, 0);
+        for (uint32_t w = 0; w < NS; w++)
+            for (uint32_t c = 0; c < NC; c++)
+                table16[(size_t)w * NC + c] = (uint16_t)walk_of[H.table[(size_t)walk_bfs[w] * S + c] & ID_MASK];
+    }
     int rc;
 #define UP(vec, field)                                                                   \
     if ((rc = upload(a, st, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
     UP(H.table, table)
     UP(hot16, hot16)
+    if (!table16.empty()) {
+        UP(table16, table16)
+        UP(walk_bfs, walk_bfs)
+    } else {
+        D.table16 = nullptr; D.walk_bfs = nullptr;
+    }
     UP(H.own_off, own_off)
     UP(H.own_pid, own_pid)
     UP(H.own1, own1)

@@ -33,6 +33,15 @@ struct DevAutomaton {
     uint32_t filter_q2;          // level-2/3 prefix length, .. 8
     uint32_t rank_bits;          // bits of the tie-break field of an occurrence key
     uint32_t ptab_log2;
+    uint32_t filter_big;         // the level-1 table is saturated: K1b puts every position to both tests
+    // K1a, automata of at most 65 535 states: the whole DFA as u16, rows of n_classes entries
+    // (no padding: 63 277 states x 28 classes x 2 B = 3.4 MiB fits one XCD's 4 MiB L2), in an
+    // order of its own: states that report nothing first (BFS order), the reporting ones after
+    // them -- "target >= walk_plain" is the whole output test.  The first rows are K1a's LDS tile.
+    const uint16_t *table16;     // n_states * n_classes (null: the automaton is too large)
+    const uint32_t *walk_bfs;    // walk order id -> BFS id (the emit path works in BFS ids)
+    uint32_t n_classes;
+    uint32_t walk_plain;         // states that report nothing
 };
 
 // How the byte stream is cut into haystacks.

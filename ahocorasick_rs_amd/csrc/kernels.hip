@@ -27,6 +27,8 @@
 // This is integer, HBM-bound work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -281,6 +283,140 @@ __global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, const DevAu
     if (threadIdx.x == 0 && GK.block_counts) GK.block_counts[blockIdx.x] = *lcount;
 }
 
+// ---------------------------------------------------------------------------
+// K1a, compact form (automata of at most 65 535 states, one haystack): the DFA as u16 with rows
+// of n_classes entries -- 3.4 MiB for the headline automaton: it stays in one XCD's L2 -- and
+// NCH independent chains per lane: a lane walks NCH adjacent chunks in lock step, so NCH dependent
+// lookups are in flight per lane instead of one.  Every chain starts from the root `warm` (>=
+// max_len - 1, a multiple of 16) bytes before its chunk and reports the matches that END inside the
+// chunk.  The haystack is read as aligned 16-byte blocks of the index space (index = position +
+// lead).  LDS: class map + the first rows of the table (walk order: states that report nothing
+// first, shallow ones first among them).
+constexpr int K1A_CHAINS = 4;
+__global__ __launch_bounds__(1024) void k1a_walk16(DevAutomaton A, const DevAutomaton *Ad, Sink GK,
+                                                   const uint8_t *__restrict__ base, uint64_t total,
+                                                   uint32_t lead, uint32_t chunk, uint32_t warm,
+                                                   uint32_t lds_rows, unsigned long long *lds_hits) {
+    constexpr int NCH = K1A_CHAINS;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *lcls = smem;
+    uint32_t *lcount = (uint32_t *)(smem + 256);
+    uint16_t *lrows = (uint16_t *)(smem + K1A_LDS_HEADER);
+    if (threadIdx.x == 0) *lcount = 0;
+    const BlockSink K = block_sink(GK, lcount);
+    const uint32_t NC = A.n_classes, plain = A.walk_plain;
+    for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) ((uint32_t *)lcls)[i] = ((const uint32_t *)A.classes)[i];
+    {
+        const uint32_t nwords = (lds_rows * NC + 1) >> 1; // table16 is padded
+        const uint32_t *src = (const uint32_t *)A.table16;
+        uint32_t *dst = (uint32_t *)lrows;
+        for (uint32_t i = threadIdx.x; i < nwords; i += blockDim.x) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint64_t nchunks = (total + chunk - 1) / chunk, ngroups = (nchunks + NCH - 1) / NCH;
+    const uint64_t total16 = (total + 15) & ~15ull;
+    uint32_t hot = 0, all = 0; // statistics: transitions served by LDS / all (lds_hits != null)
+    // (scalar variables, not arrays: the chains must live in registers)
+    // a lane reads its chains in 32-byte pieces (two quads): with 16-byte pieces every 64-byte
+    // line was fetched four times -- 4096 chains per CU keep 256 KiB of partly consumed lines
+    // alive, more than L1 and the XCD's share of L2 hold (measured: 5.5 GB fetched per GiB)
+#define K1A_LOAD(k, BLK, BLK2)                                                                  \
+    {                                                                                           \
+        const int64_t idx_ = first + (int64_t)(k) * chunk + i;                                  \
+        BLK = u32x4{0, 0, 0, 0}; BLK2 = u32x4{0, 0, 0, 0};                                      \
+        if (idx_ >= 0 && (uint64_t)idx_ < total16) BLK = *(const u32x4 *)(base + idx_);         \
+        if (idx_ + 16 >= 0 && (uint64_t)(idx_ + 16) < total16) BLK2 = *(const u32x4 *)(base + idx_ + 16); \
+    }
+#define K1A_BYTE(BLK, j) ((((j) < 4 ? BLK.x : (j) < 8 ? BLK.y : (j) < 12 ? BLK.z : BLK.w) >> (8 * ((j) & 3))) & 0xFF)
+    // one byte of one chain, everything checked (blocks that touch the ends of the stream)
+#define K1A_STEP(k, BLK, S, j)                                                                  \
+    {                                                                                           \
+        const int64_t idx_ = first + (int64_t)(k) * chunk + i + (j);                            \
+        if (idx_ >= (int64_t)lead && (uint64_t)idx_ < total) { /* outside the stream the chain rests */ \
+            const uint32_t e_ = S * NC + lcls[K1A_BYTE(BLK, j)];                                \
+            uint32_t t_;                                                                        \
+            if (S < lds_rows) { t_ = lrows[e_]; hot++; }                                        \
+            else t_ = A.table16[e_];                                                            \
+            all++;                                                                              \
+            S = t_;                                                                             \
+            if (emit && t_ >= plain) emit_state(Ad, K, A.walk_bfs[t_], (uint64_t)idx_ + 1 - lead); \
+        }                                                                                       \
+    }
+    // one byte of ALL chains (blocks inside the stream): the four class reads, then the four row
+    // reads (LDS for hot states, an exec-masked gather of the L2-resident table for cold ones) are
+    // issued back to back -- four dependent chains in flight per lane, not one
+#define K1A_STEP4(j)                                                                            \
+    {                                                                                           \
+        const uint32_t c0_ = lcls[K1A_BYTE(b0, j)], c1_ = lcls[K1A_BYTE(b1, j)];                \
+        const uint32_t c2_ = lcls[K1A_BYTE(b2, j)], c3_ = lcls[K1A_BYTE(b3, j)];                \
+        const uint32_t e0_ = s0 * NC + c0_, e1_ = s1 * NC + c1_, e2_ = s2 * NC + c2_, e3_ = s3 * NC + c3_; \
+        const bool h0_ = s0 < lds_rows, h1_ = s1 < lds_rows, h2_ = s2 < lds_rows, h3_ = s3 < lds_rows; \
+        const uint32_t l0_ = lrows[h0_ ? e0_ : 0], l1_ = lrows[h1_ ? e1_ : 0];                  \
+        const uint32_t l2_ = lrows[h2_ ? e2_ : 0], l3_ = lrows[h3_ ? e3_ : 0];                  \
+        uint32_t g0_ = 0, g1_ = 0, g2_ = 0, g3_ = 0;                                            \
+        if (!h0_) g0_ = A.table16[e0_];                                                         \
+        if (!h1_) g1_ = A.table16[e1_];                                                         \
+        if (!h2_) g2_ = A.table16[e2_];                                                         \
+        if (!h3_) g3_ = A.table16[e3_];                                                         \
+        s0 = h0_ ? l0_ : g0_; s1 = h1_ ? l1_ : g1_; s2 = h2_ ? l2_ : g2_; s3 = h3_ ? l3_ : g3_; \
+        hot += (uint32_t)h0_ + h1_ + h2_ + h3_; all += 4;                                       \
+        if (emit && (s0 >= plain || s1 >= plain || s2 >= plain || s3 >= plain)) {               \
+            const uint64_t p_ = (uint64_t)(first + i + (j)) + 1 - lead;                         \
+            if (s0 >= plain) emit_state(Ad, K, A.walk_bfs[s0], p_);                             \
+            if (s1 >= plain) emit_state(Ad, K, A.walk_bfs[s1], p_ + chunk);                     \
+            if (s2 >= plain) emit_state(Ad, K, A.walk_bfs[s2], p_ + 2ull * chunk);              \
+            if (s3 >= plain) emit_state(Ad, K, A.walk_bfs[s3], p_ + 3ull * chunk);              \
+        }                                                                                       \
+    }
+    for (uint64_t g = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; g < ngroups; g += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+        const int64_t first = (int64_t)(g * NCH * chunk) - (int64_t)warm; // index of chain 0's first byte
+        for (uint32_t i0 = 0; i0 < warm + chunk; i0 += 32) {
+            u32x4 b0, b1, b2, b3, n0, n1, n2, n3;
+            uint32_t i = i0;
+            K1A_LOAD(0, b0, n0) K1A_LOAD(1, b1, n1) K1A_LOAD(2, b2, n2) K1A_LOAD(3, b3, n3)
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if (half) { i = i0 + 16; b0 = n0; b1 = n1; b2 = n2; b3 = n3; }
+                if (i >= warm + chunk) break; // (the walk length is a multiple of 16, not of 32)
+                const bool emit = i >= warm; // (warm is a multiple of 16: a whole block is warm-up or not)
+                const int64_t lo = first + i, hi = first + 3 * (int64_t)chunk + i + 16; // first / one past the last index touched
+                if (lo >= (int64_t)lead && hi <= (int64_t)total) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) K1A_STEP4(j)
+                } else if (hi > (int64_t)lead && lo < (int64_t)total) {
+#pragma unroll
+                    for (int j = 0; j < 16; j++) {
+                        K1A_STEP(0, b0, s0, j) K1A_STEP(1, b1, s1, j) K1A_STEP(2, b2, s2, j) K1A_STEP(3, b3, s3, j)
+                    }
+                }
+            }
+        }
+    }
+#undef K1A_LOAD
+#undef K1A_BYTE
+#undef K1A_STEP
+#undef K1A_STEP4
+    if (lds_hits) { // (statistics launches only)
+        for (int o = 32; o > 0; o >>= 1) { hot += __shfl_down(hot, o); all += __shfl_down(all, o); }
+        if ((threadIdx.x & 63) == 0) { atomicAdd(&lds_hits[0], (unsigned long long)hot); atomicAdd(&lds_hits[1], (unsigned long long)all); }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && GK.block_counts) GK.block_counts[blockIdx.x] = *lcount;
+}
+
+
+
+// chunk of a chain: enough chains to fill the chip, warm-up overhead <= 1/8, a multiple of 16
+static uint32_t walk16_chunk(uint32_t warm, uint64_t total, int n_cus) {
+    uint64_t c = total / ((uint64_t)n_cus * 1024 * K1A_CHAINS);
+    c = (c + 15) & ~15ull;
+    if (c < 256) c = 256;
+    if (c < (uint64_t)warm * 8) c = (uint64_t)warm * 8;
+    if (c > (1u << 20)) c = 1u << 20;
+    return (uint32_t)c;
+}
+
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds) {
     size_t budget = max_lds > 4096 + K1A_LDS_HEADER ? max_lds - 4096 - K1A_LDS_HEADER : 0;
     size_t rows = budget / ((size_t)2 << stride2);
@@ -300,6 +436,7 @@ static uint32_t pick_chunk(uint32_t max_len, uint64_t len) {
 }
 
 uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus) {
+    if (A.table16) return (uint32_t)n_cus; // compact form: persistent, one workgroup per CU (region mode: n_cus regions)
     uint32_t chunk = pick_chunk(A.max_len, len);
     uint64_t nchunks = (len + chunk - 1) / chunk;
     uint64_t blocks = (nchunks + 1023) / 1024;
@@ -311,6 +448,44 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st) {
     if (len == 0) return hipSuccess;
+    const bool segmented = G.uniform_len != 0 || G.offsets != nullptr;
+    if (A.table16 && !segmented) { // compact form
+        static std::mutex mu16;
+        static bool attr16[64] = {};
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        {
+            std::lock_guard<std::mutex> lk(mu16);
+            if (dev < 0 || dev >= 64 || !attr16[dev]) {
+                hipError_t e = hipFuncSetAttribute((const void *)k1a_walk16,
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+                if (e != hipSuccess) return e;
+                if (dev >= 0 && dev < 64) attr16[dev] = true;
+            }
+        }
+        const uint32_t NC = A.n_classes;
+        size_t budget = max_lds > 4096 + K1A_LDS_HEADER ? max_lds - 4096 - K1A_LDS_HEADER : 0;
+        uint32_t rows16 = (uint32_t)std::min<size_t>(budget / ((size_t)2 * NC), A.n_states);
+        const size_t lds16 = K1A_LDS_HEADER + (((size_t)rows16 * NC * 2 + 15) / 16) * 16 + 16;
+        const uint32_t lead = (uint32_t)((uintptr_t)d_hay & 15);
+        const uint64_t total = lead + len;
+        const uint32_t warm = ((A.max_len ? A.max_len - 1 : 0) + 15u) & ~15u;
+        const uint32_t chunk16 = walk16_chunk(warm, total, (int)grid);
+        static unsigned long long *stats = nullptr; // ACX_WALK_STATS=1: LDS hit fraction of the walk
+        static const bool want_stats = std::getenv("ACX_WALK_STATS") != nullptr;
+        if (want_stats && !stats) { (void)hipMalloc((void **)&stats, 16); }
+        if (want_stats) (void)hipMemsetAsync(stats, 0, 16, st);
+        hipLaunchKernelGGL(k1a_walk16, dim3(grid), dim3(1024), lds16, st, A, Ad, K, d_hay - lead, total, lead,
+                           chunk16, warm, rows16, want_stats ? stats : nullptr);
+        if (want_stats) {
+            unsigned long long h[2] = {0, 0};
+            (void)hipMemcpyAsync(h, stats, 16, hipMemcpyDeviceToHost, st);
+            (void)hipStreamSynchronize(st);
+            std::fprintf(stderr, "acx: k1a_walk16 LDS rows %u of %u states, transitions from LDS %.4f (%llu of %llu)\n",
+                         rows16, A.n_states, h[1] ? (double)h[0] / (double)h[1] : 0.0, h[0], h[1]);
+        }
+        return hipGetLastError();
+    }
     uint32_t chunk = pick_chunk(A.max_len, len);
     uint32_t rows = A.hot_rows;
     uint32_t cap_rows = dfa_walk_hot_rows(A.n_states, A.stride2, max_lds);
@@ -547,7 +722,12 @@ struct K1bTables {
 
 // CP (str API, sparse mode, lead == 0): the scan also counts the UTF-8 lead bytes of every 64-byte
 // stretch it streams (the code-point fix-up then needs no second pass over the haystack).
-template <int Q, bool SLOTS, bool CP>
+// BIG (Q = 5 only; pattern sets that saturate the level-1 table, ~10^5 patterns): EVERY position is
+// put to both tests -- as the position after the gram in front of it (Y) and as the position in front
+// of the gram behind it (X): 17 LDS reads per lane-row instead of 8, twice the level-1 VALU, but
+// the false positives multiply (0.18 x 0.07 instead of their mean) and the level-2 gathers, which
+// bound the kernel on such sets, go down by a factor of five.
+template <int Q, bool SLOTS, bool CP, bool BIG>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
@@ -809,12 +989,53 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             }                                                                                    \
             MROW = m_;                                                                           \
         }
+        // BIG: position j passes iff the gram at j + 1 vouches for byte j in front of it (X) AND the
+        // gram at j vouches for byte j + 4 behind it (Y); one table row per gram j = 0 .. 16
+#define K1B_ROW_BIG(RI, VR, RX, RY, MROW)                                                        \
+        {                                                                                        \
+            uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);         \
+            uint32_t ny_ = __builtin_amdgcn_update_dpp(0u, VR.y, 0x130, 0xf, 0xf, true);         \
+            const uint32_t rx_ = (RX), ry_ = (RY); /* evaluated by ALL lanes (readfirstlane) */  \
+            uint32_t d4_ = lane == 63 ? rx_ : nx_, d5_ = lane == 63 ? ry_ : ny_;                 \
+            uint32_t d_[6] = {VR.x, VR.y, VR.z, VR.w, d4_, d5_};                                 \
+            uint32_t w_[21]; /* w_[j]: the 4 bytes starting at byte j */                         \
+            _Pragma("unroll") for (int j = 0; j < 21; j++)                                       \
+                w_[j] = (j & 3) ? __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3) : d_[j >> 2]; \
+            uint2 e_[17];                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 17; j++) {                                     \
+                const uint32_t H_ = hash_mul24(w_[j], HASH_K1) + w_[j];                          \
+                e_[j] = *(const uint2 *)((const uint8_t *)L.xy +                                 \
+                    ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u)));  \
+            }                                                                                    \
+            uint32_t m_ = 0;                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 16; j++) {                                     \
+                const uint32_t tx_ = (e_[j + 1].x >> (w_[j] & 31)) & (e_[j + 1].x >> (w_[j + 1] & 31)); \
+                const uint32_t ty_ = (e_[j].y >> (w_[j + 4] & 31)) & (e_[j].x >> (w_[j] & 31));  \
+                m_ = __builtin_amdgcn_alignbit(tx_ & ty_, m_, 1);                                \
+            }                                                                                    \
+            m_ >>= 16;                                                                           \
+            if (!interior) { /* wave-uniform: a scalar branch */                                 \
+                const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
+                uint32_t keep_ = 0;                                                              \
+                _Pragma("unroll") for (int j = 0; j < 16; j++)                                   \
+                    if (any_start && p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j; \
+                m_ &= keep_;                                                                     \
+            }                                                                                    \
+            MROW = m_;                                                                           \
+        }
         // every position of an interior tile is a legal start: no per-row masking
         const bool interior = tbase >= lead && tbase + tile_bytes <= last_start;
-        K1B_ROW(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
-        K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
-        K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
-        K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+        if (BIG && Q == 5) {
+            K1B_ROW_BIG(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
+            K1B_ROW_BIG(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
+            K1B_ROW_BIG(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
+            K1B_ROW_BIG(3, v3, vL.x, vL.y, mrow3)
+        } else {
+            K1B_ROW(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
+            K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
+            K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
+            K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+        }
         if (CP) { // lead bytes of the lane's 16 bytes of every row, summed over the 4 lanes of a 64-byte stretch
 #define K1B_LEADS(RI, VR)                                                                        \
             {                                                                                    \
@@ -871,6 +1092,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
 #undef K1B_ISSUE_ROW
 #undef K1B_ISSUE_TILE
 #undef K1B_ROW
+#undef K1B_ROW_BIG
 #undef K1B_BYTE_REG
 }
 
@@ -910,20 +1132,28 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     const K1bTables T{A.filterA, A.ptab, A.ptab_log2, A.filter_q2, A.min_len, cp_sub};
     if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
+#define ACX_K1B_LAUNCH(Q, S, C, B)                                                                         \
+    hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
 #define ACX_K1B(Q)                                                                                         \
-    if (cp_sub)                                                                                            \
-        hipExtLaunchKernelGGL((k1b_prefilter<Q, true, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
-    else if (K.hslots)                                                                                     \
-        hipExtLaunchKernelGGL((k1b_prefilter<Q, true, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
-    else                                                                                                   \
-        hipExtLaunchKernelGGL((k1b_prefilter<Q, false, false>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
+    if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, false);                                                      \
+    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, false);                                              \
+    else ACX_K1B_LAUNCH(Q, false, false, false)
     switch (A.filter_q) {
     case 1: ACX_K1B(1); break;
     case 2: ACX_K1B(2); break;
     case 3: ACX_K1B(3); break;
     case 4: ACX_K1B(4); break;
-    default: ACX_K1B(5); break;
+    default:
+        if (A.filter_big) { // saturated level-1 table: both tests for every position
+            if (cp_sub) ACX_K1B_LAUNCH(5, true, true, true);
+            else if (K.hslots) ACX_K1B_LAUNCH(5, true, false, true);
+            else ACX_K1B_LAUNCH(5, false, false, true);
+        } else {
+            ACX_K1B(5);
+        }
+        break;
     }
+#undef ACX_K1B_LAUNCH
 #undef ACX_K1B
     return hipGetLastError();
 }

@@ -69,3 +69,23 @@ except Exception as e:
 PY
   done
 fi
+if [ "$WHAT" = full ]; then
+  timeout 900 python bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; cat $OUT/bench_default.json | cut -c1-3000; tail -3 $OUT/bench_default.err
+  timeout 600 python bench.py --host --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_host.json 2> $OUT/bench_host.err; cut -c1-600 $OUT/bench_host.json; tail -3 $OUT/bench_host.err
+  for m in 1 2; do ACX_STAGE=$m timeout 600 python bench.py --host --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_host_stage$m.json 2> $OUT/bench_host_stage$m.err; echo "ACX_STAGE=$m"; cut -c1-200 $OUT/bench_host_stage$m.json; done
+  timeout 900 python bench.py --bytes 8589934592 --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_8g.json 2> $OUT/bench_8g.err; cut -c1-400 $OUT/bench_8g.json; tail -3 $OUT/bench_8g.err
+fi
+if [ "$WHAT" = k1a ]; then
+  for d in T U; do
+    ACX_WALK_STATS=${WALK_STATS:-} timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --dist $d --kernel dfa_walk > $OUT/bench_k1a_$d.json 2> $OUT/bench_k1a_$d.err
+    python - <<PY
+import json
+try:
+    d = json.load(open("$OUT/bench_k1a_$d.json")); c = d["config"]; r = d["roofline"]
+    print("K1a $d", d["value"], "GB/s", d["ms_per_step"], "ms/step K1", r["kernel_ms"], "ms", r["kernel"], "matches", c["matches_total"])
+except Exception as e:
+    print("$d failed", e); print(open("$OUT/bench_k1a_$d.err").read()[-1500:])
+PY
+    grep "acx:" $OUT/bench_k1a_$d.err | tail -1
+  done
+fi
