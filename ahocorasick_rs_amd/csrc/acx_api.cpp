@@ -982,8 +982,12 @@ int stage_host(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, const
         }
         HIPCHK(hipMemcpyAsync(w.offsets, offsets, n_off * 8, hipMemcpyHostToDevice, st));
     }
-    static const int mode = std::getenv("ACX_STAGE") ? std::atoi(std::getenv("ACX_STAGE")) : 0;
-    if (len <= STAGE_DIRECT_MAX || mode == 1) { // 1: always the runtime's pageable copy (measurements)
+    // ACX_STAGE: 1 = the runtime's own pageable copy (default: measured 54 GB/s on the MI355X box, the
+    // link's rate, once the result no longer lands in freshly faulted pages), 2 = pin the caller's
+    // pages for the call (54.8 GB/s), 3 = the ring of pinned chunks below (51 GB/s; independent of the
+    // runtime's staging)
+    static const int mode = std::getenv("ACX_STAGE") ? std::atoi(std::getenv("ACX_STAGE")) : 1;
+    if (len <= STAGE_DIRECT_MAX || mode == 1) {
         if (len) HIPCHK(hipMemcpyAsync(w.hay, hay, len, hipMemcpyHostToDevice, st));
         return ACX_OK;
     }
@@ -1186,6 +1190,8 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.filterA, filterA)
     UP(H.ptab, ptab)
     UP(H.blist, blist)
+    if (H.rbloom.empty()) H.rbloom.assign(REDIRECT_BLOOM_WORDS, 0);
+    UP(H.rbloom, rbloom)
     {
         const uint32_t *pi = nullptr;
         if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);

@@ -327,6 +327,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             return prefix_home_hash(gram & m, salt);
         };
         std::vector<uint32_t> hash_at((size_t)1 << lg, 0); // hash of the entry stored in each slot
+        A.rbloom.assign(REDIRECT_BLOOM_WORDS, 0);
         // Redirect entries first: every haystack position that starts like ANY pattern of the group
         // looks the entry up, so it must sit in its home slot (a displaced one would turn all of
         // them into HIT_RETRY traffic); then the single keys of the other groups, then the keys
@@ -355,6 +356,10 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             en[2] = k.K | (k.next << 4);
             en[3] = code;
             hash_at[idx] = h;
+            if (k.salt != Q2) { // a key behind a redirect entry
+                const uint32_t bit = redirect_bloom_bit(h);
+                A.rbloom[bit >> 5] |= 1u << (bit & 31);
+            }
         }
         // the filter of displaced keys on every home slot: without the lookup's own bit a home slot
         // holding a different key proves absence (one probe)

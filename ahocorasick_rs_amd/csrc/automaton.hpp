@@ -82,6 +82,10 @@ ACX_HD static inline uint32_t gram_hash2(uint64_t gram) {
 // every such key's hash h); PREFIX_EMPTY marks a free slot.  A lookup that finds another key in
 // its home slot goes on only if its own bit is set -- otherwise the key is not in the table.
 constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
+// Bloom filter (one bit per key, in LDS) of the keys behind redirect entries: a survivor whose group
+// redirects is looked up only if the bit of its own N bytes is set (hash = prefix_home_hash(.., N))
+constexpr uint32_t REDIRECT_BLOOM_WORDS = 1024; // 32 Kbit
+ACX_HD static inline uint32_t redirect_bloom_bit(uint32_t key_hash) { return (key_hash >> 3) & (REDIRECT_BLOOM_WORDS * 32 - 1); }
 ACX_HD static inline uint32_t prefix_more_bit(uint32_t home_hash) { return 1u << (8 + ((home_hash >> 11) & 15u)); }
 // home-slot hash of the first `salt` bytes of a key (little-endian in a u64, masked): salt = Q2,
 // the set-wide minimum key length -- all a lookup knows before it has seen an entry -- or the
@@ -126,6 +130,7 @@ struct Automaton {
     // patterns of a group (= the patterns sharing their first Q2 bytes); a group's single key is
     // filed under the hash of those Q2 bytes, several keys behind a redirect entry (automaton.cpp)
     std::vector<uint32_t> blist;       // {count, pid, pid, ...} per key shared by several patterns
+    std::vector<uint32_t> rbloom;      // REDIRECT_BLOOM_WORDS: Bloom filter of the keys behind redirect entries
     uint32_t n_prefix_keys = 0;        // entries in use
     // per pattern, 4 u32: {rank | min(len, 255) << 24, the 12 bytes that follow its first Q2 bytes}
     // -- everything the walk kernel needs to settle a short candidate with ONE 16-byte load

@@ -549,6 +549,7 @@ struct K1bLds {
     uint16_t q1[16][K1B_Q1CAP];
     uint4 hb[16][K1B_HB][2];
     uint32_t cb[16][16]; // sparse mode: hit counts of the wave's last tiles, stored 16 at a time
+    uint32_t rbloom[REDIRECT_BLOOM_WORDS]; // Bloom filter of the keys behind redirect entries
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
 
@@ -716,6 +717,7 @@ __device__ __forceinline__ uint32_t lead_bytes_in_word(uint32_t w) {
 struct K1bTables {
     const uint32_t *filterA;
     const uint32_t *ptab;
+    const uint32_t *rbloom;
     uint32_t ptab_log2, filter_q2, min_len;
     uint8_t *cp_sub; // CP: lead (non-continuation) bytes of every 64 bytes of the stream (K3's sub counts)
 };
@@ -748,6 +750,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) L.rbloom[i] = A.rbloom[i];
     }
     __syncthreads();
 
@@ -890,7 +893,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 // a group with several keys: its home slot redirects to the keys' own hash.  These
                 // dependent gathers are waited for in place (rare unless many patterns share their
                 // first Q2 bytes; the other waves of the SIMD cover them)
-                const uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
+                uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
+                if (next) { // (most such positions end here: the LDS Bloom filter of those keys says no)
+                    const uint32_t bit = redirect_bloom_bit(prefix_home_hash(low_bytes(winC, next), next));
+                    if (!((L.rbloom[bit >> 5] >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
+                }
                 if (next) code = prefix_walk(A.ptab, ptab_log2, next, winC, nullptr);
                 // a home slot holding another key proves absence unless the slot's filter of
                 // displaced keys has the window's bit: then the hit travels as HIT_RETRY and
@@ -1129,7 +1136,7 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
-    const K1bTables T{A.filterA, A.ptab, A.ptab_log2, A.filter_q2, A.min_len, cp_sub};
+    const K1bTables T{A.filterA, A.ptab, A.rbloom, A.ptab_log2, A.filter_q2, A.min_len, cp_sub};
     if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
 #define ACX_K1B_LAUNCH(Q, S, C, B)                                                                         \
