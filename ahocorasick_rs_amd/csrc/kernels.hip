@@ -1412,15 +1412,14 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     __shared__ uint64_t bmax[STAGE_BUCKETS];       // largest end per bucket
     __shared__ uint32_t hoff[STAGE_BUCKETS + 1];   // exclusive prefix of the tiles' hit counts
     __shared__ uint8_t syn[STAGE_BUCKETS][STAGE_SLOTS + 4], acc[STAGE_BUCKETS][STAGE_SLOTS + 4];
-    __shared__ uint32_t fail, stop;
-    using scan_t = rocprim::block_scan<uint32_t, MAIN_THREADS>;
-    __shared__ typename scan_t::storage_type scan_tmp;
+    __shared__ uint32_t fail, stop, tail_base;
     const uint32_t t = threadIdx.x, g = blockIdx.x;
     const uint32_t tile0 = g * GROUP_TILES;
     const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
     const uint32_t lb = tile0 - first;                               // context tiles in front
     const uint32_t nb = GROUP_TILES + lb;                            // staged buckets
-    // ---- hits of the staged tiles
+    // ---- hits of the staged tiles: exclusive prefix of the counts (wave 0: 64 tiles, wave 1: the
+    // few beyond -- nb <= 68)
     uint32_t c = 0;
     if (t < nb && first + t < T.n_tiles) {
         c = T.hcnt[hcnt_index(first + t, T.cnt_nw, T.cnt_iters)];
@@ -1428,11 +1427,24 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     }
     if (t < STAGE_BUCKETS) { bn[t] = 0; bmax[t] = 0; }
     if (t == 0) { fail = 0; stop = *abort_flag; }
-    uint32_t off = 0, H = 0;
-    scan_t().exclusive_scan(c, off, 0u, H, scan_tmp);
-    if (t <= nb) hoff[t] = off;
+    uint32_t incl = c;
+    if (t < 128) { // (lanes beyond nb carry zeros)
+        for (int o = 1; o < 64; o <<= 1) {
+            const uint32_t v = __shfl_up(incl, o);
+            if ((int)(t & 63) >= o) incl += v;
+        }
+        if (t == 63) tail_base = incl;
+    }
     __syncthreads();
+    if (t >= 64 && t < 128) incl += tail_base;
+    if (t <= nb) hoff[t] = incl - c;
+    __syncthreads();
+    const uint32_t H = hoff[nb];
     if (stop) return;
+    if (H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
+        if (t == 0) { T.btot[g] = 0; T.gocc[g] = 0; T.ghits[g] = 0; }
+        return;
+    }
     // index space: index = stream position + lead; a tile / bucket is 4 KiB of it
     const uint64_t idx_lo = (uint64_t)tile0 << TILE_BITS, idx_hi = idx_lo + ((uint64_t)GROUP_TILES << TILE_BITS);
     // occurrences whose key index is below `complete` may have unseen company: not staged.
