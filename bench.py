@@ -60,8 +60,9 @@ def parse_args(argv=None):
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
     ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
-    ap.add_argument("--dist", choices=["T", "U"], default="T",
-                    help="cfg2 haystack: T text-like (headline), U iid-uniform a-z")
+    ap.add_argument("--dist", choices=["T", "U", "Z"], default="T",
+                    help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
+                         "(calibration of the PMC traffic counters only: the scan reads, nothing else happens)")
     ap.add_argument("--kernel", choices=["auto", "dfa_walk", "prefilter"], default="auto")
     ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
                     help="(kept for round-1 scripts) batch == --config cfg3")
@@ -148,12 +149,16 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
         hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
         if cfg == "cfg2":
-            kind, seed = (1, 11) if args.dist == "T" else (0, 12)
-            ac.generate(hay.data_ptr(), nbytes, kind, seed)
+            if args.dist == "Z":
+                hay.zero_()
+                torch.cuda.synchronize()
+            else:
+                kind, seed = (1, 11) if args.dist == "T" else (0, 12)
+                ac.generate(hay.data_ptr(), nbytes, kind, seed)
+            what = {"T": "text-like (T, seed 11)", "U": "uniform a-z (U, seed 12)",
+                    "Z": "ALL-ZERO (calibration only, not a benchmark)"}[args.dist]
             w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
-                         f"{nbytes / GIB:g} GiB "
-                         f"{'text-like (T, seed 11)' if args.dist == 'T' else 'uniform a-z (U, seed 12)'}"
-                         " bytes haystack, MatchKind.Standard, non-overlapping")
+                         f"{nbytes / GIB:g} GiB {what} bytes haystack, MatchKind.Standard, non-overlapping")
         elif cfg == "cfg3":
             if nbytes % 8192:
                 raise SystemExit("--bytes must be a multiple of 8192 for cfg3")

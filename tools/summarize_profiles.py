@@ -1,16 +1,17 @@
 #!/usr/bin/env python3
 """Turn the scratch output of tools/collect_profiles.sh (gpurun_out/<round>/) into the
 committed evidence under profiles/<round>/:
-  bench_*.json                         the bench lines
-  rocprofv3_kernel_stats_bench_T.csv   rocprofv3 --kernel-trace --stats, as emitted
-  rocprofv3_kernel_summary_bench_T.txt per-kernel summary of the same trace
-  rocprofv3_pmc_bench_T.json           PMC passes: counters of the last dispatch per kernel
-  pmc_traffic.json                     HBM traffic of the dominant kernel (bench.py reads it)
+  bench_*.json                              the bench lines (cfg2 T/U, cfg3 shape, cfg4, cfg4b, cfg5, 8 GiB,
+                                            host-memory entry point, K1a)
+  rocprofv3_kernel_stats_bench_<X>.csv      rocprofv3 --kernel-trace --stats, as emitted
+  rocprofv3_kernel_summary_bench_<X>.txt    per-kernel summary + timeline of the same trace
+  rocprofv3_pmc_bench_T.json                PMC passes: mean counters per dispatch and kernel
+  pmc_traffic.json                          HBM traffic of the dominant kernel (bench.py reads it)
 usage: summarize_profiles.py [round]"""
-import collections, csv, json, os, shutil, subprocess, sys
+import collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r01"
+R = sys.argv[1] if len(sys.argv) > 1 else "r02"
 SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 
@@ -19,49 +20,75 @@ def short(n):
     return n.replace("acx::", "").replace("void ", "").split("(")[0].split("<")[0]
 
 
-for f in ("bench_T.json", "bench_U.json", "bench_T_dfa_walk.json", "smoke.log"):
-    if os.path.exists(os.path.join(SRC, f)):
-        shutil.copy(os.path.join(SRC, f), os.path.join(DST, f))
-shutil.copy(os.path.join(SRC, "trace_T", "bench_kernel_stats.csv"),
-            os.path.join(DST, "rocprofv3_kernel_stats_bench_T.csv"))
-txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"),
-                      os.path.join(SRC, "trace_T"), "--timeline", "16"], capture_output=True, text=True).stdout
-open(os.path.join(DST, "rocprofv3_kernel_summary_bench_T.txt"), "w").write(
-    "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 10 --warmup 3 --no-cpu-baseline\n" + txt)
+for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
+                                                                  ("smoke.log", "bench_comparison.txt")]:
+    if os.path.exists(f) and os.path.getsize(f):
+        shutil.copy(f, os.path.join(DST, os.path.basename(f)))
+walk_stats = []
+for d in ("T", "U"):
+    f = os.path.join(SRC, f"bench_{d}_dfa_walk.err")
+    if os.path.exists(f):
+        walk_stats += [f"{d}: " + l.strip() for l in open(f) if l.startswith("acx:")][-1:]
+if walk_stats:
+    open(os.path.join(DST, "k1a_lds_hit_fraction.txt"), "w").write(
+        "# ACX_WALK_STATS=1 python bench.py --kernel dfa_walk --dist T|U (fraction of DFA transitions served by LDS)\n"
+        + "\n".join(walk_stats) + "\n")
+for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline"),
+                 ("cfg4", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --config cfg4"),
+                 ("cfg5", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --config cfg5"),
+                 ("dfa_walk", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --kernel dfa_walk")):
+    src = os.path.join(SRC, f"trace_{tag}")
+    if not os.path.exists(os.path.join(src, "bench_kernel_stats.csv")):
+        continue
+    shutil.copy(os.path.join(src, "bench_kernel_stats.csv"), os.path.join(DST, f"rocprofv3_kernel_stats_bench_{tag}.csv"))
+    txt = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_summary.py"), src, "--timeline", "16"],
+                         capture_output=True, text=True).stdout
+    open(os.path.join(DST, f"rocprofv3_kernel_summary_bench_{tag}.txt"), "w").write(
+        f"# rocprofv3 --kernel-trace --stats -- {cmd}\n" + txt)
 
 pmc = {}
 for d in sorted(os.listdir(SRC)):
     f = os.path.join(SRC, d, "r_counter_collection.csv")
     if not d.startswith("pmc_") or not os.path.exists(f):
         continue
-    last, dur = collections.OrderedDict(), []
+    acc = collections.OrderedDict()
     for r in csv.DictReader(open(f)):
-        last.setdefault(short(r["Kernel_Name"]), {})[r["Counter_Name"]] = float(r["Counter_Value"])
+        acc.setdefault(short(r["Kernel_Name"]), {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+    dur = collections.OrderedDict()
     for r in csv.DictReader(open(os.path.join(SRC, d, "r_kernel_trace.csv"))):
-        if "k1b_prefilter" in r["Kernel_Name"]:
-            dur.append(round((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3, 1))
-    keep = {k: v for k, v in last.items() if k in ("k1b_prefilter", "k_walk_hits", "k_tile_sort", "k_tile_resolve",
-                                                   "k_tile_scan", "k_tile_write")}
-    pmc[d] = {"k1b_duration_us": dur, "counters_last_dispatch": keep}
+        dur.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    keep = ("k1b_prefilter", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_scan", "k_tile_write")
+    pmc[d] = {k: {"dispatches": len(dur.get(k, [])), "mean_duration_us": round(sum(dur[k]) / len(dur[k]), 1) if k in dur else None,
+                  "mean_counters": {c: round(sum(v) / len(v)) for c, v in cs.items()}}
+              for k, cs in acc.items() if k in keep}
 json.dump(pmc, open(os.path.join(DST, "rocprofv3_pmc_bench_T.json"), "w"), indent=1)
 
-fetch = pmc["pmc_fetch"]["counters_last_dispatch"]["k1b_prefilter"]["FETCH_SIZE"]
-write = pmc["pmc_write"]["counters_last_dispatch"]["k1b_prefilter"]["WRITE_SIZE"]
-loads_only = pmc["pmc_fetch_loads_only"]["counters_last_dispatch"]["k1b_prefilter"]["FETCH_SIZE"]
 bench = json.load(open(os.path.join(DST, "bench_T.json")))
 nbytes = bench["config"]["bytes_per_gpu"]
-traffic = {
-    "kernel": "k1b_prefilter", "workload_bytes": nbytes, "dist": "T",
-    "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "FETCH_SIZE_KB_loads_only_ablation": loads_only,
-    "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh); "
-            "gfx950 correction: FETCH_SIZE reports half of a wide coalesced stream (calibrated here: the loads-only "
-            "ablation of the same kernel reads the whole haystack and reports FETCH_SIZE_KB_loads_only_ablation), so "
-            "traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 as the MI355X guide prescribes; if the gather part "
-            "(one 128-byte line per level-1 survivor for its window, prefix-table probes) is counted 1:1 instead, "
-            "traffic is traffic_bytes_gathers_1to1",
-    "traffic_bytes": int((2 * fetch + write) * 1024),
-    "traffic_bytes_gathers_1to1": int((2 * loads_only + (fetch - loads_only) + write) * 1024),
-}
-json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
-print(json.dumps(traffic, indent=1))
-print(txt)
+try:
+    fetch = pmc["pmc_fetch"]["k1b_prefilter"]["mean_counters"]["FETCH_SIZE"]
+    write = pmc["pmc_write"]["k1b_prefilter"]["mean_counters"]["WRITE_SIZE"]
+    zero = pmc["pmc_fetch_zero_haystack"]["k1b_prefilter"]["mean_counters"]["FETCH_SIZE"]
+    factor = nbytes / (zero * 1024)  # bytes per reported byte of FETCH_SIZE for the scan's coalesced stream
+    traffic = {
+        "kernel": "k1b_prefilter", "config": "cfg2", "workload_bytes": nbytes, "dist": "T",
+        "FETCH_SIZE_KB": fetch, "WRITE_SIZE_KB": write, "FETCH_SIZE_KB_zero_haystack": zero,
+        "stream_calibration_factor": round(factor, 3),
+        "note": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (tools/collect_profiles.sh), mean "
+                "per dispatch.  gfx950 correction: FETCH_SIZE reports half of a wide coalesced stream; calibrated on "
+                "this very kernel with an all-zero haystack (nothing survives level 1: the kernel reads the haystack "
+                "and nothing else), which yields stream_calibration_factor.  traffic_bytes = (2 * FETCH_SIZE + "
+                "WRITE_SIZE) * 1024 as the MI355X guide prescribes; traffic_bytes_gathers_1to1 counts only the stream "
+                "part (the zero-haystack reading) twice and the rest (window re-reads, prefix-table probes, table "
+                "copies to LDS) once.",
+        "traffic_bytes": int((2 * fetch + write) * 1024),
+        "traffic_bytes_gathers_1to1": int((2 * zero + max(fetch - zero, 0) + write) * 1024),
+        "algorithmic_bytes": bench["roofline"]["algorithmic_bytes"],
+    }
+    traffic["traffic_over_algorithmic"] = round(traffic["traffic_bytes"] / traffic["algorithmic_bytes"], 3)
+    traffic["traffic_over_algorithmic_gathers_1to1"] = round(traffic["traffic_bytes_gathers_1to1"] / traffic["algorithmic_bytes"], 3)
+    json.dump(traffic, open(os.path.join(DST, "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(traffic, indent=1))
+except KeyError as e:
+    print("no traffic summary:", e)
+print(open(os.path.join(DST, "rocprofv3_kernel_summary_bench_T.txt")).read())
