@@ -1,9 +1,9 @@
 #!/bin/bash
-# round-2 GPU check: tests (fail fast, most basic first), then short benches.  Every command
-# bounded by `timeout`.  usage: tools/gpu_r2.sh [tests|bench|all]
+# GPU check: tests (fail fast, most basic first), then short benches.  Every command
+# bounded by `timeout`.  usage: tools/gpu_check.sh [tests|bench|all]
 set -u
 export TMPDIR=/tmp
-OUT=/root/repo/gpurun_out/r2
+OUT=/root/repo/gpurun_out/check
 mkdir -p $OUT
 cd /root/repo
 WHAT=${1:-all}
