@@ -681,6 +681,7 @@ struct FindCall {
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
     bool leads_counted = false; // the scan has written the lead-byte counts of every 64 bytes (str API)
+    bool cp_done = false;       // the write kernel has already converted the offsets to code points
     bool queued = false;    // work queued on the stream that nobody waited for yet
     bool localized = false; // batch: offsets are already local and the counts taken
 };
@@ -732,9 +733,18 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(x->ev[1], st));
     }
+    // str API, one haystack: the prefix of the lead-byte counts is ready before the write kernel
+    // needs it (it depends on the scan only), so the write kernel converts on the way out
+    const uint64_t *cp_pre = nullptr;
+    if (c.leads_counted && !c.segmented) {
+        const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
+        HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, st));
+        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
+        cp_pre = w.blockpre;
+    }
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, prof && c.pre, c.G, seg_counts, st));
+                        next_flag, w.h_pinned, seq, prof && c.pre, c.G, seg_counts, cp_pre, w.blocksub, st));
     if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
     w.flags_dirty = false; // the scan kernel left the next flag clean
     add_scan_profile(a, x, c.len);
@@ -743,6 +753,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
         x->dense_hold = 8;
         c.leads_counted = false;
+        c.cp_done = false;
         *what = Attempt::GoDense;
         return ACX_OK;
     }
@@ -752,6 +763,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
     w.final = nullptr;
     c.localized = seg_counts != nullptr;
+    c.cp_done = cp_pre != nullptr;
     c.queued = true; // k_tile_write is still running
     *what = Attempt::Done;
     return ACX_OK;
@@ -838,7 +850,7 @@ int finish_matches(FindCall &c) {
     Ctx *x = c.c;
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
-    if (!c.n_final || !(c.codepoints || (c.segmented && !c.localized))) return ACX_OK;
+    if (!c.n_final || c.cp_done || !(c.codepoints || (c.segmented && !c.localized))) return ACX_OK;
     if (c.codepoints) {
         const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
         int rc = ensure_blocks(x, c.leads_counted ? std::max<uint64_t>(nb1, 4 * c.tiles + 1) : nb1);

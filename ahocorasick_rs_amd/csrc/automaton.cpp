@@ -308,6 +308,8 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // load <= 1/4.  Sparser would save dependent probes, but measured on MI355X a table beyond
         // ~1 MiB costs K1b more (its level-2 gathers start missing L2) than the probes gain.
         while ((1u << lg) < 4 * keys.size()) lg++;
+        // (a sparser table for the sets whose table has left the L2 anyway was measured too: cfg4's 8 MiB
+        // -> 16 MiB halves the displaced keys but costs K1b 15 %: the gathers then miss the MALL more often)
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = PREFIX_EMPTY;

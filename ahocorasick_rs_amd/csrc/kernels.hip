@@ -1632,6 +1632,43 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
     }
 }
 
+// non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
+// range masked off (an aligned word never leaves the page its first / last byte of the range is
+// in, so the words at the two ends are safe to read in full) -- no byte loops
+__device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const uint8_t *end) {
+    if (p >= end) return 0;
+    const uint64_t HI = 0x8080808080808080ull;
+    const uint8_t *q = (const uint8_t *)((uintptr_t)p & ~(uintptr_t)7);
+    uint64_t valid = ~0ull << (8 * ((uintptr_t)p & 7)); // bytes of the first word at or after p
+    uint64_t c = 0;
+    for (; q < end; q += 8, valid = ~0ull) {
+        if (end - q < 8) valid &= ~0ull >> (8 * (8 - (end - q))); // bytes of the last word before end
+        const uint64_t w = *(const uint64_t *)q;
+        const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
+        c += __popcll(valid & HI) - __popcll(cont & valid);
+    }
+    return c;
+}
+
+// code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of
+// its 1 KiB block + the counts of the whole 64-byte stretches before it inside the block (ONE
+// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place
+__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
+                                                  const uint8_t *__restrict__ sub, uint64_t x) {
+    const uint64_t blk = x >> 10;
+    const uint32_t q = (uint32_t)(x & 1023) >> 6; // whole 64-byte stretches before x
+    const uint4 sv = *(const uint4 *)(sub + blk * 16);
+    const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+    uint32_t acc = 0;
+#pragma unroll
+    for (uint32_t d = 0; d < 4; d++) {
+        const uint32_t nb = q > 4 * d ? (q - 4 * d < 4 ? q - 4 * d : 4) : 0;
+        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
+        acc = __builtin_amdgcn_sad_u8(w[d] & m, 0u, acc);
+    }
+    return blockpre[blk] + acc + lead_bytes_between(hay + (x & ~63ull), hay + x);
+}
+
 // The groups' reported occurrences -> final records.  A workgroup takes WRITE_GROUPS consecutive
 // groups: their output is one contiguous stretch of 24-byte records, assembled in LDS and written as
 // a flat array of dwords (coalesced).
@@ -1639,9 +1676,11 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
 // their haystack and the per-haystack counts are taken here -- one atomic per run of matches
 // of the same haystack inside the stretch instead of a separate pass with one atomic per match.
 constexpr uint32_t WRITE_THREADS = 256, WRITE_GROUPS = 1, WRITE_MAX = WRITE_GROUPS * GROUP_MAX;
+// cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
+struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; };
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
-                                                              Segments G, uint64_t *seg_counts) {
+                                                              Segments G, uint64_t *seg_counts, CodePointTables cp) {
     __shared__ uint32_t img[WRITE_MAX * 6];
     __shared__ uint32_t hs[WRITE_MAX]; // haystack index of the matches, in output order
     __shared__ uint32_t goff[WRITE_GROUPS + 1];
@@ -1669,6 +1708,11 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; hbase = G.offsets[h]; }
             s -= hbase; e -= hbase;
             hs[i] = (uint32_t)h;
+        }
+        if (cp.blockpre) {
+            const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s);
+            e = cs + lead_bytes_between(cp.hay + s, cp.hay + e);
+            s = cs;
         }
         uint32_t *d = img + i * 6;
         d[0] = v.z; d[1] = 0; d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
@@ -1699,7 +1743,8 @@ uint32_t tile_lookback(uint32_t max_len) {
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
-                     bool count_hits, const Segments &G, uint64_t *seg_counts, hipStream_t st) {
+                     bool count_hits, const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
+                     const uint8_t *cp_sub, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
@@ -1708,7 +1753,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, count_hits ? 1 : 0, summary, abort_flag,
                        next_flag, (volatile uint64_t *)host_out, seq);
     hipLaunchKernelGGL(k_tile_write, dim3((T.n_groups + WRITE_GROUPS - 1) / WRITE_GROUPS), dim3(WRITE_THREADS), 0, st,
-                       A.rank_bits, key_mode, T, out, abort_flag, G, seg_counts);
+                       A.rank_bits, key_mode, T, out, abort_flag, G, seg_counts,
+                       CodePointTables{d_hay, cp_blockpre, cp_sub});
     return hipGetLastError();
 }
 
@@ -1915,43 +1961,6 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
                           uint64_t n, hipStream_t st) {
     return rocprim::exclusive_scan(temp, temp_bytes, in, out, (uint64_t)0, (size_t)n,
                                    rocprim::plus<uint64_t>(), st);
-}
-
-// non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
-// range masked off (an aligned word never leaves the page its first / last byte of the range is
-// in, so the words at the two ends are safe to read in full) -- no byte loops
-__device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const uint8_t *end) {
-    if (p >= end) return 0;
-    const uint64_t HI = 0x8080808080808080ull;
-    const uint8_t *q = (const uint8_t *)((uintptr_t)p & ~(uintptr_t)7);
-    uint64_t valid = ~0ull << (8 * ((uintptr_t)p & 7)); // bytes of the first word at or after p
-    uint64_t c = 0;
-    for (; q < end; q += 8, valid = ~0ull) {
-        if (end - q < 8) valid &= ~0ull >> (8 * (8 - (end - q))); // bytes of the last word before end
-        const uint64_t w = *(const uint64_t *)q;
-        const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
-        c += __popcll(valid & HI) - __popcll(cont & valid);
-    }
-    return c;
-}
-
-// code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of
-// its 1 KiB block + the counts of the whole 64-byte stretches before it inside the block (ONE
-// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place
-__device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
-                                                  const uint8_t *__restrict__ sub, uint64_t x) {
-    const uint64_t blk = x >> 10;
-    const uint32_t q = (uint32_t)(x & 1023) >> 6; // whole 64-byte stretches before x
-    const uint4 sv = *(const uint4 *)(sub + blk * 16);
-    const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
-    uint32_t acc = 0;
-#pragma unroll
-    for (uint32_t d = 0; d < 4; d++) {
-        const uint32_t nb = q > 4 * d ? (q - 4 * d < 4 ? q - 4 * d : 4) : 0;
-        const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
-        acc = __builtin_amdgcn_sad_u8(w[d] & m, 0u, acc);
-    }
-    return blockpre[blk] + acc + lead_bytes_between(hay + (x & ~63ull), hay + x);
 }
 
 // one thread per match: the start from its 1 KiB block's prefix, the end from the start

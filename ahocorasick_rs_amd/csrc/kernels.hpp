@@ -67,12 +67,14 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // the slots, out[] and the totals are meaningless.  seg_counts != null (batch, byte offsets):
 // offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
 // into seg_counts (zeroed by the caller).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
-// cannot take this path.
+// cannot take this path.  cp_blockpre != null (one haystack): the write kernel turns the byte
+// offsets into code-point indexes on the way out (prefix of the 1 KiB blocks + 64-byte sub counts).
 uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
-                     bool count_hits, const Segments &G, uint64_t *seg_counts, hipStream_t st);
+                     bool count_hits, const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
+                     const uint8_t *cp_sub, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,
