@@ -23,8 +23,11 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 
+import gen  # noqa: E402  (tests/gen.py: the seeded inputs)
+from oracle_lib import KIND_DFA, Oracle  # noqa: E402  (the checker; TEST INFRASTRUCTURE, timed beside the product)
+
+
 def datasets(names_file):
-    import gen
     short_p = ["abc", "hello", "world", "aardvark", "fish", "what", "arbitrarymonkey", "birds", "host7", "host76"]
     short_h = ["arbitrarymonkey says hello to fish host76, 0.123 my friend, but why??? {}".format(i)
                for i in range(10_000)]
@@ -70,12 +73,55 @@ def main():
             for h, lo, bo in zip(sub, loop_out, batch_out):
                 want = [h[s:e] for _, s, e in bo] if meth.endswith("strings") else bo
                 assert lo == want, (ds, label)
+            # the CPU beside it: the oracle (C restatement of the reference's algorithm) called once per
+            # haystack through ctypes, the shape of the reference's own loop.  The checker, timed -- never
+            # a path of the product.
+            mk = 2 if "longest" in label else 0
+            o = Oracle([x.encode() for x in pats], mk, KIND_DFA)
+            enc = [h.encode() for h in sub]
+            ov = bool(kw.get("overlapping"))
+            o.find_raw(enc[0], overlapping=ov)
+            t0 = time.perf_counter()
+            for h in enc:
+                o.find_raw(h, overlapping=ov)
+            cpu_us = (time.perf_counter() - t0) / len(enc) * 1e6
             rows.append((ds, label, len(pats), build_ms, loop_us, batch_s / len(hays) * 1e6,
-                         nbytes_all / batch_s / 1e6, sum(len(m) for m in batch_out)))
+                         nbytes_all / batch_s / 1e6, sum(len(m) for m in batch_out), cpu_us))
     print(f"{'dataset':8s} {'scenario':24s} {'patterns':>8s} {'build ms':>9s} {'loop us/hay':>12s} "
-          f"{'batch us/hay':>13s} {'batch MB/s':>11s} {'matches':>9s}")
+          f"{'batch us/hay':>13s} {'batch MB/s':>11s} {'matches':>9s} {'CPU oracle us/hay':>18s}")
     for r in rows:
-        print(f"{r[0]:8s} {r[1]:24s} {r[2]:8d} {r[3]:9.1f} {r[4]:12.1f} {r[5]:13.3f} {r[6]:11.1f} {r[7]:9d}")
+        print(f"{r[0]:8s} {r[1]:24s} {r[2]:8d} {r[3]:9.1f} {r[4]:12.1f} {r[5]:13.3f} {r[6]:11.1f} {r[7]:9d} {r[8]:18.2f}")
+    crossover()
+
+
+def crossover():
+    """Where one call on the GPU overtakes one call on a CPU core: the long-dataset automaton over a
+    single haystack of growing size (bytes API, byte offsets), GPU = BytesAhoCorasick call (K0 up to
+    16 KiB, the general pipeline beyond; host memory in, Python list out), CPU = the oracle's DFA
+    loop on one core."""
+    import ahocorasick_rs_amd as ac
+    names = gen.names_like()
+    pats = [x.encode() for x in names]
+    a = ac.BytesAhoCorasick(pats)
+    o = Oracle(pats, 0, KIND_DFA)
+    print("\ncrossover: one call, the long-dataset automaton (4 244 patterns), haystack size growing")
+    print(f"{'bytes':>10s} {'GPU us/call':>12s} {'CPU us/call':>12s} {'GPU MB/s':>10s} {'CPU MB/s':>10s}")
+    for n in (64, 1024, 16384, 65536, 1 << 20, 16 << 20, 256 << 20):
+        hay = gen.names_haystack(names, n, every=3)
+        reps = max(3, min(2000, (64 << 20) // n))
+        a.find_matches_as_indexes(hay)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            g = a.find_matches_as_indexes(hay)
+        gpu = (time.perf_counter() - t0) / reps
+        creps = max(1, min(reps, (16 << 20) // n))
+        o.find_raw(hay)
+        t0 = time.perf_counter()
+        for _ in range(creps):
+            c = o.find_raw(hay)
+        cpu = (time.perf_counter() - t0) / creps
+        assert [tuple(int(v) for v in r) for r in c] == g
+        print(f"{n:10d} {gpu * 1e6:12.1f} {cpu * 1e6:12.1f} {n / gpu / 1e6:10.1f} {n / cpu / 1e6:10.1f}")
 
 
 if __name__ == "__main__":
