@@ -52,7 +52,9 @@ class HostTables(ctypes.Structure):
                 ("filter_q", ctypes.c_uint32), ("filter_q2", ctypes.c_uint32),
                 ("filter_entries_log2", ctypes.c_uint32), ("prefix_table_log2", ctypes.c_uint32),
                 ("filter_density", ctypes.c_double),
-                ("n_prefix_keys", ctypes.c_uint32), ("n_prefix_lists", ctypes.c_uint32)]
+                ("n_prefix_keys", ctypes.c_uint32), ("n_prefix_lists", ctypes.c_uint32),
+                ("dense", ctypes.c_uint32), ("first_child", ctypes.c_void_p), ("in_byte", ctypes.c_void_p),
+                ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p)]
 
 
 class Profile(ctypes.Structure):
@@ -195,7 +197,12 @@ class HostAutomaton:
         self.n_states = int(t.n_states)
         self.stride = int(t.stride)
         self.classes = view(t.classes, 256, np.uint8)
-        self.table = view(t.table, self.n_states * self.stride, np.uint32).reshape(-1, self.stride)
+        self.dense = bool(t.dense)
+        self.table = view(t.table, self.n_states * self.stride if t.dense else 0, np.uint32).reshape(-1, self.stride)
+        self.first_child = view(t.first_child, self.n_states + 1, np.uint32)
+        self.in_byte = view(t.in_byte, self.n_states, np.uint8)
+        self.fail = view(t.fail, self.n_states, np.uint32)
+        self.state_flags = view(t.state_flags, self.n_states, np.uint8)
         self.own_off = view(t.own_off, self.n_states + 1, np.uint32)
         self.own_pid = view(t.own_pid, int(t.n_patterns), np.uint32)
         self.dlink = view(t.dlink, self.n_states, np.uint32)

@@ -1098,7 +1098,10 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     int code = ACX_OK;
     std::string err;
     try {
-        err = compile(blob, n_patterns ? offsets : zero_off, n_patterns, match_kind, a->host, code);
+        // implementation=DFA asks for the dense table outright (the reference's DFA, README.md:173-177,
+        // has no size limit either): keep it up to 16 GiB of the 288 GB
+        err = compile(blob, n_patterns ? offsets : zero_off, n_patterns, match_kind, a->host, code,
+                      implementation == ACX_IMPL_DFA ? (16ull << 30) : 0);
     } catch (const std::bad_alloc &) {
         delete a;
         return fail(ACX_ENOMEM, "out of host memory while compiling the automaton");
@@ -1151,7 +1154,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     }
     D.rank_bits = (uint32_t)std::max(1, bits_for(H.n_patterns ? H.n_patterns - 1 : 0));
     // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile
-    uint32_t hot_rows = dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024);
+    uint32_t hot_rows = H.dense ? dfa_walk_hot_rows(H.n_states, H.stride2, 160 * 1024) : 0;
     std::vector<uint16_t> hot16(((size_t)hot_rows << H.stride2) + 8, 0xFFFF);
     for (size_t i = 0; i < ((size_t)hot_rows << H.stride2); i++) {
         uint32_t en = H.table[i], id = en & ID_MASK;
@@ -1163,7 +1166,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     std::vector<uint32_t> walk_bfs;
     D.n_classes = H.n_classes;
     D.walk_plain = 0;
-    if (H.n_states <= 0xFFFF && H.n_patterns > 0) {
+    if (H.dense && H.n_states <= 0xFFFF && H.n_patterns > 0) {
         const uint32_t NS = H.n_states, NC = H.n_classes, S = H.stride;
         std::vector<uint8_t> reports(NS, 0); // FLAG_OUT is a property of the TARGET state
         for (size_t i = 0; i < (size_t)NS * S; i++)
@@ -1184,7 +1187,12 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     int rc;
 #define UP(vec, field)                                                                   \
     if ((rc = upload(a, st, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
-    UP(H.table, table)
+    if (H.dense) { UP(H.table, table) } else { D.table = nullptr; }
+    UP(H.first_child, first_child)
+    UP(H.in_byte, in_byte)
+    UP(H.fail, fail)
+    UP(H.sflags, sflags)
+    UP(H.root_next, root_next)
     UP(hot16, hot16)
     if (!table16.empty()) {
         UP(table16, table16)
@@ -1267,7 +1275,10 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->n_patterns = A.n_patterns; out->n_states = A.n_states;
     out->n_classes = A.n_classes; out->stride = A.stride;
     out->min_pattern_len = A.min_len; out->max_pattern_len = A.max_len;
-    out->classes = A.classes; out->table = A.table.data();
+    out->classes = A.classes; out->table = A.dense ? A.table.data() : nullptr;
+    out->dense = A.dense ? 1 : 0;
+    out->first_child = A.first_child.data(); out->in_byte = A.in_byte.data();
+    out->fail = A.fail.data(); out->state_flags = A.sflags.data();
     out->own_off = A.own_off.data(); out->own_pid = A.own_pid.data();
     out->dlink = A.dlink.data(); out->level_start = A.level_start.data();
     out->pattern_len = A.plen.data(); out->rank = A.rank.data();

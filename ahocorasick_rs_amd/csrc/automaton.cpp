@@ -9,8 +9,10 @@
 #include "automaton.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include "../../include/acx.h"
 
@@ -59,7 +61,7 @@ struct EdgeMap {
 } // namespace
 
 std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
-                    int match_kind, Automaton &A, int &code) {
+                    int match_kind, Automaton &A, int &code, uint64_t dense_limit) {
     code = ACX_OK;
     if (match_kind < 0 || match_kind > 2) { code = ACX_EINVAL; return "unknown match kind"; }
     if (n > (1ull << 24)) { code = ACX_ETOOBIG; return "more than 2^24 patterns"; }
@@ -201,17 +203,27 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     em = EdgeMap(); e_parent = {}; e_child = {}; e_byte = {}; c_off = {}; c_edge = {};
     order = {}; newid = {}; term_node = {};
 
-    // ---- dense table + fail links, in BFS order
-    const uint32_t S = A.stride;
-    A.table.assign((size_t)n_nodes * S, 0);
+    // ---- failure links (classic construction on the trie: children of s are the consecutive BFS
+    // ids [first_child[s], first_child[s + 1]), bytes ascending)
+    auto child_of = [&](uint32_t s, uint8_t b) -> uint32_t {
+        uint32_t lo = first_child[s], hi = first_child[s + 1];
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (in_byte[mid] < b) lo = mid + 1; else hi = mid;
+        }
+        return lo < first_child[s + 1] && in_byte[lo] == b ? lo : 0u;
+    };
     std::vector<uint32_t> fail(n_nodes, 0);
-    for (uint32_t s = 0; s < n_nodes; s++) {
-        uint32_t *row = A.table.data() + (size_t)s * S;
-        if (s != 0) std::memcpy(row, A.table.data() + (size_t)fail[s] * S, sizeof(uint32_t) * S);
+    for (uint32_t s = 1; s < n_nodes; s++) { // BFS order: fail[s] is final when s is reached
         for (uint32_t c = first_child[s]; c < first_child[s + 1]; c++) {
-            uint32_t cl = A.classes[in_byte[c]];
-            fail[c] = (s == 0) ? 0 : row[cl]; // delta(fail(s), byte)
-            row[cl] = c;
+            const uint8_t b = in_byte[c];
+            uint32_t f = fail[s];
+            for (;;) {
+                const uint32_t x = child_of(f, b);
+                if (x) { fail[c] = x; break; }
+                if (f == 0) { fail[c] = 0; break; }
+                f = fail[f];
+            }
         }
     }
     // ---- dictionary suffix links and output flags
@@ -225,7 +237,59 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         if (own) flags[s] |= FLAG_OWN | FLAG_OUT;
         if (A.dlink[s] != NONE) flags[s] |= FLAG_OUT;
     }
-    for (size_t i = 0; i < A.table.size(); i++) A.table[i] |= flags[A.table[i]];
+    // ---- the compressed form (always): trie edges + failure links -- "NFA" rows of a few bytes per
+    // state.  K0's anchored walk and the failure-link walk (K1a on automata without a dense table)
+    // run on it; K1b needs neither form.
+    A.root_next.assign(256, 0);
+    for (uint32_t c = first_child[0]; c < first_child[1]; c++) A.root_next[in_byte[c]] = c;
+    A.sflags.resize(n_nodes);
+    for (uint32_t s = 0; s < n_nodes; s++) A.sflags[s] = (uint8_t)(flags[s] >> 30);
+    // ---- the dense form: only while it is worth its memory (the crate's own rule of thumb: a DFA
+    // for small sets, an NFA beyond -- /root/reference/README.md:173-177).  One row per state, built
+    // level by level: a row is its failure state's row (one level up at least) + its own edges, so
+    // the states of one level are independent -- host threads share them.
+    const uint32_t S = A.stride;
+    {
+        const char *env = std::getenv("ACX_DENSE_LIMIT"); // bytes; tests force the compressed form with 0
+        const unsigned __int128 limit = env           ? (unsigned __int128)std::strtoull(env, nullptr, 10)
+                                        : dense_limit ? (unsigned __int128)dense_limit
+                                                      : ((unsigned __int128)256 << 20);
+        A.dense = (unsigned __int128)n_nodes * S * 4 <= limit;
+    }
+    if (A.dense) {
+        A.table.assign((size_t)n_nodes * S, 0);
+        auto fill = [&](uint32_t s) {
+            uint32_t *row = A.table.data() + (size_t)s * S;
+            if (s != 0) std::memcpy(row, A.table.data() + (size_t)fail[s] * S, sizeof(uint32_t) * S);
+            for (uint32_t c = first_child[s]; c < first_child[s + 1]; c++) row[A.classes[in_byte[c]]] = c;
+        };
+        const unsigned hw = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        for (size_t d = 0; d + 1 < A.level_start.size(); d++) {
+            const uint32_t lo = A.level_start[d], hi = A.level_start[d + 1];
+            if (hi <= lo) continue;
+            const unsigned T = (uint64_t)(hi - lo) * S < (1u << 18) ? 1 : hw; // small levels: not worth a thread
+            if (T == 1) { for (uint32_t s2 = lo; s2 < hi; s2++) fill(s2); continue; }
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < T; t++)
+                th.emplace_back([&, t] {
+                    const uint32_t a = lo + (uint64_t)(hi - lo) * t / T, b = lo + (uint64_t)(hi - lo) * (t + 1) / T;
+                    for (uint32_t s2 = a; s2 < b; s2++) fill(s2);
+                });
+            for (auto &x : th) x.join();
+        }
+        // the flags of the TARGET state ride on every entry
+        auto tag = [&](size_t a, size_t b) { for (size_t i = a; i < b; i++) A.table[i] |= flags[A.table[i]]; };
+        const size_t total_e = A.table.size();
+        if (total_e < (1u << 20)) tag(0, total_e);
+        else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < hw; t++) th.emplace_back(tag, total_e * t / hw, total_e * (t + 1) / hw);
+            for (auto &x : th) x.join();
+        }
+    }
+    A.first_child = first_child;
+    A.in_byte = in_byte;
+    A.fail = fail;
 
     // ---- tie-break rank (len desc, pid asc)
     {

@@ -110,7 +110,14 @@ struct Automaton {
     uint32_t n_classes = 1, stride = 1, stride2 = 0;
     uint32_t n_states = 1;
     uint8_t classes[256];
-    std::vector<uint32_t> table;       // n_states * stride
+    bool dense = true;                 // the dense table exists (n_states * stride * 4 <= ACX_DENSE_LIMIT, 256 MiB)
+    std::vector<uint32_t> table;       // n_states * stride (empty when !dense)
+    // compressed form (always): trie edges + failure links
+    std::vector<uint32_t> first_child; // n_states + 1: children of s = BFS ids [first_child[s], first_child[s + 1])
+    std::vector<uint8_t> in_byte;      // n_states: the byte on the edge INTO the state (children sorted by it)
+    std::vector<uint32_t> fail;        // n_states: failure link
+    std::vector<uint8_t> sflags;       // n_states: bit 1 = reports something (OUT), bit 0 = ends a pattern itself (OWN)
+    std::vector<uint32_t> root_next;   // 256: the root's child for every byte, or 0
     std::vector<uint32_t> own_off;     // n_states + 1
     std::vector<uint32_t> own_pid;     // patterns ending exactly at the state, id order
     std::vector<uint32_t> own1;        // n_states: single own pattern / OWN1_NONE / OWN1_MANY
@@ -144,7 +151,9 @@ struct Automaton {
 
 // Returns empty string on success, otherwise an error message; `code` receives
 // an ACX_E* value.
+// `dense_limit`: the dense transition table is kept when it is at most this many bytes
+// (0: ACX_DENSE_LIMIT, default 256 MiB); the compressed form is always built.
 std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
-                    int match_kind, Automaton &out, int &code);
+                    int match_kind, Automaton &out, int &code, uint64_t dense_limit = 0);
 
 } // namespace acx

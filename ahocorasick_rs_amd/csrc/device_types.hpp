@@ -8,7 +8,13 @@ namespace acx {
 
 // Device-resident automaton (all pointers are device pointers).
 struct DevAutomaton {
-    const uint32_t *table;       // n_states << stride2 entries: id | FLAG_OUT | FLAG_OWN
+    const uint32_t *table;       // n_states << stride2 entries: id | FLAG_OUT | FLAG_OWN; NULL: the automaton
+                                 // is kept in its compressed form only (trie edges + failure links below)
+    const uint32_t *first_child; // n_states + 1: children of s = BFS ids [first_child[s], first_child[s + 1])
+    const uint8_t *in_byte;      // n_states: byte on the edge into the state (children ascending)
+    const uint32_t *fail;        // n_states: failure link
+    const uint8_t *sflags;       // n_states: bit 1 = OUT, bit 0 = OWN
+    const uint32_t *root_next;   // 256: the root's child per byte, or 0
     const uint16_t *hot16;       // hot_rows << stride2 entries, compact copy for LDS
     const uint8_t *classes;      // 256
     const uint32_t *own_off;     // n_states + 1

@@ -179,8 +179,32 @@ struct WalkCtx {
     uint32_t hot_rows;
 };
 
+// the trie child of s on byte b (0: none): the root by table, the others by their short sorted list
+__device__ __forceinline__ uint32_t trie_child(const DevAutomaton &A, uint32_t s, uint32_t b) {
+    if (s == 0) return A.root_next[b];
+    for (uint32_t c = A.first_child[s], e = A.first_child[s + 1]; c < e; c++) {
+        const uint32_t x = A.in_byte[c];
+        if (x == b) return c;
+        if (x > b) break;
+    }
+    return 0;
+}
+
+// one step of the compressed automaton (trie edges + failure links): the classic Aho-Corasick
+// transition, for automata whose dense table is not kept.  Returns id | OUT << 31 | OWN << 30.
+__device__ __forceinline__ uint32_t nfa_step(const DevAutomaton &A, uint32_t s, uint32_t b) {
+    for (;;) {
+        const uint32_t c = trie_child(A, s, b);
+        if (c) { s = c; break; }
+        if (s == 0) break;
+        s = A.fail[s];
+    }
+    return s | ((uint32_t)A.sflags[s] << 30);
+}
+
 __device__ __forceinline__ uint32_t dfa_step(const DevAutomaton &A, const WalkCtx &W,
                                              uint32_t s, uint32_t byte) {
+    if (!A.table) return nfa_step(A, s, byte); // (uniform: the automaton has no dense table)
     uint32_t c = W.lcls[byte];
     if (s < W.hot_rows) {
         uint32_t v = W.lrows[(s << A.stride2) + c];
@@ -1792,12 +1816,21 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     for (uint32_t pos = t; pos < len; pos += 1024) {
         uint32_t s = 0;
         for (uint32_t d = 0; pos + d < len;) {
-            const uint32_t e = A.table[((size_t)s << A.stride2) + cls[sh[pos + d]]];
-            const uint32_t id = e & ID_MASK;
-            d++;
-            if (id < A.level_start[d]) break; // shallower than d: a failure transition, not an edge
+            uint32_t id, own;
+            if (A.table) {
+                const uint32_t e = A.table[((size_t)s << A.stride2) + cls[sh[pos + d]]];
+                id = e & ID_MASK;
+                d++;
+                if (id < A.level_start[d]) break; // shallower than d: a failure transition, not an edge
+                own = e & FLAG_OWN;
+            } else { // compressed automaton: trie edges only, which is all an anchored walk follows
+                id = trie_child(A, s, sh[pos + d]);
+                d++;
+                if (!id) break;
+                own = A.sflags[id] & 1u;
+            }
             s = id;
-            if (!(e & FLAG_OWN)) continue;
+            if (!own) continue;
             const uint32_t one = A.own1[s];
             uint32_t b = 0, en = 1;
             if (one == OWN1_MANY) { b = A.own_off[s]; en = A.own_off[s + 1]; }

@@ -58,7 +58,7 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
-    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5"], default="auto",
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U", "Z"], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
@@ -126,12 +126,18 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
     elif cfg in ("cfg4", "cfg4b"):
         pats = gen.gen_patterns(100000, 5, 12, gen.AZ if cfg == "cfg4" else gen.ALL_BYTES, 3 if cfg == "cfg4" else 4)
         w["mk"], impl, w["overlapping"] = capi.MATCH_STANDARD, capi.IMPL_AUTO, True
+    elif cfg == "large":
+        # construction at scale (not a BASELINE.json configuration): 1 M patterns, an automaton of
+        # ~4.9 M states that is kept in its compressed form (no dense table)
+        pats = gen.gen_patterns(1000000, 8, 16, gen.AZ, 9)
+        w["mk"], impl = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO
     else:  # cfg5
         spats = list(dict.fromkeys(gen.gen_patterns(10000, 5, 12, gen.AZ_UNI, 5)))
         pats = [p.encode() for p in spats]
         w["mk"], impl, w["codepoints"] = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO, True
+    t0 = time.perf_counter()
     ac = capi.Automaton(pats, w["mk"], impl, kernel=kern)
-    w.update(ac=ac, patterns=pats)
+    w.update(ac=ac, patterns=pats, build_s=time.perf_counter() - t0)
     if cfg == "cfg5":
         # ~1.13 bytes per character at 5 % non-ASCII: generate enough characters, cut at a
         # character boundary at or below --bytes
@@ -155,7 +161,8 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             else:
                 kind, seed = (1, 11) if args.dist == "T" else (0, 12)
                 ac.generate(hay.data_ptr(), nbytes, kind, seed)
-            what = {"T": "text-like (T, seed 11)", "U": "uniform a-z (U, seed 12)",
+            what = {"T": "text-like (T, seed 11: iid a-z letters, a space with probability 43/256 at every "
+                         "position -- geometric word lengths, not a natural-language word model -- one pattern planted per KiB)", "U": "uniform a-z (U, seed 12)",
                     "Z": "ALL-ZERO (calibration only, not a benchmark)"}[args.dist]
             w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
                          f"{nbytes / GIB:g} GiB {what} bytes haystack, MatchKind.Standard, non-overlapping")
@@ -167,6 +174,10 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             w["desc"] = ("cfg3: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, batch of "
                          f"{nbytes // 8192} x 8 KiB haystacks per GPU from one SplitMix64 stream (seed 13, "
                          "offset by rank), MatchKind.Standard, sharded by haystack, RCCL all-gather of match counts")
+        elif cfg == "large":
+            ac.generate(hay.data_ptr(), nbytes, 1, 11)
+            w["desc"] = (f"large: 1M patterns a-z len 8-16 (seed 9), implementation=None, MatchKind.LeftmostLongest, "
+                         f"one {nbytes / GIB:g} GiB text-like (T, seed 11) haystack")
         elif cfg == "cfg4":
             ac.generate(hay.data_ptr(), nbytes, 0, 12)
             w["desc"] = (f"cfg4: 100k patterns a-z len 5-12 (seed 3), implementation=None, overlapping=True, one "
@@ -315,7 +326,7 @@ def run(args) -> None:
             traffic, traffic_src = measured_traffic(kname, nbytes, args.dist, cfg)
             out["config"].update({
                 "n_patterns": len(w["patterns"]), "n_states": int(info.n_states),
-                "dfa_table_bytes": int(info.table_bytes), "scan_kernel": capi.KERNEL_NAMES[info.kernel],
+                "dfa_table_bytes": int(info.table_bytes), "build_s": round(w["build_s"], 3), "scan_kernel": capi.KERNEL_NAMES[info.kernel],
                 "raw_occurrences_per_step": int(prof.raw_occurrences // max(prof.scan_launches, 1)),
                 "prefix_hits_per_step": int(prof.prefix_hits // max(prof.scan_launches, 1)),
                 "percent_of_hbm_roofline": round(100.0 * value / (HBM_PEAK_GBPS * world), 2),

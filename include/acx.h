@@ -45,7 +45,11 @@ extern "C" {
  * yields identical results (tests/test_ac.py:23-31).  On the device it selects
  * the scan kernel: DFA = dense-DFA walk with hot rows in LDS preceded by the
  * LDS q-gram prefilter when the pattern set admits one; NFA values force the
- * plain chunked DFA walk (no prefilter); AUTO picks by pattern statistics. */
+ * plain chunked DFA walk (no prefilter); AUTO picks by pattern statistics.
+ * The dense transition table is kept when it is at most ACX_DENSE_LIMIT bytes
+ * (default 256 MiB; DFA: 16 GiB); beyond that the automaton stays in its
+ * compressed form (trie edges + failure links) and the walking kernels step
+ * that -- the reference's "DFA for small sets, NFA beyond" (README.md:173-177). */
 #define ACX_IMPL_AUTO (-1)
 #define ACX_IMPL_NONCONTIGUOUS_NFA 0
 #define ACX_IMPL_CONTIGUOUS_NFA 1
@@ -121,7 +125,10 @@ typedef struct acx_host_tables {
     uint64_t n_patterns, n_states;
     uint32_t n_classes, stride, min_pattern_len, max_pattern_len;
     const uint8_t *classes;       /* 256: byte -> class                              */
-    const uint32_t *table;        /* n_states * stride: id | OUT<<31 | OWN<<30       */
+    const uint32_t *table;        /* n_states * stride: id | OUT<<31 | OWN<<30; NULL when the dense form
+                                     is not kept (dense == 0: n_states * stride * 4 > ACX_DENSE_LIMIT,
+                                     default 256 MiB -- the reference's own "DFA for small sets, NFA
+                                     beyond", README.md:173-177)                        */
     const uint32_t *own_off;      /* n_states + 1                                    */
     const uint32_t *own_pid;      /* patterns ending exactly at a state, id order    */
     const uint32_t *dlink;        /* dictionary-suffix link or 0xFFFFFFFF            */
@@ -145,6 +152,12 @@ typedef struct acx_host_tables {
     double filter_density;        /* fraction of X bits set                            */
     uint32_t n_prefix_keys;       /* entries of prefix_table in use                    */
     uint32_t n_prefix_lists;      /* u32 words of prefix_lists                         */
+    /* the compressed form (always present): trie edges + failure links               */
+    uint32_t dense;               /* 1: `table` exists                                 */
+    const uint32_t *first_child;  /* n_states + 1: children of s = ids [first_child[s], first_child[s+1]) */
+    const uint8_t *in_byte;       /* n_states: byte on the edge into the state (children ascending)     */
+    const uint32_t *fail;         /* n_states: failure link                                             */
+    const uint8_t *state_flags;   /* n_states: bit 1 = reports something, bit 0 = ends a pattern itself */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);

@@ -67,6 +67,49 @@ def test_compiler_tables_enumerate_every_occurrence():
         h.close()
 
 
+def nfa_step(h, s: int, b: int):
+    """Test-side twin of the device's nfa_step over the compressed form (trie edges + failure links)."""
+    while True:
+        c = 0
+        for k in range(int(h.first_child[s]), int(h.first_child[s + 1])):
+            if int(h.in_byte[k]) == b:
+                c = k
+                break
+        if c:
+            s = c
+            break
+        if s == 0:
+            break
+        s = int(h.fail[s])
+    return s, int(h.state_flags[s])
+
+
+def test_compressed_form_is_the_same_automaton(monkeypatch):
+    """The compressed form (always built) steps exactly like the dense table, and with
+    ACX_DENSE_LIMIT=0 the compiler keeps the compressed form only."""
+    rng = random.Random(11)
+    for it in range(40):
+        alpha = [b"ab", b"abc", b"abcdefgh", bytes(range(256))][it % 4]
+        pats = [bytes(rng.choice(alpha) for _ in range(rng.randint(1, 6))) for _ in range(rng.randint(1, 25))]
+        h = capi.HostAutomaton(pats)
+        assert h.dense and h.table.shape[0] == h.n_states
+        assert h.first_child[0] == 1 or h.n_states == 1
+        assert h.first_child[-1] == h.n_states
+        for s in range(h.n_states):
+            kids = h.in_byte[h.first_child[s]:h.first_child[s + 1]]
+            assert all(kids[i] < kids[i + 1] for i in range(len(kids) - 1))
+            for b in set(alpha) | {0, 255}:
+                e = int(h.table[s, h.classes[b]])
+                t, fl = nfa_step(h, s, b)
+                assert (e & ID_MASK, e >> 30) == (t, fl), (pats, s, b)
+        monkeypatch.setenv("ACX_DENSE_LIMIT", "0")
+        c = capi.HostAutomaton(pats)
+        monkeypatch.delenv("ACX_DENSE_LIMIT")
+        assert not c.dense and c.table.size == 0 and c.n_states == h.n_states
+        for name in ("first_child", "in_byte", "fail", "state_flags", "own_off", "own_pid", "dlink"):
+            assert np.array_equal(getattr(c, name), getattr(h, name)), name
+
+
 def test_compiler_matches_survey_sizes():
     # SURVEY.md §8d: 10k a-z patterns len 5-12 seed 1 -> 63 277 states, 28 classes, stride 32
     h = capi.HostAutomaton(gen.gen_patterns(10000, 5, 12, gen.AZ, 1))

@@ -9,7 +9,7 @@ cd /root/repo
 WHAT=${1:-all}
 if [ "$WHAT" = tests ] || [ "$WHAT" = all ]; then
   timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_sparse_path.py tests/test_gpu_batch.py \
-      tests/test_gpu_cfg1.py tests/test_gpu_configs.py tests/test_api_gpu.py tests/test_gpu_fullsize.py -x -q -m gpu > $OUT/pytest.log 2>&1
+      tests/test_gpu_compressed.py tests/test_gpu_cfg1.py tests/test_gpu_configs.py tests/test_api_gpu.py tests/test_gpu_fullsize.py -x -q -m gpu > $OUT/pytest.log 2>&1
   echo "pytest rc=$?"; tail -25 $OUT/pytest.log
 fi
 if [ "$WHAT" = bench ] || [ "$WHAT" = all ]; then
