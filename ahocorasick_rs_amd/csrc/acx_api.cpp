@@ -1207,6 +1207,9 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.level_start, level_start)
     UP(H.plen, plen)
     UP(H.rank, rank)
+    std::vector<uint32_t> by_rank(H.rank.size() + 1, 0);
+    for (uint32_t i = 0; i < H.rank.size(); i++) by_rank[H.rank[i]] = i;
+    UP(by_rank, by_rank)
     UP(H.filterA, filterA)
     UP(H.ptab, ptab)
     UP(H.blist, blist)

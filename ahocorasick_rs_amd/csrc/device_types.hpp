@@ -24,6 +24,7 @@ struct DevAutomaton {
     const uint32_t *level_start; // max_len + 2
     const uint32_t *plen;        // n_patterns
     const uint32_t *rank;        // n_patterns
+    const uint32_t *by_rank;     // n_patterns: the pattern of a rank (inverse of rank)
     const uint32_t *filterA;     // FILTER_WORDS: level-1 {X, Y} table of the K1b prefilter
     const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, pid or list)
     const uint32_t *blist;       // candidate lists of prefixes shared by several patterns

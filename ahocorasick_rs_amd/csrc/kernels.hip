@@ -1415,27 +1415,45 @@ constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 // occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
 constexpr uint32_t STAGE_SLOTS = 24;
 static_assert(GROUP_TILES == 64, "one wave owns the output buckets of a group");
+static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit mask");
+// A staged occurrence is ONE 64-bit word (the group's LDS footprint decides how many groups a CU
+// works on at once, and the kernel is bound by the latency of its gathers, not by anything it
+// computes): [ rel : 19 | tie : rank_bits | length : 45 - rank_bits ], rel = index of the key
+// position relative to the first staged tile.  Words compare like the occurrence keys they stand
+// for.  (The sparse path takes automata whose patterns are shorter than the context tiles --
+// tile_lookback -- so a length always fits.)
+constexpr uint32_t REL_BITS = 19;
+static_assert(((GROUP_TILES + MAX_LOOKBACK) << TILE_BITS) <= (1u << REL_BITS), "group-relative key positions");
+static_assert((MAX_LOOKBACK << TILE_BITS) < (1u << (64 - REL_BITS - 24)), "pattern lengths of the sparse path");
 
 __device__ __forceinline__ uint64_t rec_key(const uint4 v) { return ((uint64_t)v.y << 32) | v.x; }
 
-// span of an occurrence record {key lo, key hi, pid, pattern length}
+// span of an occurrence record {key lo, key hi, tie (rank or pattern id), pattern length}
 __device__ __forceinline__ void span_of(uint32_t rank_bits, int key_mode, uint4 v, uint64_t *s, uint64_t *e) {
     const uint64_t x = rec_key(v) >> rank_bits;
     if (key_mode == 0) { *e = x; *s = x - v.w; }
     else { *s = x; *e = x + v.w; }
 }
 
+// span of a staged occurrence, relative to the first staged tile (a start may lie in front of it)
+__device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, uint64_t r, int32_t *s, int32_t *e) {
+    const uint32_t lb = 64 - REL_BITS - rank_bits;
+    const int32_t rel = (int32_t)(r >> (64 - REL_BITS)), L = (int32_t)(r & ((1ull << lb) - 1));
+    if (key_mode == 0) { *e = rel; *s = rel - L; }
+    else { *s = rel; *e = rel + L; }
+}
+
 __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag) {
-    // (rows padded to an odd number of quads: lane t works on row t, and a power-of-two row stride would
+    // (rows padded to an odd number of words: lane t works on row t, and a power-of-two row stride would
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
-    __shared__ uint4 st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
+    __shared__ uint64_t st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
     __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
-    __shared__ uint64_t bmax[STAGE_BUCKETS];       // largest end per bucket
+    __shared__ int32_t bmax[STAGE_BUCKETS];        // largest end per bucket
     __shared__ uint32_t hoff[STAGE_BUCKETS + 1];   // exclusive prefix of the tiles' hit counts
-    __shared__ uint8_t syn[STAGE_BUCKETS][STAGE_SLOTS + 4], acc[STAGE_BUCKETS][STAGE_SLOTS + 4];
+    __shared__ uint32_t synm[STAGE_BUCKETS], accm[STAGE_BUCKETS]; // per bucket: sync points / accepted
     __shared__ uint32_t fail, stop, tail_base;
     const uint32_t t = threadIdx.x, g = blockIdx.x;
     const uint32_t tile0 = g * GROUP_TILES;
@@ -1476,7 +1494,8 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     const uint64_t margin = A.max_len ? A.max_len - 1 : 0;
     const uint64_t first_idx = (uint64_t)first << TILE_BITS;
     const uint64_t complete = first == 0 ? 0 : first_idx + (key_mode == 0 ? margin : 0);
-    const uint64_t wlow = first == 0 ? 0 : first_idx + margin;
+    const int32_t wlow = first == 0 ? 0 : (int32_t)margin; // relative to first_idx
+    const uint32_t rank_bits = A.rank_bits, len_bits = 64 - REL_BITS - rank_bits;
     // ---- verify: one thread per hit
     for (uint32_t h = t; h < H; h += MAIN_THREADS) {
         uint32_t lo = 0, hi = nb; // tile j = the last one with hoff[j] <= h
@@ -1486,13 +1505,13 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
         }
         const uint4 *rec = T.hslots + ((uint64_t)(first + lo) * HIT_SLOTS + (h - hoff[lo])) * 2;
         const uint4 r0 = rec[0];
+        const uint4 w = rec[1]; // (unconditional: in flight together with the first half)
         const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
         uint64_t w0 = 0, w1 = 0, room = 0;
         uint32_t nc = 1, li = 0, code = r0.z;
         const bool verified = code != HIT_RETRY && (code & HIT_VERIFIED) != 0;
         bool list = false;
         if (!verified) {
-            const uint4 w = rec[1];
             w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
             room = segment_end(G, len, p) - p;
             if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
@@ -1509,51 +1528,53 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
                 if (!L) continue;
             }
-            const uint64_t key = occurrence_key(key_mode, A.rank_bits, p, L, pid, rk);
             const uint64_t kidx = (key_mode == 0 ? p + L : p) + lead;
             if (kidx < complete || kidx >= idx_hi) continue; // another group's (or nobody's) business
-            const uint32_t b = (uint32_t)((kidx >> TILE_BITS) - first);
+            const uint32_t rel = (uint32_t)(kidx - first_idx);
+            const uint32_t b = rel >> TILE_BITS;
             const uint32_t r = atomicAdd(&bn[b], 1u);
-            if (r < STAGE_SLOTS) st[b][r] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
+            if (r < STAGE_SLOTS)
+                st[b][r] = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
             else fail = 1;
         }
     }
     __syncthreads();
     if (fail) { if (t == 0) *abort_flag = 1; return; }
-    // ---- order every bucket (keys are unique), largest end per bucket
+    // ---- order every bucket (words are unique), largest end per bucket
     if (t < nb) {
         const uint32_t n = bn[t];
-        uint64_t mx = 0;
+        int32_t mx = 0;
         for (uint32_t i = 0; i < n; i++) {
-            const uint4 v = st[t][i];
-            const uint64_t kk = rec_key(v);
+            const uint64_t v = st[t][i];
             uint32_t j = i;
-            while (j > 0 && rec_key(st[t][j - 1]) > kk) { st[t][j] = st[t][j - 1]; j--; }
+            while (j > 0 && st[t][j - 1] > v) { st[t][j] = st[t][j - 1]; j--; }
             st[t][j] = v;
-            uint64_t s, e;
-            span_of(A.rank_bits, key_mode, v, &s, &e);
+            int32_t s, e;
+            staged_span(rank_bits, key_mode, v, &s, &e);
             mx = max(mx, e);
         }
         bmax[t] = mx;
     }
     __syncthreads();
-    uint32_t cnt = 0; // reported occurrences of output bucket t (wave 0)
+    uint32_t cnt = 0, accepted = 0; // reported occurrences of output bucket t (wave 0)
     if (overlapping) {
-        if (t < GROUP_TILES) cnt = bn[lb + t];
+        if (t < GROUP_TILES) { cnt = bn[lb + t]; accepted = cnt >= 32 ? 0xFFFFFFFFu : (1u << cnt) - 1; }
     } else {
         // ---- certified sync points.  Only occurrences of the last (lookback + 1) buckets can end
         // beyond the start of one in bucket t (an occurrence spans at most max_len - 1 bytes
         // besides its key position, and lookback tiles are longer than that).
         if (t < nb) {
-            uint64_t m = 0;
+            int32_t m = 0;
             for (uint32_t b = t > lookback + 1 ? t - lookback - 1 : 0; b < t; b++) m = max(m, bmax[b]);
             const uint32_t n = bn[t];
+            uint32_t sm = 0;
             for (uint32_t i = 0; i < n; i++) {
-                uint64_t s, e;
-                span_of(A.rank_bits, key_mode, st[t][i], &s, &e);
-                syn[t][i] = (s + lead >= wlow && m <= s) ? 1 : 0;
+                int32_t s, e;
+                staged_span(rank_bits, key_mode, st[t][i], &s, &e);
+                if (s >= wlow && m <= s) sm |= 1u << i;
                 m = max(m, e);
             }
+            synm[t] = sm;
         }
         __syncthreads();
         // ---- greedy chains: every output bucket from the nearest certified sync point
@@ -1561,7 +1582,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             const uint32_t ob = lb + t;
             int b = (int)ob, i = 0;
             bool ok = true;
-            while (!syn[b][i]) { // walk back to a sync point
+            while (!((synm[b] >> i) & 1u)) { // walk back to a sync point
                 if (--i < 0) {
                     do { b--; } while (b >= 0 && bn[b] == 0);
                     if (b < 0) { ok = false; break; }
@@ -1571,13 +1592,13 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             if (!ok) {
                 fail = 1; // the chain enters from beyond the context: dense path
             } else {
-                uint64_t pos = 0;
+                int32_t pos = INT32_MIN;
                 for (;;) { // forward again, to the end of bucket ob
-                    uint64_t s, e;
-                    span_of(A.rank_bits, key_mode, st[b][i], &s, &e);
+                    int32_t s, e;
+                    staged_span(rank_bits, key_mode, st[b][i], &s, &e);
                     const bool take = s >= pos;
                     if (take) pos = e;
-                    if ((uint32_t)b == ob) { acc[b][i] = take; cnt += take; }
+                    if ((uint32_t)b == ob && take) { accepted |= 1u << i; cnt++; }
                     if (++i >= (int)bn[b]) {
                         if ((uint32_t)b == ob) break;
                         do { b++; } while (bn[b] == 0); // ob is not empty: terminates there at the latest
@@ -1601,10 +1622,18 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
         if (total > GROUP_MAX) {
             if (t == 0) *abort_flag = 1;
         } else {
+            // records {key lo, key hi, tie, length} in stream coordinates (k_tile_write maps a rank to its pattern)
             uint4 *dst = T.trecs + (uint64_t)g * GROUP_MAX + (incl - cnt);
-            const uint32_t n = bn[lb + t];
-            for (uint32_t i = 0, k = 0; i < n; i++)
-                if (overlapping || acc[lb + t][i]) dst[k++] = st[lb + t][i];
+            const uint64_t base = first_idx - lead;
+            for (uint32_t k = 0; accepted; k++) {
+                const uint32_t i = __builtin_ctz(accepted);
+                accepted &= accepted - 1;
+                const uint64_t r = st[lb + t][i];
+                const uint64_t x = r >> len_bits; // rel << rank_bits | tie
+                const uint64_t key = x + (base << rank_bits);
+                dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
+                                    (uint32_t)(r & ((1ull << len_bits) - 1)));
+            }
         }
         if (t == 0) { T.btot[g] = total > GROUP_MAX ? 0 : total; T.gocc[g] = occ; T.ghits[g] = hoff[nb] - hoff[lb]; }
     }
@@ -1656,32 +1685,68 @@ __global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits,
     }
 }
 
+// lead (non-continuation) bytes among the bytes of w selected by `valid` (0x80 per byte kept)
+__device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
+    const uint64_t HI = 0x8080808080808080ull;
+    const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
+    return __popcll(valid & HI & ~cont);
+}
+
 // non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
 // range masked off (an aligned word never leaves the page its first / last byte of the range is
-// in, so the words at the two ends are safe to read in full) -- no byte loops
+// in, so the words at the two ends are safe to read in full) -- no byte loops.  Four words per
+// round, their loads issued together: a match span is one round, not a chain of dependent misses.
 __device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const uint8_t *end) {
     if (p >= end) return 0;
-    const uint64_t HI = 0x8080808080808080ull;
     const uint8_t *q = (const uint8_t *)((uintptr_t)p & ~(uintptr_t)7);
-    uint64_t valid = ~0ull << (8 * ((uintptr_t)p & 7)); // bytes of the first word at or after p
+    uint64_t first = ~0ull << (8 * ((uintptr_t)p & 7)); // bytes of the first word at or after p
     uint64_t c = 0;
-    for (; q < end; q += 8, valid = ~0ull) {
-        if (end - q < 8) valid &= ~0ull >> (8 * (8 - (end - q))); // bytes of the last word before end
-        const uint64_t w = *(const uint64_t *)q;
-        const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
-        c += __popcll(valid & HI) - __popcll(cont & valid);
+    for (; q < end; q += 32, first = ~0ull) {
+        uint64_t w[4], valid[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int64_t left = end - (q + 8 * k); // bytes of [q + 8k, end)
+            w[k] = left > 0 ? *(const uint64_t *)(q + 8 * k) : 0;
+            valid[k] = left >= 8 ? ~0ull : left > 0 ? ~0ull >> (8 * (8 - left)) : 0;
+        }
+        valid[0] &= first;
+#pragma unroll
+        for (int k = 0; k < 4; k++) c += lead_in_word(w[k], valid[k]);
+    }
+    return c;
+}
+
+// lead bytes in [base, base + n), base 64-byte aligned, n < 64: the stretch is loaded whole (four
+// 16-byte loads in flight together; it cannot leave the page of its first byte)
+__device__ __forceinline__ uint32_t lead_bytes_in_stretch(const uint8_t *base, uint32_t n) {
+    const uint4 *b = (const uint4 *)base;
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) v[k] = (uint32_t)(16 * k) < n ? b[k] : make_uint4(0, 0, 0, 0);
+    uint32_t c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const uint64_t w = k & 1 ? ((uint64_t)v[k >> 1].w << 32 | v[k >> 1].z) : ((uint64_t)v[k >> 1].y << 32 | v[k >> 1].x);
+        const int32_t left = (int32_t)n - 8 * k;
+        const uint64_t valid = left >= 8 ? ~0ull : left > 0 ? ~0ull >> (8 * (8 - left)) : 0;
+        c += lead_in_word(w, valid);
     }
     return c;
 }
 
 // code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of
 // its 1 KiB block + the counts of the whole 64-byte stretches before it inside the block (ONE
-// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place
+// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place.  Every load's address
+// depends on x only: they are all in flight together.
 __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
                                                   const uint8_t *__restrict__ sub, uint64_t x) {
     const uint64_t blk = x >> 10;
     const uint32_t q = (uint32_t)(x & 1023) >> 6; // whole 64-byte stretches before x
     const uint4 sv = *(const uint4 *)(sub + blk * 16);
+    const uint64_t pre = blockpre[blk];
+    // (uniform branch: a haystack that is not 16-byte aligned takes the word-wise count)
+    const uint32_t tail = ((uintptr_t)hay & 15) == 0 ? lead_bytes_in_stretch(hay + (x & ~63ull), (uint32_t)(x & 63))
+                                                     : (uint32_t)lead_bytes_between(hay + (x & ~63ull), hay + x);
     const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
     uint32_t acc = 0;
 #pragma unroll
@@ -1690,7 +1755,7 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
         const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
         acc = __builtin_amdgcn_sad_u8(w[d] & m, 0u, acc);
     }
-    return blockpre[blk] + acc + lead_bytes_between(hay + (x & ~63ull), hay + x);
+    return pre + acc + tail;
 }
 
 // The groups' reported occurrences -> final records.  A workgroup takes WRITE_GROUPS consecutive
@@ -1702,7 +1767,8 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
 constexpr uint32_t WRITE_THREADS = 256, WRITE_GROUPS = 1, WRITE_MAX = WRITE_GROUPS * GROUP_MAX;
 // cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
 struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; };
-__global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode, TileSpace T,
+__global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode,
+                                                              const uint32_t *__restrict__ by_rank, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
                                                               Segments G, uint64_t *seg_counts, CodePointTables cp) {
     __shared__ uint32_t img[WRITE_MAX * 6];
@@ -1739,7 +1805,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             s = cs;
         }
         uint32_t *d = img + i * 6;
-        d[0] = v.z; d[1] = 0; d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
+        d[0] = key_mode == 1 ? v.z : by_rank[v.z]; d[1] = 0; d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
     }
     __syncthreads();
     uint32_t *flat = (uint32_t *)(out + base);
@@ -1777,7 +1843,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, count_hits ? 1 : 0, summary, abort_flag,
                        next_flag, (volatile uint64_t *)host_out, seq);
     hipLaunchKernelGGL(k_tile_write, dim3((T.n_groups + WRITE_GROUPS - 1) / WRITE_GROUPS), dim3(WRITE_THREADS), 0, st,
-                       A.rank_bits, key_mode, T, out, abort_flag, G, seg_counts,
+                       A.rank_bits, key_mode, A.by_rank, T, out, abort_flag, G, seg_counts,
                        CodePointTables{d_hay, cp_blockpre, cp_sub});
     return hipGetLastError();
 }

@@ -58,6 +58,8 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
+    ap.add_argument("--ablate", default="", help="measurement only: override the configuration's match kind / "
+                    "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
     ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U", "Z"], default="T",
@@ -136,6 +138,16 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
         pats = [p.encode() for p in spats]
         w["mk"], impl, w["codepoints"] = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO, True
     t0 = time.perf_counter()
+    for kv in filter(None, (args.ablate or "").split(",")):  # measurement switches, never the judged line
+        k, v = kv.split("=")
+        if k == "mk":
+            w["mk"] = {"standard": capi.MATCH_STANDARD, "lf": capi.MATCH_LEFTMOST_FIRST, "ll": capi.MATCH_LEFTMOST_LONGEST}[v]
+        elif k == "cp":
+            w["codepoints"] = bool(int(v))
+        elif k == "ov":
+            w["overlapping"] = bool(int(v))
+        else:
+            raise SystemExit(f"--ablate: unknown switch {k}")
     ac = capi.Automaton(pats, w["mk"], impl, kernel=kern)
     w.update(ac=ac, patterns=pats, build_s=time.perf_counter() - t0)
     if cfg == "cfg5":
@@ -187,6 +199,8 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             hay = torch.from_numpy(host).to(dev)
             w["desc"] = (f"cfg4b: 100k patterns over all byte values len 5-12 (seed 4), implementation=None, "
                          f"overlapping=True, one {nbytes / GIB:g} GiB uniform-bytes haystack (seed 12)")
+    if args.ablate:
+        w["desc"] += f" [ABLATION {args.ablate}: not the configuration's own settings]"
     w.update(hay=hay, nbytes=nbytes)
     return w
 
