@@ -308,6 +308,7 @@ struct Workspace {
     uint64_t block_cap = 0;
     TileSpace T{};                    // sparse path (hit slots + tile kernels)
     uint64_t tile_cap = 0;            // tiles T is allocated for
+    uint64_t group_cap = 0;           // groups T.gstate is allocated for
     bool flags_dirty = true;          // the abort flags are not known to be zero
     acx_match_t *final = nullptr;     // sparse path: output buffer the next call writes into
     uint64_t final_cap = 0;
@@ -398,10 +399,10 @@ int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T
 
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
-    (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs);
-    (void)hipFree(T.gocc); (void)hipFree(T.ghits); (void)hipFree(T.btot); (void)hipFree(T.bbase);
+    (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
     T = TileSpace{};
     w.tile_cap = 0;
+    w.group_cap = 0;
 }
 
 void free_ws(Workspace &w, int device) {
@@ -544,11 +545,13 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
         const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
         HIPCHK(hipMalloc((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32));
         HIPCHK(hipMalloc((void **)&T.hcnt, (cap_tiles + 16 * 1024 + 16) * 4)); // + one slot per K1b wave (layout slack)
+        const uint64_t cap_super = (cap_groups + 63) / 64;
         HIPCHK(hipMalloc((void **)&T.trecs, cap_groups * GROUP_MAX * 16));
-        HIPCHK(hipMalloc((void **)&T.gocc, cap_groups * 4));
-        HIPCHK(hipMalloc((void **)&T.ghits, cap_groups * 4));
         HIPCHK(hipMalloc((void **)&T.btot, cap_groups * 4));
-        HIPCHK(hipMalloc((void **)&T.bbase, cap_groups * 4));
+        HIPCHK(hipMalloc((void **)&T.sgw, 4 * cap_super * 8));
+        HIPCHK(hipMemset(T.sgw, 0, 4 * cap_super * 8)); // both sets start clear
+        T.sg_cap = (uint32_t)cap_super;
+        w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
     }
     T.n_tiles = (uint32_t)tiles;
@@ -653,7 +656,7 @@ int wait_published(Ctx *c, uint64_t seq) {
 //
 //   small haystack:          K0, the whole call in one workgroup                 one launch
 //   sparse output (default): scan (K1b: prefix hits / K1a: occurrences) into per-tile hit slots ->
-//                            k_tile_main (verify, order, match kind) -> k_tile_scan -> k_tile_write;
+//                            k_tile_main (verify, order, match kind) -> k_tile_write (output offsets, final records);
 //                            the host returns as soon as the scan kernel has published the totals
 //   dense output:            scan emits into regions -> (walk) -> compact -> radix sort -> spans ->
 //                            resolve -> offsets -> write                         (two round trips)
@@ -744,12 +747,14 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     }
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, prof && c.pre, c.G, seg_counts, cp_pre, w.blocksub, st));
+                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, st));
     if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
     w.flags_dirty = false; // the scan kernel left the next flag clean
     add_scan_profile(a, x, c.len);
     if (w.h_pinned[5] != 0) { // the slots could not hold the output: dense path
         HIPCHK_RC(hipStreamSynchronize(st));
+        // (both sets of supergroup words clear again, whatever made the call give up)
+        HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
         if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
         x->dense_hold = 8;
         c.leads_counted = false;

@@ -111,10 +111,10 @@ struct TileSpace {
     uint32_t *hcnt;     // n_tiles (+ slack), indexed by hcnt_index(tile, cnt_nw, cnt_iters)
     uint32_t cnt_nw, cnt_iters;
     uint4 *trecs;       // groups * GROUP_MAX: the REPORTED occurrences of a group, in order
-    uint32_t *gocc;     // occurrences seen by each group (statistics)
-    uint32_t *ghits;    // prefix hits of each group's own tiles (statistics)
     uint32_t *btot;     // reported occurrences of each group
-    uint32_t *bbase;    // exclusive prefix of btot
+    uint64_t *sgw;      // 2 sets (used by the calls in turn) of 2 * sg_cap words: per supergroup of 64
+                        // groups, the sum of their counts / of their statistics (kernels.hip)
+    uint32_t sg_cap;
     uint32_t n_tiles, n_groups;
 };
 

@@ -16,7 +16,7 @@
 //   K2   k_tile_main     one workgroup per 64 tiles: verifies the hits against the pattern
 //                        bytes, orders the occurrences, applies the match kind (Standard /
 //                        LeftmostFirst / LeftmostLongest, overlapping or not) exactly as the
-//                        reference iterators would; k_tile_scan + k_tile_write compact them
+//                        reference iterators would; k_tile_write places and writes them
 //                        into the final (pattern, start, end) records
 //        dense inputs    (more occurrences than the slots hold) take the region path: K1b ->
 //                        k_walk_hits -> rocPRIM radix sort on the 64-bit key -> k_resolve
@@ -1395,8 +1395,8 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 //                 bytes, drops the occurrences into LDS buckets of 4 KiB of KEY position,
 //                 orders every bucket, applies the match kind and writes the group's REPORTED
 //                 occurrences, in order, to its stretch of trecs
-//   k_tile_scan   exclusive scan of the group totals (one workgroup); totals to pinned host memory
-//   k_tile_write  final (pattern, start, end) records, coalesced through LDS
+//   k_tile_write  the groups' output offsets (sums of supergroup words), the call's totals to
+//                 pinned host memory, final (pattern, start, end) records, coalesced through LDS
 //
 // Match kind without communication between groups.  Sorted by key, the non-overlapping greedy
 // accepts occurrence i iff start_i >= end of the last accepted one.  Occurrence i is a *sync
@@ -1425,6 +1425,13 @@ static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit
 constexpr uint32_t REL_BITS = 19;
 static_assert(((GROUP_TILES + MAX_LOOKBACK) << TILE_BITS) <= (1u << REL_BITS), "group-relative key positions");
 static_assert((MAX_LOOKBACK << TILE_BITS) < (1u << (64 - REL_BITS - 24)), "pattern lengths of the sparse path");
+// The output offset of a group = the matches of the groups in front of it.  Groups add their count
+// (and their statistics: occurrences << 32 | prefix hits) into the words of their SUPERGROUP of 64
+// groups -- relaxed atomics, nobody waits: the kernel boundary orders them before k_tile_write --
+// so that a group of k_tile_write sums n_groups / 64 supergroup words + at most 63 group counts.
+// Two sets of supergroup words are used by the calls in turn (seq & 1): k_tile_write leaves the
+// other set clear for the next call.
+constexpr uint32_t SUPER = 64;
 
 __device__ __forceinline__ uint64_t rec_key(const uint4 v) { return ((uint64_t)v.y << 32) | v.x; }
 
@@ -1446,7 +1453,7 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
-                                                            uint64_t len, uint32_t *abort_flag) {
+                                                            uint64_t len, uint32_t *abort_flag, uint64_t seq) {
     // (rows padded to an odd number of words: lane t works on row t, and a power-of-two row stride would
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
     __shared__ uint64_t st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
@@ -1484,7 +1491,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     const uint32_t H = hoff[nb];
     if (stop) return;
     if (H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
-        if (t == 0) { T.btot[g] = 0; T.gocc[g] = 0; T.ghits[g] = 0; }
+        if (t == 0) T.btot[g] = 0;
         return;
     }
     // index space: index = stream position + lead; a tile / bucket is 4 KiB of it
@@ -1635,53 +1642,16 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                                     (uint32_t)(r & ((1ull << len_bits) - 1)));
             }
         }
-        if (t == 0) { T.btot[g] = total > GROUP_MAX ? 0 : total; T.gocc[g] = occ; T.ghits[g] = hoff[nb] - hoff[lb]; }
-    }
-}
-
-// One workgroup: bbase = exclusive scan of btot; publishes {[0] occurrences, [2] prefix hits (only
-// when count_hits), [4] matches, [5] aborted, [7] seq} to host_out (pinned, system-coherent host
-// memory the host polls: seq is written last, behind a system-scope fence) and mirrors them
-// in `summary`; clears the abort flag the NEXT call will use.
-__global__ __launch_bounds__(1024) void k_tile_scan(TileSpace T, int count_hits, uint64_t *summary,
-                                                    const uint32_t *abort_flag, uint32_t *next_flag,
-                                                    volatile uint64_t *host_out, uint64_t seq) {
-    using scan_t = rocprim::block_scan<uint32_t, 1024>;
-    __shared__ typename scan_t::storage_type scan_tmp;
-    __shared__ uint64_t red[2][16];
-    const uint32_t t = threadIdx.x;
-    const bool stop = *abort_flag != 0; // stable: its writers completed
-    uint64_t hsum = 0, nsum = 0;
-    (void)count_hits;
-    const uint32_t per = (T.n_groups + 1023) / 1024, g0 = t * per;
-    uint32_t mine = 0, excl = 0, total = 0;
-    // (unrolled so that the loads of several groups are in flight together)
-    if (!stop)
-        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < T.n_groups; g++) {
-            mine += T.btot[g];
-            nsum += T.gocc[g];
-            hsum += T.ghits[g];
+        if (t == 0) {
+            // the group's count, and count and statistics added into the words of its supergroup
+            // (k_tile_write, which starts when every group is done, places the output with them)
+            const uint32_t n = total > GROUP_MAX ? 0 : total;
+            T.btot[g] = n;
+            uint64_t *sgw = T.sgw + (seq & 1) * 2 * (uint64_t)T.sg_cap;
+            __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, ((uint64_t)occ << 32) | (hoff[nb] - hoff[lb]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-    scan_t().exclusive_scan(mine, excl, 0u, total, scan_tmp);
-    if (!stop)
-        _Pragma("unroll 8") for (uint32_t g = g0; g < g0 + per && g < T.n_groups; g++) {
-            T.bbase[g] = excl;
-            excl += T.btot[g];
-        }
-    for (int o = 32; o > 0; o >>= 1) {
-        hsum += __shfl_down(hsum, o);
-        nsum += __shfl_down(nsum, o);
-    }
-    if ((t & 63) == 0) { red[0][t >> 6] = hsum; red[1][t >> 6] = nsum; }
-    __syncthreads();
-    if (t == 0) {
-        uint64_t a = 0, c = 0;
-        for (int i = 0; i < 16; i++) { a += red[0][i]; c += red[1][i]; }
-        summary[0] = c; summary[2] = a; summary[4] = total;
-        if (next_flag) *next_flag = 0;
-        host_out[0] = c; host_out[2] = a; host_out[4] = total; host_out[5] = stop ? 1 : 0;
-        __threadfence_system();
-        host_out[7] = seq;
     }
 }
 
@@ -1758,38 +1728,83 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
     return pre + acc + tail;
 }
 
-// The groups' reported occurrences -> final records.  A workgroup takes WRITE_GROUPS consecutive
-// groups: their output is one contiguous stretch of 24-byte records, assembled in LDS and written as
-// a flat array of dwords (coalesced).
+// The groups' reported occurrences -> final records.  A workgroup takes one group: its output is
+// one contiguous stretch of 24-byte records, assembled in LDS and written as a flat array of
+// dwords (coalesced).  The stretch starts at the sum of the counts of the groups in front (the
+// full supergroups' words + the counts of the groups in front inside the own supergroup).
+// Group 0 -- the first to run -- adds up ALL supergroup words and publishes the call's totals
+// {[0] occurrences, [2] prefix hits, [4] matches, [5] aborted, [7] seq} to host_out (pinned,
+// system-coherent host memory the host polls: seq is written last, behind a system-scope
+// fence), mirrors them in `summary`, clears the abort flag and the supergroup words the NEXT
+// call will use: the host returns while the records are still being written (they are consumed
+// in stream order).
 // seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
 // their haystack and the per-haystack counts are taken here -- one atomic per run of matches
 // of the same haystack inside the stretch instead of a separate pass with one atomic per match.
-constexpr uint32_t WRITE_THREADS = 256, WRITE_GROUPS = 1, WRITE_MAX = WRITE_GROUPS * GROUP_MAX;
+constexpr uint32_t WRITE_THREADS = 256, WRITE_MAX = GROUP_MAX;
 // cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
 struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; };
+struct PostOut {
+    uint64_t *summary;           // device mirror of the totals
+    volatile uint64_t *host_out; // pinned host memory the host polls
+    uint32_t *next_flag;         // the abort flag of the NEXT call: left clear
+    uint64_t seq;                // this call's sequence number
+};
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode,
                                                               const uint32_t *__restrict__ by_rank, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
-                                                              Segments G, uint64_t *seg_counts, CodePointTables cp) {
+                                                              Segments G, uint64_t *seg_counts, CodePointTables cp,
+                                                              PostOut O) {
     __shared__ uint32_t img[WRITE_MAX * 6];
     __shared__ uint32_t hs[WRITE_MAX]; // haystack index of the matches, in output order
-    __shared__ uint32_t goff[WRITE_GROUPS + 1];
-    const uint32_t t = threadIdx.x, g0 = blockIdx.x * WRITE_GROUPS;
-    if (*abort_flag) return; // stable by now: its writers completed
-    if (t == 0) {
-        uint32_t run = 0;
-        for (uint32_t k = 0; k < WRITE_GROUPS; k++) {
-            goff[k] = run;
-            if (g0 + k < T.n_groups) run += T.btot[g0 + k];
+    __shared__ uint64_t red[4];
+    __shared__ uint64_t s_base;
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    const bool stop = *abort_flag != 0; // stable by now: its writers completed
+    const uint64_t *sgw = T.sgw + (O.seq & 1) * 2 * (uint64_t)T.sg_cap;
+    const uint32_t n_super = (T.n_groups + SUPER - 1) / SUPER;
+    if (g == 0) { // the call's totals, as early as they can be known
+        uint64_t m = 0, occ = 0, hit = 0;
+        for (uint32_t k = t; k < n_super; k += WRITE_THREADS) {
+            m += sgw[k];
+            const uint64_t v = sgw[T.sg_cap + k];
+            occ += v >> 32; hit += v & 0xFFFFFFFFu;
         }
-        goff[WRITE_GROUPS] = run;
+        for (int o = 32; o > 0; o >>= 1) { m += __shfl_xor(m, o); occ += __shfl_xor(occ, o); hit += __shfl_xor(hit, o); }
+        // (three rounds through the same four words; 4 waves)
+        uint64_t tot[3];
+        const uint64_t part[3] = {m, occ, hit};
+        for (int r = 0; r < 3; r++) {
+            __syncthreads();
+            if ((t & 63) == 0) red[t >> 6] = part[r];
+            __syncthreads();
+            tot[r] = red[0] + red[1] + red[2] + red[3];
+        }
+        uint64_t *other = T.sgw + ((O.seq & 1) ^ 1) * 2 * (uint64_t)T.sg_cap;
+        for (uint32_t k = t; k < 2 * T.sg_cap; k += WRITE_THREADS) other[k] = 0;
+        if (t == 0) {
+            O.summary[0] = tot[1]; O.summary[2] = tot[2]; O.summary[4] = tot[0];
+            if (O.next_flag) *O.next_flag = 0;
+            O.host_out[0] = tot[1]; O.host_out[2] = tot[2]; O.host_out[4] = tot[0];
+            O.host_out[5] = stop ? 1 : 0;
+            __threadfence_system();
+            O.host_out[7] = O.seq;
+        }
+    }
+    if (stop) return;
+    const uint32_t n = T.btot[g];
+    if (n == 0) return;
+    if (t < 64) { // the stretch's place: the groups in front
+        const uint32_t sg = g / SUPER, gi = g % SUPER;
+        uint64_t sum = t < gi ? T.btot[sg * SUPER + t] : 0;
+        for (uint32_t k = t; k < sg; k += 64) sum += sgw[k];
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        if (t == 0) s_base = sum;
     }
     __syncthreads();
-    const uint32_t n = goff[WRITE_GROUPS], base = T.bbase[g0];
+    const uint64_t base = s_base;
     for (uint32_t i = t; i < n; i += WRITE_THREADS) {
-        uint32_t k = 0;
-        while (i >= goff[k + 1]) k++;
-        const uint4 v = T.trecs[(uint64_t)(g0 + k) * GROUP_MAX + (i - goff[k])];
+        const uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + i];
         uint64_t s, e;
         span_of(rank_bits, key_mode, v, &s, &e);
         if (seg_counts) {
@@ -1805,7 +1820,8 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             s = cs;
         }
         uint32_t *d = img + i * 6;
-        d[0] = key_mode == 1 ? v.z : by_rank[v.z]; d[1] = 0; d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
+        d[0] = key_mode == 1 ? v.z : by_rank[v.z]; d[1] = 0;
+        d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
     }
     __syncthreads();
     uint32_t *flat = (uint32_t *)(out + base);
@@ -1828,23 +1844,21 @@ uint32_t tile_lookback(uint32_t max_len) {
 }
 
 // Verify, order, resolve and compact the hits of the whole call into out[] (capacity
-// n_groups * GROUP_MAX suffices).  *abort_flag != 0 afterwards (published as host_out[5]): the
-// output did not fit the sparse path and out[] / the totals are meaningless.
+// n_groups * GROUP_MAX suffices).  host_out[5] != 0 afterwards: the output did not fit the sparse
+// path and out[] / the totals are meaningless.
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
-                     bool count_hits, const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
                      const uint8_t *cp_sub, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
-                       lead, d_hay, len, abort_flag);
-    hipLaunchKernelGGL(k_tile_scan, dim3(1), dim3(1024), 0, st, T, count_hits ? 1 : 0, summary, abort_flag,
-                       next_flag, (volatile uint64_t *)host_out, seq);
-    hipLaunchKernelGGL(k_tile_write, dim3((T.n_groups + WRITE_GROUPS - 1) / WRITE_GROUPS), dim3(WRITE_THREADS), 0, st,
-                       A.rank_bits, key_mode, A.by_rank, T, out, abort_flag, G, seg_counts,
-                       CodePointTables{d_hay, cp_blockpre, cp_sub});
+                       lead, d_hay, len, abort_flag, seq);
+    hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+                       T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub},
+                       PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
     return hipGetLastError();
 }
 

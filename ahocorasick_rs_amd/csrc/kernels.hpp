@@ -58,12 +58,13 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
                         bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st);
-// sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_scan -> k_tile_write
+// sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
-// number of tiles only, so no host round trip is needed before them.  The scan kernel publishes
-// {[0] occurrences, [2] prefix hits (count_hits only), [4] matches, [5] aborted, [7] seq} to
+// number of tiles only, so no host round trip is needed before them.  The first group of the write
+// kernel publishes {[0] occurrences, [2] prefix hits, [4] matches, [5] aborted, [7] seq} to
 // host_out (pinned host memory; [7] = seq is written last, the host may poll it while the write
-// kernel still runs) and clears *next_flag for the next call.  Aborted: the output did not fit
+// kernel still runs) and clears *next_flag for the next call.  seq: the context's call counter
+// (its parity selects the set of supergroup words, TileSpace::sgw).  Aborted: the output did not fit
 // the slots, out[] and the totals are meaningless.  seg_counts != null (batch, byte offsets):
 // offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
 // into seg_counts (zeroed by the caller).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
@@ -73,7 +74,7 @@ uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
-                     bool count_hits, const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
                      const uint8_t *cp_sub, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,

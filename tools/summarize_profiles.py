@@ -57,7 +57,7 @@ for d in sorted(os.listdir(SRC)):
     dur = collections.OrderedDict()
     for r in csv.DictReader(open(os.path.join(SRC, d, "r_kernel_trace.csv"))):
         dur.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    keep = ("k1b_prefilter", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_scan", "k_tile_write")
+    keep = ("k1b_prefilter", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_write")
     pmc[d] = {k: {"dispatches": len(dur.get(k, [])), "mean_duration_us": round(sum(dur[k]) / len(dur[k]), 1) if k in dur else None,
                   "mean_counters": {c: round(sum(v) / len(v)) for c, v in cs.items()}}
               for k, cs in acc.items() if k in keep}
