@@ -53,6 +53,7 @@ class HostTables(ctypes.Structure):
                 ("filter_entries_log2", ctypes.c_uint32), ("prefix_table_log2", ctypes.c_uint32),
                 ("filter_density", ctypes.c_double),
                 ("n_prefix_keys", ctypes.c_uint32), ("n_prefix_lists", ctypes.c_uint32),
+                ("prefix_bitmap", ctypes.c_void_p),
                 ("dense", ctypes.c_uint32), ("first_child", ctypes.c_void_p), ("in_byte", ctypes.c_void_p),
                 ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p)]
 
@@ -214,6 +215,7 @@ class HostAutomaton:
         self.prefix_table = view(t.prefix_table, (4 << int(t.prefix_table_log2)) if t.filter_q else 0,
                                  np.uint32).reshape(-1, 4)
         self.prefix_lists = view(t.prefix_lists, int(t.n_prefix_lists), np.uint32)
+        self.prefix_bitmap = view(t.prefix_bitmap, (8 << int(t.prefix_table_log2)) // 32 if t.filter_q else 0, np.uint32)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -1220,6 +1220,8 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.blist, blist)
     if (H.rbloom.empty()) H.rbloom.assign(REDIRECT_BLOOM_WORDS, 0);
     UP(H.rbloom, rbloom)
+    if (H.pbits.empty()) H.pbits.assign(4, 0);
+    UP(H.pbits, pbits)
     {
         const uint32_t *pi = nullptr;
         if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
@@ -1284,6 +1286,7 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->n_classes = A.n_classes; out->stride = A.stride;
     out->min_pattern_len = A.min_len; out->max_pattern_len = A.max_len;
     out->classes = A.classes; out->table = A.dense ? A.table.data() : nullptr;
+    out->prefix_bitmap = A.pbits.data();
     out->dense = A.dense ? 1 : 0;
     out->first_child = A.first_child.data(); out->in_byte = A.in_byte.data();
     out->fail = A.fail.data(); out->state_flags = A.sflags.data();

@@ -394,6 +394,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         };
         std::vector<uint32_t> hash_at((size_t)1 << lg, 0); // hash of the entry stored in each slot
         A.rbloom.assign(REDIRECT_BLOOM_WORDS, 0);
+        A.pbits.assign(((size_t)1 << (lg + PREFIX_BITMAP_LOG2)) / 32, 0);
         // Redirect entries first: every haystack position that starts like ANY pattern of the group
         // looks the entry up, so it must sit in its home slot (a displaced one would turn all of
         // them into HIT_RETRY traffic); then the single keys of the other groups, then the keys
@@ -425,6 +426,9 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             if (k.salt != Q2) { // a key behind a redirect entry
                 const uint32_t bit = redirect_bloom_bit(h);
                 A.rbloom[bit >> 5] |= 1u << (bit & 31);
+            } else { // filed under its first Q2 bytes: what a lookup starts from
+                const uint32_t bit = prefix_bitmap_bit(h, lg);
+                A.pbits[bit >> 5] |= 1u << (bit & 31);
             }
         }
         // the filter of displaced keys on every home slot: without the lookup's own bit a home slot

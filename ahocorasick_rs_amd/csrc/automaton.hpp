@@ -97,6 +97,14 @@ ACX_HD static inline uint32_t prefix_home_hash(uint64_t gram, uint32_t salt) {
 ACX_HD static inline uint32_t prefix_slot(uint32_t h2, uint32_t log2) {
     return log2 ? h2 >> (32 - log2) : 0;
 }
+// Bitmap in front of the prefix table (8 bits per slot, keyed like the home slot: the next finer
+// bits of the same hash): the first Q2 bytes of every group.  A table that has outgrown the L2
+// (~10^5 patterns) costs a 128-byte line from the MALL / HBM per lookup; the bitmap is an eighth
+// of a byte per slot bit, stays in the L2 and turns away the level-1 false positives (K1b, BIG).
+constexpr uint32_t PREFIX_BITMAP_LOG2 = 3;
+ACX_HD static inline uint32_t prefix_bitmap_bit(uint32_t h2, uint32_t log2) {
+    return h2 >> (32 - log2 - PREFIX_BITMAP_LOG2);
+}
 static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     uint64_t g = 0;
     for (uint32_t k = 0; k < q; k++) g |= (uint64_t)p[k] << (8 * k);
@@ -144,6 +152,7 @@ struct Automaton {
     std::vector<uint32_t> pinfo;
     std::vector<uint32_t> ptab;
     uint32_t ptab_log2 = 0;
+    std::vector<uint32_t> pbits;       // 2^(ptab_log2 + 3) bits: prefix_bitmap_bit of every group's first Q2 bytes
     // pattern bytes (kept for the synthetic text generator)
     std::vector<uint8_t> blob;
     std::vector<uint64_t> offsets;

@@ -29,6 +29,7 @@ struct DevAutomaton {
     const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, pid or list)
     const uint32_t *blist;       // candidate lists of prefixes shared by several patterns
     const uint32_t *rbloom;      // REDIRECT_BLOOM_WORDS: Bloom filter of the keys behind redirect entries
+    const uint32_t *pbits;       // 2^(ptab_log2 + 3) bits: the groups' first Q2 bytes (prefix_bitmap_bit)
     const uint4 *pinfo;          // per pattern {rank | min(len,255) << 24, 12 bytes after the first Q2}
     const uint8_t *pat_blob;     // pattern bytes (generator only)
     const uint64_t *pat_off;     // n_patterns + 1

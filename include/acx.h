@@ -152,6 +152,9 @@ typedef struct acx_host_tables {
     double filter_density;        /* fraction of X bits set                            */
     uint32_t n_prefix_keys;       /* entries of prefix_table in use                    */
     uint32_t n_prefix_lists;      /* u32 words of prefix_lists                         */
+    const uint32_t *prefix_bitmap;/* 2^(prefix_table_log2 + 3) bits: bit (hash >> (29 - prefix_table_log2)) of
+                                     the first filter_q2 bytes of every group (hash: acx_prefix_slot(gram,
+                                     filter_q2, 32)); K1b asks it before the table when the table is large */
     /* the compressed form (always present): trie edges + failure links               */
     uint32_t dense;               /* 1: `table` exists                                 */
     const uint32_t *first_child;  /* n_states + 1: children of s = ids [first_child[s], first_child[s+1]) */

@@ -196,6 +196,13 @@ def test_prefilter_tables_have_every_pattern_prefix():
                 assert cands == sorted(cands)
                 klen = min(min(len(pats[c]) for c in cands), 8)
                 assert all(pats[c][:klen] == p[:klen] for c in cands)
+        # the bitmap in front of the table: the first Q2 bytes of every pattern have their bit
+        # (bit = the top log2 + 3 bits of the hash the home slot is taken from), and it is as
+        # sparse as one bit per group in 8 bits per slot can be
+        for p_ in pats:
+            bit = capi.prefix_hash(p_[:q2], q2) >> (32 - lg - 3)
+            assert int(h.prefix_bitmap[bit >> 5]) >> (bit & 31) & 1
+        assert sum(bin(int(x)).count("1") for x in h.prefix_bitmap) <= len({p_[:q2] for p_ in pats})
         # a window that agrees with no pattern on its group's key resolves to nothing
         rng = random.Random(9)
         for _ in range(300):
