@@ -1030,7 +1030,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             uint32_t w_[20];                                                                     \
             _Pragma("unroll") for (int j = 1; j < 20; j += 2)                                    \
                 w_[j] = __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3);         \
-            uint32_t m_ = 0;                                                                     \
+            uint32_t m_ = 0, mg_ = 0;                                                            \
             _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
                 const uint32_t W_ = w_[j + 1] & GMASK;                                           \
                 const uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                                \
@@ -1039,13 +1039,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */      \
                 const uint32_t bx_ = K1B_BYTE_REG(j);                                            \
                 const uint32_t by_ = K1B_BYTE_REG(j + Q);                                        \
-                const uint32_t g_ = e_.x >> (W_ & 31); /* the gate both tests share */           \
-                const uint32_t tx_ = (e_.x >> (bx_ & 31)) & g_;                                  \
-                const uint32_t ty_ = (e_.y >> (by_ & 31)) & g_;                                  \
-                m_ = __builtin_amdgcn_alignbit(tx_, m_, 1); /* position j:   X, byte j   */      \
-                m_ = __builtin_amdgcn_alignbit(ty_, m_, 1); /* position j+1: Y, byte j+Q */      \
+                /* the gate both tests share, as 0 / ~0 (v_bfe_i32): its two low bits go into  */\
+                /* a mask of their own, one AND per row instead of one per test                */\
+                const uint32_t g_ = (uint32_t)__builtin_amdgcn_sbfe((int)e_.x, W_, 1);           \
+                mg_ = __builtin_amdgcn_alignbit(g_, mg_, 2);                                     \
+                m_ = __builtin_amdgcn_alignbit(e_.x >> (bx_ & 31), m_, 1); /* position j:   X, byte j   */ \
+                m_ = __builtin_amdgcn_alignbit(e_.y >> (by_ & 31), m_, 1); /* position j+1: Y, byte j+Q */ \
             }                                                                                    \
-            m_ >>= 16;                                                                           \
+            m_ = (m_ & mg_) >> 16;                                                               \
             if (!interior) { /* wave-uniform: a scalar branch */                                 \
                 const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
                 uint32_t keep_ = 0;                                                              \
@@ -1445,7 +1446,10 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // up.  If there is none (a chain of overlapping occurrences longer than the context: periodic
 // patterns on periodic text), or a bucket overflows, the group raises the abort flag and the
 // host redoes the call on the dense path, whose resolve is global.
-constexpr uint32_t MAIN_THREADS = 256;
+#ifndef ACX_MAIN_THREADS
+#define ACX_MAIN_THREADS 256
+#endif
+constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 // occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
 constexpr uint32_t STAGE_SLOTS = 24;
