@@ -369,11 +369,16 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         }
         A.n_prefix_keys = (uint32_t)keys.size();
         uint32_t lg = 4;
-        // load <= 1/4.  Sparser would save dependent probes, but measured on MI355X a table beyond
-        // ~1 MiB costs K1b more (its level-2 gathers start missing L2) than the probes gain.
-        while ((1u << lg) < 4 * keys.size()) lg++;
-        // (a sparser table for the sets whose table has left the L2 anyway was measured too: cfg4's 8 MiB
-        // -> 16 MiB halves the displaced keys but costs K1b 15 %: the gathers then miss the MALL more often)
+        // load <= 1/8.  A group whose entry is not in its home slot turns every haystack position that
+        // starts with its first Q2 bytes into a HIT_RETRY (a dependent lookup in k_tile_main; most
+        // of them then fail on the full key): linear probing displaces ~14 % of the keys at load 1/4,
+        // ~7 % at 1/8.  Measured on MI355X (1 GiB): 1/4 -> 1/8: k_tile_main 54 -> 51 us (10^4
+        // patterns), 100 -> 77 us (10^5), 228 -> 194 us (str, 2/3/4-byte characters), K1b unchanged
+        // (the bitmap keeps the level-1 false positives of a large set away from the table); 1/16:
+        // K1b of the 10^5 set +7 % (the table leaves the MALL more often), k_tile_main -9 us.
+        const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
+        const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env)) : 8;
+        while ((1u << lg) < inv_load * keys.size()) lg++;
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = PREFIX_EMPTY;

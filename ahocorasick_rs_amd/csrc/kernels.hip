@@ -661,6 +661,10 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
                                                      uint64_t w1, uint64_t room, uint32_t *rk) {
     const uint32_t q = A.filter_q2;
     const uint4 pi = A.pinfo[pid];
+    // patterns that can reach beyond the carried window: where the pattern's bytes lie, requested
+    // together with its info (uniform branch; the bytes themselves together with the haystack's)
+    const bool far = A.max_len > 16;
+    const uint64_t po = far ? A.pat_off[pid] : 0;
     *rk = pi.x & 0xFFFFFFu;
     uint32_t L = pi.x >> 24;
     if (L == 255) L = A.plen[pid];
@@ -676,14 +680,25 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
         uint64_t m0 = n0 >= 8 ? ~0ull : ((1ull << (8 * n0)) - 1);
         uint64_t m1 = n0 > 8 ? ((1ull << (8 * (n0 - 8))) - 1) : 0;
         ok = (((h0 ^ p0) & m0) | ((h1 ^ p1) & m1)) == 0;
-        // whatever lies beyond the carried window / pinfo (long patterns): compare in place
-        for (uint32_t d = q + n0; ok && d < L; d += 8) {
-            uint64_t a = load_window(stream, len, p + d);
-            uint64_t b;
-            __builtin_memcpy(&b, A.pat_blob + A.pat_off[pid] + d, 8); // pat_blob is padded by 16 bytes
-            uint32_t nbytes = L - d < 8 ? L - d : 8;
-            uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
-            ok = ((a ^ b) & m) == 0;
+        // whatever lies beyond the carried window / pinfo (long patterns): compare in place, four
+        // 8-byte pieces of haystack and pattern per round, their loads in flight together
+        for (uint32_t d = q + n0; far && ok && d < L; d += 32) {
+            uint64_t a[4], b[4];
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                a[k] = b[k] = 0;
+                if (d + 8 * k < L) {
+                    a[k] = load_window(stream, len, p + d + 8 * k);
+                    __builtin_memcpy(&b[k], A.pat_blob + po + d + 8 * k, 8); // pat_blob is padded by 16 bytes
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                if (d + 8 * k >= L) continue;
+                const uint32_t nbytes = L - (d + 8 * k) < 8 ? L - (d + 8 * k) : 8;
+                const uint64_t m = nbytes >= 8 ? ~0ull : ((1ull << (8 * nbytes)) - 1);
+                ok = ok && ((a[k] ^ b[k]) & m) == 0;
+            }
         }
     }
     return ok ? L : 0;
@@ -1564,24 +1579,35 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             if (code == HIT_NONE) nc = 0;
             else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
         }
-        for (uint32_t k = 0; k < nc; k++) {
-            uint32_t pid, L, rk;
-            if (verified) {
-                pid = code & ~HIT_VERIFIED; L = r0.w;
-                rk = key_mode == 1 ? 0u : A.rank[pid];
-            } else {
-                pid = list ? A.blist[li + 1 + k] : code;
-                L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
-                if (!L) continue;
-            }
+        auto stage = [&](uint32_t pid, uint32_t L, uint32_t rk) {
             const uint64_t kidx = (key_mode == 0 ? p + L : p) + lead;
-            if (kidx < complete || kidx >= idx_hi) continue; // another group's (or nobody's) business
+            if (kidx < complete || kidx >= idx_hi) return; // another group's (or nobody's) business
             const uint32_t rel = (uint32_t)(kidx - first_idx);
             const uint32_t b = rel >> TILE_BITS;
             const uint32_t r = atomicAdd(&bn[b], 1u);
             if (r < STAGE_SLOTS)
                 st[b][r] = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
             else fail = 1;
+        };
+        if (verified) {
+            const uint32_t pid = code & ~HIT_VERIFIED;
+            stage(pid, r0.w, key_mode == 1 ? 0u : A.rank[pid]);
+        } else if (!list) {
+            uint32_t rk;
+            const uint32_t L = nc ? verify_candidate(A, stream, len, p, code, w0, w1, room, &rk) : 0;
+            if (L) stage(code, L, rk);
+        } else {
+            // a list (patterns that share their key): two candidates at a time, their gathers in
+            // flight together -- a thread with a long list otherwise holds the whole group back
+            for (uint32_t k = 0; k < nc; k += 2) {
+                const bool two = k + 1 < nc;
+                const uint32_t pid0 = A.blist[li + 1 + k], pid1 = A.blist[li + 1 + (two ? k + 1 : k)];
+                uint32_t rk0, rk1;
+                const uint32_t L0 = verify_candidate(A, stream, len, p, pid0, w0, w1, room, &rk0);
+                const uint32_t L1 = verify_candidate(A, stream, len, p, pid1, w0, w1, room, &rk1);
+                if (L0) stage(pid0, L0, rk0);
+                if (two && L1) stage(pid1, L1, rk1);
+            }
         }
     }
     __syncthreads();
