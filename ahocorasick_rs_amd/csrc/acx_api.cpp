@@ -1211,6 +1211,10 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.dlink, dlink)
     UP(H.level_start, level_start)
     UP(H.plen, plen)
+    std::vector<uint32_t> pchars(H.plen.size() + 1, 0);
+    for (size_t i = 0; i < H.plen.size(); i++)
+        for (uint64_t k = H.offsets[i]; k < H.offsets[i + 1]; k++) pchars[i] += (H.blob[k] & 0xC0) != 0x80;
+    UP(pchars, pchars)
     UP(H.rank, rank)
     std::vector<uint32_t> by_rank(H.rank.size() + 1, 0);
     for (uint32_t i = 0; i < H.rank.size(); i++) by_rank[H.rank[i]] = i;

@@ -23,6 +23,7 @@ struct DevAutomaton {
     const uint32_t *dlink;       // n_states
     const uint32_t *level_start; // max_len + 2
     const uint32_t *plen;        // n_patterns
+    const uint32_t *pchars;      // n_patterns: UTF-8 lead (non-continuation) bytes of the pattern = its code points
     const uint32_t *rank;        // n_patterns
     const uint32_t *by_rank;     // n_patterns: the pattern of a rank (inverse of rank)
     const uint32_t *filterA;     // FILTER_WORDS: level-1 {X, Y} table of the K1b prefilter

@@ -1808,7 +1808,7 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
 // of the same haystack inside the stretch instead of a separate pass with one atomic per match.
 constexpr uint32_t WRITE_THREADS = 256, WRITE_MAX = GROUP_MAX;
 // cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
-struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; };
+struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; const uint32_t *pchars; };
 struct PostOut {
     uint64_t *summary;           // device mirror of the totals
     volatile uint64_t *host_out; // pinned host memory the host polls
@@ -1879,13 +1879,14 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             s -= hbase; e -= hbase;
             hs[i] = (uint32_t)h;
         }
-        if (cp.blockpre) {
+        const uint32_t pid = key_mode == 1 ? v.z : by_rank[v.z];
+        if (cp.blockpre) { // (a match is as many code points as its pattern: nothing of the span is read)
             const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s);
-            e = cs + lead_bytes_between(cp.hay + s, cp.hay + e);
+            e = cs + cp.pchars[pid];
             s = cs;
         }
         uint32_t *d = img + i * 6;
-        d[0] = key_mode == 1 ? v.z : by_rank[v.z]; d[1] = 0;
+        d[0] = pid; d[1] = 0;
         d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
     }
     __syncthreads();
@@ -1922,7 +1923,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
                        lead, d_hay, len, abort_flag, seq);
     hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
-                       T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub},
+                       T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
                        PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
     return hipGetLastError();
 }
