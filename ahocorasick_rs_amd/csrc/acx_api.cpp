@@ -326,7 +326,14 @@ struct Workspace {
 // everything one in-flight call needs
 struct Ctx {
     hipStream_t stream = nullptr, copy_stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr}; // profiling: scan start / stop, end of the call
+    // profiling: [0], [1] and [3], [4]: scan start / stop, two pairs used by the calls in turn (the time
+    // of a call's scan is read while the NEXT call's kernels run, off the path between two calls);
+    // [2]: end of the call
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    int ev_pair = 0;           // the pair the next scan launch takes
+    bool scan_pending = false; // a scan's time has not been read yet
+    int pend_pair = 0;
+    uint64_t pend_len = 0;
     hipEvent_t copy_done = nullptr;                 // staging: the last chunk has landed
     Workspace ws;
     bool post_pending = false; // profiling: ev[2] of the last call has not been read yet
@@ -616,20 +623,38 @@ void settle_post_profile(acx_automaton *a, Ctx *c) {
     if (!c->post_pending) return;
     c->post_pending = false;
     float ms = 0;
-    if (hipEventSynchronize(c->ev[2]) == hipSuccess && hipEventElapsedTime(&ms, c->ev[1], c->ev[2]) == hipSuccess) {
+    hipEvent_t scan_end = c->ev[(c->ev_pair ^ 1) ? 4 : 1]; // the pair the last launch took
+    if (hipEventSynchronize(c->ev[2]) == hipSuccess && hipEventElapsedTime(&ms, scan_end, c->ev[2]) == hipSuccess) {
         std::lock_guard<std::mutex> lk(a->prof_mu);
         a->profile.post_ms += ms;
     }
 }
 
-void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len) {
-    if (!a->prof) return;
+inline hipEvent_t scan_start_ev(Ctx *c) { return c->ev[c->ev_pair ? 3 : 0]; }
+inline hipEvent_t scan_stop_ev(Ctx *c) { return c->ev[c->ev_pair ? 4 : 1]; }
+
+// the scan time of the last profiled launch of this context, if it has not been read yet
+void settle_scan_profile(acx_automaton *a, Ctx *c) {
+    if (!c->scan_pending) return;
+    c->scan_pending = false;
     float ms = 0;
-    if (hipEventElapsedTime(&ms, c->ev[0], c->ev[1]) != hipSuccess) return;
+    hipEvent_t e0 = c->ev[c->pend_pair ? 3 : 0], e1 = c->ev[c->pend_pair ? 4 : 1];
+    if (hipEventSynchronize(e1) != hipSuccess || hipEventElapsedTime(&ms, e0, e1) != hipSuccess) return;
     std::lock_guard<std::mutex> lk(a->prof_mu);
     a->profile.scan_ms += ms;
     a->profile.scan_launches++;
-    a->profile.scan_bytes += len;
+    a->profile.scan_bytes += c->pend_len;
+}
+
+// the scan just launched with the current pair of events: its time is read later (the next launch
+// of this context takes the other pair)
+void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len) {
+    if (!a->prof) return;
+    settle_scan_profile(a, c); // (normally settled already, behind this call's own launches)
+    c->scan_pending = true;
+    c->pend_pair = c->ev_pair;
+    c->pend_len = len;
+    c->ev_pair ^= 1;
 }
 
 // Wait until the scan kernel has published sequence number `seq` to pinned host memory.  The
@@ -683,6 +708,8 @@ struct FindCall {
     uint64_t tiles;     // 4 KiB tiles of index space
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
+    bool early_event = false;   // the caller returns before the device work is done: fence it with r->done
+    bool event_at_post = false; // r->done was recorded right behind the post kernels
     bool leads_counted = false; // the scan has written the lead-byte counts of every 64 bytes (str API)
     bool cp_done = false;       // the write kernel has already converted the offsets to code points
     bool queued = false;    // work queued on the stream that nobody waited for yet
@@ -727,14 +754,14 @@ int attempt_sparse(FindCall &c, Attempt *what) {
             cp_sub = w.blocksub;
         }
         // measurement: the event pair rides on the dispatch
-        HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
-                                   prof ? x->ev[1] : nullptr, cp_sub));
+        HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
+                                   prof ? scan_stop_ev(x) : nullptr, cp_sub));
         c.leads_counted = cp_sub != nullptr;
     } else {
         HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
-        if (prof) HIPCHK_RC(hipEventRecord(x->ev[0], st));
+        if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
         HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
-        if (prof) HIPCHK_RC(hipEventRecord(x->ev[1], st));
+        if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     // str API, one haystack: the prefix of the lead-byte counts is ready before the write kernel
     // needs it (it depends on the scan only), so the write kernel converts on the way out
@@ -748,11 +775,20 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
                         next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, st));
+    // while the kernels run: the scan time of the previous call, and the event the result's
+    // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
+    settle_scan_profile(a, x);
+    if (c.early_event && !c.r->done) {
+        c.r->done = g_events.get(a->device);
+        if (c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st));
+        c.event_at_post = c.r->done != nullptr;
+    }
     if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
     w.flags_dirty = false; // the scan kernel left the next flag clean
     add_scan_profile(a, x, c.len);
     if (w.h_pinned[5] != 0) { // the slots could not hold the output: dense path
         HIPCHK_RC(hipStreamSynchronize(st));
+        c.event_at_post = false; // (the dense path queues more: the event is recorded again at the end)
         // (both sets of supergroup words clear again, whatever made the call give up)
         HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
         if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
@@ -769,7 +805,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     w.final = nullptr;
     c.localized = seg_counts != nullptr;
     c.cp_done = cp_pre != nullptr;
-    c.queued = true; // k_tile_write is still running
+    c.queued = !c.event_at_post; // k_tile_write is still running (and the event that fences it is in place)
     *what = Attempt::Done;
     return ACX_OK;
 }
@@ -791,13 +827,13 @@ int attempt_dense(FindCall &c, Attempt *what) {
     const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
     const bool prof = a->prof;
     if (c.pre) {
-        HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? x->ev[0] : nullptr,
-                                   prof ? x->ev[1] : nullptr));
+        HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
+                                   prof ? scan_stop_ev(x) : nullptr));
         HIPCHK_RC(launch_walk_hits(a->dev, c.G, H, hit_grid, K, grid, c.d_hay, c.len, st));
     } else {
-        if (prof) HIPCHK_RC(hipEventRecord(x->ev[0], st));
+        if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
         HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
-        if (prof) HIPCHK_RC(hipEventRecord(x->ev[1], st));
+        if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     HIPCHK_RC(sink_summary(w.block_counts, grid, region_cap, c.pre ? w.hit_counts : nullptr, hit_grid, hit_cap,
                            w.summary, w.region_off, st));
@@ -951,13 +987,14 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
             if (wait) {
                 HIPCHK_RC(hipStreamSynchronize(st));
             } else {
-                r->done = g_events.get(a->device);
+                if (!r->done) r->done = g_events.get(a->device);
                 if (!r->done) HIPCHK_RC(hipStreamSynchronize(st));
-                else HIPCHK_RC(hipEventRecord(r->done, st));
+                else HIPCHK_RC(hipEventRecord(r->done, st)); // (again, if a fix-up was queued behind an early record)
             }
         }
         return ACX_OK;
     };
+    c.early_event = !wait;
     const int rc = body();
     if (rc != ACX_OK) {
         (void)hipStreamSynchronize(st);
@@ -1522,7 +1559,7 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset) {
             std::lock_guard<std::mutex> lk(a->pool_mu);
             idle.swap(a->idle);
         }
-        for (Ctx *c : idle) settle_post_profile(a, c);
+        for (Ctx *c : idle) { settle_scan_profile(a, c); settle_post_profile(a, c); }
         {
             std::lock_guard<std::mutex> lk(a->pool_mu);
             a->idle.insert(a->idle.end(), idle.begin(), idle.end());
