@@ -369,15 +369,20 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         }
         A.n_prefix_keys = (uint32_t)keys.size();
         uint32_t lg = 4;
-        // load <= 1/8.  A group whose entry is not in its home slot turns every haystack position that
-        // starts with its first Q2 bytes into a HIT_RETRY (a dependent lookup in k_tile_main; most
-        // of them then fail on the full key): linear probing displaces ~14 % of the keys at load 1/4,
-        // ~7 % at 1/8.  Measured on MI355X (1 GiB): 1/4 -> 1/8: k_tile_main 54 -> 51 us (10^4
-        // patterns), 100 -> 77 us (10^5), 228 -> 194 us (str, 2/3/4-byte characters), K1b unchanged
-        // (the bitmap keeps the level-1 false positives of a large set away from the table); 1/16:
-        // K1b of the 10^5 set +7 % (the table leaves the MALL more often), k_tile_main -9 us.
+        // Load.  A group whose entry is not in its home slot turns every haystack position that starts
+        // with its first Q2 bytes into a HIT_RETRY (a dependent lookup in k_tile_main; most of them
+        // then fail on the full key): linear probing displaces ~14 % of the keys at load 1/4, ~7 % at
+        // 1/8.  But a table beyond ~1 MiB starts missing the L2 under K1b's level-2 gathers.  Measured
+        // on MI355X (1 GiB), 1/4 -> 1/8:
+        //   10^4 patterns (1 -> 2 MiB): k_tile_main 54 -> 51 us, but K1b's FETCH_SIZE +14 % (traffic
+        //     1.53x -> 1.73x of the algorithmic bytes): not worth it;
+        //   10^5 patterns (8 -> 16 MiB; the bitmap in front of the table keeps the level-1 false
+        //     positives away from it): k_tile_main 100 -> 77 us, K1b unchanged: worth it;
+        //   1/16 on that set: K1b +7 % (the table leaves the MALL more often), k_tile_main -9 us.
+        // So: 1/8 for the sets that run with the bitmap (saturated level-1 table), 1/4 otherwise.
         const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
-        const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env)) : 8;
+        const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env))
+                                        : (A.filter_q == 5 && A.filter_density > 0.2 ? 8 : 4);
         while ((1u << lg) < inv_load * keys.size()) lg++;
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);

@@ -17,6 +17,7 @@ timeout 300 python bench.py --config cfg3 --no-cpu-baseline > $OUT/bench_cfg3_sh
 for cfg in cfg4 cfg4b cfg5; do
   timeout 900 python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
 done
+timeout 900 python bench.py --config large --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_large_1M_patterns.json 2> $OUT/bench_large.err
 timeout 900 python bench.py --bytes 8589934592 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_T_8GiB.json 2> $OUT/bench_8g.err
 timeout 600 python bench.py --host --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_host_path.json 2> $OUT/bench_host.err
 for m in 2 3; do ACX_STAGE=$m timeout 600 python bench.py --host --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_host_path_stage$m.json 2>> $OUT/bench_host.err; done
