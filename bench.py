@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
+    ap.add_argument("--settle-ms", type=float, default=50.0,
+                    help="untimed steps for this many ms before the W warm-up steps (GPU power-state transient "
+                         "after a cold start; 0: none); reported as config.settle_ms")
     ap.add_argument("--ablate", default="", help="measurement only: override the configuration's match kind / "
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
     ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large"], default="auto",
@@ -270,6 +273,17 @@ def run(args) -> None:
             torch.cuda.synchronize()
 
     n_matches = 0
+    # Settle (untimed, before the W warm-up steps, disclosed in config.settle_ms): from a cold start
+    # the GPU's power controller goes through a transient of ~15 ms -- boost clocks for the first few
+    # steps, a dip while it finds the power limit, then the sustained state (per-step series:
+    # profiles/r02/step_times_cold_start.txt: 0.39 -> 0.44 -> 0.38 ms over the first 40 steps).  W = 5
+    # warm-up steps end in the middle of it; a throughput metric is about the sustained state.
+    settled = 0
+    if args.settle_ms > 0 and not args.dry_run:
+        t_end = time.perf_counter() + args.settle_ms * 1e-3
+        while time.perf_counter() < t_end:
+            n_matches = step()
+            settled += 1
     for _ in range(args.warmup):
         n_matches = step()
     if not args.dry_run:
@@ -321,6 +335,7 @@ def run(args) -> None:
                        "launcher": "self (torch.distributed.run)" if os.environ.get("ACX_BENCH_SELF_LAUNCHED")
                        else ("torch.distributed.run" if "RANK" in os.environ else "none"),
                        "per_rank_gbps": [round(x, 2) for x in per_rank],
+                       "settle_ms": 0 if args.dry_run else args.settle_ms, "settle_steps": settled,
                        "matches_per_gpu_step": int(n_matches), "matches_total": int(total_matches)},
         }
         if cfg not in ("cfg2", "cfg3"):
