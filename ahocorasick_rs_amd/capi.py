@@ -403,7 +403,8 @@ class Automaton:
         _check(lib().acx_generate_haystack(self._h, d_ptr, nbytes, kind, seed, stream_offset))
 
     # ---- measurement
-    def profile_enable(self, on: bool = True) -> None:
+    def profile_enable(self, on=True) -> None:
+        """True / 1: time every call's scan kernel; N > 1: every N-th call; False / 0: off."""
         _check(lib().acx_profile_enable(self._h, int(on)))
 
     def profile_read(self, reset: bool = True) -> Profile:

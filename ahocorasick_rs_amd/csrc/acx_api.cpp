@@ -330,6 +330,7 @@ struct Ctx {
     // of a call's scan is read while the NEXT call's kernels run, off the path between two calls);
     // [2]: end of the call
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t prof_calls = 0;   // calls of this context while profiling was on (sampling)
     int ev_pair = 0;           // the pair the next scan launch takes
     bool scan_pending = false; // a scan's time has not been read yet
     int pend_pair = 0;
@@ -364,6 +365,7 @@ struct acx_automaton {
     // profiling (accumulated over the contexts)
     std::mutex prof_mu;
     std::atomic<bool> prof{false};
+    std::atomic<int> prof_every{1}; // profiling events on every N-th call of a context
     acx_profile_t profile{};
 };
 
@@ -648,8 +650,8 @@ void settle_scan_profile(acx_automaton *a, Ctx *c) {
 
 // the scan just launched with the current pair of events: its time is read later (the next launch
 // of this context takes the other pair)
-void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len) {
-    if (!a->prof) return;
+void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len, bool timed) {
+    if (!timed) return;
     settle_scan_profile(a, c); // (normally settled already, behind this call's own launches)
     c->scan_pending = true;
     c->pend_pair = c->ev_pair;
@@ -708,6 +710,7 @@ struct FindCall {
     uint64_t tiles;     // 4 KiB tiles of index space
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
+    bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
     bool early_event = false;   // the caller returns before the device work is done: fence it with r->done
     bool event_at_post = false; // r->done was recorded right behind the post kernels
     bool leads_counted = false; // the scan has written the lead-byte counts of every 64 bytes (str API)
@@ -744,7 +747,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
-    const bool prof = a->prof;
+    const bool prof = c.timed;
     if (c.pre) {
         // str API: the scan counts the UTF-8 lead bytes on its way (aligned haystacks: the blocks of
         // the code-point prefix are then the rows of the scan's tiles)
@@ -785,7 +788,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     }
     if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
     w.flags_dirty = false; // the scan kernel left the next flag clean
-    add_scan_profile(a, x, c.len);
+    add_scan_profile(a, x, c.len, c.timed);
     if (w.h_pinned[5] != 0) { // the slots could not hold the output: dense path
         HIPCHK_RC(hipStreamSynchronize(st));
         c.event_at_post = false; // (the dense path queues more: the event is recorded again at the end)
@@ -825,7 +828,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
     const uint64_t region_cap = w.cap / grid;
     const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
     const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
-    const bool prof = a->prof;
+    const bool prof = c.timed;
     if (c.pre) {
         HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
                                    prof ? scan_stop_ev(x) : nullptr));
@@ -839,7 +842,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
                            w.summary, w.region_off, st));
     HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
     HIPCHK_RC(hipStreamSynchronize(st));
-    add_scan_profile(a, x, c.len);
+    add_scan_profile(a, x, c.len, c.timed);
     const uint64_t n_raw = w.h_pinned[0], region_max = w.h_pinned[1], hit_max = c.pre ? w.h_pinned[3] : 0;
     if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
         if (hit_max > hit_cap && (rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK)
@@ -928,7 +931,7 @@ int run_pipeline(FindCall &c) {
         if (what == Attempt::GoDense) sparse = false;
         if (what == Attempt::Done) break;
     }
-    if (a->prof) {
+    if (c.timed) {
         std::lock_guard<std::mutex> lk(a->prof_mu);
         a->profile.raw_occurrences += c.n_raw;
         a->profile.prefix_hits += c.n_hits;
@@ -995,6 +998,7 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
         return ACX_OK;
     };
     c.early_event = !wait;
+    c.timed = a->prof && (a->prof_every <= 1 || (x->prof_calls++ % (uint32_t)a->prof_every) == 0);
     const int rc = body();
     if (rc != ACX_OK) {
         (void)hipStreamSynchronize(st);
@@ -1546,6 +1550,7 @@ int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offse
 int acx_profile_enable(acx_automaton_t *a, int on) {
     if (!a) return fail(ACX_EINVAL, "null automaton");
     a->prof = on != 0;
+    a->prof_every = on > 1 ? on : 1;
     return ACX_OK;
 }
 

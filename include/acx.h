@@ -215,6 +215,9 @@ int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts);
 void acx_free_result(acx_result_t *r);
 
 /* ---- measurement hooks (HIP events on the library's stream) ---- */
+/* on = 0: off; 1: every call carries the event pair around its scan kernel; N > 1: every N-th call of
+ * a context does (the pair costs the dispatch ~6 us: a sampled measurement leaves the other calls
+ * alone).  The totals of acx_profile_read cover the measured calls only. */
 int acx_profile_enable(acx_automaton_t *a, int on);
 int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
 
