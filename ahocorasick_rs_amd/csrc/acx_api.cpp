@@ -336,6 +336,7 @@ struct Ctx {
     int pend_pair = 0;
     uint64_t pend_len = 0;
     hipEvent_t copy_done = nullptr;                 // staging: the last chunk has landed
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr; // str API: the code-point prefix runs beside k_tile_main
     Workspace ws;
     bool post_pending = false; // profiling: ev[2] of the last call has not been read yet
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
@@ -441,6 +442,8 @@ void destroy_ctx(Ctx *c, int device) {
     free_ws(c->ws, device);
     for (auto &e : c->ev) if (e) (void)hipEventDestroy(e);
     if (c->copy_done) (void)hipEventDestroy(c->copy_done);
+    if (c->fork_ev) (void)hipEventDestroy(c->fork_ev);
+    if (c->join_ev) (void)hipEventDestroy(c->join_ev);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -453,6 +456,8 @@ Ctx *create_ctx() { // the automaton's device is current
               hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking) == hipSuccess;
     for (auto &e : c->ev) ok = ok && hipEventCreate(&e) == hipSuccess;
     ok = ok && hipEventCreateWithFlags(&c->copy_done, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) == hipSuccess;
     if (!ok) { destroy_ctx(c, 0); return nullptr; }
     return c;
 }
@@ -748,6 +753,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     const bool prof = c.timed;
+    hipEvent_t side_after = nullptr;
     if (c.pre) {
         // str API: the scan counts the UTF-8 lead bytes on its way (aligned haystacks: the blocks of
         // the code-point prefix are then the rows of the scan's tiles)
@@ -757,8 +763,11 @@ int attempt_sparse(FindCall &c, Attempt *what) {
             cp_sub = w.blocksub;
         }
         // measurement: the event pair rides on the dispatch
+        // (str API, one haystack: the code-point prefix runs on the second stream as soon as the scan
+        // is done -- the event it waits for rides on the scan's own dispatch, no packet in between)
+        side_after = cp_sub && !c.segmented ? (prof ? scan_stop_ev(x) : x->fork_ev) : nullptr;
         HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
-                                   prof ? scan_stop_ev(x) : nullptr, cp_sub));
+                                   prof ? scan_stop_ev(x) : side_after, cp_sub));
         c.leads_counted = cp_sub != nullptr;
     } else {
         HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
@@ -768,16 +777,24 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     }
     // str API, one haystack: the prefix of the lead-byte counts is ready before the write kernel
     // needs it (it depends on the scan only), so the write kernel converts on the way out
+    // (three small latency-bound kernels, ~30 us: on the context's second stream, beside k_tile_main,
+    // which does not need them; the write kernel waits for both)
     const uint64_t *cp_pre = nullptr;
+    hipEvent_t before_write = nullptr;
     if (c.leads_counted && !c.segmented) {
         const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
-        HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, st));
-        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
+        hipStream_t side = x->copy_stream;
+        if (!side_after) { side_after = x->fork_ev; HIPCHK_RC(hipEventRecord(x->fork_ev, st)); }
+        HIPCHK_RC(hipStreamWaitEvent(side, side_after, 0));
+        HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, side));
+        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, side));
+        HIPCHK_RC(hipEventRecord(x->join_ev, side));
+        before_write = x->join_ev;
         cp_pre = w.blockpre;
     }
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, st));
+                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, st));
     // while the kernels run: the scan time of the previous call, and the event the result's
     // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
     settle_scan_profile(a, x);

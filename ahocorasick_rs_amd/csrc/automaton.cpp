@@ -379,10 +379,23 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         //   10^5 patterns (8 -> 16 MiB; the bitmap in front of the table keeps the level-1 false
         //     positives away from it): k_tile_main 100 -> 77 us, K1b unchanged: worth it;
         //   1/16 on that set: K1b +7 % (the table leaves the MALL more often), k_tile_main -9 us.
-        // So: 1/8 for the sets that run with the bitmap (saturated level-1 table), 1/4 otherwise.
+        //   10^4 patterns over a-z + 2/3/4-byte characters (str API; every occurrence of a 4-byte
+        //     character is a 5-byte prefix of ~12 patterns: 3.6 M hits per GiB, a third of them retries
+        //     of displaced groups): k_tile_main 221 -> 189 us (1/8), 183 (1/16), 171 (1/32, a 5 MiB
+        //     table), K1b unchanged: worth it.
+        // So: 1/8 for the sets that run with the bitmap (saturated level-1 table); for the sets where
+        // more than 5 % of the patterns have a UTF-8 lead byte of a multi-byte character among their
+        // first Q2 bytes (few characters per key: many true prefix hits) 1/32 up to 65 536 keys
+        // (a table of at most 32 MiB), 1/8 beyond; 1/4 otherwise.
+        uint64_t multibyte = 0;
+        for (uint64_t i = 0; i < n; i++)
+            for (uint32_t k = 0; k < Q2; k++)
+                if (pb[A.offsets[i] + k] >= 0xC0) { multibyte++; break; }
         const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
         const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env))
-                                        : (A.filter_q == 5 && A.filter_density > 0.2 ? 8 : 4);
+                                        : 20 * multibyte > n && keys.size() <= 65536         ? 32
+                                          : (A.filter_q == 5 && A.filter_density > 0.2) || 20 * multibyte > n ? 8
+                                                                                                : 4;
         while ((1u << lg) < inv_load * keys.size()) lg++;
         A.ptab_log2 = lg;
         A.ptab.assign((size_t)4 << lg, 0);

@@ -1916,12 +1916,16 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipStream_t st) {
+                     const uint8_t *cp_sub, hipEvent_t before_write, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
                        lead, d_hay, len, abort_flag, seq);
+    if (before_write) { // (what the write kernel needs from another stream: the code-point prefix)
+        hipError_t e = hipStreamWaitEvent(st, before_write, 0);
+        if (e != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
                        T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
                        PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});

@@ -75,7 +75,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipStream_t st);
+                     const uint8_t *cp_sub, hipEvent_t before_write, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,

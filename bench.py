@@ -280,6 +280,9 @@ def run(args) -> None:
     # warm-up steps end in the middle of it; a throughput metric is about the sustained state.
     settled = 0
     if args.settle_ms > 0 and not args.dry_run:
+        n_matches = step()  # (the first call allocates the workspaces: tens of ms, not part of the settle time)
+        settled += 1
+        sync()
         t_end = time.perf_counter() + args.settle_ms * 1e-3
         while time.perf_counter() < t_end:
             n_matches = step()
