@@ -246,7 +246,8 @@ def run(args) -> None:
     counts_all = torch.zeros(world, dtype=torch.int64, device=dev)
     last = {}
 
-    def step() -> int:
+    def hot() -> int:
+        """one pass of the hot path over this rank's batch (no collective)"""
         if args.dry_run:
             n = 1000 + rank
         elif args.host:
@@ -260,6 +261,10 @@ def run(args) -> None:
             if last.get("keep"):
                 last["matches"] = r.matches()
             r.free()
+        return n
+
+    def step() -> int:
+        n = hot()
         if dist is not None:  # C1: per-shard match counts -> global output offsets
             counts_local.fill_(n)
             dist.all_gather_into_tensor(counts_all, counts_local)
@@ -280,12 +285,13 @@ def run(args) -> None:
     # warm-up steps end in the middle of it; a throughput metric is about the sustained state.
     settled = 0
     if args.settle_ms > 0 and not args.dry_run:
-        n_matches = step()  # (the first call allocates the workspaces: tens of ms, not part of the settle time)
+        # (the hot path only: the ranks settle by time, each for itself -- no collective in here)
+        n_matches = hot()  # the first call allocates the workspaces: tens of ms, not part of the settle time
         settled += 1
         sync()
         t_end = time.perf_counter() + args.settle_ms * 1e-3
         while time.perf_counter() < t_end:
-            n_matches = step()
+            n_matches = hot()
             settled += 1
     for _ in range(args.warmup):
         n_matches = step()
