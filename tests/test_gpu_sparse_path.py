@@ -244,3 +244,30 @@ def test_small_call_kernel_code_points():
         assert got == Oracle([p.encode() for p in pats], mk, KIND_DFA).find_str(hay)
         for pid, s, e in got:  # offsets are code-point indexes: slicing the str gives the pattern
             assert hay[s:e] == pats[pid]
+
+
+def test_profile_hooks_every_call_and_sampled():
+    # acx_profile_enable(a, 1): every call carries the event pair around its scan kernel;
+    # N > 1: every N-th call of a context; the totals cover the measured calls only
+    pats = gen.gen_patterns(2000, 5, 9, gen.AZ, 77)
+    hay = gen.gen_textlike(1 << 20, 78, pats, 2048).tobytes()
+    a = capi.Automaton(pats, 0, kernel=capi.KERNEL_PREFILTER)
+    o = Oracle(pats, 0, KIND_DFA)
+    want = o.find_raw(hay, overlapping=False)
+    for every, calls, measured in ((1, 6, 6), (4, 8, 2), (3, 7, 3)):
+        a.profile_enable(every)
+        a.profile_read(reset=True)
+        for _ in range(calls):
+            assert np.array_equal(cols(a.find(hay)), want)
+        p = a.profile_read(reset=True)
+        # (the sampling phase continues across enable calls: between floor and ceil of calls / every)
+        assert calls // every <= p.scan_launches <= -(-calls // every), (every, p.scan_launches)
+        if every == 1:
+            assert p.scan_launches == measured
+        assert p.scan_bytes == p.scan_launches * len(hay) and p.scan_ms > 0
+        assert p.raw_occurrences >= p.scan_launches * len(want)
+    a.profile_enable(False)
+    a.profile_read(reset=True)
+    assert np.array_equal(cols(a.find(hay)), want)
+    assert a.profile_read().scan_launches == 0
+    a.close()
