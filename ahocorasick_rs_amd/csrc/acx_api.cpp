@@ -42,7 +42,8 @@ int fail(int code, const std::string &msg) {
     return code;
 }
 int hipfail(hipError_t e, const char *what) {
-    return fail(ACX_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
+    (void)hipGetLastError(); // the runtime's "last error" is sticky: the next launch check must not see this one
+    return fail(e == hipErrorOutOfMemory ? ACX_ENOMEM : ACX_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
 }
 #define HIPCHK(expr)                                   \
     do {                                               \
@@ -493,8 +494,8 @@ struct Lease {
 int ensure_common(Ctx *c) {
     Workspace &w = c->ws;
     if (!w.summary) {
-        HIPCHK(hipMalloc((void **)&w.summary, 64));
-        HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 8192));
+        HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [5], [6] abort flags, [8], [9] scratch
+        HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 16400)); // counts of <= 8192 regions + their exact bases
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
         // polled by the host while kernels still run: system-coherent
@@ -520,6 +521,12 @@ int ensure_occ_capacity(Ctx *c, uint64_t want) {
     Workspace &w = c->ws;
     if (want <= w.cap) return ACX_OK;
     uint64_t cap = std::max<uint64_t>(want, 1u << 16);
+    if (std::getenv("ACX_DEBUG_MEM")) {
+        size_t fr = 0, tot = 0;
+        (void)hipMemGetInfo(&fr, &tot);
+        std::fprintf(stderr, "acx: ensure_occ_capacity want %llu (old cap %llu), device free %.1f of %.1f GiB\n",
+                     (unsigned long long)want, (unsigned long long)w.cap, fr / 1073741824.0, tot / 1073741824.0);
+    }
     for (int i = 0; i < 2; i++) {
         (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]);
         w.keys[i] = nullptr; w.pids[i] = nullptr;
@@ -715,6 +722,8 @@ struct FindCall {
     uint64_t tiles;     // 4 KiB tiles of index space
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
+    bool exact_regions = false; // dense path, second pass: regions at the exclusive prefix of the first pass's counts
+    uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
     bool early_event = false;   // the caller returns before the device work is done: fence it with r->done
     bool event_at_post = false; // r->done was recorded right behind the post kernels
@@ -842,7 +851,9 @@ int attempt_dense(FindCall &c, Attempt *what) {
     const uint32_t hit_grid = c.pre ? prefilter_hit_regions(c.scan_grid) : 0;
     const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : c.scan_grid; // occurrence regions
     const uint64_t hit_cap = c.pre ? w.hit_total / hit_grid : 0;
-    const uint64_t region_cap = w.cap / grid;
+    // exact_regions (second pass after an occurrence region overflowed): every region gets the room
+    // it asked for in the first pass, at the exclusive prefix of the counts (stored behind the counts)
+    const uint64_t region_cap = c.exact_regions ? 0 : w.cap / grid;
     const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
     const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
     const bool prof = c.timed;
@@ -855,19 +866,36 @@ int attempt_dense(FindCall &c, Attempt *what) {
         HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
-    HIPCHK_RC(sink_summary(w.block_counts, grid, region_cap, c.pre ? w.hit_counts : nullptr, hit_grid, hit_cap,
-                           w.summary, w.region_off, st));
+    HIPCHK_RC(sink_summary(w.block_counts, grid, c.exact_regions ? ~0ull : region_cap, c.pre ? w.hit_counts : nullptr,
+                           hit_grid, hit_cap, w.summary, w.region_off, st));
     HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
     HIPCHK_RC(hipStreamSynchronize(st));
     add_scan_profile(a, x, c.len, c.timed);
     const uint64_t n_raw = w.h_pinned[0], region_max = w.h_pinned[1], hit_max = c.pre ? w.h_pinned[3] : 0;
-    if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
-        if (hit_max > hit_cap && (rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK)
-            return rc;
-        // hits that overflowed were dropped, so the occurrence count is a lower bound
-        uint64_t want = (uint64_t)grid * (region_max + region_max / 8 + 64);
-        if (hit_max > hit_cap) want = std::max(want, w.cap * 4);
-        if ((rc = ensure_occ_capacity(x, want)) != ACX_OK) return rc;
+    if (c.exact_regions) {
+        if (n_raw != c.exact_total || (c.pre && hit_max > hit_cap))
+            return fail(ACX_EDEVICE, "the second pass of the dense path counted differently");
+    } else if (region_max > region_cap || hit_max > hit_cap) { // a sink region overflowed: grow, redo
+        if (hit_max > hit_cap) {
+            // hits that overflowed were dropped, so the occurrence counts are lower bounds: more room for
+            // both, uniform regions (the hit regions are balanced: a wave's tiles are spread over the stream)
+            if ((rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
+            uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64), w.cap * 4);
+            if (want > (1ull << 33)) want = std::max<uint64_t>(w.cap * 4, 1ull << 33); // (the exact pass sizes the rest)
+            if ((rc = ensure_occ_capacity(x, want)) != ACX_OK) return rc;
+        } else {
+            // the regions' counts are exact (a full region keeps counting): the second pass puts every
+            // region at the exclusive prefix of the counts -- room for exactly the occurrences there are,
+            // however unevenly they are spread (grid * the fullest region can be 100x that)
+            uint64_t *bases = w.block_counts + grid;
+            HIPCHK_RC(sink_summary(w.block_counts, grid, ~0ull, nullptr, 0, 0, w.summary + 8, bases, st));
+            HIPCHK_RC(hipMemcpyAsync(w.h_pinned + 10, bases + grid, 8, hipMemcpyDeviceToHost, st));
+            HIPCHK_RC(hipStreamSynchronize(st));
+            c.exact_total = w.h_pinned[10];
+            if (c.exact_total >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+            if ((rc = ensure_occ_capacity(x, c.exact_total + 64)) != ACX_OK) return rc;
+            c.exact_regions = true;
+        }
         *what = Attempt::Again;
         return ACX_OK;
     }

@@ -131,6 +131,18 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         }
         term_node[i] = cur;
     }
+    // Leftmost kinds: of several identical patterns only the first can ever be reported (the
+    // reference's tie-break: lowest index), so the later ones stay out of every table -- a set with
+    // the same short pattern thousands of times would otherwise multiply the occurrences the device
+    // enumerates before it resolves them.  (Standard keeps them: an overlapping search reports all.)
+    std::vector<uint8_t> dup(n, 0);
+    if (match_kind != ACX_MATCH_STANDARD) {
+        std::vector<uint8_t> seen(n_nodes, 0);
+        for (uint64_t i = 0; i < n; i++) {
+            if (seen[term_node[i]]) dup[i] = 1;
+            seen[term_node[i]] = 1;
+        }
+    }
     A.n_states = n_nodes;
     {
         unsigned __int128 tb = (unsigned __int128)n_nodes * A.stride * 4;
@@ -186,12 +198,12 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     }
     // own lists (stable: pattern id order)
     A.own_off.assign((size_t)n_nodes + 1, 0);
-    for (uint64_t i = 0; i < n; i++) A.own_off[newid[term_node[i]] + 1]++;
+    for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_off[newid[term_node[i]] + 1]++;
     for (uint32_t s = 0; s < n_nodes; s++) A.own_off[s + 1] += A.own_off[s];
-    A.own_pid.resize(n);
+    A.own_pid.assign(n, 0); // (n entries whatever is filed: the C ABI's view has this size)
     {
         std::vector<uint32_t> fill(A.own_off.begin(), A.own_off.end() - 1);
-        for (uint64_t i = 0; i < n; i++) A.own_pid[fill[newid[term_node[i]]]++] = (uint32_t)i;
+        for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_pid[fill[newid[term_node[i]]]++] = (uint32_t)i;
     }
     A.own1.assign(n_nodes, OWN1_NONE);
     for (uint32_t s = 0; s < n_nodes; s++) {
@@ -338,15 +350,17 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // into blist; next = N > K: look the first N bytes up (salt N).
         std::vector<uint64_t> g1(n);              // first Q2 bytes of every pattern
         for (uint64_t i = 0; i < n; i++) g1[i] = gram_of(pb + A.offsets[i], Q2);
-        std::vector<uint32_t> by_g1(n);
-        std::iota(by_g1.begin(), by_g1.end(), 0u);
+        std::vector<uint32_t> by_g1; // (without the identical later copies of a pattern: leftmost kinds)
+        by_g1.reserve(n);
+        for (uint64_t i = 0; i < n; i++) if (!dup[i]) by_g1.push_back((uint32_t)i);
         std::stable_sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] < g1[b]; });
+        const size_t n_filed = by_g1.size();
         struct Key { uint64_t gram; uint32_t K, next, salt; std::vector<uint32_t> pids; };
         std::vector<Key> keys;
-        for (size_t b = 0; b < n;) {
+        for (size_t b = 0; b < n_filed;) {
             size_t e = b;
             uint32_t Lg = FILTER2_MAX_Q;
-            while (e < n && g1[by_g1[e]] == g1[by_g1[b]]) {
+            while (e < n_filed && g1[by_g1[e]] == g1[by_g1[b]]) {
                 Lg = std::min<uint32_t>(Lg, std::min<uint32_t>(A.plen[by_g1[e]], FILTER2_MAX_Q));
                 e++;
             }

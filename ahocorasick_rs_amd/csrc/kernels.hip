@@ -69,8 +69,16 @@ struct BlockSink {
     uint32_t cnt_nw, cnt_iters;
 };
 
-__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount, uint32_t quads = 1) {
-    return BlockSink{K.recs + (uint64_t)blockIdx.x * K.region_cap * quads, lcount, K.region_cap, K.key_mode,
+// region_cap == 0 (second pass of the dense path): the regions lie at the exclusive prefix of the
+// first pass's counts, stored behind the counts: block_counts[gridDim.x + b]
+__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount) {
+    uint64_t base = (uint64_t)blockIdx.x * K.region_cap, cap = K.region_cap;
+    if (K.region_cap == 0 && K.block_counts && !K.hslots) {
+        const uint64_t *rb = K.block_counts + gridDim.x;
+        base = rb[blockIdx.x];
+        cap = rb[blockIdx.x + 1] - base;
+    }
+    return BlockSink{K.recs + base, lcount, cap, K.key_mode,
                      K.hslots, K.hcnt, K.abort_flag, K.lead, K.cnt_nw, K.cnt_iters};
 }
 
@@ -1291,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_sink_compact(const uint4 *recs, const u
                                                       uint64_t region_cap, uint64_t *keys_out,
                                                       uint32_t *pids_out) {
     uint64_t o0 = offsets[blockIdx.x], n = offsets[blockIdx.x + 1] - o0;
-    const uint4 *r = recs + (uint64_t)blockIdx.x * region_cap;
+    const uint4 *r = recs + (region_cap ? (uint64_t)blockIdx.x * region_cap : o0); // (0: exact regions, contiguous)
     for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
         uint4 v = r[i];
         keys_out[o0 + i] = ((uint64_t)v.y << 32) | v.x;

@@ -271,3 +271,26 @@ def test_profile_hooks_every_call_and_sampled():
     assert np.array_equal(cols(a.find(hay)), want)
     assert a.profile_read().scan_launches == 0
     a.close()
+
+
+@pytest.mark.parametrize("kernel", KERNELS + [None])
+def test_dense_output_concentrated_in_one_place(kernel):
+    # millions of occurrences in the first fifth of the haystack, (almost) none elsewhere: the regions
+    # of the dense path fill very unevenly -- its second pass gives every region exactly the room its
+    # first pass counted (capacity = grid x the fullest region would be two orders of magnitude more)
+    import random
+    rng = random.Random(5)
+    pats = list({bytes(rng.choice(b"abc") for _ in range(rng.randint(1, 8))) for _ in range(3000)})
+    dense = bytes(rng.choice(b"abc") for _ in range(400_000))
+    hay = dense + b"z" * 1_600_000
+    for mk in (1, 0):
+        a = capi.Automaton(pats, mk, kernel=kernel)
+        o = Oracle(pats, mk, KIND_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            want = o.find_raw(hay, overlapping=ov)
+            assert len(want) > 100_000
+            assert np.array_equal(cols(a.find(hay, overlapping=ov)), want), (mk, ov)
+        # and the handle still answers an ordinary call afterwards
+        small = b"zzabcabczz" * 100
+        assert np.array_equal(cols(a.find(small)), o.find_raw(small, overlapping=False))
+        a.close()
