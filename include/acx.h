@@ -34,7 +34,11 @@ extern "C" {
                                 src/lib.rs:36-39, 52-54                        */
 #define ACX_ENOMEM (-4)
 #define ACX_EDEVICE (-5)     /* HIP runtime / no device / kernel failure      */
-#define ACX_ETOOBIG (-6)     /* automaton or haystack exceeds an encoding limit*/
+#define ACX_ETOOBIG (-6)     /* automaton or haystack exceeds an encoding limit: 2^24 patterns, 2^30
+                                states, a haystack stream of 2^38 bytes, or a call on the dense
+                                output path that enumerates 2^32 occurrences or more before the
+                                match kind is applied (e.g. thousands of identical short patterns
+                                in a Standard set over a long haystack)                          */
 
 /* enum PyMatchKind, src/lib.rs:92-108 */
 #define ACX_MATCH_STANDARD 0
