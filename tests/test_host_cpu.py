@@ -110,6 +110,23 @@ def test_compressed_form_is_the_same_automaton(monkeypatch):
             assert np.array_equal(getattr(c, name), getattr(h, name)), name
 
 
+def test_leftmost_kinds_file_only_the_first_of_identical_patterns():
+    """Of several identical patterns only the first can be reported by a leftmost kind (lowest index
+    wins): the later copies stay out of the own lists and of the prefix table's candidate lists;
+    Standard keeps them all (an overlapping search reports every one)."""
+    pats = [b"abcde", b"xyzzy", b"abcde", b"abcdefgh", b"abcde", b"xyzzy", b"q" * 9, b"abcdefgh"]
+    for mk in (0, 1, 2):
+        h = capi.HostAutomaton(pats, mk)
+        filed = sorted(int(x) for s in range(h.n_states) for x in h.own_pid[h.own_off[s]:h.own_off[s + 1]])
+        want = list(range(len(pats))) if mk == 0 else [0, 1, 3, 6]
+        assert filed == want, (mk, filed)
+        lg, q2 = int(h.t.prefix_table_log2), int(h.t.filter_q2)
+        for pid, p_ in enumerate(pats):
+            cands = prefix_candidates(h, lg, q2, (p_ + b"\0" * 16)[:16])
+            assert (pid in cands) == (pid in want), (mk, pid, cands)
+            assert all(c in want for c in cands)
+
+
 def test_compiler_matches_survey_sizes():
     # SURVEY.md §8d: 10k a-z patterns len 5-12 seed 1 -> 63 277 states, 28 classes, stride 32
     h = capi.HostAutomaton(gen.gen_patterns(10000, 5, 12, gen.AZ, 1))
