@@ -58,6 +58,9 @@ def parse_args(argv=None):
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--bytes", type=int, default=GIB, help="haystack bytes per GPU")
+    ap.add_argument("--callers", type=int, default=1,
+                    help="information only: issue the K timed steps from this many host threads at once "
+                         "(concurrent calls on one handle); the metric says so")
     ap.add_argument("--settle-ms", type=float, default=50.0,
                     help="untimed steps for this many ms before the W warm-up steps (GPU power-state transient "
                          "after a cold start; 0: none); reported as config.settle_ms")
@@ -304,8 +307,20 @@ def run(args) -> None:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        n_matches = step()
+    if args.callers > 1 and dist is None and not args.dry_run:
+        # (information only, never the default: K steps issued by several host threads at once -- the
+        # reference releases the GIL around a search, src/lib.rs:238, and a handle here serves up to
+        # ACX_MAX_CONCURRENCY calls side by side, each on its own stream)
+        import threading
+        per = [args.steps // args.callers + (1 if i < args.steps % args.callers else 0) for i in range(args.callers)]
+        ths = [threading.Thread(target=lambda k=k: [hot() for _ in range(k)]) for k in per]
+        for th in ths:
+            th.start()
+        for th in ths:
+            th.join()
+    else:
+        for _ in range(args.steps):
+            n_matches = step()
     sync()
     if dist is not None:
         dist.barrier()
@@ -354,6 +369,9 @@ def run(args) -> None:
         if args.host:
             out["metric"] = ("host-memory entry point GB/s (acx_find: pageable host bytes in -> host match array "
                              f"out, PCIe-inclusive), {cfg}")
+        if args.callers > 1:
+            out["metric"] += f" ({args.callers} concurrent callers on one handle: not the headline)"
+            out["config"]["callers"] = args.callers
         if args.dry_run:
             out["metric"] = "dry run (launcher / collective plumbing only)"
             out["data"] = "none"
