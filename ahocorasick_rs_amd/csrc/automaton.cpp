@@ -144,13 +144,8 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         }
     }
     A.n_states = n_nodes;
-    {
-        unsigned __int128 tb = (unsigned __int128)n_nodes * A.stride * 4;
-        if (tb > ((unsigned __int128)48 << 30)) {
-            code = ACX_ETOOBIG;
-            return "dense DFA would exceed 48 GiB";
-        }
-    }
+    // (no limit on n_states * stride here: a dense table is built only below ACX_DENSE_LIMIT, the
+    // compressed form -- 13 B per state -- serves every automaton of up to 2^30 states)
     // children CSR by parent (creation ids), children sorted by byte
     std::vector<uint32_t> c_off(n_nodes + 1, 0);
     for (uint32_t p : e_parent) c_off[p + 1]++;
