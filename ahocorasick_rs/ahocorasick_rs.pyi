@@ -34,7 +34,7 @@ class AhoCorasick:
     ) -> list[str]: ...
     # extension (not in the reference): one device pass over many haystacks
     def find_matches_as_indexes_batch(
-        self, haystacks: Sequence[str], overlapping: bool = False
+        self, haystacks: Sequence[str], overlapping: bool = False, devices: Optional[Sequence[int]] = None
     ) -> list[list[tuple[int, int, int]]]: ...
     def _info(self) -> dict[str, Any]: ...
 
@@ -49,6 +49,6 @@ class BytesAhoCorasick:
         self, haystack: Buffer, overlapping: bool = False
     ) -> list[tuple[int, int, int]]: ...
     def find_matches_as_indexes_batch(
-        self, haystacks: Sequence[Buffer], overlapping: bool = False
+        self, haystacks: Sequence[Buffer], overlapping: bool = False, devices: Optional[Sequence[int]] = None
     ) -> list[list[tuple[int, int, int]]]: ...
     def _info(self) -> dict[str, Any]: ...

@@ -26,6 +26,7 @@ MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
 IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
 KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
 KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
+ABI_VERSION = 3  # ACX_VERSION of include/acx.h this binding was written against
 
 MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
 
@@ -93,6 +94,9 @@ def lib() -> ctypes.CDLL:
     L = ctypes.CDLL(os.environ.get("ACX_LIB", _SO), mode=ctypes.RTLD_GLOBAL)  # ACX_LIB: experiments with variant builds
     vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     L.acx_version.restype = i32
+    if L.acx_version() != ABI_VERSION:
+        raise ImportError(f"libacx_hip.so speaks C ABI version {L.acx_version()}, this binding version {ABI_VERSION}: "
+                          "rebuild (python -c 'import __graft_entry__ as g; g.build()')")
     L.acx_last_error.restype = ctypes.c_char_p
     L.acx_device_count.argtypes = [ctypes.POINTER(i32)]
     L.acx_set_device.argtypes = [i32]
@@ -115,6 +119,11 @@ def lib() -> ctypes.CDLL:
     L.acx_find_batch.argtypes = [vp, vp, vp, u64, i32, i32, ctypes.POINTER(vp),
                                  ctypes.POINTER(u64), vp]
     L.acx_find_device.argtypes = [vp, vp, u64, vp, u64, u64, i32, i32, ctypes.POINTER(vp)]
+    L.acx_replicate.argtypes = [vp, i32, ctypes.POINTER(vp)]
+    L.acx_automaton_device.argtypes = [vp]
+    L.acx_shard_range.argtypes = [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u64)]
+    L.acx_shard_range.restype = None
+    L.acx_find_batch_multi.argtypes = [vp, i32, vp, vp, u64, i32, i32, ctypes.POINTER(vp), ctypes.POINTER(u64), vp]
     L.acx_result_count.argtypes = [vp]
     L.acx_result_count.restype = u64
     L.acx_result_device_matches.argtypes = [vp]
@@ -154,6 +163,12 @@ def _check(rc: int) -> None:
         if rc == ENOMEM:
             raise MemoryError(msg)
         raise AcxError(rc, msg)
+
+
+def shard_range(n_items: int, shard: int, n_shards: int) -> Tuple[int, int]:
+    lo, hi = ctypes.c_uint64(), ctypes.c_uint64()
+    lib().acx_shard_range(n_items, shard, n_shards, ctypes.byref(lo), ctypes.byref(hi))
+    return int(lo.value), int(hi.value)
 
 
 def device_count() -> int:
@@ -386,6 +401,28 @@ class Automaton:
         _check(lib().acx_find_batch(self._h, blob.ctypes.data, off.ctypes.data, len(haystacks),
                                     int(overlapping), int(codepoints), ctypes.byref(out),
                                     ctypes.byref(n), counts.ctypes.data))
+        return _take_matches(out.value, n.value), counts
+
+    def replicate(self, device: int) -> "Automaton":
+        """the same automaton compiled again on another device (acx_replicate)"""
+        h = ctypes.c_void_p()
+        _check(lib().acx_replicate(self._h, device, ctypes.byref(h)))
+        r = Automaton.__new__(Automaton)
+        r._h = h.value
+        return r
+
+    def find_batch_multi(self, others: Sequence["Automaton"], haystacks: Sequence[bytes], overlapping: bool = False,
+                         codepoints: bool = False) -> Tuple[np.ndarray, np.ndarray]:
+        """acx_find_batch_multi over [self] + others: one host thread per handle, contiguous ranges of
+        haystacks, identical to find_batch on one handle"""
+        hs = [self] + list(others)
+        arr = (ctypes.c_void_p * len(hs))(*[h._h for h in hs])
+        blob, off = pack(haystacks)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        counts = np.zeros(len(haystacks), dtype=np.uint64)
+        _check(lib().acx_find_batch_multi(arr, len(hs), blob.ctypes.data, off.ctypes.data, len(haystacks),
+                                          int(overlapping), int(codepoints), ctypes.byref(out), ctypes.byref(n),
+                                          counts.ctypes.data))
         return _take_matches(out.value, n.value), counts
 
     # ---- device-resident entry point

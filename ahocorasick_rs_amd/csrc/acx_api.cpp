@@ -157,6 +157,22 @@ struct BufCache {
         alloc = (alloc + 4095) / 4096 * 4096;
         DeviceScope ds(dev);
         hipError_t e = hipMalloc(out, alloc);
+        if (e == hipErrorOutOfMemory) { // give back everything the cache holds idle, then try once more
+            (void)hipGetLastError();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                sweep_locked();
+                for (const Ent &f : free_list) {
+                    live.erase(f.p);
+                    DeviceScope fs(f.dev);
+                    (void)hipFree(f.p);
+                }
+                free_list.clear();
+                cached = 0;
+            }
+            e = hipMalloc(out, alloc);
+            if (e != hipSuccess) e = hipMalloc(out, alloc = bytes);
+        }
         if (e == hipSuccess) {
             std::lock_guard<std::mutex> lk(mu);
             live[*out] = {*out, alloc, dev};
@@ -354,6 +370,7 @@ struct acx_automaton {
     const DevAutomaton *d_dev = nullptr; // the same struct, resident in HBM
     std::vector<void *> allocs;
     int kernel = ACX_KERNEL_DFA_WALK;
+    int implementation = ACX_IMPL_AUTO; // the caller's hint (replicas are built with the same one)
     int n_cus = 1;
     size_t max_lds = 65536;
     uint64_t table_bytes = 0;
@@ -881,7 +898,9 @@ int attempt_dense(FindCall &c, Attempt *what) {
             // both, uniform regions (the hit regions are balanced: a wave's tiles are spread over the stream)
             if ((rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
             uint64_t want = std::max((uint64_t)grid * (region_max + region_max / 8 + 64), w.cap * 4);
-            if (want > (1ull << 33)) want = std::max<uint64_t>(w.cap * 4, 1ull << 33); // (the exact pass sizes the rest)
+            // (bounded growth: ~72 B of workspace per record; once the hit regions hold everything the
+            // counts are exact and the second pass sizes the occurrence buffer exactly)
+            want = std::min<uint64_t>(want, std::max<uint64_t>(w.cap * 4, 1ull << 28));
             if ((rc = ensure_occ_capacity(x, want)) != ACX_OK) return rc;
         } else {
             // the regions' counts are exact (a full region keeps counting): the second pass puts every
@@ -967,7 +986,7 @@ int run_pipeline(FindCall &c) {
     c.scan_grid = c.pre ? prefilter_grid(c.d_hay, c.len, a->n_cus) : dfa_walk_grid(a->dev, c.len, a->n_cus);
     c.lead = (uint32_t)((uintptr_t)c.d_hay & 15);
     c.tiles = prefilter_tiles(c.d_hay, c.len);
-    static const bool no_sparse_env = std::getenv("ACX_NO_BUCKET") != nullptr; // tests / profiling: force the dense path
+    const bool no_sparse_env = std::getenv("ACX_NO_BUCKET") != nullptr; // tests / profiling: force the dense path (read per call)
     bool sparse = a->sparse_ok && x->dense_hold == 0 && !no_sparse_env && c.tiles < (1ull << 26);
     for (int attempt = 0;; attempt++) {
         if (attempt == 6) return fail(ACX_EDEVICE, "occurrence buffer overflow persisted");
@@ -1329,11 +1348,13 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     std::vector<uint32_t>().swap(H.table);
     a->sparse_ok = tile_lookback(H.max_len) <= MAX_LOOKBACK;
     // kernel selection
+    // The Implementation hint never selects a slower scan (the reference's README recommends the
+    // contiguous NFA as the sensible default, README.md:173-177: a caller following that advice must
+    // not pay for it): it only decides how large a dense table is kept (acx_build above).  The plain
+    // DFA walk stays reachable through acx_set_kernel / ACX_KERNEL=dfa_walk.
     bool prefilter_ok = H.filter_q >= 3 && a->max_lds >= prefilter_lds_bytes();
-    if (implementation == ACX_IMPL_NONCONTIGUOUS_NFA || implementation == ACX_IMPL_CONTIGUOUS_NFA)
-        a->kernel = ACX_KERNEL_DFA_WALK;
-    else
-        a->kernel = prefilter_ok ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
+    a->implementation = implementation;
+    a->kernel = prefilter_ok ? ACX_KERNEL_PREFILTER : ACX_KERNEL_DFA_WALK;
     if (const char *envk = std::getenv("ACX_KERNEL")) {
         if (!std::strcmp(envk, "dfa_walk")) { a->kernel = ACX_KERNEL_DFA_WALK; a->kernel_forced = true; }
         else if (!std::strcmp(envk, "prefilter") && H.filter_q >= 1 &&
@@ -1590,6 +1611,79 @@ int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offse
     if (rc != ACX_OK && *out) { acx_free_matches(*out); *out = nullptr; *n_out = 0; }
     acx_free_result(r);
     return rc;
+}
+
+int acx_replicate(const acx_automaton_t *a, int device, acx_automaton_t **out) {
+    if (!a || !out) return fail(ACX_EINVAL, "null argument");
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || device < 0 || device >= ndev)
+        return fail(ACX_EINVAL, "device ordinal out of range");
+    const int saved = g_device;
+    g_device = device;
+    // (the host copy keeps the pattern bytes and offsets: the replica is compiled from them)
+    const int rc = acx_build(a->host.blob.data(), a->host.offsets.data(), a->host.n_patterns, a->host.match_kind,
+                             a->implementation, out);
+    g_device = saved;
+    if (rc == ACX_OK && a->kernel_forced) (void)acx_set_kernel(*out, a->kernel);
+    return rc;
+}
+
+int acx_automaton_device(const acx_automaton_t *a) { return a ? a->device : -1; }
+
+void acx_shard_range(uint64_t n_items, int shard, int n_shards, uint64_t *lo, uint64_t *hi) {
+    const uint64_t base = n_items / (uint64_t)n_shards, extra = n_items % (uint64_t)n_shards;
+    const uint64_t s = (uint64_t)shard;
+    *lo = s * base + std::min<uint64_t>(s, extra);
+    *hi = *lo + base + (s < extra ? 1 : 0);
+}
+
+int acx_find_batch_multi(acx_automaton_t *const *handles, int n_handles, const uint8_t *hay,
+                         const uint64_t *offsets, uint64_t n_hay, int overlapping, int codepoints,
+                         acx_match_t **out, uint64_t *n_out, uint64_t *counts) {
+    if (!handles || n_handles < 1 || !out || !n_out || !offsets) return fail(ACX_EINVAL, "null argument");
+    for (int i = 0; i < n_handles; i++)
+        if (!handles[i]) return fail(ACX_EINVAL, "null automaton");
+    if (n_handles == 1) return acx_find_batch(handles[0], hay, offsets, n_hay, overlapping, codepoints, out, n_out, counts);
+    *out = nullptr; *n_out = 0;
+    // one host thread per handle, each on its contiguous range of haystacks (acx_shard_range: the
+    // same split as distributed.shard_range, so the concatenation over shards is the batch in
+    // order); the only thing combined afterwards are the shards' match counts (their exclusive
+    // prefix = where a shard's matches go in the output)
+    struct Shard { acx_match_t *m = nullptr; uint64_t n = 0; int rc = ACX_OK; std::string err; uint64_t lo = 0, hi = 0; };
+    std::vector<Shard> sh((size_t)n_handles);
+    std::vector<std::thread> th;
+    for (int i = 0; i < n_handles; i++) {
+        acx_shard_range(n_hay, i, n_handles, &sh[i].lo, &sh[i].hi);
+        th.emplace_back([&, i] {
+            Shard &s = sh[(size_t)i];
+            s.rc = acx_find_batch(handles[i], hay, offsets + s.lo, s.hi - s.lo, overlapping, codepoints, &s.m, &s.n,
+                                  counts ? counts + s.lo : nullptr);
+            if (s.rc != ACX_OK) s.err = acx_last_error(); // (thread-local: carried to the caller's thread)
+        });
+    }
+    for (auto &t : th) t.join();
+    int rc = ACX_OK;
+    uint64_t total = 0;
+    for (auto &s : sh) {
+        if (s.rc != ACX_OK && rc == ACX_OK) rc = fail(s.rc, s.err);
+        total += s.n;
+    }
+    acx_match_t *all = nullptr;
+    if (rc == ACX_OK && total) {
+        all = (acx_match_t *)std::malloc(total * sizeof(acx_match_t));
+        if (!all) rc = fail(ACX_ENOMEM, "out of memory");
+    }
+    uint64_t at = 0;
+    for (auto &s : sh) {
+        if (rc == ACX_OK && s.n) std::memcpy(all + at, s.m, s.n * sizeof(acx_match_t));
+        at += s.n;
+        acx_free_matches(s.m);
+    }
+    if (rc != ACX_OK) return rc;
+    *out = all;
+    *n_out = total;
+    return ACX_OK;
 }
 
 int acx_profile_enable(acx_automaton_t *a, int on) {

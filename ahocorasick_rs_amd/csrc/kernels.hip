@@ -59,7 +59,7 @@ __device__ __forceinline__ u32x4 load16_stream(const uint8_t *p) {
 //   their START lies in, as records k_tile_main takes without verification
 struct BlockSink {
     uint4 *recs;
-    uint32_t *lcount; // LDS
+    unsigned long long *lcount; // LDS (64-bit: a region's count never wraps, the host tests the sum for ACX_ETOOBIG)
     uint64_t region_cap;
     int key_mode;
     uint4 *hslots;
@@ -71,7 +71,7 @@ struct BlockSink {
 
 // region_cap == 0 (second pass of the dense path): the regions lie at the exclusive prefix of the
 // first pass's counts, stored behind the counts: block_counts[gridDim.x + b]
-__device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount) {
+__device__ __forceinline__ BlockSink block_sink(const Sink &K, unsigned long long *lcount) {
     uint64_t base = (uint64_t)blockIdx.x * K.region_cap, cap = K.region_cap;
     if (K.region_cap == 0 && K.block_counts && !K.hslots) {
         const uint64_t *rb = K.block_counts + gridDim.x;
@@ -85,7 +85,7 @@ __device__ __forceinline__ BlockSink block_sink(const Sink &K, uint32_t *lcount)
 // region mode: store one occurrence (ONE 16-byte store) into the next slot of the region
 // (records carry the pattern's length so that nothing downstream has to gather it again)
 __device__ __forceinline__ void emit_key(const BlockSink &K, uint64_t key, uint32_t pid, uint32_t plen) {
-    uint32_t slot = atomicAdd(K.lcount, 1u); // LDS atomic
+    const uint64_t slot = atomicAdd(K.lcount, 1ull); // LDS atomic
     if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
 }
 
@@ -98,11 +98,11 @@ __device__ __forceinline__ void emit_key_agg(const BlockSink &K, bool ok, uint64
     const uint32_t lane = threadIdx.x & 63;
     const unsigned long long below_me = (1ull << lane) - 1;
     const uint32_t leader = (uint32_t)__builtin_ctzll(fm);
-    uint32_t sbase = 0;
-    if (lane == leader) sbase = atomicAdd(K.lcount, (uint32_t)__popcll(fm));
+    unsigned long long sbase = 0;
+    if (lane == leader) sbase = atomicAdd(K.lcount, (unsigned long long)__popcll(fm));
     sbase = __shfl(sbase, leader);
     if (ok) {
-        uint32_t slot = sbase + (uint32_t)__popcll(fm & below_me);
+        const uint64_t slot = sbase + (uint32_t)__popcll(fm & below_me);
         if (slot < K.region_cap) K.recs[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, plen);
     }
 }
@@ -121,7 +121,7 @@ constexpr uint32_t HIT_RETRY = 0xFFFFFFFEu; // K1b found another key in the home
 // The emit paths are cold and out of line; they read the automaton through a
 // pointer to its device-resident copy so that the kernels never have to spill
 // their by-value kernel arguments to scratch for them.
-__device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink K, uint32_t pid,
+__device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink &K, uint32_t pid,
                                          uint64_t end) {
     uint64_t key;
     const uint32_t plen = A->plen[pid];
@@ -147,8 +147,11 @@ __device__ __forceinline__ void emit_one(const DevAutomaton *A, const BlockSink 
 
 // every pattern that ends at state s (own patterns, then the dictionary-suffix
 // chain: progressively shorter suffixes)
-__device__ __noinline__ void emit_state(const DevAutomaton *A, const BlockSink K, uint32_t s,
+// (the sink view lives in LDS and travels as a pointer: by value it was a 592-byte scratch frame
+// in front of every call site of this cold path)
+__device__ __noinline__ void emit_state(const DevAutomaton *A, const BlockSink *Kp, uint32_t s,
                                         uint64_t end) {
+    const BlockSink K = *Kp;
     for (uint32_t t = s; t != NONE; t = A->dlink[t]) {
         uint32_t b = A->own_off[t], e = A->own_off[t + 1];
         for (uint32_t k = b; k < e; k++) emit_one(A, K, A->own_pid[k], end);
@@ -223,7 +226,7 @@ __device__ __forceinline__ uint32_t dfa_step(const DevAutomaton &A, const WalkCt
 
 template <bool EMIT>
 __device__ __forceinline__ uint32_t walk_span(const DevAutomaton &A, const DevAutomaton *Ad,
-                                              const WalkCtx &W, const BlockSink &K,
+                                              const WalkCtx &W, const BlockSink *K,
                                               const uint8_t *hay, uint64_t pos, uint64_t lim,
                                               uint32_t s) {
 #define ACX_STEP(BYTE, POS)                                            \
@@ -261,10 +264,11 @@ __global__ __launch_bounds__(1024) void k1a_dfa_walk(DevAutomaton A, const DevAu
                                                      uint32_t lds_rows) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lcls = smem;
-    uint32_t *lcount = (uint32_t *)(smem + 256);
+    unsigned long long *lcount = (unsigned long long *)(smem + 256);
     uint16_t *lrows = (uint16_t *)(smem + K1A_LDS_HEADER);
-    if (threadIdx.x == 0) *lcount = 0;
-    const BlockSink K = block_sink(GK, lcount);
+    __shared__ BlockSink sK;
+    if (threadIdx.x == 0) { *lcount = 0; sK = block_sink(GK, lcount); }
+    const BlockSink *K = &sK;
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x)
         ((uint32_t *)lcls)[i] = ((const uint32_t *)A.classes)[i];
     {
@@ -332,10 +336,11 @@ __global__ __launch_bounds__(1024) void k1a_walk16(DevAutomaton A, const DevAuto
     constexpr int NCH = K1A_CHAINS;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *lcls = smem;
-    uint32_t *lcount = (uint32_t *)(smem + 256);
+    unsigned long long *lcount = (unsigned long long *)(smem + 256);
     uint16_t *lrows = (uint16_t *)(smem + K1A_LDS_HEADER);
-    if (threadIdx.x == 0) *lcount = 0;
-    const BlockSink K = block_sink(GK, lcount);
+    __shared__ BlockSink sK;
+    if (threadIdx.x == 0) { *lcount = 0; sK = block_sink(GK, lcount); }
+    const BlockSink *K = &sK;
     const uint32_t NC = A.n_classes, plain = A.walk_plain;
     for (uint32_t i = threadIdx.x; i < 64; i += blockDim.x) ((uint32_t *)lcls)[i] = ((const uint32_t *)A.classes)[i];
     {
@@ -671,7 +676,8 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
     const uint4 pi = A.pinfo[pid];
     // patterns that can reach beyond the carried window: where the pattern's bytes lie, requested
     // together with its info (uniform branch; the bytes themselves together with the haystack's)
-    const bool far = A.max_len > 16;
+    // (pinfo covers the first filter_q2 + 12 bytes of a pattern: anything longer has bytes to compare in place)
+    const bool far = A.max_len > A.filter_q2 + 12;
     const uint64_t po = far ? A.pat_off[pid] : 0;
     *rk = pi.x & 0xFFFFFFu;
     uint32_t L = pi.x >> 24;
@@ -724,7 +730,7 @@ __device__ __forceinline__ uint64_t occurrence_key(int key_mode, uint32_t rank_b
 __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, Sink H, uint32_t h_grid,
                                                    Sink GK, const uint8_t *__restrict__ stream,
                                                    uint64_t len) {
-    __shared__ uint32_t lcount;
+    __shared__ unsigned long long lcount;
     if (threadIdx.x == 0) lcount = 0;
     __syncthreads();
     const BlockSink K = block_sink(GK, &lcount);

@@ -15,6 +15,7 @@
 
 #include <cstdint>
 #include <cstring>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -202,9 +203,54 @@ PyObject *info_dict(acx_automaton_t *a) {
                          i.match_kind, "device", i.device, "filter_q", i.filter_q);
 }
 
+// Replicas of an object's automaton on other devices (find_matches_as_indexes_batch(devices=[...])):
+// built on first use, owned by the Python object.
+typedef std::map<int, acx_automaton_t *> Replicas;
+
+void free_replicas(Replicas *r) {
+    if (!r) return;
+    for (auto &kv : *r) acx_free_automaton(kv.second);
+    delete r;
+}
+
+// devices (None, or a sequence of device ordinals) -> the handles the batch is sharded over
+bool batch_handles(acx_automaton_t *a, PyObject *devices, Replicas **replicas, std::vector<acx_automaton_t *> *out) {
+    out->clear();
+    if (!devices || devices == Py_None) { out->push_back(a); return true; }
+    PyObject *seq = PySequence_Fast(devices, "devices must be a sequence of device ordinals");
+    if (!seq) return false;
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    if (n == 0) {
+        Py_DECREF(seq);
+        PyErr_SetString(PyExc_ValueError, "devices must name at least one device");
+        return false;
+    }
+    for (Py_ssize_t i = 0; i < n; i++) {
+        const long d = PyLong_AsLong(PySequence_Fast_GET_ITEM(seq, i));
+        if (d == -1 && PyErr_Occurred()) { Py_DECREF(seq); return false; }
+        if (d == acx_automaton_device(a)) { out->push_back(a); continue; }
+        if (!*replicas) *replicas = new Replicas();
+        auto it = (*replicas)->find((int)d);
+        if (it == (*replicas)->end()) {
+            acx_automaton_t *r = nullptr;
+            const int rc = acx_replicate(a, (int)d, &r);
+            if (rc != ACX_OK) { Py_DECREF(seq); raise_acx(rc); return false; }
+            it = (*replicas)->emplace((int)d, r).first;
+        }
+        out->push_back(it->second);
+    }
+    Py_DECREF(seq);
+    return true;
+}
+
 // Batched search shared by both classes: `items` are str (utf8 = true) or
-// buffers.  Returns list[list[tuple]].
-PyObject *find_batch_impl(acx_automaton_t *a, PyObject *haystacks, int overlapping, bool utf8) {
+// buffers.  Returns list[list[tuple]].  devices: None = the object's own device; a sequence of
+// ordinals = the batch is cut into that many contiguous ranges of haystacks, one host thread per
+// device (acx_find_batch_multi).
+PyObject *find_batch_impl(acx_automaton_t *a, PyObject *haystacks, int overlapping, bool utf8,
+                          PyObject *devices, Replicas **replicas) {
+    std::vector<acx_automaton_t *> handles;
+    if (!batch_handles(a, devices, replicas, &handles)) return nullptr;
     PyObject *seq = PySequence_Fast(haystacks, "haystacks must be a sequence");
     if (!seq) return nullptr;
     Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
@@ -235,8 +281,8 @@ PyObject *find_batch_impl(acx_automaton_t *a, PyObject *haystacks, int overlappi
     acx_match_t *m = nullptr; uint64_t total = 0;
     int rc;
     Py_BEGIN_ALLOW_THREADS
-    rc = acx_find_batch(a, blob.data(), off.data(), (uint64_t)n, overlapping,
-                        (utf8 && !all_ascii) ? 1 : 0, &m, &total, counts.data());
+    rc = acx_find_batch_multi(handles.data(), (int)handles.size(), blob.data(), off.data(), (uint64_t)n, overlapping,
+                              (utf8 && !all_ascii) ? 1 : 0, &m, &total, counts.data());
     Py_END_ALLOW_THREADS
     Py_DECREF(seq);
     if (rc != ACX_OK) return raise_acx(rc);
@@ -259,11 +305,13 @@ struct AcObject {
     PyObject_HEAD
     acx_automaton_t *ac;
     PyObject *patterns; // list[str] or NULL   (src/lib.rs:30-33 `patterns: Option<Vec<Py<PyString>>>`)
+    Replicas *replicas; // automata on other devices (batch calls with devices=[...]), or NULL
 };
 
 void ac_dealloc(PyObject *self) {
     AcObject *o = reinterpret_cast<AcObject *>(self);
     if (o->ac) acx_free_automaton(o->ac);
+    free_replicas(o->replicas);
     Py_XDECREF(o->patterns);
     PyTypeObject *tp = Py_TYPE(self);
     tp->tp_free(self);
@@ -334,6 +382,7 @@ PyObject *ac_new(PyTypeObject *type, PyObject *args, PyObject *kwargs) {
     AcObject *self = reinterpret_cast<AcObject *>(type->tp_alloc(type, 0));
     if (!self) { acx_free_automaton(ac); Py_DECREF(kept); return nullptr; }
     self->ac = ac;
+    self->replicas = nullptr;
     if (do_store) self->patterns = kept;
     else { self->patterns = nullptr; Py_DECREF(kept); }
     return reinterpret_cast<PyObject *>(self);
@@ -404,13 +453,14 @@ PyObject *ac_find_strings(PyObject *self_, PyObject *args, PyObject *kwargs) {
 }
 
 PyObject *ac_find_batch(PyObject *self_, PyObject *args, PyObject *kwargs) {
-    static const char *kw[] = {"haystacks", "overlapping", nullptr};
-    PyObject *hs, *ov = nullptr; int overlapping = 0;
-    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|O:find_matches_as_indexes_batch",
-                                     const_cast<char **>(kw), &hs, &ov))
+    static const char *kw[] = {"haystacks", "overlapping", "devices", nullptr};
+    PyObject *hs, *ov = nullptr, *devs = nullptr; int overlapping = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|OO:find_matches_as_indexes_batch",
+                                     const_cast<char **>(kw), &hs, &ov, &devs))
         return nullptr;
     if (ov && !parse_bool(ov, "overlapping", &overlapping)) return nullptr;
-    return find_batch_impl(reinterpret_cast<AcObject *>(self_)->ac, hs, overlapping, true);
+    AcObject *self = reinterpret_cast<AcObject *>(self_);
+    return find_batch_impl(self->ac, hs, overlapping, true, devs, &self->replicas);
 }
 
 PyObject *ac_info(PyObject *self_, PyObject *) {
@@ -430,7 +480,9 @@ PyMethodDef ac_methods[] = {
     {"find_matches_as_indexes_batch", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(ac_find_batch)),
      METH_VARARGS | METH_KEYWORDS,
      "[extension] one device pass over many haystacks; equals "
-     "[self.find_matches_as_indexes(h, overlapping) for h in haystacks]."},
+     "[self.find_matches_as_indexes(h, overlapping) for h in haystacks].  devices=[ordinals]: the batch "
+     "is cut into contiguous ranges of haystacks, one per device (replicas of the automaton are built on "
+     "first use), scanned side by side from one host thread each."},
     {"_info", ac_info, METH_NOARGS, "[extension] automaton / device facts as a dict."},
     {nullptr, nullptr, 0, nullptr},
 };
@@ -451,11 +503,13 @@ PyType_Slot ac_slots[] = {
 struct BacObject {
     PyObject_HEAD
     acx_automaton_t *ac;
+    Replicas *replicas;
 };
 
 void bac_dealloc(PyObject *self) {
     BacObject *o = reinterpret_cast<BacObject *>(self);
     if (o->ac) acx_free_automaton(o->ac);
+    free_replicas(o->replicas);
     PyTypeObject *tp = Py_TYPE(self);
     tp->tp_free(self);
     Py_DECREF(tp);
@@ -501,7 +555,86 @@ PyObject *bac_new(PyTypeObject *type, PyObject *args, PyObject *kwargs) {
     BacObject *self = reinterpret_cast<BacObject *>(type->tp_alloc(type, 0));
     if (!self) { acx_free_automaton(ac); return nullptr; }
     self->ac = ac;
+    self->replicas = nullptr;
     return reinterpret_cast<PyObject *>(self);
+}
+
+// ---- device-resident haystacks (extends the buffer adapter of src/lib.rs:276-340): an object that
+// is no host buffer but exports __dlpack__ (a torch / cupy tensor in HBM) is searched where it lies
+// -- no H2D copy.  DLPack structs (dlpack.h, ABI v0: the capsule "dltensor"):
+struct DLDeviceC { int32_t device_type; int32_t device_id; };
+struct DLDataTypeC { uint8_t code; uint8_t bits; uint16_t lanes; };
+struct DLTensorC { void *data; DLDeviceC device; int32_t ndim; DLDataTypeC dtype; int64_t *shape; int64_t *strides; uint64_t byte_offset; };
+struct DLManagedTensorC { DLTensorC dl_tensor; void *manager_ctx; void (*deleter)(DLManagedTensorC *); };
+constexpr int32_t kDLCPU = 1, kDLCUDA = 2, kDLCUDAHost = 3, kDLROCM = 10, kDLROCMHost = 11;
+
+// haystack -> (pointer, length, on_device).  Returns the capsule to release afterwards (new reference).
+PyObject *dlpack_view(PyObject *hay, int want_device, const uint8_t **ptr, uint64_t *len, bool *on_device) {
+    PyObject *cap = PyObject_CallMethod(hay, "__dlpack__", nullptr);
+    if (!cap) return nullptr;
+    DLManagedTensorC *mt = PyCapsule_IsValid(cap, "dltensor")
+                               ? static_cast<DLManagedTensorC *>(PyCapsule_GetPointer(cap, "dltensor")) : nullptr;
+    if (!mt) {
+        Py_DECREF(cap);
+        PyErr_SetString(PyExc_TypeError, "__dlpack__ did not return a 'dltensor' capsule");
+        return nullptr;
+    }
+    const DLTensorC &t = mt->dl_tensor;
+    const char *err = nullptr;
+    uint64_t n = 1;
+    for (int32_t d = 0; d < t.ndim; d++) n *= (uint64_t)t.shape[d];
+    if (t.ndim > 1) err = "Only one-dimensional sequences are supported";                  // src/lib.rs:288-292
+    else if (t.dtype.code != 1 || t.dtype.bits != 8 || t.dtype.lanes != 1) err = "buffer contents are not compatible with u8";
+    else if (t.ndim == 1 && t.strides && t.shape[0] > 1 && t.strides[0] != 1) err = "Must be a contiguous sequence of bytes"; // :293-297
+    const bool dev = t.device.device_type == kDLROCM || t.device.device_type == kDLCUDA;
+    const bool host = t.device.device_type == kDLCPU || t.device.device_type == kDLROCMHost ||
+                      t.device.device_type == kDLCUDAHost;
+    if (!err && !dev && !host) err = "unsupported DLPack device type";
+    if (!err && dev && t.device.device_id != want_device) {
+        PyErr_Format(PyExc_ValueError, "haystack lives on device %d, the automaton on device %d",
+                     (int)t.device.device_id, want_device);
+        Py_DECREF(cap);
+        return nullptr;
+    }
+    if (err) {
+        PyErr_SetString(err[0] == 'b' ? PyExc_BufferError : PyExc_TypeError, err);
+        Py_DECREF(cap);
+        return nullptr;
+    }
+    *ptr = static_cast<const uint8_t *>(t.data) + t.byte_offset;
+    *len = n;
+    *on_device = dev;
+    return cap;
+}
+
+void dlpack_release(PyObject *cap) { // we consumed the capsule: rename it and run the producer's deleter
+    if (!cap) return;
+    if (PyCapsule_IsValid(cap, "dltensor")) {
+        DLManagedTensorC *mt = static_cast<DLManagedTensorC *>(PyCapsule_GetPointer(cap, "dltensor"));
+        PyCapsule_SetName(cap, "used_dltensor");
+        if (mt && mt->deleter) mt->deleter(mt);
+    }
+    Py_DECREF(cap);
+}
+
+// device-resident search -> list of tuples (the records come back with ONE D2H copy of the result)
+PyObject *find_on_device(acx_automaton_t *a, const uint8_t *d_hay, uint64_t len, int overlapping) {
+    acx_result_t *r = nullptr;
+    std::vector<acx_match_t> m;
+    int rc;
+    Py_BEGIN_ALLOW_THREADS
+    // the producer's kernels may still be writing the tensor on its own stream: the library's
+    // streams are non-blocking ones, so order the search behind everything queued on the device
+    rc = acx_device_synchronize();
+    if (rc == ACX_OK) rc = acx_find_device(a, d_hay, len, nullptr, 0, 0, overlapping, 0, &r);
+    if (rc == ACX_OK) {
+        m.resize((size_t)acx_result_count(r));
+        if (!m.empty()) rc = acx_result_copy(r, m.data());
+    }
+    if (r) acx_free_result(r);
+    Py_END_ALLOW_THREADS
+    if (rc != ACX_OK) return raise_acx(rc);
+    return matches_to_list(m.data(), (uint64_t)m.size());
 }
 
 // src/lib.rs:422-434: byte offsets, no fix-up
@@ -509,6 +642,22 @@ PyObject *bac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
     BacObject *self = reinterpret_cast<BacObject *>(self_);
     PyObject *hay; int overlapping;
     if (!parse_find_args(args, kwargs, "O|O:find_matches_as_indexes", &hay, &overlapping)) return nullptr;
+    if (!PyObject_CheckBuffer(hay) && PyObject_HasAttrString(hay, "__dlpack__")) {
+        const uint8_t *p = nullptr; uint64_t len = 0; bool on_device = false;
+        PyObject *cap = dlpack_view(hay, acx_automaton_device(self->ac), &p, &len, &on_device);
+        if (!cap) return nullptr;
+        PyObject *res;
+        if (on_device) {
+            res = find_on_device(self->ac, p, len, overlapping);
+        } else { // (host memory behind DLPack: the ordinary entry point)
+            acx_match_t *m = nullptr; uint64_t n = 0;
+            const int rc = find_nogil(self->ac, p, len, overlapping, 0, &m, &n);
+            res = rc != ACX_OK ? raise_acx(rc) : matches_to_list(m, n);
+            if (rc == ACX_OK) acx_free_matches(m);
+        }
+        dlpack_release(cap);
+        return res;
+    }
     Py_buffer v;
     if (!get_bytes_view(hay, &v)) return nullptr;
     acx_match_t *m = nullptr; uint64_t n = 0;
@@ -521,13 +670,14 @@ PyObject *bac_find_indexes(PyObject *self_, PyObject *args, PyObject *kwargs) {
 }
 
 PyObject *bac_find_batch(PyObject *self_, PyObject *args, PyObject *kwargs) {
-    static const char *kw[] = {"haystacks", "overlapping", nullptr};
-    PyObject *hs, *ov = nullptr; int overlapping = 0;
-    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|O:find_matches_as_indexes_batch",
-                                     const_cast<char **>(kw), &hs, &ov))
+    static const char *kw[] = {"haystacks", "overlapping", "devices", nullptr};
+    PyObject *hs, *ov = nullptr, *devs = nullptr; int overlapping = 0;
+    if (!PyArg_ParseTupleAndKeywords(args, kwargs, "O|OO:find_matches_as_indexes_batch",
+                                     const_cast<char **>(kw), &hs, &ov, &devs))
         return nullptr;
     if (ov && !parse_bool(ov, "overlapping", &overlapping)) return nullptr;
-    return find_batch_impl(reinterpret_cast<BacObject *>(self_)->ac, hs, overlapping, false);
+    BacObject *self = reinterpret_cast<BacObject *>(self_);
+    return find_batch_impl(self->ac, hs, overlapping, false, devs, &self->replicas);
 }
 
 PyObject *bac_info(PyObject *self_, PyObject *) {
@@ -543,7 +693,9 @@ PyMethodDef bac_methods[] = {
     {"find_matches_as_indexes_batch", reinterpret_cast<PyCFunction>(reinterpret_cast<void (*)()>(bac_find_batch)),
      METH_VARARGS | METH_KEYWORDS,
      "[extension] one device pass over many haystacks; equals "
-     "[self.find_matches_as_indexes(h, overlapping) for h in haystacks]."},
+     "[self.find_matches_as_indexes(h, overlapping) for h in haystacks].  devices=[ordinals]: the batch "
+     "is cut into contiguous ranges of haystacks, one per device (replicas of the automaton are built on "
+     "first use), scanned side by side from one host thread each."},
     {"_info", bac_info, METH_NOARGS, "[extension] automaton / device facts as a dict."},
     {nullptr, nullptr, 0, nullptr},
 };

@@ -68,9 +68,14 @@ def parse_args(argv=None):
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
     ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
-    ap.add_argument("--dist", choices=["T", "U", "Z"], default="T",
+    ap.add_argument("--dist", choices=["T", "U", "Z", "D"], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
-                         "(calibration of the PMC traffic counters only: the scan reads, nothing else happens)")
+                         "(calibration of the PMC traffic counters only: the scan reads, nothing else happens), "
+                         "D dense: one pattern planted every 32 bytes (>= 1 occurrence per 32 B: the region path)")
+    ap.add_argument("--no-target-size", action="store_true",
+                    help="skip the in-process run at north_star's target size (8 GiB) that fills config.target_8gib")
+    ap.add_argument("--no-cold", action="store_true",
+                    help="skip the second timed region without the settle phase (config.value_no_settle)")
     ap.add_argument("--kernel", choices=["auto", "dfa_walk", "prefilter"], default="auto")
     ap.add_argument("--workload", choices=["auto", "single", "batch"], default="auto",
                     help="(kept for round-1 scripts) batch == --config cfg3")
@@ -123,6 +128,7 @@ def resolve_config(args, world: int) -> str:
 
 
 def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
+    import numpy as np
     """-> dict(ac, hay (device tensor), nbytes, find kwargs, description, patterns, match_kind,
     overlapping)."""
     nbytes = args.bytes
@@ -176,12 +182,27 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             if args.dist == "Z":
                 hay.zero_()
                 torch.cuda.synchronize()
+            elif args.dist == "D":
+                # dense output: uniform a-z with a pattern planted at every multiple of 32 bytes (chunks built
+                # on the host from one 16 MiB period: the content repeats, the scan does not care)
+                per = gen.gen_uniform(16 << 20, gen.AZ, 12)
+                rng = gen.SplitMix64(77)
+                for k in range(0, len(per) - 32, 32):
+                    p = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
+                    per[k:k + len(p)] = p
+                dper = torch.from_numpy(per).to(dev)
+                for off in range(0, nbytes, len(per)):
+                    n_ = min(len(per), nbytes - off)
+                    hay[off:off + n_] = dper[:n_]
+                torch.cuda.synchronize()
             else:
                 kind, seed = (1, 11) if args.dist == "T" else (0, 12)
                 ac.generate(hay.data_ptr(), nbytes, kind, seed)
             what = {"T": "text-like (T, seed 11: iid a-z letters, a space with probability 43/256 at every "
                          "position -- geometric word lengths, not a natural-language word model -- one pattern planted per KiB)", "U": "uniform a-z (U, seed 12)",
-                    "Z": "ALL-ZERO (calibration only, not a benchmark)"}[args.dist]
+                    "Z": "ALL-ZERO (calibration only, not a benchmark)",
+                    "D": "DENSE (uniform a-z, one pattern planted every 32 bytes, 16 MiB period: the region path, "
+                         "not the headline)"}[args.dist]
             w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
                          f"{nbytes / GIB:g} GiB {what} bytes haystack, MatchKind.Standard, non-overlapping")
         elif cfg == "cfg3":
@@ -281,54 +302,78 @@ def run(args) -> None:
             torch.cuda.synchronize()
 
     n_matches = 0
-    # Settle (untimed, before the W warm-up steps, disclosed in config.settle_ms): from a cold start
-    # the GPU's power controller goes through a transient of ~15 ms -- boost clocks for the first few
-    # steps, a dip while it finds the power limit, then the sustained state (per-step series:
-    # profiles/r02/step_times_cold_start.txt: 0.39 -> 0.44 -> 0.38 ms over the first 40 steps).  W = 5
-    # warm-up steps end in the middle of it; a throughput metric is about the sustained state.
+    n_gathers = [0]
+    _step = step
+
+    def step() -> int:  # (counts the collectives: config.collective says what ran)
+        if dist is not None:
+            n_gathers[0] += 1
+        return _step()
+
+    def timed_region(steps: int, warmup: int, profile: bool):
+        """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides"""
+        n = 0
+        for _ in range(warmup):
+            n = step()
+        if profile and not args.dry_run:
+            # the kernel time is measured live in the timed region, on every 4th step (the event pair
+            # costs the dispatch it rides on ~6 us; roofline.kernel_ms_samples says how many were taken)
+            w["ac"].profile_enable(4 if steps >= 8 else 1)
+            w["ac"].profile_read(reset=True)
+        if dist is not None:
+            dist.barrier()
+        sync()
+        t0 = time.perf_counter()
+        if args.callers > 1 and dist is None and not args.dry_run:
+            # (information only, never the default: K steps issued by several host threads at once -- the
+            # reference releases the GIL around a search, src/lib.rs:238, and a handle here serves up to
+            # ACX_MAX_CONCURRENCY calls side by side, each on its own stream)
+            import threading
+            per = [steps // args.callers + (1 if i < steps % args.callers else 0) for i in range(args.callers)]
+            ths = [threading.Thread(target=lambda k=k: [hot() for _ in range(k)]) for k in per]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+        else:
+            for _ in range(steps):
+                n = step()
+        sync()
+        if dist is not None:
+            dist.barrier()
+        dt = time.perf_counter() - t0
+        pr = None
+        if profile and not args.dry_run:
+            pr = w["ac"].profile_read(reset=True)
+            w["ac"].profile_enable(False)
+        return dt, n, pr
+
+    # ---- (1) the cold number, on the record next to the settled one (config.value_no_settle): the very
+    # same W warm-up + K timed steps WITHOUT the settle phase, from an idle GPU (2 s of idleness put the
+    # power controller back into its start-up transient: profiles/r02/step_times_cold_start.txt)
+    cold = None
+    if not args.dry_run and not args.no_cold and args.settle_ms > 0:
+        n_matches = hot()  # the first call allocates the workspaces: tens of ms, part of neither region
+        sync()
+        time.sleep(2.0)
+        dt, n_matches, _ = timed_region(args.steps, args.warmup, False)
+        cold = dt
+        time.sleep(0.5)
+    # ---- (2) settle (untimed, before the W warm-up steps, disclosed in config.settle_ms): from a cold
+    # start the GPU's power controller goes through a transient of ~15 ms -- boost clocks for the first
+    # few steps, a dip while it finds the power limit, then the sustained state.  W = 5 warm-up steps
+    # end in the middle of it; a throughput metric is about the sustained state.
     settled = 0
     if args.settle_ms > 0 and not args.dry_run:
         # (the hot path only: the ranks settle by time, each for itself -- no collective in here)
-        n_matches = hot()  # the first call allocates the workspaces: tens of ms, not part of the settle time
+        n_matches = hot()
         settled += 1
         sync()
         t_end = time.perf_counter() + args.settle_ms * 1e-3
         while time.perf_counter() < t_end:
             n_matches = hot()
             settled += 1
-    for _ in range(args.warmup):
-        n_matches = step()
-    if not args.dry_run:
-        # the kernel time is measured live in the timed region, on every 4th step (the event pair
-        # costs the dispatch it rides on ~6 us; roofline.kernel_ms_samples says how many were taken)
-        w["ac"].profile_enable(4 if args.steps >= 8 else 1)
-        w["ac"].profile_read(reset=True)
-    if dist is not None:
-        dist.barrier()
-    sync()
-    t0 = time.perf_counter()
-    if args.callers > 1 and dist is None and not args.dry_run:
-        # (information only, never the default: K steps issued by several host threads at once -- the
-        # reference releases the GIL around a search, src/lib.rs:238, and a handle here serves up to
-        # ACX_MAX_CONCURRENCY calls side by side, each on its own stream)
-        import threading
-        per = [args.steps // args.callers + (1 if i < args.steps % args.callers else 0) for i in range(args.callers)]
-        ths = [threading.Thread(target=lambda k=k: [hot() for _ in range(k)]) for k in per]
-        for th in ths:
-            th.start()
-        for th in ths:
-            th.join()
-    else:
-        for _ in range(args.steps):
-            n_matches = step()
-    sync()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    prof = None
-    if not args.dry_run:
-        prof = w["ac"].profile_read(reset=True)
-        w["ac"].profile_enable(False)
+    elapsed, n_matches, prof = timed_region(args.steps, args.warmup, True)
 
     total_matches = n_matches
     per_rank = [nbytes * args.steps / elapsed / 1e9]
@@ -339,6 +384,10 @@ def run(args) -> None:
         per_rank = [nbytes * args.steps / float(x) / 1e9 for x in every.cpu().tolist()]
         elapsed = float(every.max().item())  # MAX over ranks
         total_matches = int(counts_all.sum().item())
+        if cold is not None:
+            t = torch.tensor([cold], dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, t)
+            cold = float(every.max().item())
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -362,6 +411,10 @@ def run(args) -> None:
                        else ("torch.distributed.run" if "RANK" in os.environ else "none"),
                        "per_rank_gbps": [round(x, 2) for x in per_rank],
                        "settle_ms": 0 if args.dry_run else args.settle_ms, "settle_steps": settled,
+                       "value_no_settle": None if cold is None else round(world * nbytes * args.steps / cold / 1e9, 2),
+                       "ms_per_step_no_settle": None if cold is None else round(cold / args.steps * 1e3, 4),
+                       "collective": {"backend": dist.get_backend() if dist is not None else None,
+                                      "all_gathers": n_gathers[0], "what": "per-rank match counts (8 B per rank)"},
                        "matches_per_gpu_step": int(n_matches), "matches_total": int(total_matches)},
         }
         if cfg not in ("cfg2", "cfg3"):
@@ -396,6 +449,9 @@ def run(args) -> None:
                 "kernel_ms_samples": int(prof.scan_launches),
                 "algorithmic_bytes": int(algo_bytes),
             }
+            if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_target_size
+                    and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
+                out["config"]["target_8gib"] = target_size_run(w, torch, dev)
             if world == 1 and not args.no_cpu_baseline:
                 last["keep"] = True
                 step()  # one more pass, keeping the match stream for the SHA-256 comparison
@@ -404,6 +460,39 @@ def run(args) -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def target_size_run(w, torch, dev, nbytes: int = 8 * GIB, steps: int = 5, warmup: int = 2):
+    """north_star's target size in the same process: the same automaton over ONE 8 GiB text-like haystack
+    (same generator, seed 11; match offsets beyond 2^32), W warm-up + K timed steps behind the settled
+    state of the main run.  -> {bytes, steps, ms_per_step, gbps, frac (of 8 TB/s), matches}"""
+    try:
+        free, _ = torch.cuda.mem_get_info()
+        if free < nbytes * 2:
+            return {"skipped": f"only {free >> 30} GiB of HBM free"}
+        ac = w["ac"]
+        hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ac.generate(hay.data_ptr(), nbytes, 1, 11)
+        n = 0
+        for _ in range(warmup + 1):  # (+1: the first call at this size grows the workspaces)
+            r = ac.find_device(hay.data_ptr(), nbytes)
+            n = r.count
+            r.free()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            r = ac.find_device(hay.data_ptr(), nbytes)
+            n = r.count
+            r.free()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        del hay
+        gbps = nbytes / dt / 1e9
+        return {"bytes": nbytes, "steps": steps, "warmup": warmup, "ms_per_step": round(dt * 1e3, 4),
+                "gbps": round(gbps, 2), "frac": round(gbps / HBM_PEAK_GBPS, 4), "matches": int(n)}
+    except Exception as e:  # never take the headline down
+        return {"skipped": f"failed: {e!r}"}
 
 
 def measured_traffic(kernel: str, nbytes: int, dist_name: str, cfg: str):

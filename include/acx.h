@@ -23,7 +23,10 @@
 extern "C" {
 #endif
 
-#define ACX_VERSION 1
+/* 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
+ * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
+ * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
+#define ACX_VERSION 3
 
 /* status codes */
 #define ACX_OK 0
@@ -46,14 +49,13 @@ extern "C" {
 #define ACX_MATCH_LEFTMOST_LONGEST 2
 
 /* enum Implementation (+ None), src/lib.rs:111-128.  A hint only: every value
- * yields identical results (tests/test_ac.py:23-31).  On the device it selects
- * the scan kernel: DFA = dense-DFA walk with hot rows in LDS preceded by the
- * LDS q-gram prefilter when the pattern set admits one; NFA values force the
- * plain chunked DFA walk (no prefilter); AUTO picks by pattern statistics.
- * The dense transition table is kept when it is at most ACX_DENSE_LIMIT bytes
- * (default 256 MiB; DFA: 16 GiB); beyond that the automaton stays in its
- * compressed form (trie edges + failure links) and the walking kernels step
- * that -- the reference's "DFA for small sets, NFA beyond" (README.md:173-177). */
+ * yields identical results (tests/test_ac.py:23-31) and NO value selects a slower
+ * scan kernel (the reference recommends the contiguous NFA as the default trade-off,
+ * README.md:173-177).  It decides how large a dense transition table is kept: at most
+ * ACX_DENSE_LIMIT bytes (default 256 MiB; DFA: 16 GiB); beyond that the automaton stays
+ * in its compressed form (trie edges + failure links) and the walking kernels step
+ * that -- the reference's "DFA for small sets, NFA beyond".  The scan kernel is picked
+ * from the pattern statistics (acx_info.kernel; override: acx_set_kernel / ACX_KERNEL). */
 #define ACX_IMPL_AUTO (-1)
 #define ACX_IMPL_NONCONTIGUOUS_NFA 0
 #define ACX_IMPL_CONTIGUOUS_NFA 1
@@ -191,6 +193,12 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len,
              int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out);
 void acx_free_matches(acx_match_t *m);
 
+/* Precondition of codepoints = 1 (all entry points): haystack AND patterns are valid UTF-8 -- what
+ * the reference's str API guarantees by construction (src/lib.rs:147-160, 232).  The device converts
+ * a match's start through the lead-byte counts and takes its end as start + the pattern's own code
+ * points; for a pattern that ends inside a character the reference's table would hold usize::MAX
+ * (src/lib.rs:73-88) -- that input cannot come from a str and is not supported here. */
+
 /* ---- batched host form (new API; parity definition:
  * batch(hs)[i] == find(hs[i])).  `hay` is the concatenation
  * of n_hay haystacks delimited by offsets[n_hay + 1]; counts[n_hay] receives
@@ -199,6 +207,22 @@ void acx_free_matches(acx_match_t *m);
 int acx_find_batch(acx_automaton_t *a, const uint8_t *hay, const uint64_t *offsets,
                    uint64_t n_hay, int overlapping, int codepoints,
                    acx_match_t **out, uint64_t *n_out, uint64_t *counts);
+
+/* ---- one process, several devices (north_star: "a batched find_matches_as_indexes over many
+ * haystacks shards naturally across the 8 GPUs"; the reference's shape is ONE call from ONE process,
+ * benchmarks/test_comparison.py:113-124).  acx_replicate compiles the automaton of `a` again on
+ * another device (same patterns, match kind, implementation hint).  acx_find_batch_multi cuts the
+ * batch into n_handles contiguous ranges of haystacks (acx_shard_range: sizes differ by at most one),
+ * runs acx_find_batch on every handle from its own host thread and concatenates: the result is
+ * identical to acx_find_batch on one handle.  No device-to-device traffic; the shards' match counts
+ * are combined on the host (the multi-PROCESS form all-gathers them over RCCL instead:
+ * ahocorasick_rs_amd/distributed.py). */
+int acx_replicate(const acx_automaton_t *a, int device, acx_automaton_t **out);
+int acx_automaton_device(const acx_automaton_t *a);
+void acx_shard_range(uint64_t n_items, int shard, int n_shards, uint64_t *lo, uint64_t *hi);
+int acx_find_batch_multi(acx_automaton_t *const *handles, int n_handles, const uint8_t *hay,
+                         const uint64_t *offsets, uint64_t n_hay, int overlapping, int codepoints,
+                         acx_match_t **out, uint64_t *n_out, uint64_t *counts);
 
 /* ---- device-resident form (what bench.py times).  d_hay is a device pointer
  * to `len` bytes on the automaton's device.  Batches: either d_offsets

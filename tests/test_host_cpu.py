@@ -24,7 +24,22 @@ def test_c_abi_exports_every_declared_symbol():
     L = capi.lib()
     for n in names:
         assert hasattr(L, n), n
-    assert L.acx_version() == 1
+    assert L.acx_version() == capi.ABI_VERSION == int(re.search(r"#define ACX_VERSION (\d+)", hdr).group(1))
+
+
+def test_shard_range_twin_of_the_distributed_helper():
+    """acx_shard_range (the single-process multi-device batch) cuts a batch exactly like
+    distributed.shard_range (the multi-process form): contiguous, in order, sizes differ by at most one."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("acx_distributed", os.path.join(ROOT, "ahocorasick_rs_amd", "distributed.py"))
+    D = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(D)
+    for n in (0, 1, 2, 7, 8, 9, 1000, 131072, 1048577):
+        for world in (1, 2, 3, 8):
+            cuts = [capi.shard_range(n, r, world) for r in range(world)]
+            assert cuts == [D.shard_range(n, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == n
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
 
 
 def walk_all_occurrences(h, hay: bytes):

@@ -3,7 +3,10 @@
 (alphabets from 2 letters to all bytes to UTF-8 with 2/3/4-byte characters, 1 .. 30 000
 patterns, duplicates, nested patterns) and haystacks of 0 .. 48 MiB (text-like, uniform, dense,
 planted), all match kinds, overlapping, byte offsets and code points, both scan kernels.
-usage: gpu_fuzz.py [seconds] [seed]   -- prints one line per case, exits non-zero on a mismatch."""
+usage: gpu_fuzz.py [seconds] [seed]   -- prints one line per case, exits non-zero on a mismatch.
+tests/test_gpu_fuzz.py runs a bounded, seeded slice of it (fuzz(budget, seed, max_size_log2)) under -m gpu.
+UTF-8 cases only ever hold patterns made of whole characters (a str pattern cannot end inside one:
+the precondition of codepoints = 1, include/acx.h)."""
 import os, random, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -12,8 +15,8 @@ import gen
 from oracle_lib import KIND_DFA, Oracle, byte_to_code_point
 from ahocorasick_rs_amd import capi
 
-budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
+rng = random.Random(20260927)
+MAX_SIZE_LOG2 = 25.5
 ALPHAS = [("ab", b"ab"), ("abc", b"abc"), ("a-h", b"abcdefgh"), ("a-z", gen.AZ), ("a-z+sp", gen.AZ + b" "),
           ("bytes", bytes(range(256))), ("utf8", None)]
 UNI = "abcdefghijklmnopqrstuvwxyz" + "é☃\U0001F926"
@@ -38,7 +41,7 @@ def make_case():
             pats += [pats[rng.randrange(n_pat)].decode()[:rng.randint(1, 4)].encode() for _ in range(n_pat // 10 + 1)]
         else:
             pats += [pats[rng.randrange(n_pat)][:rng.randint(1, 6)] for _ in range(n_pat // 10 + 1)]
-    size = int(2 ** rng.uniform(0, 25.5)) if rng.random() < 0.9 else rng.choice([0, 1, 4095, 4096, 4097, 262144, 262145])
+    size = int(2 ** rng.uniform(0, MAX_SIZE_LOG2)) if rng.random() < 0.9 else rng.choice([0, 1, 4095, 4096, 4097, 262144, 262145])
     if alpha is not None and len(alpha) <= 8:  # small alphabets: the output is many times the input -- keep it bounded
         size = min(size, (1 << 18) if lo <= 2 else (1 << 21))
     kind = rng.choice(["uniform", "text", "planted", "dense"])
@@ -63,52 +66,65 @@ def make_case():
     return name, kind, pats, bytes(hay)
 
 
-t_end = time.time() + budget
-cases = fails = 0
-while time.time() < t_end:
-    name, kind, pats, hay = make_case()
-    mk = rng.randrange(3)
-    kernel = rng.choice([None, capi.KERNEL_DFA_WALK, capi.KERNEL_PREFILTER])
-    ov = mk == 0 and rng.random() < 0.4
-    cp = name == "utf8" and rng.random() < 0.7
-    if os.environ.get("FUZZ_ONLY") and os.environ["FUZZ_ONLY"] != name:
-        continue
-    try:
-        a = capi.Automaton(pats, mk, kernel=kernel)
-    except capi.AcxError as e:
-        print("build error", e); continue
-    o = Oracle(pats, mk, KIND_DFA)
-    want = o.find_raw(hay, overlapping=ov)
-    if cp and len(want):
-        b2c = byte_to_code_point(hay)
-        want = np.stack([want[:, 0], b2c[want[:, 1].astype(np.int64)], b2c[want[:, 2].astype(np.int64)]], 1)
-    if len(want) > 20_000_000:
-        a.close(); continue
-    try:
-        got = cols(a.find(hay, overlapping=ov, codepoints=cp))
-    except (capi.AcxError, ValueError, MemoryError) as e:
-        print("find error", name, kind, len(pats), len(hay), mk, ov, cp, kernel, len(want), e, flush=True)
-        fails += 1; a.close(); continue
-    ok = np.array_equal(got, want)
-    # the same bytes at an unaligned device address, and again (buffers of the previous call in flight)
-    got2 = cols(a.find(np.frombuffer(b"x" * 3 + hay, dtype=np.uint8)[3:], overlapping=ov, codepoints=cp))
-    ok = ok and np.array_equal(got2, want)
-    cases += 1
-    if not ok:
-        for tag, g in (("aligned", got), ("unaligned", got2)):
-            if np.array_equal(g, want):
-                continue
-            m = min(len(g), len(want))
-            d = np.nonzero((g[:m] != want[:m]).any(1))[0]
-            i = int(d[0]) if len(d) else m
-            print(f"  {tag}: got {len(g)} want {len(want)} rows, first difference at row {i}: got "
-                  f"{g[i].tolist() if i < len(g) else None} want {want[i].tolist() if i < len(want) else None}", flush=True)
-    print(f"{'ok  ' if ok else 'FAIL'} {name:7s} {kind:8s} pats {len(pats):6d} hay {len(hay):9d} mk {mk} ov {int(ov)} cp {int(cp)} "
-          f"kernel {kernel} matches {len(want)}", flush=True)
-    if not ok:
-        fails += 1
-        np.save(f"/root/repo/gpurun_out/fuzz_fail_{cases}_hay.npy", np.frombuffer(hay, dtype=np.uint8))
-        open(f"/root/repo/gpurun_out/fuzz_fail_{cases}_pats.txt", "w").write(repr((pats, mk, ov, cp, kernel)))
-    a.close()
-print(f"{cases} cases, {fails} failures")
-sys.exit(1 if fails else 0)
+
+def fuzz(budget: float, seed: int, max_size_log2: float = 25.5, save_failures: bool = True):
+    """-> (cases, failures); deterministic in (seed, max_size_log2) up to where the time budget cuts it"""
+    global rng, MAX_SIZE_LOG2
+    rng = random.Random(seed)
+    MAX_SIZE_LOG2 = max_size_log2
+    t_end = time.time() + budget
+    cases = fails = 0
+    while time.time() < t_end:
+        name, kind, pats, hay = make_case()
+        mk = rng.randrange(3)
+        kernel = rng.choice([None, capi.KERNEL_DFA_WALK, capi.KERNEL_PREFILTER])
+        ov = mk == 0 and rng.random() < 0.4
+        cp = name == "utf8" and rng.random() < 0.7
+        if os.environ.get("FUZZ_ONLY") and os.environ["FUZZ_ONLY"] != name:
+            continue
+        try:
+            a = capi.Automaton(pats, mk, kernel=kernel)
+        except capi.AcxError as e:
+            print("build error", e); continue
+        o = Oracle(pats, mk, KIND_DFA)
+        want = o.find_raw(hay, overlapping=ov)
+        if cp and len(want):
+            b2c = byte_to_code_point(hay)
+            want = np.stack([want[:, 0], b2c[want[:, 1].astype(np.int64)], b2c[want[:, 2].astype(np.int64)]], 1)
+        if len(want) > 20_000_000:
+            a.close(); continue
+        try:
+            got = cols(a.find(hay, overlapping=ov, codepoints=cp))
+        except (capi.AcxError, ValueError, MemoryError) as e:
+            print("find error", name, kind, len(pats), len(hay), mk, ov, cp, kernel, len(want), e, flush=True)
+            fails += 1; a.close(); continue
+        ok = np.array_equal(got, want)
+        # the same bytes at an unaligned device address, and again (buffers of the previous call in flight)
+        got2 = cols(a.find(np.frombuffer(b"x" * 3 + hay, dtype=np.uint8)[3:], overlapping=ov, codepoints=cp))
+        ok = ok and np.array_equal(got2, want)
+        cases += 1
+        if not ok:
+            for tag, g in (("aligned", got), ("unaligned", got2)):
+                if np.array_equal(g, want):
+                    continue
+                m = min(len(g), len(want))
+                d = np.nonzero((g[:m] != want[:m]).any(1))[0]
+                i = int(d[0]) if len(d) else m
+                print(f"  {tag}: got {len(g)} want {len(want)} rows, first difference at row {i}: got "
+                      f"{g[i].tolist() if i < len(g) else None} want {want[i].tolist() if i < len(want) else None}", flush=True)
+        print(f"{'ok  ' if ok else 'FAIL'} {name:7s} {kind:8s} pats {len(pats):6d} hay {len(hay):9d} mk {mk} ov {int(ov)} cp {int(cp)} "
+              f"kernel {kernel} matches {len(want)}", flush=True)
+        if not ok:
+            fails += 1
+            if save_failures:
+                np.save(f"/root/repo/gpurun_out/fuzz_fail_{cases}_hay.npy", np.frombuffer(hay, dtype=np.uint8))
+                open(f"/root/repo/gpurun_out/fuzz_fail_{cases}_pats.txt", "w").write(repr((pats, mk, ov, cp, kernel)))
+        a.close()
+    return cases, fails
+
+
+if __name__ == "__main__":
+    n_cases, n_fails = fuzz(float(sys.argv[1]) if len(sys.argv) > 1 else 120.0,
+                            int(sys.argv[2]) if len(sys.argv) > 2 else 20260927)
+    print(f"{n_cases} cases, {n_fails} failures")
+    sys.exit(1 if n_fails else 0)
