@@ -495,7 +495,7 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
             std::lock_guard<std::mutex> lk(mu16);
             if (dev < 0 || dev >= 64 || !attr16[dev]) {
                 hipError_t e = hipFuncSetAttribute((const void *)k1a_walk16,
-                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+                                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)(max_lds - 2048));
                 if (e != hipSuccess) return e;
                 if (dev >= 0 && dev < 64) attr16[dev] = true;
             }
@@ -537,7 +537,7 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
         std::lock_guard<std::mutex> lk(mu);
         if (dev < 0 || dev >= 64 || !attr_set[dev]) {
             hipError_t e = hipFuncSetAttribute((const void *)k1a_dfa_walk,
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds);
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)(max_lds - 2048));
             if (e != hipSuccess) return e;
             if (dev >= 0 && dev < 64) attr_set[dev] = true;
         }
