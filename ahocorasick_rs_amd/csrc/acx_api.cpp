@@ -797,8 +797,25 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         c.leads_counted = cp_sub != nullptr;
     } else {
         HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
+        // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk); its survivor
+        // records take the place of K1b's dense-path hit sink.  More survivors than their regions hold
+        // (1 per 16 haystack bytes): the walk raises the abort flag, the call is redone on the dense
+        // path, which walks in chunks (ACX_NO_PFAC: always the chunked walk -- measurements).
+        static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
+        const bool pfac = pfac_available(a->dev) && !no_pfac;
+        uint32_t pgrid = 0;
+        uint64_t surv_total = 0;
+        if (pfac) {
+            pgrid = pfac_scan_grid(c.d_hay, c.len, a->n_cus);
+            surv_total = pfac_workspace_words(c.len, pgrid);
+            if ((rc = ensure_hits(x, (surv_total + 3) / 4)) != ACX_OK) return rc; // (records of 32 B there, u64 words here)
+        }
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
-        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+        if (pfac)
+            HIPCHK_RC(launch_pfac(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
+                                  pgrid * 16, st));
+        else
+            HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     // str API, one haystack: the prefix of the lead-byte counts is ready before the write kernel
@@ -1294,6 +1311,50 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
             for (uint32_t c = 0; c < NC; c++)
                 table16[(size_t)w * NC + c] = (uint16_t)walk_of[H.table[(size_t)walk_bfs[w] * S + c] & ID_MASK];
     }
+    // K1a's failureless form: trie records for every state, the first three levels as tables
+    std::vector<uint32_t> t3b, t3r, grec;
+    if (H.n_classes <= 32 && H.n_patterns > 0) {
+        const uint32_t NS = H.n_states;
+        grec.assign((size_t)4 * NS, 0);
+        for (uint32_t s2 = 0; s2 < NS; s2++) {
+            uint32_t bm = 0;
+            for (uint32_t c = H.first_child[s2]; c < H.first_child[s2 + 1]; c++) bm |= 1u << H.classes[H.in_byte[c]];
+            grec[4 * (size_t)s2] = bm;
+            grec[4 * (size_t)s2 + 1] = H.first_child[s2] | ((H.sflags[s2] & 1u) ? GREC_OWN : 0u);
+            grec[4 * (size_t)s2 + 2] = H.own1[s2];
+        }
+        // (a used byte is alone in its class, so the children of a node have distinct classes, ascending
+        // like their bytes: child = first child + the set bits below the class)
+        auto child = [&](uint32_t s2, uint32_t c) -> uint32_t {
+            const uint32_t bm = grec[4 * (size_t)s2];
+            if (!((bm >> c) & 1u)) return 0;
+            return H.first_child[s2] + (uint32_t)__builtin_popcount(bm & ((1u << c) - 1u));
+        };
+        t3b.assign(32768, 0);
+        t3r.assign(2 * 32768, 0);
+        for (uint32_t c0 = 0; c0 < H.n_classes; c0++)
+            for (uint32_t c1 = 0; c1 < H.n_classes; c1++)
+                for (uint32_t c2 = 0; c2 < H.n_classes; c2++) {
+                    const uint32_t idx = (c0 << 10) | (c1 << 5) | c2;
+                    const uint32_t n1 = child(0, c0), n2 = n1 ? child(n1, c1) : 0, n3 = n2 ? child(n2, c2) : 0;
+                    const bool ends = (n1 && (H.sflags[n1] & 1u)) || (n2 && (H.sflags[n2] & 1u)) || (n3 && (H.sflags[n3] & 1u));
+                    t3b[idx] = ends ? ~0u : (n3 ? grec[4 * (size_t)n3] : 0u);
+                    t3r[2 * (size_t)idx] = n3 ? grec[4 * (size_t)n3] : 0u;
+                    t3r[2 * (size_t)idx + 1] = (n3 ? H.first_child[n3] : 0u) | (ends ? T3R_SHORT : 0u);
+                }
+    }
+    D.cls_linear = 0; D.cls_lo = 0;
+    if (!t3b.empty()) { // is the class map linear (every byte between the lowest and the highest pattern byte its own class)?
+        uint32_t lo = 256;
+        for (uint32_t b = 0; b < 256; b++) if (H.classes[b] != 0) { lo = b; break; }
+        bool lin = lo < 256 && lo > 0;
+        for (uint32_t b = 0; lin && b < 256; b++) {
+            const int32_t want = std::max(0, std::min((int32_t)b - (int32_t)lo + 1, (int32_t)H.n_classes - 1));
+            lin = H.classes[b] == (uint32_t)want;
+        }
+        D.cls_linear = lin ? 1u : 0u;
+        D.cls_lo = lin ? lo : 0u;
+    }
     int rc;
 #define UP(vec, field)                                                                   \
     if ((rc = upload(a, st, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
@@ -1309,6 +1370,16 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         UP(walk_bfs, walk_bfs)
     } else {
         D.table16 = nullptr; D.walk_bfs = nullptr;
+    }
+    if (!t3b.empty()) {
+        UP(t3b, t3b)
+        const uint32_t *p2 = nullptr;
+        if ((rc = upload(a, st, t3r.data(), t3r.size(), &p2)) != ACX_OK) return destroy(rc);
+        D.t3r = reinterpret_cast<const uint2 *>(p2);
+        if ((rc = upload(a, st, grec.data(), grec.size(), &p2)) != ACX_OK) return destroy(rc);
+        D.grec = reinterpret_cast<const uint4 *>(p2);
+    } else {
+        D.t3b = nullptr; D.t3r = nullptr; D.grec = nullptr;
     }
     UP(H.own_off, own_off)
     UP(H.own_pid, own_pid)

@@ -86,7 +86,8 @@ constexpr uint32_t PREFIX_EMPTY = 0xFFFFFFFFu;
 // redirects is looked up only if the bit of its own N bytes is set (hash = prefix_home_hash(.., N))
 constexpr uint32_t REDIRECT_BLOOM_WORDS = 1024; // 32 Kbit
 ACX_HD static inline uint32_t redirect_bloom_bit(uint32_t key_hash) { return (key_hash >> 3) & (REDIRECT_BLOOM_WORDS * 32 - 1); }
-ACX_HD static inline uint32_t prefix_more_bit(uint32_t home_hash) { return 1u << (8 + ((home_hash >> 11) & 15u)); }
+ACX_HD static inline uint32_t prefix_more_index(uint32_t home_hash) { return (home_hash >> 11) & 15u; }
+ACX_HD static inline uint32_t prefix_more_bit(uint32_t home_hash) { return 1u << (8 + prefix_more_index(home_hash)); }
 // home-slot hash of the first `salt` bytes of a key (little-endian in a u64, masked): salt = Q2,
 // the set-wide minimum key length -- all a lookup knows before it has seen an entry -- or the
 // key length a redirect entry names

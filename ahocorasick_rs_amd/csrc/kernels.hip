@@ -627,7 +627,7 @@ __device__ __forceinline__ uint64_t low_bytes(uint64_t w, uint32_t n) { // the f
 
 // Does the window (8 haystack bytes, little-endian) start with the entry's key?  (e.z != PREFIX_EMPTY)
 __device__ __forceinline__ bool entry_matches(const uint4 e, uint64_t w0) {
-    const uint32_t sh = (64u - 8u * (e.z & 15u)) & 63u; // key length 1..8
+    const uint32_t sh = (0u - (e.z << 3)) & 56u; // 64 - 8 * key length (1..8), mod 64
     return (((((uint64_t)e.y << 32) | e.x) ^ w0) << sh) == 0;
 }
 
@@ -888,7 +888,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // nxtL = the 8 bytes that follow the tile (lane 63's look-ahead), read by all
     // lanes from one address.
     const uint64_t last_block = total16 - 16;
-    u32x4 nxt0, nxt1, nxt2, nxt3;
+    // (ONE set of registers for the tile: the prefetch of the wave's next tile is issued when level 1
+    // has finished with the rows and lands in the same registers -- round 2 kept a second set and copied)
+    u32x4 nxt0, nxt1, nxt2, nxt3; // the tile's rows ("nxt": loaded one iteration ahead)
     uint2 nxtL;
     // PLAIN loads, not non-temporal ones: the survivors' windows are re-read one iteration later
     // and should still be in the XCD's L2 (measured: nt tile loads cost the kernel 15-20 %).
@@ -964,8 +966,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 // displaced keys has the window's bit: then the hit travels as HIT_RETRY and
                 // k_tile_main / k_walk_hits look the window up (no dependent gathers here: walking
                 // the probe sequence in place was measured at +15 % of the kernel on the headline set)
-                const bool retry = act && !same && (entC.z & prefix_more_bit(gram_hash2(winC & q2mask) + q2salt));
-                cntC += hit_push((same && code != HIT_NONE) || retry, (uint64_t)tileC * tile_bytes + offC - lead,
+                // (the four bits of the window's hash that select the filter bit travel in the offset's spare bits)
+                const bool retry = act && !same && ((entC.z >> (8 + (BIG ? prefix_more_index(gram_hash2(winC & q2mask) + q2salt) : offC >> 16))) & 1u);
+                cntC += hit_push((same && code != HIT_NONE) || retry, (uint64_t)tileC * tile_bytes + (offC & 0xFFFFu) - lead,
                                  same ? code : HIT_RETRY, winC, winC1, tileC, cntC);
             }
             if (stC == 2) { // the tile is complete
@@ -1009,16 +1012,26 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         } else {
             // ---- stage B -> C: hash the windows, fetch their home slots
             if (nB) {
-                if (lane < nB)
-                    entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winB & q2mask) + q2salt, ptab_log2) * 4);
-                offC = offB; winC = winB; winC1 = winB1;
+                const uint32_t hB = gram_hash2(winB & q2mask) + q2salt;
+                if (lane < nB) entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
+                offC = offB | (prefix_more_index(hB) << 16); winC = winB; winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
             // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
             if (q1c) {
+                // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
+                const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
                 if (lane < q1c) {
                     offB = q1[lane];
-                    load_window16(stream, len, (uint64_t)tileQ * tile_bytes + offB - lead, &winB, &winB1);
+                    const uint64_t p_ = (uint64_t)tileQ * tile_bytes + offB - lead;
+                    if (inside) {
+                        u32x4 w_;
+                        __builtin_memcpy(&w_, stream + p_, 16);
+                        winB = ((uint64_t)w_.y << 32) | w_.x;
+                        winB1 = ((uint64_t)w_.w << 32) | w_.z;
+                    } else {
+                        load_window16(stream, len, p_, &winB, &winB1);
+                    }
                 }
             }
         }
@@ -1032,9 +1045,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // Everything loaded during the previous iteration (the tile prefetch and the level-2
         // windows / slots) is consumed from here on.  Passing the tile through an empty asm makes
         // the compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
-        u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
-        uint2 vL = nxtL;
-        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL.x), "+v"(vL.y));
+        asm volatile("" : "+v"(nxt0), "+v"(nxt1), "+v"(nxt2), "+v"(nxt3), "+v"(nxtL.x), "+v"(nxtL.y));
         // the previous tile's remaining survivors: its last batch (possibly empty)
         advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
         if (tile >= ntiles) continue;
@@ -1122,15 +1133,15 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // every position of an interior tile is a legal start: no per-row masking
         const bool interior = tbase >= lead && tbase + tile_bytes <= last_start;
         if (BIG && Q == 5) {
-            K1B_ROW_BIG(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
-            K1B_ROW_BIG(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
-            K1B_ROW_BIG(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
-            K1B_ROW_BIG(3, v3, vL.x, vL.y, mrow3)
+            K1B_ROW_BIG(0, nxt0, __builtin_amdgcn_readfirstlane(nxt1.x), __builtin_amdgcn_readfirstlane(nxt1.y), mrow0)
+            K1B_ROW_BIG(1, nxt1, __builtin_amdgcn_readfirstlane(nxt2.x), __builtin_amdgcn_readfirstlane(nxt2.y), mrow1)
+            K1B_ROW_BIG(2, nxt2, __builtin_amdgcn_readfirstlane(nxt3.x), __builtin_amdgcn_readfirstlane(nxt3.y), mrow2)
+            K1B_ROW_BIG(3, nxt3, nxtL.x, nxtL.y, mrow3)
         } else {
-            K1B_ROW(0, v0, __builtin_amdgcn_readfirstlane(v1.x), __builtin_amdgcn_readfirstlane(v1.y), mrow0)
-            K1B_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), __builtin_amdgcn_readfirstlane(v2.y), mrow1)
-            K1B_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), __builtin_amdgcn_readfirstlane(v3.y), mrow2)
-            K1B_ROW(3, v3, vL.x, vL.y, mrow3)
+            K1B_ROW(0, nxt0, __builtin_amdgcn_readfirstlane(nxt1.x), __builtin_amdgcn_readfirstlane(nxt1.y), mrow0)
+            K1B_ROW(1, nxt1, __builtin_amdgcn_readfirstlane(nxt2.x), __builtin_amdgcn_readfirstlane(nxt2.y), mrow1)
+            K1B_ROW(2, nxt2, __builtin_amdgcn_readfirstlane(nxt3.x), __builtin_amdgcn_readfirstlane(nxt3.y), mrow2)
+            K1B_ROW(3, nxt3, nxtL.x, nxtL.y, mrow3)
         }
         if (CP) { // lead bytes of the lane's 16 bytes of every row, summed over the 4 lanes of a 64-byte stretch
 #define K1B_LEADS(RI, VR)                                                                        \
@@ -1150,7 +1161,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 c_ += __shfl_xor(c_, 2);                                                         \
                 if ((lane & 3) == 0) A.cp_sub[(tile * 4 + (RI)) * 16 + (lane >> 2)] = (uint8_t)c_; \
             }
-            K1B_LEADS(0, v0) K1B_LEADS(1, v1) K1B_LEADS(2, v2) K1B_LEADS(3, v3)
+            K1B_LEADS(0, nxt0) K1B_LEADS(1, nxt1) K1B_LEADS(2, nxt2) K1B_LEADS(3, nxt3)
 #undef K1B_LEADS
         }
         // Prefetch of the wave's next tile, issued LATE: the compaction below, level 2 at the top
@@ -1159,23 +1170,23 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // no prefetch at all (loads at the top of the tile's own iteration): 308.
         K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
-        uint32_t mlo = mrow0 | (mrow1 << 16), mhi = mrow2 | (mrow3 << 16);
+        // (one 64-bit mask per lane; the round is branch-free: the lowest set bit by two v_ffbl, lanes
+        // without a survivor compute along and do not store)
+        uint64_t m64 = (uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32);
         while (true) {
-            unsigned long long act = __ballot((mlo | mhi) != 0);
+            const bool has = m64 != 0;
+            const unsigned long long act = __ballot(has);
             if (!act) break;
-            uint32_t np = __popcll(act);
+            const uint32_t np = __popcll(act);
             if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u); // dense survivors: a full batch moves on now
-            if (mlo | mhi) {
-                uint32_t pos;
-                if (mlo) { pos = __builtin_ctz(mlo); mlo &= mlo - 1; }
-                else { pos = 32 + __builtin_ctz(mhi); mhi &= mhi - 1; }
-                uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
-                                                                __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
-                q1[slot] = (uint16_t)(((pos >> 4) << 10) + lane * 16 + (pos & 15)); // offset in the tile
-            }
+            const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
+            m64 &= m64 - 1;
+            const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+            if (has) q1[slot] = (uint16_t)(((pos >> 4) << 10) + lane * 16 + (pos & 15)); // offset in the tile
             q1c += np;
-            __builtin_amdgcn_wave_barrier();
         }
+        __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
     }
     hit_flush();
@@ -1251,6 +1262,348 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     }
 #undef ACX_K1B_LAUNCH
 #undef ACX_K1B
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// K1a, failureless form: every position walks the trie (automata of at most 32 byte classes)
+// ---------------------------------------------------------------------------
+// The goto function of the Aho-Corasick automaton, walked from EVERY haystack position (no failure
+// links: an occurrence is found by the walk that starts at its first byte -- the form of the DFA walk
+// that has no dependent chain across positions).  Two kernels:
+//   k1a_scan   streams the haystack exactly like K1b (one coalesced 16-byte load per lane and row, the
+//              next unit prefetched into registers) and settles the first FOUR levels of every walk in
+//              LDS: the class triple of bytes j .. j+2 indexes t3b (128 KiB in LDS: the children bitmap of
+//              the depth-3 node, 0 when the trie has no such path), bit class(byte j+3) says whether the
+//              walk reaches depth 4.  ~2 % of the positions of a 10^4-pattern set over text do; they are
+//              ballot-compacted, re-read their 8-byte window (L2) one step later and leave as 8-byte
+//              survivor records {position, class triple, classes of bytes 3 and 4} in per-wave regions.
+//   k1a_walk   one thread per survivor: depth 3 -> 4 from the record alone (t3r, HBM / L2), the levels
+//              below from the trie records (grec, 16 B per state) and the haystack; every pattern that
+//              ends on the way is an occurrence (start, pattern, length): into the hit slots of its tile
+//              (sparse output) or the occurrence regions (dense output), exactly like the chunked walk.
+// Patterns of at most 3 bytes: t3b holds ~0 for every triple with such a pattern on its path, and the
+// walk then starts from the root.  The last positions of a haystack (fewer than 4 bytes left) survive
+// unconditionally.
+struct K1aLds {
+    uint32_t t3b[32768];
+    uint8_t cls[256]; // class << 2
+    uint16_t q1[16][64];
+};
+static_assert(sizeof(K1aLds) <= 160 * 1024, "K1a LDS image exceeds 160 KiB");
+constexpr uint64_t SURV_POS_MASK = (1ull << 38) - 1;
+
+struct SurvivorSink {
+    uint64_t *recs;      // regions * cap records
+    uint64_t *counts;    // one per region (keeps counting past cap)
+    uint64_t cap;        // records per region
+    uint32_t regions;
+};
+
+// LIN: the class map is linear -- class(b) = clamp(b - cls_lo + 1, 0, n_classes - 1): every byte between
+// the lowest and the highest byte of the patterns is its own class (a-z, digits, ...): the classes are
+// computed (two VALU operations per byte) instead of looked up -- the kernel is bound by its LDS reads
+// (one t3b entry per position: 16 per lane and row).
+template <bool LIN>
+__global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3b, const uint8_t *__restrict__ classes,
+                                                  SurvivorSink S, const uint8_t *__restrict__ hay, uint64_t len,
+                                                  uint64_t lead, uint32_t min_len, uint32_t cls_lo, uint32_t n_classes) {
+    __shared__ __attribute__((aligned(16))) K1aLds L;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    uint16_t *q1 = L.q1[wave];
+    {
+        const uint4 *src = (const uint4 *)t3b;
+        uint4 *dst = (uint4 *)L.t3b;
+        for (uint32_t i = threadIdx.x; i < sizeof(L.t3b) / 16; i += blockDim.x) dst[i] = src[i];
+        if (threadIdx.x < 256) L.cls[threadIdx.x] = (uint8_t)(classes[threadIdx.x] << 2);
+    }
+    __syncthreads();
+    const uint8_t *stream = hay + lead;
+    const uint64_t total = lead + len, total16 = (total + 15) & ~15ull;
+    const uint64_t last_start = total >= min_len ? total - min_len : 0; // last index a pattern can start at
+    const bool any_start = total >= lead + min_len;
+    const uint64_t tile_bytes = 4096;
+    const uint64_t ntiles = (total + tile_bytes - 1) / tile_bytes;
+    const uint64_t gw = (uint64_t)blockIdx.x * 16 + wave, nw = (uint64_t)gridDim.x * 16;
+    const uint32_t region = blockIdx.x * 16 + wave;
+    uint64_t *const srec = S.recs + (uint64_t)region * S.cap;
+    const uint32_t hcap = (uint32_t)(S.cap < 0xFFFFFFFFull ? S.cap : 0xFFFFFFFFull);
+    uint32_t hcur = 0, q1c = 0;
+    const uint64_t last_block = total16 - 16;
+    u32x4 nxt0, nxt1, nxt2, nxt3;
+    uint32_t nxtL;
+#define K1A_ISSUE_ROW(DST, TILE, R)                                                              \
+    {                                                                                            \
+        uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
+        DST = *(const u32x4 *)(hay + (off_ < last_block ? off_ : last_block));                   \
+    }
+#define K1A_ISSUE_TILE(TILE)                                                                     \
+    {                                                                                            \
+        const uint64_t tb_ = (TILE) * tile_bytes;                                                \
+        if (tb_ + tile_bytes <= last_block) {                                                    \
+            const uint8_t *tp_ = hay + tb_ + lane * 16;                                          \
+            nxt0 = *(const u32x4 *)(tp_); nxt1 = *(const u32x4 *)(tp_ + 1024);                   \
+            nxt2 = *(const u32x4 *)(tp_ + 2048); nxt3 = *(const u32x4 *)(tp_ + 3072);           \
+            nxtL = *(const uint32_t *)(hay + tb_ + tile_bytes);                                  \
+        } else {                                                                                 \
+            K1A_ISSUE_ROW(nxt0, TILE, 0) K1A_ISSUE_ROW(nxt1, TILE, 1) K1A_ISSUE_ROW(nxt2, TILE, 2) \
+            K1A_ISSUE_ROW(nxt3, TILE, 3)                                                         \
+            uint64_t off_ = tb_ + tile_bytes;                                                    \
+            nxtL = *(const uint32_t *)(hay + (off_ < last_block ? off_ : last_block));           \
+        }                                                                                        \
+    }
+    K1A_ISSUE_TILE(gw)
+    // ---- survivors: Q1 (offsets of the tile under compaction) -> windows in flight -> records
+    uint32_t nB = 0;
+    uint64_t posB = 0, winB = 0;
+    auto advance = [&](uint32_t tileQ) __attribute__((always_inline)) {
+        if (nB) { // the windows requested by the previous advance: classes of bytes 0 .. 4, the record
+            if (lane < nB) {
+                const uint32_t lo = (uint32_t)winB, hi = (uint32_t)(winB >> 32);
+                const uint32_t c0 = L.cls[lo & 0xFF] >> 2, c1 = L.cls[(lo >> 8) & 0xFF] >> 2, c2 = L.cls[(lo >> 16) & 0xFF] >> 2;
+                const uint32_t c3 = L.cls[lo >> 24] >> 2, c4 = L.cls[hi & 0xFF] >> 2;
+                const uint64_t rec = posB | ((uint64_t)((c0 << 10) | (c1 << 5) | c2) << 38) | ((uint64_t)c3 << 53) |
+                                     ((uint64_t)c4 << 58);
+                const uint32_t slot = hcur + lane;
+                if (slot < hcap) srec[slot] = rec;
+            }
+            hcur += nB; // keeps counting past the capacity
+        }
+        if (q1c) {
+            if (lane < q1c) {
+                posB = (uint64_t)tileQ * tile_bytes + q1[lane] - lead;
+                winB = load_window(stream, len, posB);
+            }
+        }
+        nB = q1c;
+        q1c = 0;
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (uint64_t tile = gw; tile < ntiles + 2 * nw; tile += nw) {
+        u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
+        uint32_t vL = nxtL;
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL));
+        advance((uint32_t)(tile - nw)); // the previous tile's remaining survivors
+        if (tile >= ntiles) continue;
+        const uint64_t tbase = tile * tile_bytes;
+        // every position of an interior tile is a legal start with at least 4 bytes behind it
+        const bool interior = tbase >= lead && tbase + tile_bytes + 4 <= last_start;
+        uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
+        // one row: 16 positions per lane; the walk of position j needs bytes j .. j+3: three bytes of
+        // the lane behind by DPP (lane 63: the next row's first bytes, scalar)
+        const int32_t cls_off = 4 - 4 * (int32_t)cls_lo, cls_max = 4 * (int32_t)n_classes - 4;
+#define K1A_BYTE(k) ((d_[(k) >> 2] >> (8 * ((k) & 3))) & 0xFF)
+#define K1A_CLS(k) (LIN ? (uint32_t)max(0, min((int32_t)(K1A_BYTE(k) << 2) + cls_off, cls_max)) \
+                        : (uint32_t)L.cls[K1A_BYTE(k)])
+#define K1A_ROW(RI, VR, RX, MROW)                                                                \
+        {                                                                                        \
+            const uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);   \
+            const uint32_t rx_ = (RX);                                                           \
+            const uint32_t d_[5] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_};             \
+            uint32_t x_[19]; /* class << 2 of the lane's bytes 0 .. 18 */                        \
+            _Pragma("unroll") for (int k = 0; k < 19; k++) x_[k] = K1A_CLS(k);                   \
+            uint32_t m_ = 0;                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 16; j++) {                                     \
+                const uint32_t a_ = (((x_[j] << 5) | x_[j + 1]) << 5) | x_[j + 2]; /* byte offset of the entry */ \
+                const uint32_t bm_ = *(const uint32_t *)((const uint8_t *)L.t3b + a_);           \
+                m_ = __builtin_amdgcn_alignbit(bm_ >> (x_[j + 3] >> 2), m_, 1);                  \
+            }                                                                                    \
+            m_ >>= 16;                                                                           \
+            if (!interior) { /* wave-uniform: a scalar branch */                                 \
+                const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
+                uint32_t keep_ = 0, force_ = 0;                                                  \
+                _Pragma("unroll") for (int j = 0; j < 16; j++) {                                 \
+                    if (any_start && p0_ + j >= lead && p0_ + j <= last_start) keep_ |= 1u << j; \
+                    if (p0_ + j + 4 > total) force_ |= 1u << j; /* bytes behind the end took part in the test */ \
+                }                                                                                \
+                m_ = (m_ | force_) & keep_;                                                      \
+            }                                                                                    \
+            MROW = m_;                                                                           \
+        }
+        K1A_ROW(0, v0, __builtin_amdgcn_readfirstlane(v1.x), mrow0)
+        K1A_ROW(1, v1, __builtin_amdgcn_readfirstlane(v2.x), mrow1)
+        K1A_ROW(2, v2, __builtin_amdgcn_readfirstlane(v3.x), mrow2)
+        K1A_ROW(3, v3, vL, mrow3)
+        K1A_ISSUE_TILE(tile + nw)
+        uint64_t m64 = (uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32);
+        while (true) { // (branch-free rounds, as in K1b)
+            const bool has = m64 != 0;
+            const unsigned long long act = __ballot(has);
+            if (!act) break;
+            const uint32_t np = __popcll(act);
+            if (q1c + np > 64) advance((uint32_t)tile);
+            const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
+            m64 &= m64 - 1;
+            const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+            if (has) q1[slot] = (uint16_t)(((pos >> 4) << 10) + lane * 16 + (pos & 15));
+            q1c += np;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) S.counts[region] = hcur;
+#undef K1A_ISSUE_ROW
+#undef K1A_ISSUE_TILE
+#undef K1A_CLS
+#undef K1A_BYTE
+#undef K1A_ROW
+}
+
+// Survivors of the scan, second level: one thread per record, two dependent gathers, no divergence --
+// depth 3 -> 4 from the record alone (t3r by the class triple), depth 4 -> 5 from the depth-4 node's
+// record and the class of byte 4 (also in the record).  ~95 % of the scan's survivors end here; the
+// walks that go on (and the positions whose first levels hold the end of a short pattern: from the
+// root) leave as {position, node, depth} for k1a_walk.  (One kernel did all of it at first: the few
+// lanes that follow a real occurrence to its end held their waves back for every record -- 468 us on
+// the headline input against 2 x 60.)
+struct DeepSink {
+    uint4 *recs;       // regions * cap records {position lo, position hi, node, depth}
+    uint64_t *counts;  // one per region
+    uint64_t cap;
+};
+__global__ __launch_bounds__(256) void k1a_sift(const uint2 *__restrict__ t3r, const uint4 *__restrict__ grec,
+                                                Segments G, SurvivorSink S, DeepSink D, uint32_t *abort_flag,
+                                                uint64_t len) {
+    __shared__ uint32_t cnt2;
+    for (uint32_t b = blockIdx.x; b < S.regions; b += gridDim.x) {
+        if (threadIdx.x == 0) cnt2 = 0;
+        __syncthreads();
+        uint64_t n = S.counts[b];
+        if (n > S.cap) { // survivors were dropped: the caller redoes the call another way
+            n = S.cap;
+            if (threadIdx.x == 0 && abort_flag) *abort_flag = 1;
+        }
+        const uint64_t *recs = S.recs + (uint64_t)b * S.cap;
+        uint4 *out = D.recs + (uint64_t)b * D.cap;
+        // (four records of a thread in flight: the kernel is two dependent gathers per record and nothing else)
+        for (uint64_t i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
+            uint64_t rec[4];
+            uint2 e[4];
+            uint4 r[4];
+            uint32_t node[4], d[4];
+            bool go[4], lvl[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) rec[k] = i0 + k * blockDim.x < n ? recs[i0 + k * blockDim.x] : ~0ull;
+#pragma unroll
+            for (int k = 0; k < 4; k++) e[k] = t3r[(uint32_t)(rec[k] >> 38) & 0x7FFFu];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint64_t pos = rec[k] & SURV_POS_MASK;
+                const uint64_t room = rec[k] == ~0ull ? 0 : segment_end(G, len, pos) - pos;
+                node[k] = 0; d[k] = 0;
+                go[k] = rec[k] != ~0ull; // (a short pattern on the path, or the haystack ends within 5 bytes: from the root)
+                lvl[k] = go[k] && !(e[k].y & T3R_SHORT) && room >= 5;
+                if (lvl[k]) {
+                    const uint32_t c3 = (uint32_t)(rec[k] >> 53) & 31u;
+                    go[k] = (e[k].x >> c3) & 1u;
+                    node[k] = (e[k].y & ID_MASK) + __popc(e[k].x & ((1u << c3) - 1u));
+                    d[k] = 4;
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) r[k] = lvl[k] && go[k] ? grec[node[k]] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (lvl[k] && go[k]) go[k] = (r[k].y & GREC_OWN) || ((r[k].x >> ((uint32_t)(rec[k] >> 58) & 31u)) & 1u);
+                if (go[k]) {
+                    const uint64_t pos = rec[k] & SURV_POS_MASK;
+                    const uint32_t slot = atomicAdd(&cnt2, 1u);
+                    if (slot < D.cap) out[slot] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), node[k], d[k]);
+                }
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            D.counts[b] = cnt2;
+            if (cnt2 > D.cap && abort_flag) *abort_flag = 1;
+        }
+        __syncthreads();
+    }
+}
+
+// the walks that go on: trie records + haystack bytes, every pattern that ends on the way is an occurrence
+__global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomaton *Ad, Segments G, DeepSink D,
+                                                uint32_t regions, Sink GK, const uint8_t *__restrict__ stream,
+                                                uint64_t len) {
+    __shared__ unsigned long long lcount;
+    __shared__ BlockSink sK;
+    __shared__ uint8_t cls[256];
+    if (threadIdx.x == 0) { lcount = 0; sK = block_sink(GK, &lcount); }
+    cls[threadIdx.x] = A.classes[threadIdx.x];
+    __syncthreads();
+    const BlockSink *K = &sK;
+    for (uint32_t b = blockIdx.x; b < regions; b += gridDim.x) {
+        uint64_t n = D.counts[b];
+        if (n > D.cap) n = D.cap; // (k1a_sift raised the abort flag)
+        const uint4 *recs = D.recs + (uint64_t)b * D.cap;
+        for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint4 it = recs[i];
+            const uint64_t pos = ((uint64_t)it.y << 32) | it.x;
+            const uint64_t room = segment_end(G, len, pos) - pos;
+            uint32_t node = it.z, d = it.w;
+            // the next 8 haystack bytes in one load (patterns of up to d + 8 bytes never touch the stream again)
+            uint64_t w = load_window(stream, len, pos + d);
+            uint32_t wd = d;
+            for (;;) {
+                const uint4 r = A.grec[node];
+                if (r.y & GREC_OWN) {
+                    if (r.z == OWN1_MANY) {
+                        for (uint32_t k = A.own_off[node]; k < A.own_off[node + 1]; k++) emit_one(Ad, *K, A.own_pid[k], pos + d);
+                    } else if (K->hslots) { // (the pattern's length is the depth: nothing to gather)
+                        const uint64_t tile = (pos + K->lead) >> TILE_BITS;
+                        const uint32_t slot = atomicAdd(&K->hcnt[hcnt_index(tile, K->cnt_nw, K->cnt_iters)], 1u);
+                        if (slot < HIT_SLOTS)
+                            K->hslots[(tile * HIT_SLOTS + slot) * 2] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), HIT_VERIFIED | r.z, d);
+                        else
+                            *K->abort_flag = 1;
+                    } else {
+                        emit_one(Ad, *K, r.z, pos + d);
+                    }
+                }
+                if (d >= room) break;
+                if (d - wd >= 8) { w = load_window(stream, len, pos + d); wd = d; }
+                const uint32_t c = cls[(w >> (8 * (d - wd))) & 0xFF];
+                if (!((r.x >> c) & 1u)) break;
+                node = (r.y & ID_MASK) + __popc(r.x & ((1u << c) - 1u));
+                d++;
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && GK.block_counts) GK.block_counts[blockIdx.x] = lcount;
+}
+
+bool pfac_available(const DevAutomaton &A) { return A.t3b != nullptr; }
+uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
+    const uint64_t total = ((uintptr_t)d_hay & 15) + len;
+    uint64_t blocks = ((total + 4095) / 4096 + 15) / 16;
+    if (blocks > (uint64_t)n_cus) blocks = n_cus;
+    return blocks ? (uint32_t)blocks : 1;
+}
+// survivor records the scan may leave before the call gives up: 1 per 16 haystack bytes (8 B each), and
+// 1 in 8 of them may go on beyond depth 5 (16 B each): the u64 words of workspace both take
+uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid) {
+    const uint64_t regions = (uint64_t)scan_grid * 16;
+    const uint64_t cap = len / 16 / regions + 1024, cap2 = cap / 8 + 256;
+    return regions * (cap + 2 * cap2);
+}
+hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,
+                       const uint8_t *d_hay, uint64_t len, uint32_t scan_grid, uint64_t *work, uint64_t *counts,
+                       uint32_t walk_grid, hipStream_t st) {
+    if (len == 0) return hipSuccess;
+    const uint64_t lead = (uintptr_t)d_hay & 15;
+    const uint32_t regions = scan_grid * 16;
+    const uint64_t cap = len / 16 / regions + 1024, cap2 = cap / 8 + 256;
+    const SurvivorSink S{work, counts, cap, regions};
+    const DeepSink D{(uint4 *)(work + (uint64_t)regions * cap), counts + regions, cap2};
+    if (A.cls_linear)
+        hipLaunchKernelGGL(k1a_scan<true>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, S, d_hay - lead, len,
+                           lead, A.min_len, A.cls_lo, A.n_classes);
+    else
+        hipLaunchKernelGGL(k1a_scan<false>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, S, d_hay - lead, len,
+                           lead, A.min_len, 0u, A.n_classes);
+    hipLaunchKernelGGL(k1a_sift, dim3(regions), dim3(256), 0, st, A.t3r, A.grec, G, S, D, K.abort_flag, len);
+    hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, regions, K, d_hay, len);
     return hipGetLastError();
 }
 
@@ -1820,7 +2173,11 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
 // seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
 // their haystack and the per-haystack counts are taken here -- one atomic per run of matches
 // of the same haystack inside the stretch instead of a separate pass with one atomic per match.
-constexpr uint32_t WRITE_THREADS = 256, WRITE_MAX = GROUP_MAX;
+constexpr uint32_t WRITE_THREADS = 256;
+// matches of a group assembled in LDS at a time: the image decides how many groups a CU works on at
+// once (the whole 1024-match stretch of round 2 took 28 KB: 5 groups per CU, 16.5 us; 7 KB: all 8 the
+// waves allow, 13.6 us on the headline input)
+constexpr uint32_t WRITE_CHUNK = 256;
 // cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
 struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; const uint32_t *pchars; };
 struct PostOut {
@@ -1834,8 +2191,8 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
                                                               acx_match_t *out, const uint32_t *abort_flag,
                                                               Segments G, uint64_t *seg_counts, CodePointTables cp,
                                                               PostOut O) {
-    __shared__ uint32_t img[WRITE_MAX * 6];
-    __shared__ uint32_t hs[WRITE_MAX]; // haystack index of the matches, in output order
+    __shared__ uint32_t img[WRITE_CHUNK * 6];
+    __shared__ uint32_t hs[WRITE_CHUNK]; // haystack index of the matches, in output order
     __shared__ uint64_t red[4];
     __shared__ uint64_t s_base;
     const uint32_t t = threadIdx.x, g = blockIdx.x;
@@ -1882,38 +2239,42 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     }
     __syncthreads();
     const uint64_t base = s_base;
-    for (uint32_t i = t; i < n; i += WRITE_THREADS) {
-        const uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + i];
-        uint64_t s, e;
-        span_of(rank_bits, key_mode, v, &s, &e);
-        if (seg_counts) {
-            uint64_t h, hbase;
-            if (G.uniform_len) { h = s / G.uniform_len; hbase = h * G.uniform_len; }
-            else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; hbase = G.offsets[h]; }
-            s -= hbase; e -= hbase;
-            hs[i] = (uint32_t)h;
+    for (uint32_t c0 = 0; c0 < n; c0 += WRITE_CHUNK) {
+        const uint32_t m = n - c0 < WRITE_CHUNK ? n - c0 : WRITE_CHUNK;
+        for (uint32_t i = t; i < m; i += WRITE_THREADS) {
+            const uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + c0 + i];
+            uint64_t s, e;
+            span_of(rank_bits, key_mode, v, &s, &e);
+            if (seg_counts) {
+                uint64_t h, hbase;
+                if (G.uniform_len) { h = s / G.uniform_len; hbase = h * G.uniform_len; }
+                else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; hbase = G.offsets[h]; }
+                s -= hbase; e -= hbase;
+                hs[i] = (uint32_t)h;
+            }
+            const uint32_t pid = key_mode == 1 ? v.z : by_rank[v.z];
+            if (cp.blockpre) { // (a match is as many code points as its pattern: nothing of the span is read)
+                const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s);
+                e = cs + cp.pchars[pid];
+                s = cs;
+            }
+            uint32_t *d = img + i * 6;
+            d[0] = pid; d[1] = 0;
+            d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
         }
-        const uint32_t pid = key_mode == 1 ? v.z : by_rank[v.z];
-        if (cp.blockpre) { // (a match is as many code points as its pattern: nothing of the span is read)
-            const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s);
-            e = cs + cp.pchars[pid];
-            s = cs;
+        __syncthreads();
+        uint32_t *flat = (uint32_t *)(out + base + c0);
+        for (uint32_t k = t; k < m * 6; k += WRITE_THREADS) flat[k] = img[k];
+        if (seg_counts) { // (a run of matches of one haystack cut by a chunk boundary adds twice: same sum)
+            for (uint32_t c = t; c < m; c += WRITE_THREADS) {
+                const uint32_t h = hs[c];
+                if (c > 0 && hs[c - 1] == h) continue; // not the head of its run
+                uint32_t run = 1;
+                while (c + run < m && hs[c + run] == h) run++;
+                atomicAdd((unsigned long long *)&seg_counts[h], (unsigned long long)run);
+            }
         }
-        uint32_t *d = img + i * 6;
-        d[0] = pid; d[1] = 0;
-        d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
-    }
-    __syncthreads();
-    uint32_t *flat = (uint32_t *)(out + base);
-    for (uint32_t k = t; k < n * 6; k += WRITE_THREADS) flat[k] = img[k];
-    if (seg_counts) {
-        for (uint32_t c = t; c < n; c += WRITE_THREADS) {
-            const uint32_t h = hs[c];
-            if (c > 0 && hs[c - 1] == h) continue; // not the head of its run
-            uint32_t run = 1;
-            while (c + run < n && hs[c + run] == h) run++;
-            atomicAdd((unsigned long long *)&seg_counts[h], (unsigned long long)run);
-        }
+        __syncthreads();
     }
 }
 

@@ -19,6 +19,19 @@ uint32_t dfa_walk_grid(const DevAutomaton &A, uint64_t len, int n_cus);
 hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G,
                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st);
+// K1a, failureless form (automata of at most 32 byte classes; kernels.hip): k1a_scan settles the first
+// four levels of the walk of every position in LDS and leaves the survivors as 8-byte records in
+// per-wave regions; k1a_sift takes them one level on (two gathers each, no divergence); k1a_walk
+// finishes the few walks that go on and emits the occurrences into K (hit slots: K.hcnt zero
+// beforehand, walk_grid arbitrary; regions: walk_grid = the number of occurrence regions).
+// work: pfac_workspace_words() u64 words; counts: 2 * scan_grid * 16 u64 words.  More survivors than the
+// regions hold: K.abort_flag (hit-slot mode).
+bool pfac_available(const DevAutomaton &A);
+uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
+uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid);
+hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,
+                       const uint8_t *d_hay, uint64_t len, uint32_t scan_grid, uint64_t *work, uint64_t *counts,
+                       uint32_t walk_grid, hipStream_t st);
 // K1b: LDS q-gram prefilter + exact prefix table.  Emits prefix hits: into the hit slots of
 // their tile (K.hslots != null; every tile's count is written) or into per-wave regions
 // (prefilter_hit_regions(grid) of them, dense path).

@@ -69,29 +69,42 @@ def test_implementation_hint_never_selects_the_slow_kernel():
         a.close()
 
 
+_DLPACK_SCRIPT = r"""
+import sys
+import torch  # first: one process holds ONE HIP runtime, and torch must be the one to load it (package docs)
+sys.path[:0] = [sys.argv[1], sys.argv[2]]
+import gen
+import ahocorasick_rs as ref_api
+pats = gen.gen_patterns(3000, 5, 12, gen.AZ, 1)
+host = gen.gen_textlike(8 << 20, 11, pats)
+ac = ref_api.BytesAhoCorasick(pats, matchkind=ref_api.MatchKind.LeftmostLongest)
+want = ac.find_matches_as_indexes(host.tobytes())
+t = torch.from_numpy(host).to("cuda:0")
+assert ac.find_matches_as_indexes(t) == want and len(want) > 1000
+assert ac.find_matches_as_indexes(t[1234567:]) == ac.find_matches_as_indexes(host[1234567:].tobytes())
+# host tensors go through the same protocol; small ones take K0
+assert ac.find_matches_as_indexes(torch.from_numpy(host[:5000])) == ac.find_matches_as_indexes(host[:5000].tobytes())
+std = ref_api.BytesAhoCorasick(pats)
+assert std.find_matches_as_indexes(t, overlapping=True) == std.find_matches_as_indexes(host.tobytes(), overlapping=True)
+for bad, exc in ((t.reshape(2, -1), TypeError), (t.to(torch.int8), BufferError), (t[::2], TypeError)):
+    try:
+        ac.find_matches_as_indexes(bad)
+    except exc:
+        pass
+    else:
+        raise AssertionError(f"no {exc.__name__}")
+print("DLPACK_OK")
+"""
+
+
 def test_facade_accepts_device_resident_tensor():
     """BytesAhoCorasick.find_matches_as_indexes(tensor in HBM) == the bytes call, no H2D copy of the
-    haystack (the tensor is searched where it lies; tools/trace in profiles/r03 shows the copy-free
-    call)."""
-    torch = pytest.importorskip("torch")
-    import ahocorasick_rs as ref_api
-    pats = gen.gen_patterns(3000, 5, 12, gen.AZ, 1)
-    host = gen.gen_textlike(8 << 20, 11, pats)
-    ac = ref_api.BytesAhoCorasick(pats, matchkind=ref_api.MatchKind.LeftmostLongest)
-    want = ac.find_matches_as_indexes(host.tobytes())
-    t = torch.from_numpy(host).to("cuda:0")
-    assert ac.find_matches_as_indexes(t) == want
-    assert ac.find_matches_as_indexes(t[1234567:]) == ac.find_matches_as_indexes(host[1234567:].tobytes())
-    # host tensors go through the same protocol; small ones take K0
-    assert ac.find_matches_as_indexes(torch.from_numpy(host[:5000])) == ac.find_matches_as_indexes(host[:5000].tobytes())
-    std = ref_api.BytesAhoCorasick(pats)
-    assert std.find_matches_as_indexes(t, overlapping=True) == std.find_matches_as_indexes(host.tobytes(), overlapping=True)
-    with pytest.raises(TypeError):
-        ac.find_matches_as_indexes(t.reshape(2, -1))
-    with pytest.raises(BufferError):
-        ac.find_matches_as_indexes(t.to(torch.int8))
-    with pytest.raises(TypeError):
-        ac.find_matches_as_indexes(t[::2])
+    haystack (the tensor is searched where it lies).  In a process of its own: torch has to be the
+    first to load the HIP runtime, whatever ran before in this session."""
+    pytest.importorskip("torch")
+    p = subprocess.run([sys.executable, "-c", _DLPACK_SCRIPT, ROOT, os.path.join(ROOT, "tests")],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "DLPACK_OK" in p.stdout, p.stderr[-3000:]
 
 
 def test_batch_over_devices_single_process():
