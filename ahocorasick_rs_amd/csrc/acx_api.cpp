@@ -1335,7 +1335,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         for (uint32_t c0 = 0; c0 < H.n_classes; c0++)
             for (uint32_t c1 = 0; c1 < H.n_classes; c1++)
                 for (uint32_t c2 = 0; c2 < H.n_classes; c2++) {
-                    const uint32_t idx = (c0 << 10) | (c1 << 5) | c2;
+                    const uint32_t idx = (c0 * H.n_classes + c1) * H.n_classes + c2; // (stride n_classes: see k1a_scan)
                     const uint32_t n1 = child(0, c0), n2 = n1 ? child(n1, c1) : 0, n3 = n2 ? child(n2, c2) : 0;
                     const bool ends = (n1 && (H.sflags[n1] & 1u)) || (n2 && (H.sflags[n2] & 1u)) || (n3 && (H.sflags[n3] & 1u));
                     t3b[idx] = ends ? ~0u : (n3 ? grec[4 * (size_t)n3] : 0u);

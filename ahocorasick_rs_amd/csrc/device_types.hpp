@@ -54,11 +54,12 @@ struct DevAutomaton {
     uint32_t walk_plain;         // states that report nothing
     // K1a, failureless form (automata of at most 32 byte classes): every haystack position walks the
     // trie -- the goto function only, no failure links: an occurrence is found from its own start.  The
-    // first three levels are ONE LDS lookup by the class triple (32 x 32 x 32 entries, 128 KiB), the
-    // levels below are records in HBM (L2-resident).  null: the automaton has more classes.
-    const uint32_t *t3b;         // 32768: children bitmap (bit = class) of the depth-3 node of a class triple; 0: no
+    // first three levels are ONE LDS lookup by the class triple ((c0 * n_classes + c1) * n_classes + c2:
+    // at most 32^3 entries, 128 KiB), the levels below are records in HBM (L2-resident).  null: the
+    // automaton has more classes.
+    const uint32_t *t3b;         // children bitmap (bit = class) of the depth-3 node of a class triple; 0: no
                                  // such path; ~0: a pattern of <= 3 bytes ends on the path (the walk looks at it)
-    const uint2 *t3r;            // 32768 x {children bitmap, first child | T3R_SHORT}: the walk's entry by class triple
+    const uint2 *t3r;            // {children bitmap, first child | T3R_SHORT} by class triple: the depth-3 node's record
     const uint4 *grec;           // n_states x {children bitmap, first child | GREC_OWN, own1, 0}: trie records
     uint32_t cls_linear, cls_lo; // 1: class(b) = clamp(b - cls_lo + 1, 0, n_classes - 1) (contiguous alphabets)
 };

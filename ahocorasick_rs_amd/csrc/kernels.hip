@@ -1272,49 +1272,54 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
 // links: an occurrence is found by the walk that starts at its first byte -- the form of the DFA walk
 // that has no dependent chain across positions).  Two kernels:
 //   k1a_scan   streams the haystack exactly like K1b (one coalesced 16-byte load per lane and row, the
-//              next unit prefetched into registers) and settles the first FOUR levels of every walk in
-//              LDS: the class triple of bytes j .. j+2 indexes t3b (128 KiB in LDS: the children bitmap of
-//              the depth-3 node, 0 when the trie has no such path), bit class(byte j+3) says whether the
-//              walk reaches depth 4.  ~2 % of the positions of a 10^4-pattern set over text do; they are
-//              ballot-compacted, re-read their 8-byte window (L2) one step later and leave as 8-byte
-//              survivor records {position, class triple, classes of bytes 3 and 4} in per-wave regions.
-//   k1a_walk   one thread per survivor: depth 3 -> 4 from the record alone (t3r, HBM / L2), the levels
-//              below from the trie records (grec, 16 B per state) and the haystack; every pattern that
-//              ends on the way is an occurrence (start, pattern, length): into the hit slots of its tile
-//              (sparse output) or the occurrence regions (dense output), exactly like the chunked walk.
+//              wave's next tile prefetched into the registers level 1 has finished with) and settles the
+//              first FOUR levels of every walk in LDS: the class triple of bytes j .. j+2 indexes t3b
+//              (n_classes^3 words, at most 128 KiB: the children bitmap of the depth-3 node, 0 when the
+//              trie has no such path), bit class(byte j+3) says whether the walk reaches depth 4.  ~2 % of
+//              the positions of a 10^4-pattern set over text do; they are ballot-compacted into a per-wave
+//              queue and move through a software pipeline, one stage per step like K1b's level 2 (every
+//              gather has a tile of level-1 work to land in): window gather (8 bytes, L2) -> the depth-3
+//              node's record by the class triple (t3r) -> the depth-4 node's record (grec) -> does the
+//              walk go on beyond depth 4, or does a pattern end there?  ~5 % of the survivors: they leave
+//              as 32-byte items {position, node, depth, the window} in per-wave regions.
+//   k1a_walk   one thread per item: the levels below from the trie records (grec, 16 B per state, L2) and
+//              the window; every pattern that ends on the way is an occurrence (start, pattern, length):
+//              into the hit slots of its tile (sparse output) or the occurrence regions (dense output),
+//              exactly like the chunked walk.
 // Patterns of at most 3 bytes: t3b holds ~0 for every triple with such a pattern on its path, and the
-// walk then starts from the root.  The last positions of a haystack (fewer than 4 bytes left) survive
-// unconditionally.
+// walk of such a position starts from the root (k1a_walk).  The last positions of a haystack (fewer than
+// 4 bytes left) survive unconditionally.
 struct K1aLds {
     uint32_t t3b[32768];
     uint8_t cls[256]; // class << 2
     uint16_t q1[16][64];
 };
 static_assert(sizeof(K1aLds) <= 160 * 1024, "K1a LDS image exceeds 160 KiB");
-constexpr uint64_t SURV_POS_MASK = (1ull << 38) - 1;
+constexpr uint32_t ITEM_ROOT = 0x80000000u; // item.w: walk from the root (a short pattern, or the end of the haystack)
 
-struct SurvivorSink {
-    uint64_t *recs;      // regions * cap records
-    uint64_t *counts;    // one per region (keeps counting past cap)
-    uint64_t cap;        // records per region
+struct DeepSink {
+    uint4 *recs;       // regions * cap items of two quads: {position lo, position hi, node, depth | ITEM_ROOT}
+                       // {window lo, hi, the node's record: children bitmap, first child | GREC_OWN}
+    uint64_t *counts;  // one per region (keeps counting past cap)
+    uint64_t cap;
     uint32_t regions;
 };
 
 // LIN: the class map is linear -- class(b) = clamp(b - cls_lo + 1, 0, n_classes - 1): every byte between
 // the lowest and the highest byte of the patterns is its own class (a-z, digits, ...): the classes are
-// computed (two VALU operations per byte) instead of looked up -- the kernel is bound by its LDS reads
-// (one t3b entry per position: 16 per lane and row).
+// computed instead of looked up.
 template <bool LIN>
 __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3b, const uint8_t *__restrict__ classes,
-                                                  SurvivorSink S, const uint8_t *__restrict__ hay, uint64_t len,
-                                                  uint64_t lead, uint32_t min_len, uint32_t cls_lo, uint32_t n_classes) {
+                                                  const uint2 *__restrict__ t3r, const uint4 *__restrict__ grec,
+                                                  DeepSink D, const uint8_t *__restrict__ hay, uint64_t len,
+                                                  uint64_t lead, uint32_t min_len, uint32_t cls_lo, uint32_t NC) {
     __shared__ __attribute__((aligned(16))) K1aLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
     {
         const uint4 *src = (const uint4 *)t3b;
         uint4 *dst = (uint4 *)L.t3b;
-        for (uint32_t i = threadIdx.x; i < sizeof(L.t3b) / 16; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < (NC * NC * NC + 3) / 4; i += blockDim.x) dst[i] = src[i];
         if (threadIdx.x < 256) L.cls[threadIdx.x] = (uint8_t)(classes[threadIdx.x] << 2);
     }
     __syncthreads();
@@ -1326,12 +1331,12 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
     const uint64_t ntiles = (total + tile_bytes - 1) / tile_bytes;
     const uint64_t gw = (uint64_t)blockIdx.x * 16 + wave, nw = (uint64_t)gridDim.x * 16;
     const uint32_t region = blockIdx.x * 16 + wave;
-    uint64_t *const srec = S.recs + (uint64_t)region * S.cap;
-    const uint32_t hcap = (uint32_t)(S.cap < 0xFFFFFFFFull ? S.cap : 0xFFFFFFFFull);
-    uint32_t hcur = 0, q1c = 0;
+    uint4 *const drec = D.recs + (uint64_t)region * D.cap * 2;
+    const uint32_t dcap = (uint32_t)(D.cap < 0xFFFFFFFFull ? D.cap : 0xFFFFFFFFull);
+    uint32_t dcur = 0, q1c = 0;
     const uint64_t last_block = total16 - 16;
-    u32x4 nxt0, nxt1, nxt2, nxt3;
-    uint32_t nxtL;
+    u32x4 v0, v1, v2, v3; // the tile's rows: loaded one iteration ahead, into the registers level 1 is done with
+    uint32_t vL;
 #define K1A_ISSUE_ROW(DST, TILE, R)                                                              \
     {                                                                                            \
         uint64_t off_ = (TILE) * tile_bytes + (uint64_t)(R) * 1024 + lane * 16;                  \
@@ -1342,46 +1347,71 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
         const uint64_t tb_ = (TILE) * tile_bytes;                                                \
         if (tb_ + tile_bytes <= last_block) {                                                    \
             const uint8_t *tp_ = hay + tb_ + lane * 16;                                          \
-            nxt0 = *(const u32x4 *)(tp_); nxt1 = *(const u32x4 *)(tp_ + 1024);                   \
-            nxt2 = *(const u32x4 *)(tp_ + 2048); nxt3 = *(const u32x4 *)(tp_ + 3072);           \
-            nxtL = *(const uint32_t *)(hay + tb_ + tile_bytes);                                  \
+            v0 = *(const u32x4 *)(tp_); v1 = *(const u32x4 *)(tp_ + 1024);                       \
+            v2 = *(const u32x4 *)(tp_ + 2048); v3 = *(const u32x4 *)(tp_ + 3072);               \
+            vL = *(const uint32_t *)(hay + tb_ + tile_bytes);                                    \
         } else {                                                                                 \
-            K1A_ISSUE_ROW(nxt0, TILE, 0) K1A_ISSUE_ROW(nxt1, TILE, 1) K1A_ISSUE_ROW(nxt2, TILE, 2) \
-            K1A_ISSUE_ROW(nxt3, TILE, 3)                                                         \
+            K1A_ISSUE_ROW(v0, TILE, 0) K1A_ISSUE_ROW(v1, TILE, 1) K1A_ISSUE_ROW(v2, TILE, 2)     \
+            K1A_ISSUE_ROW(v3, TILE, 3)                                                           \
             uint64_t off_ = tb_ + tile_bytes;                                                    \
-            nxtL = *(const uint32_t *)(hay + (off_ < last_block ? off_ : last_block));           \
+            vL = *(const uint32_t *)(hay + (off_ < last_block ? off_ : last_block));             \
         }                                                                                        \
     }
     K1A_ISSUE_TILE(gw)
-    // ---- survivors: Q1 (offsets of the tile under compaction) -> windows in flight -> records
-    uint32_t nB = 0;
-    uint64_t posB = 0, winB = 0;
+    // ---- survivors: Q1 (offsets of the tile under compaction) -> W (windows in flight) -> T (depth-3
+    // records in flight) -> G (depth-4 records in flight) -> items.  One batch of up to 64 per stage.
+    uint32_t nW = 0, nT = 0, nG = 0;
+    uint64_t posW = 0, winW = 0, posT = 0, winT = 0, posG = 0, winG = 0;
+    uint2 eT = make_uint2(0, 0);
+    uint32_t c34T = 0, nodeG = 0, c4G = 0;
+    uint4 rG = make_uint4(0, 0, 0, 0);
+    bool rootG = false, liveG = false;
     auto advance = [&](uint32_t tileQ) __attribute__((always_inline)) {
-        if (nB) { // the windows requested by the previous advance: classes of bytes 0 .. 4, the record
-            if (lane < nB) {
-                const uint32_t lo = (uint32_t)winB, hi = (uint32_t)(winB >> 32);
-                const uint32_t c0 = L.cls[lo & 0xFF] >> 2, c1 = L.cls[(lo >> 8) & 0xFF] >> 2, c2 = L.cls[(lo >> 16) & 0xFF] >> 2;
-                const uint32_t c3 = L.cls[lo >> 24] >> 2, c4 = L.cls[hi & 0xFF] >> 2;
-                const uint64_t rec = posB | ((uint64_t)((c0 << 10) | (c1 << 5) | c2) << 38) | ((uint64_t)c3 << 53) |
-                                     ((uint64_t)c4 << 58);
-                const uint32_t slot = hcur + lane;
-                if (slot < hcap) srec[slot] = rec;
+        // ---- stage G: the depth-4 node's record has landed: does the walk go on, or a pattern end here?
+        if (nG) {
+            const bool go = lane < nG && (rootG || (liveG && ((rG.y & GREC_OWN) || ((rG.x >> c4G) & 1u))));
+            const unsigned long long fm = __ballot(go);
+            if (fm) {
+                const uint32_t slot = dcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+                if (go && slot < dcap) {
+                    drec[2 * (uint64_t)slot] = make_uint4((uint32_t)posG, (uint32_t)(posG >> 32), rootG ? 0u : nodeG,
+                                                          rootG ? ITEM_ROOT : 4u);
+                    drec[2 * (uint64_t)slot + 1] = make_uint4((uint32_t)winG, (uint32_t)(winG >> 32), rG.x, rG.y);
+                }
+                dcur += (uint32_t)__popcll(fm); // keeps counting past the capacity
             }
-            hcur += nB; // keeps counting past the capacity
         }
+        // ---- stage T -> G: the depth-3 record by the class triple has landed: the depth-4 node, its record
+        if (nT) {
+            const uint32_t c3 = c34T & 31u;
+            rootG = (eT.y & T3R_SHORT) != 0 || posT + 5 > len; // (a short pattern on the path, or the stream ends: from the root)
+            liveG = !rootG && ((eT.x >> c3) & 1u);
+            nodeG = (eT.y & ID_MASK) + __popc(eT.x & ((1u << c3) - 1u));
+            if (lane < nT && liveG) rG = grec[nodeG];
+            posG = posT; winG = winT; c4G = c34T >> 5;
+        }
+        nG = nT;
+        // ---- stage W -> T: the window has landed: classes of bytes 0 .. 4, the depth-3 record
+        if (nW) {
+            const uint32_t lo = (uint32_t)winW, hi = (uint32_t)(winW >> 32);
+            const uint32_t c0 = L.cls[lo & 0xFF] >> 2, c1 = L.cls[(lo >> 8) & 0xFF] >> 2, c2 = L.cls[(lo >> 16) & 0xFF] >> 2;
+            c34T = (L.cls[lo >> 24] >> 2) | ((uint32_t)(L.cls[hi & 0xFF] >> 2) << 5);
+            if (lane < nW) eT = t3r[(c0 * NC + c1) * NC + c2];
+            posT = posW; winT = winW;
+        }
+        nT = nW;
+        // ---- stage Q -> W: the 8-byte windows of the queued survivors
         if (q1c) {
             if (lane < q1c) {
-                posB = (uint64_t)tileQ * tile_bytes + q1[lane] - lead;
-                winB = load_window(stream, len, posB);
+                posW = (uint64_t)tileQ * tile_bytes + q1[lane] - lead;
+                winW = load_window(stream, len, posW);
             }
         }
-        nB = q1c;
+        nW = q1c;
         q1c = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    for (uint64_t tile = gw; tile < ntiles + 2 * nw; tile += nw) {
-        u32x4 v0 = nxt0, v1 = nxt1, v2 = nxt2, v3 = nxt3;
-        uint32_t vL = nxtL;
+    for (uint64_t tile = gw; tile < ntiles + 4 * nw; tile += nw) {
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL));
         advance((uint32_t)(tile - nw)); // the previous tile's remaining survivors
         if (tile >= ntiles) continue;
@@ -1389,24 +1419,28 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
         // every position of an interior tile is a legal start with at least 4 bytes behind it
         const bool interior = tbase >= lead && tbase + tile_bytes + 4 <= last_start;
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
+        const int32_t cls_off = 1 - (int32_t)cls_lo, cls_max = (int32_t)NC - 1;
+        const uint32_t NC4 = 4 * NC, NCNC4 = 4 * NC * NC;
         // one row: 16 positions per lane; the walk of position j needs bytes j .. j+3: three bytes of
-        // the lane behind by DPP (lane 63: the next row's first bytes, scalar)
-        const int32_t cls_off = 4 - 4 * (int32_t)cls_lo, cls_max = 4 * (int32_t)n_classes - 4;
+        // the lane behind by DPP (lane 63: the next row's first bytes, scalar).  x = class; the
+        // entry of a triple lies at ((x0 * NC + x1) * NC + x2) words (the stride is NC, not 32: the
+        // bank of an entry then depends on all three classes -- with a stride of 32 every position in
+        // front of a space met in ONE bank: 5.5-way conflicts measured)
 #define K1A_BYTE(k) ((d_[(k) >> 2] >> (8 * ((k) & 3))) & 0xFF)
-#define K1A_CLS(k) (LIN ? (uint32_t)max(0, min((int32_t)(K1A_BYTE(k) << 2) + cls_off, cls_max)) \
-                        : (uint32_t)L.cls[K1A_BYTE(k)])
+#define K1A_CLS(k) (LIN ? (uint32_t)max(0, min((int32_t)K1A_BYTE(k) + cls_off, cls_max)) \
+                        : (uint32_t)L.cls[K1A_BYTE(k)] >> 2)
 #define K1A_ROW(RI, VR, RX, MROW)                                                                \
         {                                                                                        \
             const uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);   \
             const uint32_t rx_ = (RX);                                                           \
             const uint32_t d_[5] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_};             \
-            uint32_t x_[19]; /* class << 2 of the lane's bytes 0 .. 18 */                        \
+            uint32_t x_[19]; /* classes of the lane's bytes 0 .. 18 */                           \
             _Pragma("unroll") for (int k = 0; k < 19; k++) x_[k] = K1A_CLS(k);                   \
             uint32_t m_ = 0;                                                                     \
             _Pragma("unroll") for (int j = 0; j < 16; j++) {                                     \
-                const uint32_t a_ = (((x_[j] << 5) | x_[j + 1]) << 5) | x_[j + 2]; /* byte offset of the entry */ \
+                const uint32_t a_ = __umul24(x_[j], NCNC4) + __umul24(x_[j + 1], NC4) + (x_[j + 2] << 2); \
                 const uint32_t bm_ = *(const uint32_t *)((const uint8_t *)L.t3b + a_);           \
-                m_ = __builtin_amdgcn_alignbit(bm_ >> (x_[j + 3] >> 2), m_, 1);                  \
+                m_ = __builtin_amdgcn_alignbit(bm_ >> x_[j + 3], m_, 1);                         \
             }                                                                                    \
             m_ >>= 16;                                                                           \
             if (!interior) { /* wave-uniform: a scalar branch */                                 \
@@ -1441,7 +1475,7 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (lane == 0) S.counts[region] = hcur;
+    if (lane == 0) D.counts[region] = dcur;
 #undef K1A_ISSUE_ROW
 #undef K1A_ISSUE_TILE
 #undef K1A_CLS
@@ -1449,82 +1483,10 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
 #undef K1A_ROW
 }
 
-// Survivors of the scan, second level: one thread per record, two dependent gathers, no divergence --
-// depth 3 -> 4 from the record alone (t3r by the class triple), depth 4 -> 5 from the depth-4 node's
-// record and the class of byte 4 (also in the record).  ~95 % of the scan's survivors end here; the
-// walks that go on (and the positions whose first levels hold the end of a short pattern: from the
-// root) leave as {position, node, depth} for k1a_walk.  (One kernel did all of it at first: the few
-// lanes that follow a real occurrence to its end held their waves back for every record -- 468 us on
-// the headline input against 2 x 60.)
-struct DeepSink {
-    uint4 *recs;       // regions * cap records {position lo, position hi, node, depth}
-    uint64_t *counts;  // one per region
-    uint64_t cap;
-};
-__global__ __launch_bounds__(256) void k1a_sift(const uint2 *__restrict__ t3r, const uint4 *__restrict__ grec,
-                                                Segments G, SurvivorSink S, DeepSink D, uint32_t *abort_flag,
-                                                uint64_t len) {
-    __shared__ uint32_t cnt2;
-    for (uint32_t b = blockIdx.x; b < S.regions; b += gridDim.x) {
-        if (threadIdx.x == 0) cnt2 = 0;
-        __syncthreads();
-        uint64_t n = S.counts[b];
-        if (n > S.cap) { // survivors were dropped: the caller redoes the call another way
-            n = S.cap;
-            if (threadIdx.x == 0 && abort_flag) *abort_flag = 1;
-        }
-        const uint64_t *recs = S.recs + (uint64_t)b * S.cap;
-        uint4 *out = D.recs + (uint64_t)b * D.cap;
-        // (four records of a thread in flight: the kernel is two dependent gathers per record and nothing else)
-        for (uint64_t i0 = threadIdx.x; i0 < n; i0 += 4 * blockDim.x) {
-            uint64_t rec[4];
-            uint2 e[4];
-            uint4 r[4];
-            uint32_t node[4], d[4];
-            bool go[4], lvl[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) rec[k] = i0 + k * blockDim.x < n ? recs[i0 + k * blockDim.x] : ~0ull;
-#pragma unroll
-            for (int k = 0; k < 4; k++) e[k] = t3r[(uint32_t)(rec[k] >> 38) & 0x7FFFu];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint64_t pos = rec[k] & SURV_POS_MASK;
-                const uint64_t room = rec[k] == ~0ull ? 0 : segment_end(G, len, pos) - pos;
-                node[k] = 0; d[k] = 0;
-                go[k] = rec[k] != ~0ull; // (a short pattern on the path, or the haystack ends within 5 bytes: from the root)
-                lvl[k] = go[k] && !(e[k].y & T3R_SHORT) && room >= 5;
-                if (lvl[k]) {
-                    const uint32_t c3 = (uint32_t)(rec[k] >> 53) & 31u;
-                    go[k] = (e[k].x >> c3) & 1u;
-                    node[k] = (e[k].y & ID_MASK) + __popc(e[k].x & ((1u << c3) - 1u));
-                    d[k] = 4;
-                }
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) r[k] = lvl[k] && go[k] ? grec[node[k]] : make_uint4(0, 0, 0, 0);
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (lvl[k] && go[k]) go[k] = (r[k].y & GREC_OWN) || ((r[k].x >> ((uint32_t)(rec[k] >> 58) & 31u)) & 1u);
-                if (go[k]) {
-                    const uint64_t pos = rec[k] & SURV_POS_MASK;
-                    const uint32_t slot = atomicAdd(&cnt2, 1u);
-                    if (slot < D.cap) out[slot] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), node[k], d[k]);
-                }
-            }
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            D.counts[b] = cnt2;
-            if (cnt2 > D.cap && abort_flag) *abort_flag = 1;
-        }
-        __syncthreads();
-    }
-}
-
-// the walks that go on: trie records + haystack bytes, every pattern that ends on the way is an occurrence
+// the walks that go on: trie records + the window (+ haystack bytes beyond it), every pattern that ends
+// on the way is an occurrence
 __global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomaton *Ad, Segments G, DeepSink D,
-                                                uint32_t regions, Sink GK, const uint8_t *__restrict__ stream,
-                                                uint64_t len) {
+                                                Sink GK, const uint8_t *__restrict__ stream, uint64_t len) {
     __shared__ unsigned long long lcount;
     __shared__ BlockSink sK;
     __shared__ uint8_t cls[256];
@@ -1532,20 +1494,27 @@ __global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomat
     cls[threadIdx.x] = A.classes[threadIdx.x];
     __syncthreads();
     const BlockSink *K = &sK;
-    for (uint32_t b = blockIdx.x; b < regions; b += gridDim.x) {
+    for (uint32_t b = blockIdx.x; b < D.regions; b += gridDim.x) {
         uint64_t n = D.counts[b];
-        if (n > D.cap) n = D.cap; // (k1a_sift raised the abort flag)
-        const uint4 *recs = D.recs + (uint64_t)b * D.cap;
+        if (n > D.cap) { // items were dropped: the caller redoes the call another way
+            n = D.cap;
+            if (threadIdx.x == 0 && GK.abort_flag) *GK.abort_flag = 1;
+        }
+        const uint4 *recs = D.recs + (uint64_t)b * D.cap * 2;
         for (uint64_t i = threadIdx.x; i < n; i += blockDim.x) {
-            const uint4 it = recs[i];
+            const uint4 it = recs[2 * i], wq = recs[2 * i + 1];
             const uint64_t pos = ((uint64_t)it.y << 32) | it.x;
             const uint64_t room = segment_end(G, len, pos) - pos;
-            uint32_t node = it.z, d = it.w;
-            // the next 8 haystack bytes in one load (patterns of up to d + 8 bytes never touch the stream again)
-            uint64_t w = load_window(stream, len, pos + d);
-            uint32_t wd = d;
+            uint32_t node = it.z, d = it.w & ~ITEM_ROOT;
+            if (d > room) continue; // (the levels the scan settled reached beyond the end of this haystack)
+            uint64_t w = ((uint64_t)wq.y << 32) | wq.x; // haystack bytes pos + wd .. pos + wd + 7
+            uint32_t wd = 0;
+            bool first = !(it.w & ITEM_ROOT);
             for (;;) {
-                const uint4 r = A.grec[node];
+                // (the record of an item's first node travelled with it -- unless a pattern ends there: its id did not)
+                uint4 r = make_uint4(wq.z, wq.w, 0u, 0u);
+                if (!first || (wq.w & GREC_OWN)) r = A.grec[node];
+                first = false;
                 if (r.y & GREC_OWN) {
                     if (r.z == OWN1_MANY) {
                         for (uint32_t k = A.own_off[node]; k < A.own_off[node + 1]; k++) emit_one(Ad, *K, A.own_pid[k], pos + d);
@@ -1580,30 +1549,25 @@ uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     if (blocks > (uint64_t)n_cus) blocks = n_cus;
     return blocks ? (uint32_t)blocks : 1;
 }
-// survivor records the scan may leave before the call gives up: 1 per 16 haystack bytes (8 B each), and
-// 1 in 8 of them may go on beyond depth 5 (16 B each): the u64 words of workspace both take
+// items the scan may leave before the call gives up: 1 per 64 haystack bytes (32 B each: half a byte of
+// workspace per haystack byte; the headline input leaves 1 per 500): the u64 words they take
+static uint64_t pfac_region_cap(uint64_t len, uint32_t scan_grid) { return len / 64 / ((uint64_t)scan_grid * 16) + 1024; }
 uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid) {
-    const uint64_t regions = (uint64_t)scan_grid * 16;
-    const uint64_t cap = len / 16 / regions + 1024, cap2 = cap / 8 + 256;
-    return regions * (cap + 2 * cap2);
+    return (uint64_t)scan_grid * 16 * pfac_region_cap(len, scan_grid) * 4;
 }
 hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,
                        const uint8_t *d_hay, uint64_t len, uint32_t scan_grid, uint64_t *work, uint64_t *counts,
                        uint32_t walk_grid, hipStream_t st) {
     if (len == 0) return hipSuccess;
     const uint64_t lead = (uintptr_t)d_hay & 15;
-    const uint32_t regions = scan_grid * 16;
-    const uint64_t cap = len / 16 / regions + 1024, cap2 = cap / 8 + 256;
-    const SurvivorSink S{work, counts, cap, regions};
-    const DeepSink D{(uint4 *)(work + (uint64_t)regions * cap), counts + regions, cap2};
+    const DeepSink D{(uint4 *)work, counts, pfac_region_cap(len, scan_grid), scan_grid * 16};
     if (A.cls_linear)
-        hipLaunchKernelGGL(k1a_scan<true>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, S, d_hay - lead, len,
-                           lead, A.min_len, A.cls_lo, A.n_classes);
+        hipLaunchKernelGGL(k1a_scan<true>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
+                           d_hay - lead, len, lead, A.min_len, A.cls_lo, A.n_classes);
     else
-        hipLaunchKernelGGL(k1a_scan<false>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, S, d_hay - lead, len,
-                           lead, A.min_len, 0u, A.n_classes);
-    hipLaunchKernelGGL(k1a_sift, dim3(regions), dim3(256), 0, st, A.t3r, A.grec, G, S, D, K.abort_flag, len);
-    hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, regions, K, d_hay, len);
+        hipLaunchKernelGGL(k1a_scan<false>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
+                           d_hay - lead, len, lead, A.min_len, 0u, A.n_classes);
+    hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, K, d_hay, len);
     return hipGetLastError();
 }
 

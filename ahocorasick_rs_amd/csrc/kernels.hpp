@@ -20,12 +20,11 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
                            const Sink &K, const uint8_t *d_hay, uint64_t len, uint32_t grid,
                            size_t max_lds, hipStream_t st);
 // K1a, failureless form (automata of at most 32 byte classes; kernels.hip): k1a_scan settles the first
-// four levels of the walk of every position in LDS and leaves the survivors as 8-byte records in
-// per-wave regions; k1a_sift takes them one level on (two gathers each, no divergence); k1a_walk
-// finishes the few walks that go on and emits the occurrences into K (hit slots: K.hcnt zero
-// beforehand, walk_grid arbitrary; regions: walk_grid = the number of occurrence regions).
-// work: pfac_workspace_words() u64 words; counts: 2 * scan_grid * 16 u64 words.  More survivors than the
-// regions hold: K.abort_flag (hit-slot mode).
+// four levels of the walk of every position in LDS, takes the survivors one level on in a software
+// pipeline of gathers and leaves the walks that go on as 32-byte items in per-wave regions; k1a_walk
+// finishes them and emits the occurrences into K (hit slots: K.hcnt zero beforehand, walk_grid
+// arbitrary; regions: walk_grid = the number of occurrence regions).  work: pfac_workspace_words() u64
+// words; counts: scan_grid * 16 u64 words.  More items than the regions hold: K.abort_flag (hit-slot mode).
 bool pfac_available(const DevAutomaton &A);
 uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
 uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid);
