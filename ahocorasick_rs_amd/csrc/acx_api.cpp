@@ -1330,30 +1330,42 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
             if (!((bm >> c) & 1u)) return 0;
             return H.first_child[s2] + (uint32_t)__builtin_popcount(bm & ((1u << c) - 1u));
         };
-        t3b.assign(32768, 0);
         t3r.assign(2 * 32768, 0);
         for (uint32_t c0 = 0; c0 < H.n_classes; c0++)
             for (uint32_t c1 = 0; c1 < H.n_classes; c1++)
                 for (uint32_t c2 = 0; c2 < H.n_classes; c2++) {
-                    const uint32_t idx = (c0 * H.n_classes + c1) * H.n_classes + c2; // (stride n_classes: see k1a_scan)
+                    const uint32_t idx = (c0 * H.n_classes + c1) * H.n_classes + c2;
                     const uint32_t n1 = child(0, c0), n2 = n1 ? child(n1, c1) : 0, n3 = n2 ? child(n2, c2) : 0;
                     const bool ends = (n1 && (H.sflags[n1] & 1u)) || (n2 && (H.sflags[n2] & 1u)) || (n3 && (H.sflags[n3] & 1u));
-                    t3b[idx] = ends ? ~0u : (n3 ? grec[4 * (size_t)n3] : 0u);
                     t3r[2 * (size_t)idx] = n3 ? grec[4 * (size_t)n3] : 0u;
                     t3r[2 * (size_t)idx + 1] = (n3 ? H.first_child[n3] : 0u) | (ends ? T3R_SHORT : 0u);
                 }
-    }
-    D.cls_linear = 0; D.cls_lo = 0;
-    if (!t3b.empty()) { // is the class map linear (every byte between the lowest and the highest pattern byte its own class)?
-        uint32_t lo = 256;
-        for (uint32_t b = 0; b < 256; b++) if (H.classes[b] != 0) { lo = b; break; }
-        bool lin = lo < 256 && lo > 0;
-        for (uint32_t b = 0; lin && b < 256; b++) {
-            const int32_t want = std::max(0, std::min((int32_t)b - (int32_t)lo + 1, (int32_t)H.n_classes - 1));
-            lin = H.classes[b] == (uint32_t)want;
+        // level 1 of the scan works on symbols (the low five bits of a byte), not classes: no class
+        // lookup per byte, and automata with any class map share one kernel.  Every trie path of depth
+        // 3 ORs the symbols of its node's children into the entry of its symbol triple; a pattern that
+        // ends on the way makes every entry below it pass.
+        t3b.assign(K1A_T3B_WORDS, 0);
+        auto entry = [&](uint32_t s0, uint32_t s1, uint32_t s2) -> uint32_t & { return t3b[((s0 << 5) | s1) * 33 + s2]; };
+        for (uint32_t e1 = H.first_child[0]; e1 < H.first_child[1]; e1++) {
+            const uint32_t s0 = H.in_byte[e1] & 31u;
+            if (H.sflags[e1] & 1u) {
+                for (uint32_t s1 = 0; s1 < 32; s1++) for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
+                continue;
+            }
+            for (uint32_t e2 = H.first_child[e1]; e2 < H.first_child[e1 + 1]; e2++) {
+                const uint32_t s1 = H.in_byte[e2] & 31u;
+                if (H.sflags[e2] & 1u) {
+                    for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
+                    continue;
+                }
+                for (uint32_t e3 = H.first_child[e2]; e3 < H.first_child[e2 + 1]; e3++) {
+                    uint32_t bm = 0;
+                    if (H.sflags[e3] & 1u) bm = ~0u;
+                    for (uint32_t e4 = H.first_child[e3]; e4 < H.first_child[e3 + 1]; e4++) bm |= 1u << (H.in_byte[e4] & 31u);
+                    entry(s0, s1, H.in_byte[e3] & 31u) |= bm;
+                }
+            }
         }
-        D.cls_linear = lin ? 1u : 0u;
-        D.cls_lo = lin ? lo : 0u;
     }
     int rc;
 #define UP(vec, field)                                                                   \

@@ -57,12 +57,16 @@ struct DevAutomaton {
     // first three levels are ONE LDS lookup by the class triple ((c0 * n_classes + c1) * n_classes + c2:
     // at most 32^3 entries, 128 KiB), the levels below are records in HBM (L2-resident).  null: the
     // automaton has more classes.
-    const uint32_t *t3b;         // children bitmap (bit = class) of the depth-3 node of a class triple; 0: no
-                                 // such path; ~0: a pattern of <= 3 bytes ends on the path (the walk looks at it)
+    const uint32_t *t3b;         // level 1 of the scan, K1A_T3B_WORDS words (LDS): by the SYMBOLS (low five bits) of
+                                 // three bytes, the symbols a fourth byte can have on a trie path of depth 4 (bit =
+                                 // symbol); ~0: a pattern of <= 3 bytes ends on the path.  A superset test (bytes
+                                 // that share their low five bits alias); the records below are exact
     const uint2 *t3r;            // {children bitmap, first child | T3R_SHORT} by class triple: the depth-3 node's record
     const uint4 *grec;           // n_states x {children bitmap, first child | GREC_OWN, own1, 0}: trie records
-    uint32_t cls_linear, cls_lo; // 1: class(b) = clamp(b - cls_lo + 1, 0, n_classes - 1) (contiguous alphabets)
 };
+// entry of the symbols (s0, s1, s2): word ((s0 << 5 | s1) * 33 + s2) -- the odd stride puts the sum of two
+// symbols into the LDS bank (with a stride of 32 every position in front of a space met in ONE bank)
+constexpr uint32_t K1A_T3B_WORDS = 1024 * 33;
 constexpr uint32_t T3R_SHORT = 0x80000000u; // a pattern ends within the first three levels: walk from the root
 constexpr uint32_t GREC_OWN = 0x80000000u;  // a pattern ends exactly at this node
 

@@ -1273,10 +1273,12 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
 // that has no dependent chain across positions).  Two kernels:
 //   k1a_scan   streams the haystack exactly like K1b (one coalesced 16-byte load per lane and row, the
 //              wave's next tile prefetched into the registers level 1 has finished with) and settles the
-//              first FOUR levels of every walk in LDS: the class triple of bytes j .. j+2 indexes t3b
-//              (n_classes^3 words, at most 128 KiB: the children bitmap of the depth-3 node, 0 when the
-//              trie has no such path), bit class(byte j+3) says whether the walk reaches depth 4.  ~2 % of
-//              the positions of a 10^4-pattern set over text do; they are ballot-compacted into a per-wave
+//              first FOUR levels of every walk in LDS: the SYMBOLS (low five bits) of bytes j .. j+2
+//              index t3b (132 KiB: which symbols a fourth byte can have on a trie path through such a
+//              triple, 0 when there is none), bit symbol(byte j+3) says whether the walk can reach depth
+//              4 -- exact for an alphabet whose bytes differ in their low five bits (a-z + space), a
+//              superset otherwise (the stages below work on the exact byte classes).  ~2 % of the
+//              positions of a 10^4-pattern set over text pass; they are ballot-compacted into a per-wave
 //              queue and move through a software pipeline, one stage per step like K1b's level 2 (every
 //              gather has a tile of level-1 work to land in): window gather (8 bytes, L2) -> the depth-3
 //              node's record by the class triple (t3r) -> the depth-4 node's record (grec) -> does the
@@ -1290,7 +1292,7 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
 // walk of such a position starts from the root (k1a_walk).  The last positions of a haystack (fewer than
 // 4 bytes left) survive unconditionally.
 struct K1aLds {
-    uint32_t t3b[32768];
+    uint32_t t3b[K1A_T3B_WORDS];
     uint8_t cls[256]; // class << 2
     uint16_t q1[16][64];
 };
@@ -1305,21 +1307,17 @@ struct DeepSink {
     uint32_t regions;
 };
 
-// LIN: the class map is linear -- class(b) = clamp(b - cls_lo + 1, 0, n_classes - 1): every byte between
-// the lowest and the highest byte of the patterns is its own class (a-z, digits, ...): the classes are
-// computed instead of looked up.
-template <bool LIN>
 __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3b, const uint8_t *__restrict__ classes,
                                                   const uint2 *__restrict__ t3r, const uint4 *__restrict__ grec,
                                                   DeepSink D, const uint8_t *__restrict__ hay, uint64_t len,
-                                                  uint64_t lead, uint32_t min_len, uint32_t cls_lo, uint32_t NC) {
+                                                  uint64_t lead, uint32_t min_len, uint32_t NC) {
     __shared__ __attribute__((aligned(16))) K1aLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
     {
         const uint4 *src = (const uint4 *)t3b;
         uint4 *dst = (uint4 *)L.t3b;
-        for (uint32_t i = threadIdx.x; i < (NC * NC * NC + 3) / 4; i += blockDim.x) dst[i] = src[i];
+        for (uint32_t i = threadIdx.x; i < K1A_T3B_WORDS / 4; i += blockDim.x) dst[i] = src[i];
         if (threadIdx.x < 256) L.cls[threadIdx.x] = (uint8_t)(classes[threadIdx.x] << 2);
     }
     __syncthreads();
@@ -1419,28 +1417,27 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
         // every position of an interior tile is a legal start with at least 4 bytes behind it
         const bool interior = tbase >= lead && tbase + tile_bytes + 4 <= last_start;
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
-        const int32_t cls_off = 1 - (int32_t)cls_lo, cls_max = (int32_t)NC - 1;
-        const uint32_t NC4 = 4 * NC, NCNC4 = 4 * NC * NC;
         // one row: 16 positions per lane; the walk of position j needs bytes j .. j+3: three bytes of
-        // the lane behind by DPP (lane 63: the next row's first bytes, scalar).  x = class; the
-        // entry of a triple lies at ((x0 * NC + x1) * NC + x2) words (the stride is NC, not 32: the
-        // bank of an entry then depends on all three classes -- with a stride of 32 every position in
-        // front of a space met in ONE bank: 5.5-way conflicts measured)
-#define K1A_BYTE(k) ((d_[(k) >> 2] >> (8 * ((k) & 3))) & 0xFF)
-#define K1A_CLS(k) (LIN ? (uint32_t)max(0, min((int32_t)K1A_BYTE(k) + cls_off, cls_max)) \
-                        : (uint32_t)L.cls[K1A_BYTE(k)] >> 2)
+        // the lane behind by DPP (lane 63: the next row's first bytes, scalar).  s2 = symbol << 2 (four
+        // of them per AND: (dword << 2) & 0x7C7C7C7C), y2 = (s2[k] << 5) | s2[k+1]; the entry of position
+        // j lies at byte y2[j] * 33 + s2[j+2] (one v_mad_u32_u24), the bit is byte j+3's low five bits
+        // (the shift takes them by itself)
+#define K1A_BYTE(R, k) ((R[(k) >> 2] >> (8 * ((k) & 3))) & 0xFFu)
 #define K1A_ROW(RI, VR, RX, MROW)                                                                \
         {                                                                                        \
             const uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);   \
             const uint32_t rx_ = (RX);                                                           \
             const uint32_t d_[5] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_};             \
-            uint32_t x_[19]; /* classes of the lane's bytes 0 .. 18 */                           \
-            _Pragma("unroll") for (int k = 0; k < 19; k++) x_[k] = K1A_CLS(k);                   \
+            uint32_t t_[5];                                                                      \
+            _Pragma("unroll") for (int k = 0; k < 5; k++) t_[k] = (d_[k] << 2) & 0x7C7C7C7Cu;    \
+            uint32_t s2_[19], y2_[17];                                                           \
+            _Pragma("unroll") for (int k = 0; k < 19; k++) s2_[k] = K1A_BYTE(t_, k);             \
+            _Pragma("unroll") for (int k = 0; k < 17; k++) y2_[k] = (s2_[k] << 5) | s2_[k + 1];  \
             uint32_t m_ = 0;                                                                     \
             _Pragma("unroll") for (int j = 0; j < 16; j++) {                                     \
-                const uint32_t a_ = __umul24(x_[j], NCNC4) + __umul24(x_[j + 1], NC4) + (x_[j + 2] << 2); \
+                const uint32_t a_ = __umul24(y2_[j], 33u) + s2_[j + 2];                          \
                 const uint32_t bm_ = *(const uint32_t *)((const uint8_t *)L.t3b + a_);           \
-                m_ = __builtin_amdgcn_alignbit(bm_ >> x_[j + 3], m_, 1);                         \
+                m_ = __builtin_amdgcn_alignbit(bm_ >> (K1A_BYTE(d_, j + 3) & 31u), m_, 1);       \
             }                                                                                    \
             m_ >>= 16;                                                                           \
             if (!interior) { /* wave-uniform: a scalar branch */                                 \
@@ -1478,7 +1475,6 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
     if (lane == 0) D.counts[region] = dcur;
 #undef K1A_ISSUE_ROW
 #undef K1A_ISSUE_TILE
-#undef K1A_CLS
 #undef K1A_BYTE
 #undef K1A_ROW
 }
@@ -1561,12 +1557,8 @@ hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segm
     if (len == 0) return hipSuccess;
     const uint64_t lead = (uintptr_t)d_hay & 15;
     const DeepSink D{(uint4 *)work, counts, pfac_region_cap(len, scan_grid), scan_grid * 16};
-    if (A.cls_linear)
-        hipLaunchKernelGGL(k1a_scan<true>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
-                           d_hay - lead, len, lead, A.min_len, A.cls_lo, A.n_classes);
-    else
-        hipLaunchKernelGGL(k1a_scan<false>, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
-                           d_hay - lead, len, lead, A.min_len, 0u, A.n_classes);
+    hipLaunchKernelGGL(k1a_scan, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
+                       d_hay - lead, len, lead, A.min_len, A.n_classes);
     hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, K, d_hay, len);
     return hipGetLastError();
 }

@@ -73,6 +73,8 @@ int main() {
     rep("tiles 1024x256 rows4 depth2 plain", timeit([&] { k_tiles<false, 4, 2, 1><<<256, 1024>>>(d, n, o); }));
     rep("tiles 1024x256 rows4 depth2 nt LDS150K", timeit([&] { k_tiles<true, 4, 2, 150><<<256, 1024>>>(d, n, o); }));
     rep("tiles 1024x512 rows4 depth2 nt (2 blk/CU)", timeit([&] { k_tiles<true, 4, 2, 1><<<512, 1024>>>(d, n, o); }));
+    rep("tiles 1024x256 rows4 depth1 plain LDS150K (K1b's shape)", timeit([&] { k_tiles<false, 4, 1, 150><<<256, 1024>>>(d, n, o); }));
+    rep("tiles 1024x256 rows4 depth2 plain LDS150K", timeit([&] { k_tiles<false, 4, 2, 150><<<256, 1024>>>(d, n, o); }));
     rep("tiles 1024x256 rows2 depth2 nt", timeit([&] { k_tiles<true, 2, 2, 1><<<256, 1024>>>(d, n, o); }));
     rep("tiles 1024x256 rows2 depth4 nt", timeit([&] { k_tiles<true, 2, 4, 1><<<256, 1024>>>(d, n, o); }));
     return 0;
