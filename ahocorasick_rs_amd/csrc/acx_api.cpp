@@ -760,9 +760,15 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     int rc = ensure_tiles(a, x, c.tiles);
     if (rc) return rc;
     TileSpace &T = w.T;
-    // hit counts: contiguous per K1b wave (K1a: plain per-tile arrival counters)
-    T.cnt_nw = c.pre ? c.scan_grid * 16 : 1;
-    T.cnt_iters = c.pre ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
+    // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk) instead of the
+    // chunked one (ACX_NO_PFAC: always the chunked walk -- measurements)
+    static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
+    const bool pfac = !c.pre && pfac_available(a->dev) && !no_pfac;
+    const uint32_t pgrid = pfac ? pfac_scan_grid(c.d_hay, c.len, a->n_cus) : 0;
+    // hit counts: contiguous per wave of the scan (K1b, k1a_scan); the chunked walk: plain per-tile
+    // arrival counters
+    T.cnt_nw = c.pre ? c.scan_grid * 16 : pfac ? pgrid * 16 : 1;
+    T.cnt_iters = T.cnt_nw > 1 ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
     const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX;
     if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
     if (!w.final) {
@@ -796,17 +802,13 @@ int attempt_sparse(FindCall &c, Attempt *what) {
                                    prof ? scan_stop_ev(x) : side_after, cp_sub));
         c.leads_counted = cp_sub != nullptr;
     } else {
-        HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
-        // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk); its survivor
-        // records take the place of K1b's dense-path hit sink.  More survivors than their regions hold
-        // (1 per 16 haystack bytes): the walk raises the abort flag, the call is redone on the dense
-        // path, which walks in chunks (ACX_NO_PFAC: always the chunked walk -- measurements).
-        static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
-        const bool pfac = pfac_available(a->dev) && !no_pfac;
-        uint32_t pgrid = 0;
+        // the failureless walk: the scan writes the hits it settles itself and every tile's count, the
+        // walk appends to them; its survivor records take the place of K1b's dense-path hit sink.  More
+        // survivors than their regions hold (1 per 16 haystack bytes): the walk raises the abort flag, the
+        // call is redone on the dense path, which walks in chunks.
+        if (!pfac) HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
         uint64_t surv_total = 0;
         if (pfac) {
-            pgrid = pfac_scan_grid(c.d_hay, c.len, a->n_cus);
             surv_total = pfac_workspace_words(c.len, pgrid);
             if ((rc = ensure_hits(x, (surv_total + 3) / 4)) != ACX_OK) return rc; // (records of 32 B there, u64 words here)
         }
@@ -1312,7 +1314,8 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                 table16[(size_t)w * NC + c] = (uint16_t)walk_of[H.table[(size_t)walk_bfs[w] * S + c] & ID_MASK];
     }
     // K1a's failureless form: trie records for every state, the first three levels as tables
-    std::vector<uint32_t> t3b, t3r, grec;
+    std::vector<uint32_t> t3b, t3r, grec, tail_pid;
+    std::vector<uint8_t> tail_len;
     if (H.n_classes <= 32 && H.n_patterns > 0) {
         const uint32_t NS = H.n_states;
         grec.assign((size_t)4 * NS, 0);
@@ -1322,6 +1325,19 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
             grec[4 * (size_t)s2] = bm;
             grec[4 * (size_t)s2 + 1] = H.first_child[s2] | ((H.sflags[s2] & 1u) ? GREC_OWN : 0u);
             grec[4 * (size_t)s2 + 2] = H.own1[s2];
+        }
+        // tails: a node without a pattern of its own whose subtree is one chain of at most 8 edges that
+        // ends in a leaf with exactly one pattern (children have higher BFS ids: bottom-up in one pass)
+        {
+            std::vector<uint8_t> tl(NS, 0xFF);
+            std::vector<uint32_t> tp(NS, 0);
+            for (uint32_t s2 = NS; s2-- > 1;) {
+                const uint32_t c0 = H.first_child[s2], nc = H.first_child[s2 + 1] - c0;
+                const bool own = (H.sflags[s2] & 1u) != 0;
+                if (nc == 0 && own && H.own1[s2] != OWN1_MANY) { tl[s2] = 0; tp[s2] = H.own1[s2]; }
+                else if (nc == 1 && !own && tl[c0] < 8) { tl[s2] = (uint8_t)(tl[c0] + 1); tp[s2] = tp[c0]; }
+            }
+            tail_len.swap(tl); tail_pid.swap(tp);
         }
         // (a used byte is alone in its class, so the children of a node have distinct classes, ascending
         // like their bytes: child = first child + the set bits below the class)
@@ -1365,6 +1381,19 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                     entry(s0, s1, H.in_byte[e3] & 31u) |= bm;
                 }
             }
+        }
+        // (last: t3r above was filled from the plain records) the tail nodes' records
+        for (uint32_t s2 = 1; s2 < NS; s2++) {
+            if (tail_len[s2] == 0xFF) continue;
+            uint32_t by[2] = {0, 0};
+            for (uint32_t k = 0, n = s2; k < tail_len[s2]; k++) {
+                n = H.first_child[n];
+                by[k >> 2] |= (uint32_t)H.in_byte[n] << (8 * (k & 3));
+            }
+            grec[4 * (size_t)s2] = by[0];
+            grec[4 * (size_t)s2 + 1] = GREC_TAIL | ((uint32_t)tail_len[s2] << 24);
+            grec[4 * (size_t)s2 + 2] = tail_pid[s2];
+            grec[4 * (size_t)s2 + 3] = by[1];
         }
     }
     int rc;

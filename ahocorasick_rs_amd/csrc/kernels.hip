@@ -1295,6 +1295,7 @@ struct K1aLds {
     uint32_t t3b[K1A_T3B_WORDS];
     uint8_t cls[256]; // class << 2
     uint16_t q1[16][64];
+    uint32_t cb[16][16]; // hit counts of the wave's last tiles, stored 16 at a time
 };
 static_assert(sizeof(K1aLds) <= 160 * 1024, "K1a LDS image exceeds 160 KiB");
 constexpr uint32_t ITEM_ROOT = 0x80000000u; // item.w: walk from the root (a short pattern, or the end of the haystack)
@@ -1309,8 +1310,8 @@ struct DeepSink {
 
 __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3b, const uint8_t *__restrict__ classes,
                                                   const uint2 *__restrict__ t3r, const uint4 *__restrict__ grec,
-                                                  DeepSink D, const uint8_t *__restrict__ hay, uint64_t len,
-                                                  uint64_t lead, uint32_t min_len, uint32_t NC) {
+                                                  DeepSink D, Sink GK, Segments G, const uint8_t *__restrict__ hay,
+                                                  uint64_t len, uint64_t lead, uint32_t min_len, uint32_t NC) {
     __shared__ __attribute__((aligned(16))) K1aLds L;
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     uint16_t *q1 = L.q1[wave];
@@ -1357,26 +1358,69 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
     }
     K1A_ISSUE_TILE(gw)
     // ---- survivors: Q1 (offsets of the tile under compaction) -> W (windows in flight) -> T (depth-3
-    // records in flight) -> G (depth-4 records in flight) -> items.  One batch of up to 64 per stage.
+    // records in flight) -> G (depth-4 records in flight) -> hits / items.  One batch of up to 64 per
+    // stage; a stage holds: 0 nothing, 1 a batch, 2 the last batch of its tile (as in K1b: batches reach
+    // stage G in tile order, the batches of a tile back to back, ONE running count numbers its hit slots).
+    // Stage G settles what it can by itself: the record of a node whose subtree is ONE pattern's remaining
+    // bytes (GREC_TAIL: up to 8 of them, compared with the 16-byte window) -- on a set of random patterns
+    // practically every node of depth 4 -- is an occurrence or nothing, written straight into the hit
+    // slots of the tile (this wave is their only producer so far; k1a_walk appends with atomics later).
+    uint32_t stW = 0, stT = 0, stG = 0, tileW = 0, tileT = 0, tileG = 0;
     uint32_t nW = 0, nT = 0, nG = 0;
-    uint64_t posW = 0, winW = 0, posT = 0, winT = 0, posG = 0, winG = 0;
+    uint32_t cntG = 0, kG = 0; // hits of tileG pushed so far; tiles of this wave that have left stage G
+    uint64_t posW = 0, winW = 0, winW1 = 0, posT = 0, winT = 0, winT1 = 0, posG = 0, winG = 0, winG1 = 0;
     uint2 eT = make_uint2(0, 0);
     uint32_t c34T = 0, nodeG = 0, c4G = 0;
     uint4 rG = make_uint4(0, 0, 0, 0);
     bool rootG = false, liveG = false;
-    auto advance = [&](uint32_t tileQ) __attribute__((always_inline)) {
-        // ---- stage G: the depth-4 node's record has landed: does the walk go on, or a pattern end here?
-        if (nG) {
-            const bool go = lane < nG && (rootG || (liveG && ((rG.y & GREC_OWN) || ((rG.x >> c4G) & 1u))));
-            const unsigned long long fm = __ballot(go);
-            if (fm) {
-                const uint32_t slot = dcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
-                if (go && slot < dcap) {
-                    drec[2 * (uint64_t)slot] = make_uint4((uint32_t)posG, (uint32_t)(posG >> 32), rootG ? 0u : nodeG,
-                                                          rootG ? ITEM_ROOT : 4u);
-                    drec[2 * (uint64_t)slot + 1] = make_uint4((uint32_t)winG, (uint32_t)(winG >> 32), rG.x, rG.y);
+    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
+        // ---- stage G: the depth-4 node's record has landed
+        if (stG) {
+            if (nG) {
+                const bool in = lane < nG;
+                const bool tail = in && !rootG && liveG && (rG.y & GREC_TAIL);
+                // a tail: the pattern's remaining bytes against haystack bytes 4 .. 4 + n - 1 of the window
+                const uint32_t tn = (rG.y >> 24) & 15u;
+                const uint64_t tb = ((uint64_t)rG.w << 32) | rG.x;
+                const uint64_t hb = (winG >> 32) | (winG1 << 32);
+                const uint32_t sh = (0u - (tn << 3)) & 63u;
+                bool hit = tail && (tn == 0 || ((tb ^ hb) << sh) == 0);
+                if (hit) hit = 4 + tn <= segment_end(G, len, posG) - posG; // (rare lanes: the end of this haystack)
+                const unsigned long long hm = __ballot(hit);
+                if (hm) {
+                    const uint32_t slot = cntG + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
+                    if (hit) {
+                        if (slot < HIT_SLOTS)
+                            GK.hslots[((uint64_t)tileG * HIT_SLOTS + slot) * 2] =
+                                make_uint4((uint32_t)posG, (uint32_t)(posG >> 32), HIT_VERIFIED | rG.z, 4 + tn);
+                        else
+                            *GK.abort_flag = 1; // more hits than the tile holds: dense input
+                    }
+                    cntG += (uint32_t)__popcll(hm);
                 }
-                dcur += (uint32_t)__popcll(fm); // keeps counting past the capacity
+                // everything else the walk looks at: from the root (short patterns, the end of the
+                // stream), or from this node when a pattern ends here or the next byte has a child
+                const bool go = in && (rootG || (liveG && !(rG.y & GREC_TAIL) && ((rG.y & GREC_OWN) || ((rG.x >> c4G) & 1u))));
+                const unsigned long long fm = __ballot(go);
+                if (fm) {
+                    const uint32_t slot = dcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
+                    if (go && slot < dcap) {
+                        drec[2 * (uint64_t)slot] = make_uint4((uint32_t)posG, (uint32_t)(posG >> 32), rootG ? 0u : nodeG,
+                                                              rootG ? ITEM_ROOT : 4u);
+                        drec[2 * (uint64_t)slot + 1] = make_uint4((uint32_t)winG, (uint32_t)(winG >> 32), rG.x, rG.y);
+                    }
+                    dcur += (uint32_t)__popcll(fm); // keeps counting past the capacity
+                }
+            }
+            if (stG == 2) { // the tile is complete: its count, through LDS, 16 tiles of the wave per store
+                if (lane == 0) L.cb[wave][kG & 15] = cntG < HIT_SLOTS ? cntG : HIT_SLOTS;
+                if ((kG & 15) == 15) {
+                    __builtin_amdgcn_wave_barrier();
+                    if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kG - 15) + lane] = L.cb[wave][lane];
+                    __builtin_amdgcn_wave_barrier();
+                }
+                kG++;
+                cntG = 0;
             }
         }
         // ---- stage T -> G: the depth-3 record by the class triple has landed: the depth-4 node, its record
@@ -1386,32 +1430,42 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
             liveG = !rootG && ((eT.x >> c3) & 1u);
             nodeG = (eT.y & ID_MASK) + __popc(eT.x & ((1u << c3) - 1u));
             if (lane < nT && liveG) rG = grec[nodeG];
-            posG = posT; winG = winT; c4G = c34T >> 5;
+            posG = posT; winG = winT; winG1 = winT1; c4G = c34T >> 5;
         }
-        nG = nT;
+        nG = nT; stG = stT; tileG = tileT;
         // ---- stage W -> T: the window has landed: classes of bytes 0 .. 4, the depth-3 record
         if (nW) {
             const uint32_t lo = (uint32_t)winW, hi = (uint32_t)(winW >> 32);
             const uint32_t c0 = L.cls[lo & 0xFF] >> 2, c1 = L.cls[(lo >> 8) & 0xFF] >> 2, c2 = L.cls[(lo >> 16) & 0xFF] >> 2;
             c34T = (L.cls[lo >> 24] >> 2) | ((uint32_t)(L.cls[hi & 0xFF] >> 2) << 5);
             if (lane < nW) eT = t3r[(c0 * NC + c1) * NC + c2];
-            posT = posW; winT = winW;
+            posT = posW; winT = winW; winT1 = winW1;
         }
-        nT = nW;
-        // ---- stage Q -> W: the 8-byte windows of the queued survivors
+        nT = nW; stT = stW; tileT = tileW;
+        // ---- stage Q -> W: the 16-byte windows of the queued survivors
         if (q1c) {
+            // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
+            const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
             if (lane < q1c) {
                 posW = (uint64_t)tileQ * tile_bytes + q1[lane] - lead;
-                winW = load_window(stream, len, posW);
+                if (inside) {
+                    u32x4 w_;
+                    __builtin_memcpy(&w_, stream + posW, 16);
+                    winW = ((uint64_t)w_.y << 32) | w_.x;
+                    winW1 = ((uint64_t)w_.w << 32) | w_.z;
+                } else {
+                    load_window16(stream, len, posW, &winW, &winW1);
+                }
             }
         }
-        nW = q1c;
+        nW = q1c; stW = stQ; tileW = tileQ;
         q1c = 0;
         __builtin_amdgcn_wave_barrier();
     };
     for (uint64_t tile = gw; tile < ntiles + 4 * nw; tile += nw) {
         asm volatile("" : "+v"(v0), "+v"(v1), "+v"(v2), "+v"(v3), "+v"(vL));
-        advance((uint32_t)(tile - nw)); // the previous tile's remaining survivors
+        // the previous tile's remaining survivors: its last batch (possibly empty)
+        advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
         if (tile >= ntiles) continue;
         const uint64_t tbase = tile * tile_bytes;
         // every position of an interior tile is a legal start with at least 4 bytes behind it
@@ -1462,7 +1516,7 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
             const unsigned long long act = __ballot(has);
             if (!act) break;
             const uint32_t np = __popcll(act);
-            if (q1c + np > 64) advance((uint32_t)tile);
+            if (q1c + np > 64) advance((uint32_t)tile, 1u);
             const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
             m64 &= m64 - 1;
             const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
@@ -1471,6 +1525,10 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
             q1c += np;
         }
         __builtin_amdgcn_wave_barrier();
+    }
+    if (kG & 15) { // the counts of the wave's last tiles
+        __builtin_amdgcn_wave_barrier();
+        if (lane < (kG & 15)) GK.hcnt[gw * GK.cnt_iters + (kG & ~15u) + lane] = L.cb[wave][lane];
     }
     if (lane == 0) D.counts[region] = dcur;
 #undef K1A_ISSUE_ROW
@@ -1511,6 +1569,29 @@ __global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomat
                 uint4 r = make_uint4(wq.z, wq.w, 0u, 0u);
                 if (!first || (wq.w & GREC_OWN)) r = A.grec[node];
                 first = false;
+                if (r.y & GREC_TAIL) { // ONE pattern's remaining bytes below this node: compare them and stop
+                    const uint32_t tn = (r.y >> 24) & 15u;
+                    bool same = d + tn <= room;
+                    for (uint32_t k = 0; same && k < tn; k++) {
+                        if (d + k - wd >= 8) { w = load_window(stream, len, pos + d + k); wd = d + k; }
+                        const uint32_t hb = (uint32_t)(w >> (8 * (d + k - wd))) & 0xFFu;
+                        const uint32_t tb = ((k < 4 ? r.x : r.w) >> (8 * (k & 3))) & 0xFFu;
+                        same = hb == tb;
+                    }
+                    if (same) {
+                        if (K->hslots) {
+                            const uint64_t tile = (pos + K->lead) >> TILE_BITS;
+                            const uint32_t slot = atomicAdd(&K->hcnt[hcnt_index(tile, K->cnt_nw, K->cnt_iters)], 1u);
+                            if (slot < HIT_SLOTS)
+                                K->hslots[(tile * HIT_SLOTS + slot) * 2] = make_uint4((uint32_t)pos, (uint32_t)(pos >> 32), HIT_VERIFIED | r.z, d + tn);
+                            else
+                                *K->abort_flag = 1;
+                        } else {
+                            emit_one(Ad, *K, r.z, pos + d + tn);
+                        }
+                    }
+                    break;
+                }
                 if (r.y & GREC_OWN) {
                     if (r.z == OWN1_MANY) {
                         for (uint32_t k = A.own_off[node]; k < A.own_off[node + 1]; k++) emit_one(Ad, *K, A.own_pid[k], pos + d);
@@ -1557,7 +1638,7 @@ hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segm
     if (len == 0) return hipSuccess;
     const uint64_t lead = (uintptr_t)d_hay & 15;
     const DeepSink D{(uint4 *)work, counts, pfac_region_cap(len, scan_grid), scan_grid * 16};
-    hipLaunchKernelGGL(k1a_scan, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D,
+    hipLaunchKernelGGL(k1a_scan, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D, K, G,
                        d_hay - lead, len, lead, A.min_len, A.n_classes);
     hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, K, d_hay, len);
     return hipGetLastError();
