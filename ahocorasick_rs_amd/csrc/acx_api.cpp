@@ -740,6 +740,7 @@ struct FindCall {
     // results
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
     bool exact_regions = false; // dense path, second pass: regions at the exclusive prefix of the first pass's counts
+    bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
     uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
     bool early_event = false;   // the caller returns before the device work is done: fence it with r->done
@@ -809,13 +810,13 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         if (!pfac) HIPCHK_RC(hipMemsetAsync(T.hcnt, 0, (c.tiles + 1) * 4, st)); // arrival counters of the walk's emission
         uint64_t surv_total = 0;
         if (pfac) {
-            surv_total = pfac_workspace_words(c.len, pgrid);
+            surv_total = pfac_workspace_words(c.len, pgrid, false);
             if ((rc = ensure_hits(x, (surv_total + 3) / 4)) != ACX_OK) return rc; // (records of 32 B there, u64 words here)
         }
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
         if (pfac)
             HIPCHK_RC(launch_pfac(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
-                                  pgrid * 16, st));
+                                  pgrid * 16, false, st));
         else
             HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
@@ -885,28 +886,46 @@ int attempt_dense(FindCall &c, Attempt *what) {
     if (rc) return rc;
     if (c.pre && (rc = ensure_hits(x, std::max<uint64_t>(1u << 16, c.len / 64))) != ACX_OK) return rc;
     const uint32_t hit_grid = c.pre ? prefilter_hit_regions(c.scan_grid) : 0;
-    const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : c.scan_grid; // occurrence regions
+    // K1a: the failureless walk here too (one occurrence region per block of k1a_walk); the chunked walk
+    // when the automaton has none, or when its items did not fit
+    static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
+    const bool pfac = !c.pre && pfac_available(a->dev) && !no_pfac && !c.chunked_walk;
+    const uint32_t pgrid = pfac ? pfac_scan_grid(c.d_hay, c.len, a->n_cus) : 0;
+    if (pfac && (rc = ensure_hits(x, (pfac_workspace_words(c.len, pgrid, true) + 3) / 4)) != ACX_OK) return rc;
+    const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : pfac ? pgrid * 16 : c.scan_grid; // occurrence regions
     const uint64_t hit_cap = c.pre ? w.hit_total / hit_grid : 0;
     // exact_regions (second pass after an occurrence region overflowed): every region gets the room
     // it asked for in the first pass, at the exclusive prefix of the counts (stored behind the counts)
     const uint64_t region_cap = c.exact_regions ? 0 : w.cap / grid;
     const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
-    const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
+    uint32_t *items_overflow = (uint32_t *)(w.summary + 4);
+    const Sink K{w.recs, w.block_counts, region_cap, c.key_mode, nullptr, nullptr, pfac ? items_overflow : nullptr, c.lead, 1, 0};
     const bool prof = c.timed;
     if (c.pre) {
         HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
                                    prof ? scan_stop_ev(x) : nullptr));
         HIPCHK_RC(launch_walk_hits(a->dev, c.G, H, hit_grid, K, grid, c.d_hay, c.len, st));
     } else {
+        if (pfac) HIPCHK_RC(hipMemsetAsync(w.summary + 4, 0, 8, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
-        HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+        if (pfac)
+            HIPCHK_RC(launch_pfac(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
+                                  grid, true, st));
+        else
+            HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     HIPCHK_RC(sink_summary(w.block_counts, grid, c.exact_regions ? ~0ull : region_cap, c.pre ? w.hit_counts : nullptr,
                            hit_grid, hit_cap, w.summary, w.region_off, st));
-    HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 40, hipMemcpyDeviceToHost, st));
     HIPCHK_RC(hipStreamSynchronize(st));
     add_scan_profile(a, x, c.len, c.timed);
+    if (pfac && (uint32_t)w.h_pinned[4] != 0) { // more items than 1 per 16 bytes: the chunked walk has no such limit
+        c.chunked_walk = true;
+        c.exact_regions = false;
+        *what = Attempt::Again;
+        return ACX_OK;
+    }
     const uint64_t n_raw = w.h_pinned[0], region_max = w.h_pinned[1], hit_max = c.pre ? w.h_pinned[3] : 0;
     if (c.exact_regions) {
         if (n_raw != c.exact_total || (c.pre && hit_max > hit_cap))
@@ -931,7 +950,9 @@ int attempt_dense(FindCall &c, Attempt *what) {
             HIPCHK_RC(hipStreamSynchronize(st));
             c.exact_total = w.h_pinned[10];
             if (c.exact_total >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
-            if ((rc = ensure_occ_capacity(x, c.exact_total + 64)) != ACX_OK) return rc;
+            // (an eighth of headroom: the NEXT call's uniform regions -- capacity / grid each -- then hold an
+            // output that is spread as evenly as this one, and it needs no second pass)
+            if ((rc = ensure_occ_capacity(x, c.exact_total + c.exact_total / 8 + 64 * (uint64_t)grid)) != ACX_OK) return rc;
             c.exact_regions = true;
         }
         *what = Attempt::Again;

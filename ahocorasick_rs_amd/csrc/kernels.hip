@@ -1365,6 +1365,7 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
     // bytes (GREC_TAIL: up to 8 of them, compared with the 16-byte window) -- on a set of random patterns
     // practically every node of depth 4 -- is an occurrence or nothing, written straight into the hit
     // slots of the tile (this wave is their only producer so far; k1a_walk appends with atomics later).
+    const bool slots = GK.hslots != nullptr; // sparse output (else: everything becomes an item of the walk)
     uint32_t stW = 0, stT = 0, stG = 0, tileW = 0, tileT = 0, tileG = 0;
     uint32_t nW = 0, nT = 0, nG = 0;
     uint32_t cntG = 0, kG = 0; // hits of tileG pushed so far; tiles of this wave that have left stage G
@@ -1386,7 +1387,8 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
                 const uint32_t sh = (0u - (tn << 3)) & 63u;
                 bool hit = tail && (tn == 0 || ((tb ^ hb) << sh) == 0);
                 if (hit) hit = 4 + tn <= segment_end(G, len, posG) - posG; // (rare lanes: the end of this haystack)
-                const unsigned long long hm = __ballot(hit);
+                // (dense output -- no hit slots: the occurrence goes the walk's way, into its region)
+                const unsigned long long hm = slots ? __ballot(hit) : 0ull;
                 if (hm) {
                     const uint32_t slot = cntG + __builtin_amdgcn_mbcnt_hi((uint32_t)(hm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)hm, 0));
                     if (hit) {
@@ -1400,7 +1402,8 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
                 }
                 // everything else the walk looks at: from the root (short patterns, the end of the
                 // stream), or from this node when a pattern ends here or the next byte has a child
-                const bool go = in && (rootG || (liveG && !(rG.y & GREC_TAIL) && ((rG.y & GREC_OWN) || ((rG.x >> c4G) & 1u))));
+                const bool go = in && (rootG || (!slots && hit) ||
+                                       (liveG && !(rG.y & GREC_TAIL) && ((rG.y & GREC_OWN) || ((rG.x >> c4G) & 1u))));
                 const unsigned long long fm = __ballot(go);
                 if (fm) {
                     const uint32_t slot = dcur + __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
@@ -1412,7 +1415,7 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
                     dcur += (uint32_t)__popcll(fm); // keeps counting past the capacity
                 }
             }
-            if (stG == 2) { // the tile is complete: its count, through LDS, 16 tiles of the wave per store
+            if (slots && stG == 2) { // the tile is complete: its count, through LDS, 16 tiles of the wave per store
                 if (lane == 0) L.cb[wave][kG & 15] = cntG < HIT_SLOTS ? cntG : HIT_SLOTS;
                 if ((kG & 15) == 15) {
                     __builtin_amdgcn_wave_barrier();
@@ -1526,7 +1529,7 @@ __global__ __launch_bounds__(1024) void k1a_scan(const uint32_t *__restrict__ t3
         }
         __builtin_amdgcn_wave_barrier();
     }
-    if (kG & 15) { // the counts of the wave's last tiles
+    if (slots && (kG & 15)) { // the counts of the wave's last tiles
         __builtin_amdgcn_wave_barrier();
         if (lane < (kG & 15)) GK.hcnt[gw * GK.cnt_iters + (kG & ~15u) + lane] = L.cb[wave][lane];
     }
@@ -1565,9 +1568,10 @@ __global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomat
             uint32_t wd = 0;
             bool first = !(it.w & ITEM_ROOT);
             for (;;) {
-                // (the record of an item's first node travelled with it -- unless a pattern ends there: its id did not)
+                // (the record of an item's first node travelled with it -- unless a pattern ends there or it is a
+                // tail: the pattern's id / the tail's second half did not)
                 uint4 r = make_uint4(wq.z, wq.w, 0u, 0u);
-                if (!first || (wq.w & GREC_OWN)) r = A.grec[node];
+                if (!first || (wq.w & (GREC_OWN | GREC_TAIL))) r = A.grec[node];
                 first = false;
                 if (r.y & GREC_TAIL) { // ONE pattern's remaining bytes below this node: compare them and stop
                     const uint32_t tn = (r.y >> 24) & 15u;
@@ -1627,17 +1631,20 @@ uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     return blocks ? (uint32_t)blocks : 1;
 }
 // items the scan may leave before the call gives up: 1 per 64 haystack bytes (32 B each: half a byte of
-// workspace per haystack byte; the headline input leaves 1 per 500): the u64 words they take
-static uint64_t pfac_region_cap(uint64_t len, uint32_t scan_grid) { return len / 64 / ((uint64_t)scan_grid * 16) + 1024; }
-uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid) {
-    return (uint64_t)scan_grid * 16 * pfac_region_cap(len, scan_grid) * 4;
+// workspace per haystack byte; the headline input leaves 1 per 500); dense output: 1 per 16 bytes (a
+// one-byte pattern that every 26th letter matches is 1 per 26): the u64 words they take
+static uint64_t pfac_region_cap(uint64_t len, uint32_t scan_grid, bool dense) {
+    return len / (dense ? 16 : 64) / ((uint64_t)scan_grid * 16) + 1024;
+}
+uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid, bool dense) {
+    return (uint64_t)scan_grid * 16 * pfac_region_cap(len, scan_grid, dense) * 4;
 }
 hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,
                        const uint8_t *d_hay, uint64_t len, uint32_t scan_grid, uint64_t *work, uint64_t *counts,
-                       uint32_t walk_grid, hipStream_t st) {
+                       uint32_t walk_grid, bool dense, hipStream_t st) {
     if (len == 0) return hipSuccess;
     const uint64_t lead = (uintptr_t)d_hay & 15;
-    const DeepSink D{(uint4 *)work, counts, pfac_region_cap(len, scan_grid), scan_grid * 16};
+    const DeepSink D{(uint4 *)work, counts, pfac_region_cap(len, scan_grid, dense), scan_grid * 16};
     hipLaunchKernelGGL(k1a_scan, dim3(scan_grid), dim3(1024), 0, st, A.t3b, A.classes, A.t3r, A.grec, D, K, G,
                        d_hay - lead, len, lead, A.min_len, A.n_classes);
     hipLaunchKernelGGL(k1a_walk, dim3(walk_grid), dim3(256), 0, st, A, Ad, G, D, K, d_hay, len);

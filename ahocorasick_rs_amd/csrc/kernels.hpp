@@ -22,15 +22,18 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 // K1a, failureless form (automata of at most 32 byte classes; kernels.hip): k1a_scan settles the first
 // four levels of the walk of every position in LDS, takes the survivors one level on in a software
 // pipeline of gathers and leaves the walks that go on as 32-byte items in per-wave regions; k1a_walk
-// finishes them and emits the occurrences into K (hit slots: K.hcnt zero beforehand, walk_grid
-// arbitrary; regions: walk_grid = the number of occurrence regions).  work: pfac_workspace_words() u64
-// words; counts: scan_grid * 16 u64 words.  More items than the regions hold: K.abort_flag (hit-slot mode).
+// finishes them and emits the occurrences into K.  Hit slots (K.hslots != null, walk_grid arbitrary): the
+// scan settles the occurrences below tail nodes itself and writes every tile's count (layout: K.cnt_nw
+// = scan_grid * 16 waves), the walk appends with atomics.  Regions (dense output: walk_grid = scan_grid *
+// 16 = the number of occurrence regions, one per block of the walk): everything goes through the walk.
+// work: pfac_workspace_words() u64 words; counts: scan_grid * 16 u64 words.  More items than the
+// regions hold: *K.abort_flag = 1 (both modes).
 bool pfac_available(const DevAutomaton &A);
 uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
-uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid);
+uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid, bool dense);
 hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,
                        const uint8_t *d_hay, uint64_t len, uint32_t scan_grid, uint64_t *work, uint64_t *counts,
-                       uint32_t walk_grid, hipStream_t st);
+                       uint32_t walk_grid, bool dense, hipStream_t st);
 // K1b: LDS q-gram prefilter + exact prefix table.  Emits prefix hits: into the hit slots of
 // their tile (K.hslots != null; every tile's count is written) or into per-wave regions
 // (prefilter_hit_regions(grid) of them, dense path).

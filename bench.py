@@ -66,7 +66,7 @@ def parse_args(argv=None):
                          "after a cold start; 0: none); reported as config.settle_ms")
     ap.add_argument("--ablate", default="", help="measurement only: override the configuration's match kind / "
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
-    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large"], default="auto",
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U", "Z", "D"], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
@@ -137,6 +137,12 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
     if cfg in ("cfg2", "cfg3"):
         pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
         w["mk"], impl = capi.MATCH_STANDARD, capi.IMPL_DFA
+    elif cfg in ("mixed", "mixedx"):
+        # cfg2's set plus a 2-byte and a 1-byte pattern (mixed lengths: K1b cannot take the set).  mixed: the
+        # short patterns are rare in the haystack (b"qz": 1 per 676 letter pairs, b"~": never); mixedx: the
+        # round-2 VERDICT's example b"ab" + b"x" -- one occurrence per ~22 bytes of a-z text: dense output
+        pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1) + ([b"qz", b"~"] if cfg == "mixed" else [b"ab", b"x"])
+        w["mk"], impl = capi.MATCH_STANDARD, capi.IMPL_DFA
     elif cfg in ("cfg4", "cfg4b"):
         pats = gen.gen_patterns(100000, 5, 12, gen.AZ if cfg == "cfg4" else gen.ALL_BYTES, 3 if cfg == "cfg4" else 4)
         w["mk"], impl, w["overlapping"] = capi.MATCH_STANDARD, capi.IMPL_AUTO, True
@@ -178,7 +184,7 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
     else:
         hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()
-        if cfg == "cfg2":
+        if cfg in ("cfg2", "mixed", "mixedx"):
             if args.dist == "Z":
                 hay.zero_()
                 torch.cuda.synchronize()
@@ -205,6 +211,10 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
                          "not the headline)"}[args.dist]
             w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
                          f"{nbytes / GIB:g} GiB {what} bytes haystack, MatchKind.Standard, non-overlapping")
+            if cfg != "cfg2":
+                w["desc"] = (f"{cfg} (not a BASELINE configuration): cfg2's set + " +
+                             ("b'qz' + b'~' (short patterns that are rare in the haystack)" if cfg == "mixed"
+                              else "b'ab' + b'x' (one occurrence per ~22 bytes: dense output)") + "; " + w["desc"][6:])
         elif cfg == "cfg3":
             if nbytes % 8192:
                 raise SystemExit("--bytes must be a multiple of 8192 for cfg3")

@@ -219,3 +219,22 @@ def test_cfg3_full_per_gpu_size_counts_and_samples():
         want = o.find_raw(host[h * L:(h + 1) * L])
         assert np.array_equal(m[starts[h]:starts[h + 1]], want), h
     a.close()
+
+
+@pytest.mark.parametrize("short", [[b"qz", b"~"], [b"ab", b"x"], [b"b", b"abcd"]], ids=["rare", "frequent", "readme"])
+def test_mixed_length_sets_leave_the_prefilter_for_the_failureless_walk(short):
+    """A dictionary with a 1- or 2-byte pattern in it (VERDICT round 2, item 3): K1b cannot take it;
+    the set runs the failureless walk (k1a_scan marks every triple below a short pattern, k1a_walk
+    starts those positions at the root).  Rare short patterns stay on the sparse path, frequent ones
+    (b"x": every 26th letter) end on the dense path -- every kind equals the oracle either way.
+    ([b"b", b"abcd"] is the vector of /root/reference/README.md:106-108.)"""
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1) + short
+    hay = gen.gen_textlike(4 << 20, 11, pats[:10000]).tobytes()
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk)
+        assert capi.KERNEL_NAMES[a.info.kernel] == "dfa_walk"
+        o = Oracle(pats, mk, KIND_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
+            assert np.array_equal(got, want), (mk, ov, short)
+        a.close()
