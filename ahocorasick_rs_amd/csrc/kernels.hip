@@ -1055,6 +1055,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         uint32_t mrow0 = 0, mrow1 = 0, mrow2 = 0, mrow3 = 0;
         // a register whose LOW byte is byte k of the lane's 24-byte view: an odd window,
         // a dword, or a dword shifted by 16 (only bits [4:0] are consumed)
+#define K1B_SCHED_BARRIER __builtin_amdgcn_sched_barrier(0);
 #define K1B_BYTE_REG(k) (((k) & 1) ? w_[(k)] : (((k) & 2) ? d_[(k) >> 2] >> 16 : d_[(k) >> 2]))
 #define K1B_ROW(RI, VR, RX, RY, MROW)                                                            \
         {                                                                                        \
@@ -1071,11 +1072,20 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             _Pragma("unroll") for (int j = 1; j < 20; j += 2)                                    \
                 w_[j] = __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3);         \
             uint32_t m_ = 0, mg_ = 0;                                                            \
+            /* all eight table reads of the row are issued before the first test (the scheduler    */\
+            /* otherwise keeps ONE read in flight: ds_read, s_waitcnt lgkmcnt(0), test, next read; */\
+            /* measured: -2.6 us of 282 -- the other waves covered most of that latency already)    */\
+            uint2 e8_[8];                                                                        \
             _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
                 const uint32_t W_ = w_[j + 1] & GMASK;                                           \
                 const uint32_t H_ = hash_mul24(W_, HASH_K1) + W_;                                \
-                const uint2 e_ = *(const uint2 *)((const uint8_t *)L.xy +                        \
+                e8_[j >> 1] = *(const uint2 *)((const uint8_t *)L.xy +                           \
                     ((H_ >> (32 - FILTER_ENTRIES_LOG2 - 3)) & ((FILTER_WORDS * 4 - 1) & ~7u)));  \
+            }                                                                                    \
+            K1B_SCHED_BARRIER                                                                    \
+            _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
+                const uint32_t W_ = w_[j + 1] & GMASK;                                           \
+                const uint2 e_ = e8_[j >> 1];                                                    \
                 /* byte j: low byte of d_[j / 4] (j % 4 == 0) or of d_ >> 16 (j % 4 == 2) */      \
                 const uint32_t bx_ = K1B_BYTE_REG(j);                                            \
                 const uint32_t by_ = K1B_BYTE_REG(j + Q);                                        \
