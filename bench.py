@@ -276,11 +276,34 @@ def run(args) -> None:
     world_observed = dist.get_world_size() if dist is not None else 1
     cfg, nbytes = w["cfg"], w["nbytes"]
 
-    # the count all-gather of a step overlaps the next step's scan (two buffers used in turn; the last
-    # one is waited for inside the timed region): nothing on the data path depends on it
+    # The count all-gather of a step overlaps the next step's scan: a helper thread issues it (the host
+    # side of a torch collective -- filling the 8-byte tensor, enqueueing, waiting -- is ~80 us of Python
+    # and launch overhead, a fifth of a step, and the main thread is inside the library with the GIL
+    # released meanwhile); two buffers are used in turn, the last gather is waited for inside the timed
+    # region.  Nothing on the data path depends on it.
     counts_local = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(2)]
     counts_all = [torch.zeros(world, dtype=torch.int64, device=dev) for _ in range(2)]
-    pending = [None, 0]  # [work handle of the all-gather in flight, steps issued]
+    pending = [None, 0]  # [unused, steps issued]
+    gather_q = None
+    if dist is not None:
+        import queue
+        import threading
+        gather_q = queue.Queue()
+
+        def gather_worker():
+            if not args.dry_run:
+                torch.cuda.set_device(dev)
+            while True:
+                item = gather_q.get()
+                if item is None:
+                    gather_q.task_done()
+                    return
+                k, n = item
+                counts_local[k].fill_(n)
+                dist.all_gather_into_tensor(counts_all[k], counts_local[k])
+                gather_q.task_done()
+
+        threading.Thread(target=gather_worker, daemon=True).start()
     last = {}
 
     def hot() -> int:
@@ -301,18 +324,15 @@ def run(args) -> None:
         return n
 
     def gather_wait() -> None:
-        if pending[0] is not None:
-            pending[0].wait()
-            pending[0] = None
+        if gather_q is not None:
+            gather_q.join()
 
     def step() -> int:
         n = hot()
         if dist is not None:  # C1: per-shard match counts -> global output offsets
-            gather_wait()  # (the previous step's)
             k = pending[1] & 1
             pending[1] += 1
-            counts_local[k].fill_(n)
-            pending[0] = dist.all_gather_into_tensor(counts_all[k], counts_local[k], async_op=True)
+            gather_q.put((k, n))
         return n
 
     if args.host and not args.dry_run:
@@ -336,6 +356,7 @@ def run(args) -> None:
         n = 0
         for _ in range(warmup):
             n = step()
+        gather_wait()  # (the helper thread is idle whenever this thread talks to the communicator)
         if profile and not args.dry_run:
             # the kernel time is measured live in the timed region, on every 4th step (the event pair
             # costs the dispatch it rides on ~6 us; roofline.kernel_ms_samples says how many were taken)

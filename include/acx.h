@@ -66,8 +66,9 @@ extern "C" {
  * sort, resolve, output; one launch) -- unless a scan kernel was chosen explicitly with
  * acx_set_kernel / ACX_KERNEL or the output is too dense for it. */
 #define ACX_KERNEL_AUTO 0
-#define ACX_KERNEL_DFA_WALK 1   /* K1a: chunked DFA walk, hot rows in LDS      */
-#define ACX_KERNEL_PREFILTER 2  /* K1b: LDS q-gram prefilter + DFA verification */
+#define ACX_KERNEL_DFA_WALK 1   /* K1a: the DFA walk -- failureless form, first four levels in LDS;
+                                 * chunked walk for automata of more than 32 byte classes */
+#define ACX_KERNEL_PREFILTER 2  /* K1b: LDS q-gram prefilter + exact prefix keys + verification */
 
 /* One match: the tuple `(u64, usize, usize)` of src/lib.rs:234, 427. */
 typedef struct acx_match {
@@ -87,7 +88,7 @@ typedef struct acx_info {
     uint32_t min_pattern_len;
     uint32_t max_pattern_len;
     uint64_t table_bytes; /* dense DFA in HBM                                  */
-    uint32_t lds_hot_rows;/* rows staged in LDS by K1a                         */
+    uint32_t lds_hot_rows;/* rows staged in LDS by K1a's chunked walk          */
     int32_t kernel;       /* ACX_KERNEL_* actually selected                    */
     int32_t match_kind;
     int32_t device;       /* HIP device ordinal the tables live on             */

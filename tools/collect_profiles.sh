@@ -26,6 +26,10 @@ for d in T U; do
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --dist $d --kernel dfa_walk > $OUT/bench_${d}_dfa_walk.json 2> $OUT/bench_${d}_dfa_walk.err
   ACX_NO_PFAC=1 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target-size --no-cold --dist $d --kernel dfa_walk > $OUT/bench_${d}_dfa_walk_chunked.json 2> $OUT/bench_${d}_dfa_walk_chunked.err
 done
+# mixed-length sets (K1a by the library's own choice): rare short patterns, and the round-2 VERDICT's example
+for cfg in mixed mixedx; do
+  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+done
 # the dense (region) path: a dense input, and the headline input forced onto it
 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dist D > $OUT/bench_dense_D.json 2> $OUT/bench_dense_D.err
 ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_forced_dense_path.json 2> $OUT/bench_T_forced_dense_path.err
@@ -33,6 +37,7 @@ ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-basel
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_one_rank_rccl.json 2> $OUT/bench_T_one_rank_rccl.err
 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison.txt 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
+[ -x tools/ubench_stream.bin ] && timeout 120 tools/ubench_stream.bin > $OUT/ubench_stream.txt 2>&1
 fi
 if [ "$PART" = all ] || [ "$PART" = trace ]; then
 cd /tmp

@@ -21,7 +21,7 @@ def short(n):
 
 
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
-                                                                  ("smoke.log", "bench_comparison.txt")]:
+                                                                  ("smoke.log", "bench_comparison.txt", "ubench_stream.txt")]:
     if os.path.exists(f) and os.path.getsize(f):
         if f.endswith(".json"):  # (only the JSON line: RCCL prints its banner to stdout)
             lines = [l for l in open(f) if l.startswith("{")]
