@@ -741,6 +741,7 @@ struct FindCall {
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
     bool exact_regions = false; // dense path, second pass: regions at the exclusive prefix of the first pass's counts
     bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
+    bool counts_zeroed = false; // batch: the per-haystack counts are zero or being accumulated into
     uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
     bool early_event = false;   // the caller returns before the device work is done: fence it with r->done
@@ -841,6 +842,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
                         next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, st));
+    if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
     // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
     settle_scan_profile(a, x);
@@ -993,6 +995,18 @@ int attempt_dense(FindCall &c, Attempt *what) {
     return ACX_OK;
 }
 
+// batch: the per-haystack counts start at zero.  No memset in front of the scan (it delayed the scan's
+// launch by a dispatch and ~15 us of host time on every batch call): the sparse path has k_tile_main
+// clear them on its way, every other path clears them here, when it gets to them.
+int zero_counts(FindCall &c) {
+    if (c.segmented && !c.counts_zeroed) {
+        HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, c.c->stream));
+        c.queued = true;
+    }
+    c.counts_zeroed = true;
+    return ACX_OK;
+}
+
 // everything after the matches exist: code points (str API), local offsets + counts (batches)
 int finish_matches(FindCall &c) {
     Ctx *x = c.c;
@@ -1007,9 +1021,12 @@ int finish_matches(FindCall &c) {
         else HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, w.blocksub, st));
         HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
     }
-    if (c.segmented)
+    if (c.segmented) {
+        int rc = zero_counts(c);
+        if (rc) return rc;
         HIPCHK_RC(localize(c.G, c.d_hay, c.len, w.blockpre, w.blocksub, c.codepoints, c.r->d_matches, c.n_final,
                            c.r->d_counts, st));
+    }
     else
         HIPCHK_RC(to_code_points(c.d_hay, c.len, w.blockpre, w.blocksub, c.r->d_matches, c.n_final, st));
     c.queued = true;
@@ -1042,6 +1059,7 @@ int run_pipeline(FindCall &c) {
     }
     c.r->n = c.n_final;
     if ((rc = finish_matches(c)) != ACX_OK) return rc;
+    if ((rc = zero_counts(c)) != ACX_OK) return rc; // (a batch without a match never got to them)
     static const bool prof_post = std::getenv("ACX_PROFILE_POST") != nullptr;
     if (a->prof && prof_post) { // end of the post stage (costs the next call a wait for this one's last kernel)
         HIPCHK_RC(hipEventRecord(x->ev[2], x->stream));
@@ -1073,8 +1091,6 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
     auto body = [&]() -> int {
         if (segmented) {
             HIPCHK_RC(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
-            HIPCHK_RC(hipMemsetAsync(r->d_counts, 0, std::max<uint64_t>(G.n_hay, 1) * 8, st));
-            c.queued = true;
         }
         if (allow_small && !segmented && small_ok(a, len)) { // small haystack: the whole call in one workgroup (K0)
             HIPCHK_RC(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));

@@ -1928,7 +1928,12 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
-                                                            uint64_t len, uint32_t *abort_flag, uint64_t seq) {
+                                                            uint64_t len, uint32_t *abort_flag, uint64_t seq,
+                                                            uint64_t *seg_counts, uint64_t n_seg) {
+    // (batch: the per-haystack counts k_tile_write adds to -- cleared here, no memset in front of the scan)
+    if (seg_counts)
+        for (uint64_t i = (uint64_t)blockIdx.x * MAIN_THREADS + threadIdx.x; i < n_seg; i += (uint64_t)gridDim.x * MAIN_THREADS)
+            seg_counts[i] = 0;
     // (rows padded to an odd number of words: lane t works on row t, and a power-of-two row stride would
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
     __shared__ uint64_t st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
@@ -2350,7 +2355,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
-                       lead, d_hay, len, abort_flag, seq);
+                       lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
     if (before_write) { // (what the write kernel needs from another stream: the code-point prefix)
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;

@@ -82,7 +82,7 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // (its parity selects the set of supergroup words, TileSpace::sgw).  Aborted: the output did not fit
 // the slots, out[] and the totals are meaningless.  seg_counts != null (batch, byte offsets):
 // offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
-// into seg_counts (zeroed by the caller).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
+// into seg_counts (cleared by k_tile_main).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
 // cannot take this path.  cp_blockpre != null (one haystack): the write kernel turns the byte
 // offsets into code-point indexes on the way out (prefix of the 1 KiB blocks + 64-byte sub counts).
 uint32_t tile_lookback(uint32_t max_len);

@@ -1,5 +1,5 @@
 cd /root/repo
 export TMPDIR=/tmp
-mkdir -p gpurun_out/r03
-timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-target-size > gpurun_out/r03/bench_T_one_rank_rccl.json 2> gpurun_out/r03/bench_T_one_rank_rccl.err
-grep "^{" gpurun_out/r03/bench_T_one_rank_rccl.json | python -c "import json,sys;d=json.loads(sys.stdin.read());print(d['value'],d['ms_per_step'],d['config']['value_no_settle'],d['config']['collective'])" || tail -5 gpurun_out/r03/bench_T_one_rank_rccl.err
+timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_round3.py tests/test_gpu_configs.py tests/test_api_gpu.py tests/test_gpu_sparse_path.py -x -q -m gpu 2>&1 | tail -4
+for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold --config cfg3 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('cfg3',d['value'],d['ms_per_step'])"; done
+ACX_LIB=/root/repo/variants/libacx_sb1.so timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold --config cfg3 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('cfg3 before',d['value'],d['ms_per_step'])"
