@@ -105,7 +105,10 @@ struct Segments {
 // retry exactly).
 constexpr uint32_t TILE_BITS = 12;    // tile = 4 KiB of index space
 constexpr uint32_t HIT_SLOTS = 64;    // hit records per tile (HBM is 288 GB: half a byte of workspace per haystack byte)
-constexpr uint32_t GROUP_TILES = 64;  // tiles per workgroup of k_tile_main (256 KiB)
+#ifndef ACX_GROUP_TILES
+#define ACX_GROUP_TILES 64
+#endif
+constexpr uint32_t GROUP_TILES = ACX_GROUP_TILES;  // tiles per workgroup of k_tile_main (64: 256 KiB)
 constexpr uint32_t GROUP_MAX = 1024;  // reported matches per group
 constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group
 // Where a tile's hit count lives: the counts of the tiles ONE K1b wave scans (tile, tile + nw,

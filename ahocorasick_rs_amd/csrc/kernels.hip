@@ -1889,7 +1889,7 @@ constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 // occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
 constexpr uint32_t STAGE_SLOTS = 24;
-static_assert(GROUP_TILES == 64, "one wave owns the output buckets of a group");
+static_assert(GROUP_TILES <= 64, "one wave owns the output buckets of a group");
 static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit mask");
 // A staged occurrence is ONE 64-bit word (the group's LDS footprint decides how many groups a CU
 // works on at once, and the kernel is bound by the latency of its gathers, not by anything it
@@ -2110,7 +2110,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     }
     // ---- compact the reported occurrences of the 64 output buckets into the group's stretch
     if (t < 64) {
-        uint32_t incl = cnt, occ = bn[lb + t];
+        uint32_t incl = cnt, occ = t < GROUP_TILES ? bn[lb + t] : 0u;
         for (int o = 1; o < 64; o <<= 1) {
             const uint32_t v = __shfl_up(incl, o);
             if ((int)t >= o) incl += v;

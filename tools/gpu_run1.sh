@@ -1,5 +1,4 @@
 cd /root/repo
 export TMPDIR=/tmp
-timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_round3.py tests/test_gpu_configs.py tests/test_api_gpu.py tests/test_gpu_sparse_path.py -x -q -m gpu 2>&1 | tail -4
-for i in 1 2; do timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold --config cfg3 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('cfg3',d['value'],d['ms_per_step'])"; done
-ACX_LIB=/root/repo/variants/libacx_sb1.so timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold --config cfg3 | python -c "import json,sys;d=json.loads(sys.stdin.read());print('cfg3 before',d['value'],d['ms_per_step'])"
+TAG=_g bash tools/gpu_trace_ab.sh "" z g32t256 g32t192 g32t128 g48t256 z 2>&1 | grep -E "==|k1b_prefilter<|k_tile_main   |k_tile_write   "
+for v in z g32t256 g32t192 g48t256; do ACX_LIB=/root/repo/variants/libacx_$v.so timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold | python -c "import json,sys;d=json.loads(sys.stdin.read());print('$v',d['value'],d['ms_per_step'],d['config']['matches_total'])"; done
