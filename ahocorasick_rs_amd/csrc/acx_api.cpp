@@ -106,7 +106,7 @@ EventPool g_events;
 // were known): it waits in `deferred` until its event has fired.
 struct BufCache {
     struct Ent { void *p; size_t bytes; int dev; };
-    struct Deferred { void *p; int dev; hipEvent_t ev; };
+    struct Deferred { void *p; void *p2; int dev; hipEvent_t ev; }; // (p2: a second buffer behind the same event, or null)
     std::mutex mu;
     std::vector<Ent> free_list;
     std::vector<Deferred> deferred;
@@ -131,6 +131,7 @@ struct BufCache {
             if (hipEventQuery(deferred[i].ev) == hipErrorNotReady) { i++; continue; }
             g_events.put(deferred[i].dev, deferred[i].ev);
             release_locked(deferred[i].p, deferred[i].dev);
+            if (deferred[i].p2) release_locked(deferred[i].p2, deferred[i].dev);
             deferred.erase(deferred.begin() + i);
         }
     }
@@ -181,14 +182,16 @@ struct BufCache {
     }
     // ev != null: work that writes the buffer may still be running; ev fires when it is done
     // (ownership of the event passes to the cache)
-    void put(void *p, int dev, hipEvent_t ev = nullptr) {
+    void put(void *p, int dev, hipEvent_t ev = nullptr, void *p2 = nullptr) {
+        if (!p) { p = p2; p2 = nullptr; }
         if (!p) { g_events.put(dev, ev); return; }
         std::lock_guard<std::mutex> lk(mu);
         if (ev) {
-            if (hipEventQuery(ev) == hipErrorNotReady) { deferred.push_back({p, dev, ev}); return; }
+            if (hipEventQuery(ev) == hipErrorNotReady) { deferred.push_back({p, p2, dev, ev}); return; }
             g_events.put(dev, ev);
         }
         release_locked(p, dev);
+        if (p2) release_locked(p2, dev);
     }
 };
 BufCache g_bufs;
@@ -1667,15 +1670,9 @@ int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts) {
 void acx_free_result(acx_result_t *r) {
     if (!r) return;
     // the buffers may still be written by the call's last kernels: the cache holds them back until
-    // the event has fired (one event guards both buffers: the second waits for it here)
-    if (r->done && r->d_counts) {
-        DeviceScope ds(r->device);
-        (void)hipEventSynchronize(r->done);
-        g_events.put(r->device, r->done);
-        r->done = nullptr;
-    }
-    g_bufs.put(r->d_matches, r->device, r->done);
-    g_bufs.put(r->d_counts, r->device);
+    // the event has fired (one event guards both buffers; nobody waits here -- a batch caller that
+    // frees a result and starts the next call used to sit out the write kernel in this function)
+    g_bufs.put(r->d_matches, r->device, r->done, r->d_counts);
     delete r;
 }
 
