@@ -26,7 +26,7 @@ MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
 IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
 KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
 KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
-ABI_VERSION = 3  # ACX_VERSION of include/acx.h this binding was written against
+ABI_VERSION = 4  # ACX_VERSION of include/acx.h this binding was written against
 
 MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
 
@@ -56,7 +56,8 @@ class HostTables(ctypes.Structure):
                 ("n_prefix_keys", ctypes.c_uint32), ("n_prefix_lists", ctypes.c_uint32),
                 ("prefix_bitmap", ctypes.c_void_p),
                 ("dense", ctypes.c_uint32), ("first_child", ctypes.c_void_p), ("in_byte", ctypes.c_void_p),
-                ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p)]
+                ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p),
+                ("walk_t3b", ctypes.c_void_p), ("walk_t3r", ctypes.c_void_p), ("walk_grec", ctypes.c_void_p)]
 
 
 class Profile(ctypes.Structure):
@@ -231,6 +232,12 @@ class HostAutomaton:
                                  np.uint32).reshape(-1, 4)
         self.prefix_lists = view(t.prefix_lists, int(t.n_prefix_lists), np.uint32)
         self.prefix_bitmap = view(t.prefix_bitmap, (8 << int(t.prefix_table_log2)) // 32 if t.filter_q else 0, np.uint32)
+        # K1a's failureless walk (automata of at most 32 byte classes, else empty)
+        nc = int(t.n_classes)
+        self.n_classes = nc
+        self.walk_t3b = view(t.walk_t3b, 33 * 1024 if t.walk_t3b else 0, np.uint32)
+        self.walk_t3r = view(t.walk_t3r, 2 * nc ** 3 if t.walk_t3r else 0, np.uint32).reshape(-1, 2)
+        self.walk_grec = view(t.walk_grec, 4 * self.n_states if t.walk_grec else 0, np.uint32).reshape(-1, 4)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -1353,89 +1353,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
             for (uint32_t c = 0; c < NC; c++)
                 table16[(size_t)w * NC + c] = (uint16_t)walk_of[H.table[(size_t)walk_bfs[w] * S + c] & ID_MASK];
     }
-    // K1a's failureless form: trie records for every state, the first three levels as tables
-    std::vector<uint32_t> t3b, t3r, grec, tail_pid;
-    std::vector<uint8_t> tail_len;
-    if (H.n_classes <= 32 && H.n_patterns > 0) {
-        const uint32_t NS = H.n_states;
-        grec.assign((size_t)4 * NS, 0);
-        for (uint32_t s2 = 0; s2 < NS; s2++) {
-            uint32_t bm = 0;
-            for (uint32_t c = H.first_child[s2]; c < H.first_child[s2 + 1]; c++) bm |= 1u << H.classes[H.in_byte[c]];
-            grec[4 * (size_t)s2] = bm;
-            grec[4 * (size_t)s2 + 1] = H.first_child[s2] | ((H.sflags[s2] & 1u) ? GREC_OWN : 0u);
-            grec[4 * (size_t)s2 + 2] = H.own1[s2];
-        }
-        // tails: a node without a pattern of its own whose subtree is one chain of at most 8 edges that
-        // ends in a leaf with exactly one pattern (children have higher BFS ids: bottom-up in one pass)
-        {
-            std::vector<uint8_t> tl(NS, 0xFF);
-            std::vector<uint32_t> tp(NS, 0);
-            for (uint32_t s2 = NS; s2-- > 1;) {
-                const uint32_t c0 = H.first_child[s2], nc = H.first_child[s2 + 1] - c0;
-                const bool own = (H.sflags[s2] & 1u) != 0;
-                if (nc == 0 && own && H.own1[s2] != OWN1_MANY) { tl[s2] = 0; tp[s2] = H.own1[s2]; }
-                else if (nc == 1 && !own && tl[c0] < 8) { tl[s2] = (uint8_t)(tl[c0] + 1); tp[s2] = tp[c0]; }
-            }
-            tail_len.swap(tl); tail_pid.swap(tp);
-        }
-        // (a used byte is alone in its class, so the children of a node have distinct classes, ascending
-        // like their bytes: child = first child + the set bits below the class)
-        auto child = [&](uint32_t s2, uint32_t c) -> uint32_t {
-            const uint32_t bm = grec[4 * (size_t)s2];
-            if (!((bm >> c) & 1u)) return 0;
-            return H.first_child[s2] + (uint32_t)__builtin_popcount(bm & ((1u << c) - 1u));
-        };
-        t3r.assign(2 * 32768, 0);
-        for (uint32_t c0 = 0; c0 < H.n_classes; c0++)
-            for (uint32_t c1 = 0; c1 < H.n_classes; c1++)
-                for (uint32_t c2 = 0; c2 < H.n_classes; c2++) {
-                    const uint32_t idx = (c0 * H.n_classes + c1) * H.n_classes + c2;
-                    const uint32_t n1 = child(0, c0), n2 = n1 ? child(n1, c1) : 0, n3 = n2 ? child(n2, c2) : 0;
-                    const bool ends = (n1 && (H.sflags[n1] & 1u)) || (n2 && (H.sflags[n2] & 1u)) || (n3 && (H.sflags[n3] & 1u));
-                    t3r[2 * (size_t)idx] = n3 ? grec[4 * (size_t)n3] : 0u;
-                    t3r[2 * (size_t)idx + 1] = (n3 ? H.first_child[n3] : 0u) | (ends ? T3R_SHORT : 0u);
-                }
-        // level 1 of the scan works on symbols (the low five bits of a byte), not classes: no class
-        // lookup per byte, and automata with any class map share one kernel.  Every trie path of depth
-        // 3 ORs the symbols of its node's children into the entry of its symbol triple; a pattern that
-        // ends on the way makes every entry below it pass.
-        t3b.assign(K1A_T3B_WORDS, 0);
-        auto entry = [&](uint32_t s0, uint32_t s1, uint32_t s2) -> uint32_t & { return t3b[((s0 << 5) | s1) * 33 + s2]; };
-        for (uint32_t e1 = H.first_child[0]; e1 < H.first_child[1]; e1++) {
-            const uint32_t s0 = H.in_byte[e1] & 31u;
-            if (H.sflags[e1] & 1u) {
-                for (uint32_t s1 = 0; s1 < 32; s1++) for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
-                continue;
-            }
-            for (uint32_t e2 = H.first_child[e1]; e2 < H.first_child[e1 + 1]; e2++) {
-                const uint32_t s1 = H.in_byte[e2] & 31u;
-                if (H.sflags[e2] & 1u) {
-                    for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
-                    continue;
-                }
-                for (uint32_t e3 = H.first_child[e2]; e3 < H.first_child[e2 + 1]; e3++) {
-                    uint32_t bm = 0;
-                    if (H.sflags[e3] & 1u) bm = ~0u;
-                    for (uint32_t e4 = H.first_child[e3]; e4 < H.first_child[e3 + 1]; e4++) bm |= 1u << (H.in_byte[e4] & 31u);
-                    entry(s0, s1, H.in_byte[e3] & 31u) |= bm;
-                }
-            }
-        }
-        // (last: t3r above was filled from the plain records) the tail nodes' records
-        for (uint32_t s2 = 1; s2 < NS; s2++) {
-            if (tail_len[s2] == 0xFF) continue;
-            uint32_t by[2] = {0, 0};
-            for (uint32_t k = 0, n = s2; k < tail_len[s2]; k++) {
-                n = H.first_child[n];
-                by[k >> 2] |= (uint32_t)H.in_byte[n] << (8 * (k & 3));
-            }
-            grec[4 * (size_t)s2] = by[0];
-            grec[4 * (size_t)s2 + 1] = GREC_TAIL | ((uint32_t)tail_len[s2] << 24);
-            grec[4 * (size_t)s2 + 2] = tail_pid[s2];
-            grec[4 * (size_t)s2 + 3] = by[1];
-        }
-    }
+    // (K1a's failureless form -- walk_t3b / walk_t3r / walk_grec -- is part of the host compiler's output)
     int rc;
 #define UP(vec, field)                                                                   \
     if ((rc = upload(a, st, (vec).data(), (vec).size(), &D.field)) != ACX_OK) return destroy(rc);
@@ -1452,12 +1370,12 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     } else {
         D.table16 = nullptr; D.walk_bfs = nullptr;
     }
-    if (!t3b.empty()) {
-        UP(t3b, t3b)
+    if (!H.walk_t3b.empty()) {
+        UP(H.walk_t3b, t3b)
         const uint32_t *p2 = nullptr;
-        if ((rc = upload(a, st, t3r.data(), t3r.size(), &p2)) != ACX_OK) return destroy(rc);
+        if ((rc = upload(a, st, H.walk_t3r.data(), H.walk_t3r.size(), &p2)) != ACX_OK) return destroy(rc);
         D.t3r = reinterpret_cast<const uint2 *>(p2);
-        if ((rc = upload(a, st, grec.data(), grec.size(), &p2)) != ACX_OK) return destroy(rc);
+        if ((rc = upload(a, st, H.walk_grec.data(), H.walk_grec.size(), &p2)) != ACX_OK) return destroy(rc);
         D.grec = reinterpret_cast<const uint4 *>(p2);
     } else {
         D.t3b = nullptr; D.t3r = nullptr; D.grec = nullptr;
@@ -1553,6 +1471,9 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->dense = A.dense ? 1 : 0;
     out->first_child = A.first_child.data(); out->in_byte = A.in_byte.data();
     out->fail = A.fail.data(); out->state_flags = A.sflags.data();
+    out->walk_t3b = A.walk_t3b.empty() ? nullptr : A.walk_t3b.data();
+    out->walk_t3r = A.walk_t3r.empty() ? nullptr : A.walk_t3r.data();
+    out->walk_grec = A.walk_grec.empty() ? nullptr : A.walk_grec.data();
     out->own_off = A.own_off.data(); out->own_pid = A.own_pid.data();
     out->dlink = A.dlink.data(); out->level_start = A.level_start.data();
     out->pattern_len = A.plen.data(); out->rank = A.rank.data();

@@ -471,7 +471,98 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             if (hm != e) A.ptab[4 * (size_t)hm + 2] |= prefix_more_bit(hash_at[e]);
         }
     }
+    build_walk_tables(A);
     return std::string();
+}
+
+
+// K1a's failureless form (automata of at most 32 byte classes): trie records for every state
+// (walk_grec), the depth-3 node by class triple (walk_t3r), and level 1 of the scan: by the symbols
+// (low five bits) of three bytes, the symbols a fourth byte can have on a trie path (walk_t3b).
+void build_walk_tables(Automaton &A) {
+    A.walk_t3b.clear(); A.walk_t3r.clear(); A.walk_grec.clear();
+    if (A.n_classes > 32 || A.n_patterns == 0) return;
+    std::vector<uint32_t> &t3b = A.walk_t3b, &t3r = A.walk_t3r, &grec = A.walk_grec;
+    std::vector<uint32_t> tail_pid;
+    std::vector<uint8_t> tail_len;
+    const uint32_t NS = A.n_states;
+    grec.assign((size_t)4 * NS, 0);
+    for (uint32_t s2 = 0; s2 < NS; s2++) {
+        uint32_t bm = 0;
+        for (uint32_t c = A.first_child[s2]; c < A.first_child[s2 + 1]; c++) bm |= 1u << A.classes[A.in_byte[c]];
+        grec[4 * (size_t)s2] = bm;
+        grec[4 * (size_t)s2 + 1] = A.first_child[s2] | ((A.sflags[s2] & 1u) ? GREC_OWN : 0u);
+        grec[4 * (size_t)s2 + 2] = A.own1[s2];
+    }
+    // tails: a node without a pattern of its own whose subtree is one chain of at most 8 edges that
+    // ends in a leaf with exactly one pattern (children have higher BFS ids: bottom-up in one pass)
+    {
+        std::vector<uint8_t> tl(NS, 0xFF);
+        std::vector<uint32_t> tp(NS, 0);
+        for (uint32_t s2 = NS; s2-- > 1;) {
+            const uint32_t c0 = A.first_child[s2], nc = A.first_child[s2 + 1] - c0;
+            const bool own = (A.sflags[s2] & 1u) != 0;
+            if (nc == 0 && own && A.own1[s2] != OWN1_MANY) { tl[s2] = 0; tp[s2] = A.own1[s2]; }
+            else if (nc == 1 && !own && tl[c0] < 8) { tl[s2] = (uint8_t)(tl[c0] + 1); tp[s2] = tp[c0]; }
+        }
+        tail_len.swap(tl); tail_pid.swap(tp);
+    }
+    // (a used byte is alone in its class, so the children of a node have distinct classes, ascending
+    // like their bytes: child = first child + the set bits below the class)
+    auto child = [&](uint32_t s2, uint32_t c) -> uint32_t {
+        const uint32_t bm = grec[4 * (size_t)s2];
+        if (!((bm >> c) & 1u)) return 0;
+        return A.first_child[s2] + (uint32_t)__builtin_popcount(bm & ((1u << c) - 1u));
+    };
+    t3r.assign(2 * 32768, 0);
+    for (uint32_t c0 = 0; c0 < A.n_classes; c0++)
+        for (uint32_t c1 = 0; c1 < A.n_classes; c1++)
+            for (uint32_t c2 = 0; c2 < A.n_classes; c2++) {
+                const uint32_t idx = (c0 * A.n_classes + c1) * A.n_classes + c2;
+                const uint32_t n1 = child(0, c0), n2 = n1 ? child(n1, c1) : 0, n3 = n2 ? child(n2, c2) : 0;
+                const bool ends = (n1 && (A.sflags[n1] & 1u)) || (n2 && (A.sflags[n2] & 1u)) || (n3 && (A.sflags[n3] & 1u));
+                t3r[2 * (size_t)idx] = n3 ? grec[4 * (size_t)n3] : 0u;
+                t3r[2 * (size_t)idx + 1] = (n3 ? A.first_child[n3] : 0u) | (ends ? T3R_SHORT : 0u);
+            }
+    // level 1 of the scan works on symbols (the low five bits of a byte), not classes: no class
+    // lookup per byte, and automata with any class map share one kernel.  Every trie path of depth
+    // 3 ORs the symbols of its node's children into the entry of its symbol triple; a pattern that
+    // ends on the way makes every entry below it pass.
+    t3b.assign(K1A_T3B_WORDS, 0);
+    auto entry = [&](uint32_t s0, uint32_t s1, uint32_t s2) -> uint32_t & { return t3b[((s0 << 5) | s1) * 33 + s2]; };
+    for (uint32_t e1 = A.first_child[0]; e1 < A.first_child[1]; e1++) {
+        const uint32_t s0 = A.in_byte[e1] & 31u;
+        if (A.sflags[e1] & 1u) {
+            for (uint32_t s1 = 0; s1 < 32; s1++) for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
+            continue;
+        }
+        for (uint32_t e2 = A.first_child[e1]; e2 < A.first_child[e1 + 1]; e2++) {
+            const uint32_t s1 = A.in_byte[e2] & 31u;
+            if (A.sflags[e2] & 1u) {
+                for (uint32_t s2 = 0; s2 < 32; s2++) entry(s0, s1, s2) = ~0u;
+                continue;
+            }
+            for (uint32_t e3 = A.first_child[e2]; e3 < A.first_child[e2 + 1]; e3++) {
+                uint32_t bm = 0;
+                if (A.sflags[e3] & 1u) bm = ~0u;
+                for (uint32_t e4 = A.first_child[e3]; e4 < A.first_child[e3 + 1]; e4++) bm |= 1u << (A.in_byte[e4] & 31u);
+                entry(s0, s1, A.in_byte[e3] & 31u) |= bm;
+            }
+        }
+    }
+    // (last: t3r above was filled from the plain records) the tail nodes' records
+    for (uint32_t s2 = 1; s2 < NS; s2++) {
+        if (tail_len[s2] == 0xFF) continue;
+        uint32_t by[2] = {0, 0};
+        for (uint32_t k = 0, n = s2; k < tail_len[s2]; k++) {
+            n = A.first_child[n];
+            by[k >> 2] |= (uint32_t)A.in_byte[n] << (8 * (k & 3));
+        }
+        grec[4 * (size_t)s2] = by[0];
+        grec[4 * (size_t)s2 + 1] = GREC_TAIL | ((uint32_t)tail_len[s2] << 24);
+        grec[4 * (size_t)s2 + 2] = tail_pid[s2];
+        grec[4 * (size_t)s2 + 3] = by[1];
+    }
 }
 
 } // namespace acx

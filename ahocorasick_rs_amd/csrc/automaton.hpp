@@ -112,6 +112,16 @@ static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     return g;
 }
 
+// K1a's failureless walk: the records of the trie
+// entry of the symbols (s0, s1, s2) in walk_t3b: word ((s0 << 5 | s1) * 33 + s2) -- the odd stride puts the
+// sum of two symbols into the LDS bank (with a stride of 32 every position in front of a space met in ONE bank)
+constexpr uint32_t K1A_T3B_WORDS = 1024 * 33;
+constexpr uint32_t T3R_SHORT = 0x80000000u; // a pattern ends within the first three levels: walk from the root
+constexpr uint32_t GREC_OWN = 0x80000000u;  // a pattern ends exactly at this node
+// a node whose subtree is the rest of ONE pattern (no branch, no other pattern end on the way, at most 8
+// bytes): its record is {bytes 0..3, GREC_TAIL | n << 24, the pattern, bytes 4..7} -- compared, not walked
+constexpr uint32_t GREC_TAIL = 0x40000000u;
+
 struct Automaton {
     int match_kind = 0;
     uint64_t n_patterns = 0;
@@ -154,6 +164,10 @@ struct Automaton {
     std::vector<uint32_t> ptab;
     uint32_t ptab_log2 = 0;
     std::vector<uint32_t> pbits;       // 2^(ptab_log2 + 3) bits: prefix_bitmap_bit of every group's first Q2 bytes
+    // K1a's failureless walk (n_classes <= 32, else empty): see build_walk_tables()
+    std::vector<uint32_t> walk_t3b;    // K1A_T3B_WORDS: entry of the symbols (s0, s1, s2) = word ((s0 << 5 | s1) * 33 + s2)
+    std::vector<uint32_t> walk_t3r;    // n_classes^3 x {children bitmap, first child | T3R_SHORT}, stride n_classes
+    std::vector<uint32_t> walk_grec;   // n_states x 4: trie record or tail record
     // pattern bytes (kept for the synthetic text generator)
     std::vector<uint8_t> blob;
     std::vector<uint64_t> offsets;
@@ -165,5 +179,6 @@ struct Automaton {
 // (0: ACX_DENSE_LIMIT, default 256 MiB); the compressed form is always built.
 std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                     int match_kind, Automaton &out, int &code, uint64_t dense_limit = 0);
+void build_walk_tables(Automaton &A); // (called by compile)
 
 } // namespace acx

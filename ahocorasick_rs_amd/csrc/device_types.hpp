@@ -63,16 +63,9 @@ struct DevAutomaton {
                                  // that share their low five bits alias); the records below are exact
     const uint2 *t3r;            // {children bitmap, first child | T3R_SHORT} by class triple: the depth-3 node's record
     const uint4 *grec;           // n_states x {children bitmap, first child | GREC_OWN, own1, 0}: trie records
-                                 // (or a GREC_TAIL record, see below)
+                                 // (or a GREC_TAIL record: automaton.hpp)
 };
-// entry of the symbols (s0, s1, s2): word ((s0 << 5 | s1) * 33 + s2) -- the odd stride puts the sum of two
-// symbols into the LDS bank (with a stride of 32 every position in front of a space met in ONE bank)
-constexpr uint32_t K1A_T3B_WORDS = 1024 * 33;
-constexpr uint32_t T3R_SHORT = 0x80000000u; // a pattern ends within the first three levels: walk from the root
-constexpr uint32_t GREC_OWN = 0x80000000u;  // a pattern ends exactly at this node
-// a node whose subtree is the rest of ONE pattern (no branch, no other pattern end on the way, at most 8
-// bytes): its record is {bytes 0..3, GREC_TAIL | n << 24, the pattern, bytes 4..7} -- compared, not walked
-constexpr uint32_t GREC_TAIL = 0x40000000u;
+// (K1A_T3B_WORDS, T3R_SHORT, GREC_OWN, GREC_TAIL: automaton.hpp)
 
 // How the byte stream is cut into haystacks.
 struct Segments {

@@ -23,10 +23,11 @@
 extern "C" {
 #endif
 
-/* 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
+/* 4: acx_host_tables_t grew (walk_t3b / walk_t3r / walk_grec, round 3);
+ * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 3
+#define ACX_VERSION 4
 
 /* status codes */
 #define ACX_OK 0
@@ -168,6 +169,15 @@ typedef struct acx_host_tables {
     const uint8_t *in_byte;       /* n_states: byte on the edge into the state (children ascending)     */
     const uint32_t *fail;         /* n_states: failure link                                             */
     const uint8_t *state_flags;   /* n_states: bit 1 = reports something, bit 0 = ends a pattern itself */
+    /* K1a's failureless walk (n_classes <= 32, else NULL; layouts: csrc/automaton.hpp)                 */
+    const uint32_t *walk_t3b;     /* 33 792 words: by the symbols (low five bits) s0, s1, s2 of three bytes,
+                                     word ((s0 << 5 | s1) * 33 + s2): the symbols a fourth byte can have on a
+                                     trie path of depth 4; ~0: a pattern of <= 3 bytes ends on the path       */
+    const uint32_t *walk_t3r;     /* n_classes^3 x {children bitmap by class, first child | SHORT << 31}: the
+                                     depth-3 node of a class triple ((c0 * n_classes + c1) * n_classes + c2) */
+    const uint32_t *walk_grec;    /* n_states x 4: {children bitmap, first child | OWN << 31, own pattern, 0}
+                                     or a tail {bytes 0-3, 1 << 30 | n << 24, pattern, bytes 4-7}: the rest
+                                     of the only pattern below the node, n <= 8 bytes                         */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);

@@ -370,3 +370,84 @@ def test_no_cpu_fallback_without_a_device():
     assert "no HIP device" in str(e.value)
     with pytest.raises(Exception):
         capi.Automaton([b"hello"])
+
+
+def failureless_walk_occurrences(h, hay: bytes):
+    """Test-side twin of k1a_scan + k1a_walk over the host compiler's walk tables (NOT a product
+    path): level 1 on symbols, the depth-3 record by class triple, the depth-4 record (a tail is
+    compared, not walked), everything else walked from its node or from the root."""
+    OWN, TAIL, SHORT, MANY = 1 << 31, 1 << 30, 1 << 31, 0xFFFFFFFE
+    nc, n, out = h.n_classes, len(hay), []
+    cls = [int(c) for c in h.classes]
+
+    def emit_own(node, pos, d, own1):
+        if own1 == MANY:
+            for k in range(int(h.own_off[node]), int(h.own_off[node + 1])):
+                out.append((int(h.own_pid[k]), pos, pos + d))
+        else:
+            out.append((own1, pos, pos + d))
+
+    def walk(pos, node, d, first_rec=None):
+        while True:
+            r = [int(x) for x in (h.walk_grec[node] if first_rec is None else first_rec)]
+            first_rec = None
+            if r[1] & TAIL:
+                tn = (r[1] >> 24) & 15
+                tail = (r[0] | (r[3] << 32)).to_bytes(8, "little")[:tn]
+                if pos + d + tn <= n and hay[pos + d:pos + d + tn] == tail:
+                    out.append((r[2], pos, pos + d + tn))
+                return
+            if r[1] & OWN:
+                emit_own(node, pos, d, r[2])
+            if pos + d >= n:
+                return
+            c = cls[hay[pos + d]]
+            if not (r[0] >> c) & 1:
+                return
+            node = (r[1] & ID_MASK) + bin(r[0] & ((1 << c) - 1)).count("1")
+            d += 1
+
+    for pos in range(n):
+        if pos + 4 <= n:  # level 1: is there a trie path (or a short pattern) for the symbols of 4 bytes?
+            s = [b & 31 for b in hay[pos:pos + 4]]
+            if not (int(h.walk_t3b[((s[0] << 5) | s[1]) * 33 + s[2]]) >> s[3]) & 1:
+                continue
+        c = [cls[b] for b in hay[pos:pos + 5]] + [0] * 5
+        x, y = (int(v) for v in h.walk_t3r[(c[0] * nc + c[1]) * nc + c[2]]) if pos + 3 <= n else (0, SHORT)
+        if (y & SHORT) or pos + 5 > n:
+            walk(pos, 0, 0)
+            continue
+        if not (x >> c[3]) & 1:
+            continue
+        node = (y & ID_MASK) + bin(x & ((1 << c[3]) - 1)).count("1")
+        walk(pos, node, 4)
+    return out
+
+
+def test_failureless_walk_tables_enumerate_every_occurrence():
+    """walk_t3b (symbols: a superset test -- alphabets that alias in their low five bits), walk_t3r,
+    walk_grec with tail records; short patterns, nested patterns, duplicates; > 32 classes: no tables."""
+    rng = random.Random(11)
+    alphas = [b"ab", b"abc", b"abcdefgh", bytes(range(97, 123)) + b" ", b"aAbBcC!", bytes(range(40, 70))]
+    for it in range(240):
+        alpha = alphas[it % len(alphas)]
+        lo = rng.choice([1, 1, 2, 3, 4, 5])
+        pats = [bytes(rng.choice(alpha) for _ in range(rng.randint(lo, lo + rng.choice([0, 2, 6, 14]))))
+                for _ in range(rng.randint(1, 40))]
+        if it % 3 == 0:
+            pats += [pats[rng.randrange(len(pats))] for _ in range(3)]               # duplicates
+            pats += [pats[rng.randrange(len(pats))][:rng.randint(1, 5)] for _ in range(3)]  # prefixes of others
+        hay = bytearray(rng.choice(alpha) for _ in range(rng.randint(0, 400)))
+        for _ in range(6):  # planted occurrences, some cut by the end of the haystack
+            p = pats[rng.randrange(len(pats))]
+            at = rng.randint(0, max(len(hay) - 1, 0))
+            hay[at:at + len(p)] = p
+        hay = bytes(hay[:400])
+        h = capi.HostAutomaton(pats)
+        assert len(h.walk_t3b) == 33 * 1024 and len(h.walk_grec) == h.n_states
+        got = sorted(failureless_walk_occurrences(h, hay))
+        assert got == sorted(occurrences(pats, hay)), (it, pats[:5])
+        h.close()
+    h = capi.HostAutomaton([bytes([b]) * 3 for b in range(64)])  # 65 byte classes
+    assert len(h.walk_t3b) == 0 and len(h.walk_t3r) == 0 and len(h.walk_grec) == 0
+    h.close()
