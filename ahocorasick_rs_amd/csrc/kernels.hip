@@ -676,8 +676,11 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
     const uint4 pi = A.pinfo[pid];
     // patterns that can reach beyond the carried window: where the pattern's bytes lie, requested
     // together with its info (uniform branch; the bytes themselves together with the haystack's)
-    // (pinfo covers the first filter_q2 + 12 bytes of a pattern: anything longer has bytes to compare in place)
-    const bool far = A.max_len > A.filter_q2 + 12;
+    // (the carried window holds the haystack's first 16 bytes, pinfo the pattern's first filter_q2 + 12: a
+    // pattern that is longer than EITHER has bytes to compare in place.  Round 2 tested the window only --
+    // and let 14..16-byte patterns behind a short prefix through; the first fix of round 3 tested pinfo
+    // only -- and let 17..20-byte patterns behind an 8-byte prefix through: found by tools/gpu_fuzz.py)
+    const bool far = A.max_len > (A.filter_q2 + 12 < 16 ? A.filter_q2 + 12 : 16);
     const uint64_t po = far ? A.pat_off[pid] : 0;
     *rk = pi.x & 0xFFFFFFu;
     uint32_t L = pi.x >> 24;

@@ -31,12 +31,14 @@ def cols(a):
 
 
 @pytest.mark.parametrize("kernel", [None, capi.KERNEL_PREFILTER, capi.KERNEL_DFA_WALK])
-@pytest.mark.parametrize("min_len", [1, 2, 3])
-@pytest.mark.parametrize("max_len", [14, 15, 16, 17])
+@pytest.mark.parametrize("min_len", [1, 2, 3, 8, 12])
+@pytest.mark.parametrize("max_len", [14, 15, 16, 17, 18, 20, 21])
 def test_long_tail_bytes_are_verified(kernel, min_len, max_len):
-    """A pattern longer than filter_q2 + 12 bytes has bytes pinfo does not hold: near misses that
-    differ only in the last bytes must not be reported (round-2 regression: the in-place comparison
-    was gated on max_len > 16)."""
+    """A pattern has bytes to compare in place when it is longer than what pinfo holds (filter_q2 + 12
+    bytes) OR longer than the 16 haystack bytes that travel with a hit: near misses that differ only in
+    the last bytes must not be reported.  (Round 2 gated the comparison on max_len > 16 only: 14..16-byte
+    patterns behind a 1..3-byte prefix slipped through; round 3's first fix gated it on filter_q2 + 12
+    only: 17..20-byte patterns behind an 8-byte prefix did -- found by the fuzzer.)"""
     short = b"abcdefghijklmnopqrstuvwxyz"[:min_len]
     long_p = b"abcdefghijklmnopqrstuvwxyz"[:max_len]
     pats = [short, long_p]
@@ -237,4 +239,27 @@ def test_mixed_length_sets_leave_the_prefilter_for_the_failureless_walk(short):
         for ov in ([False, True] if mk == 0 else [False]):
             got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
             assert np.array_equal(got, want), (mk, ov, short)
+        a.close()
+
+
+def test_fuzz_case_long_tail_behind_an_eight_byte_prefix_dense_output():
+    """The case tools/gpu_fuzz.py (seed 424242) reported against round 3's first fix of the tail
+    gate: a 15- and a 20-byte pattern (filter_q2 = 8, pinfo covers 20 bytes, the carried window 16),
+    planted every few bytes so that truncated copies abound and the call takes the dense path: the
+    copies that differ from the 20-byte pattern in bytes 16..19 were reported."""
+    pats = [b"usrtgsyauibwlnq", b"pffthapvlcxzctugopqc"]
+    rng = np.random.default_rng(164)
+    hay = bytearray(rng.choice(np.frombuffer(gen.AZ + b" ", dtype=np.uint8), 42722).tobytes())
+    p = 0
+    while p < len(hay) - 32:
+        x = pats[int(rng.integers(0, 2))]
+        hay[p:p + len(x)] = x
+        p += int(rng.choice([9, 13, 17, 22]))
+    hay = bytes(hay)
+    for kernel in (None, capi.KERNEL_PREFILTER, capi.KERNEL_DFA_WALK):
+        a = capi.Automaton(pats, 0, kernel=kernel)
+        o = Oracle(pats, 0, KIND_DFA)
+        for ov in (False, True):
+            got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
+            assert len(want) > 300 and np.array_equal(got, want), (kernel, ov, len(got), len(want))
         a.close()
