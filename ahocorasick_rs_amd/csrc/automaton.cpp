@@ -9,6 +9,9 @@
 #include "automaton.hpp"
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <numeric>
@@ -17,6 +20,21 @@
 #include "../../include/acx.h"
 
 namespace acx {
+// ACX_BUILD_TIMES=1: the host compiler's phases on stderr
+struct PhaseClock {
+    bool on = std::getenv("ACX_BUILD_TIMES") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    const char *name = "start";
+    void next(const char *n) {
+        if (on) {
+            auto now = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "acx build: %-42s %8.1f ms\n", name, std::chrono::duration<double, std::milli>(now - t).count());
+            t = now;
+        }
+        name = n;
+    }
+};
+#define ACX_PHASE(N) phase_clock.next(N)
 
 namespace {
 
@@ -62,6 +80,7 @@ struct EdgeMap {
 
 std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                     int match_kind, Automaton &A, int &code, uint64_t dense_limit) {
+    PhaseClock phase_clock;
     code = ACX_OK;
     if (match_kind < 0 || match_kind > 2) { code = ACX_EINVAL; return "unknown match kind"; }
     if (n > (1ull << 24)) { code = ACX_ETOOBIG; return "more than 2^24 patterns"; }
@@ -86,6 +105,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     for (uint64_t i = 0; i <= n; i++) A.offsets[i] = n ? offsets[i] - offsets[0] : 0;
     const uint8_t *pb = A.blob.data();
 
+    ACX_PHASE("byte classes");
     // ---- byte classes
     {
         bool bound[256] = {false};
@@ -104,33 +124,95 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         while (A.stride < A.n_classes) { A.stride <<= 1; A.stride2++; }
     }
 
-    // ---- trie in creation order
-    EdgeMap em;
+    ACX_PHASE("trie: sort the patterns");
+    // ---- trie + BFS numbering in one go, from the patterns in lexicographic order.  The final numbering
+    // -- BFS, the children of a state by ascending byte -- lists the states of one depth in the
+    // lexicographic order of their paths, which is the order a walk over the SORTED patterns meets them
+    // in: a new state at depth d is simply the next id of its depth.  (Until round 3 the trie was built in
+    // creation order through a hash map of edges and renumbered by a queue: 1.9 of the 3.8 s of a 10^6-
+    // pattern set; now a sort, two linear passes over the pattern bytes, no hash map.)
+    unsigned hw_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("ACX_BUILD_THREADS")) hw_threads = (unsigned)std::max(1, std::atoi(e));
+    std::vector<uint32_t> sorted(n);
     {
-        uint64_t cap = 1024;
-        while (cap < total * 2 + 16) cap <<= 1;
-        em.init(cap);
-    }
-    std::vector<uint32_t> e_parent, e_child; // edge list, creation order
-    std::vector<uint8_t> e_byte;
-    e_parent.reserve(total); e_child.reserve(total); e_byte.reserve(total);
-    std::vector<uint32_t> term_node(n);
-    uint32_t n_nodes = 1;
-    for (uint64_t i = 0; i < n; i++) {
-        uint32_t cur = 0;
-        for (uint64_t k = A.offsets[i]; k < A.offsets[i + 1]; k++) {
-            uint64_t key = ((uint64_t)cur << 8) | pb[k];
-            uint32_t nx = em.find(key);
-            if (nx == NONE) {
-                if (n_nodes >= ID_MASK) { code = ACX_ETOOBIG; return "more than 2^30 states"; }
-                nx = n_nodes++;
-                em.insert(key, nx);
-                e_parent.push_back(cur); e_child.push_back(nx); e_byte.push_back(pb[k]);
-            }
-            cur = nx;
+        // bucket by first byte, the buckets sorted side by side
+        uint64_t bcnt[257] = {0};
+        for (uint64_t i = 0; i < n; i++) bcnt[pb[A.offsets[i]] + 1]++;
+        for (int b = 0; b < 256; b++) bcnt[b + 1] += bcnt[b];
+        {
+            uint64_t fill[256];
+            for (int b = 0; b < 256; b++) fill[b] = bcnt[b];
+            for (uint64_t i = 0; i < n; i++) sorted[fill[pb[A.offsets[i]]]++] = (uint32_t)i;
         }
-        term_node[i] = cur;
+        auto less = [&](uint32_t a, uint32_t b) {
+            const uint64_t la = A.offsets[a + 1] - A.offsets[a], lb = A.offsets[b + 1] - A.offsets[b];
+            const int c = std::memcmp(pb + A.offsets[a], pb + A.offsets[b], (size_t)std::min(la, lb));
+            if (c) return c < 0;
+            if (la != lb) return la < lb;
+            return a < b;
+        };
+        std::atomic<int> next_bucket{0};
+        auto work = [&]() {
+            for (int b; (b = next_bucket.fetch_add(1)) < 256;)
+                if (bcnt[b + 1] - bcnt[b] > 1) std::sort(sorted.begin() + bcnt[b], sorted.begin() + bcnt[b + 1], less);
+        };
+        if (n < 50000 || hw_threads == 1) {
+            work();
+        } else {
+            std::vector<std::thread> th;
+            for (unsigned t = 0; t < hw_threads; t++) th.emplace_back(work);
+            for (auto &t : th) t.join();
+        }
     }
+    ACX_PHASE("trie: prefixes, states per depth, ids");
+    // pass 1: the longest common prefix with the pattern in front, the states of every depth
+    std::vector<uint32_t> lcp(n, 0);
+    std::vector<uint64_t> per_depth((size_t)A.max_len + 2, 0);
+    per_depth[0] = 1;
+    for (uint64_t k = 0; k < n; k++) {
+        const uint32_t i = sorted[k];
+        const uint8_t *x = pb + A.offsets[i];
+        const uint64_t L = A.offsets[i + 1] - A.offsets[i];
+        uint64_t c = 0;
+        if (k) {
+            const uint32_t j = sorted[k - 1];
+            const uint8_t *y = pb + A.offsets[j];
+            const uint64_t Lj = A.offsets[j + 1] - A.offsets[j], m = std::min(L, Lj);
+            while (c < m && x[c] == y[c]) c++;
+        }
+        lcp[k] = (uint32_t)c;
+        for (uint64_t d = c + 1; d <= L; d++) per_depth[d]++;
+    }
+    uint64_t n_nodes64 = 0;
+    A.level_start.assign((size_t)A.max_len + 2, 0);
+    for (size_t d = 0; d <= (size_t)A.max_len; d++) { A.level_start[d] = (uint32_t)std::min<uint64_t>(n_nodes64, ID_MASK); n_nodes64 += per_depth[d]; }
+    if (n_nodes64 >= ID_MASK) { code = ACX_ETOOBIG; return "more than 2^30 states"; }
+    const uint32_t n_nodes = (uint32_t)n_nodes64;
+    A.level_start[(size_t)A.max_len + 1] = n_nodes;
+    // pass 2: ids, edge bytes, first children, the state every pattern ends in
+    std::vector<uint32_t> first_child(n_nodes + 1, NONE);
+    std::vector<uint8_t> in_byte(n_nodes, 0);
+    std::vector<uint32_t> term_node(n);
+    {
+        std::vector<uint32_t> next_id(A.level_start.begin(), A.level_start.end() - 1);
+        std::vector<uint32_t> path((size_t)A.max_len + 1, 0);
+        for (uint64_t k = 0; k < n; k++) {
+            const uint32_t i = sorted[k];
+            const uint8_t *x = pb + A.offsets[i];
+            const uint64_t L = A.offsets[i + 1] - A.offsets[i];
+            for (uint64_t d = (uint64_t)lcp[k] + 1; d <= L; d++) {
+                const uint32_t id = next_id[d]++;
+                in_byte[id] = x[d - 1];
+                if (first_child[path[d - 1]] == NONE) first_child[path[d - 1]] = id;
+                path[d] = id;
+            }
+            term_node[i] = path[L];
+        }
+        first_child[n_nodes] = n_nodes;
+        for (uint32_t s2 = n_nodes; s2-- > 0;)
+            if (first_child[s2] == NONE) first_child[s2] = first_child[s2 + 1]; // (no children: an empty range)
+    }
+    sorted = {}; lcp = {};
     // Leftmost kinds: of several identical patterns only the first can ever be reported (the
     // reference's tie-break: lowest index), so the later ones stay out of every table -- a set with
     // the same short pattern thousands of times would otherwise multiply the occurrences the device
@@ -146,59 +228,14 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     A.n_states = n_nodes;
     // (no limit on n_states * stride here: a dense table is built only below ACX_DENSE_LIMIT, the
     // compressed form -- 13 B per state -- serves every automaton of up to 2^30 states)
-    // children CSR by parent (creation ids), children sorted by byte
-    std::vector<uint32_t> c_off(n_nodes + 1, 0);
-    for (uint32_t p : e_parent) c_off[p + 1]++;
-    for (uint32_t i = 0; i < n_nodes; i++) c_off[i + 1] += c_off[i];
-    std::vector<uint32_t> c_edge(e_parent.size());
-    {
-        std::vector<uint32_t> fill(c_off.begin(), c_off.end() - 1);
-        for (uint32_t e = 0; e < e_parent.size(); e++) c_edge[fill[e_parent[e]]++] = e;
-        for (uint32_t p = 0; p < n_nodes; p++)
-            std::sort(c_edge.begin() + c_off[p], c_edge.begin() + c_off[p + 1],
-                      [&](uint32_t a, uint32_t b) { return e_byte[a] < e_byte[b]; });
-    }
-    // ---- BFS numbering
-    std::vector<uint32_t> order(n_nodes), newid(n_nodes);
-    std::vector<uint32_t> depth(n_nodes);
-    {
-        uint32_t qh = 0, qt = 0;
-        order[qt++] = 0; newid[0] = 0; depth[0] = 0;
-        while (qh < qt) {
-            uint32_t u = order[qh];
-            for (uint32_t k = c_off[u]; k < c_off[u + 1]; k++) {
-                uint32_t v = e_child[c_edge[k]];
-                newid[v] = qt; depth[qt] = depth[qh] + 1;
-                order[qt++] = v;
-            }
-            qh++;
-        }
-    }
-    A.level_start.assign((size_t)A.max_len + 2, n_nodes);
-    for (uint32_t s = n_nodes; s-- > 0;) A.level_start[depth[s]] = s;
-    // BFS-id children: first_child (contiguous) + bytes
-    std::vector<uint32_t> first_child(n_nodes + 1);
-    std::vector<uint8_t> in_byte(n_nodes, 0);
-    {
-        uint32_t next = 1;
-        for (uint32_t s = 0; s < n_nodes; s++) {
-            uint32_t u = order[s];
-            first_child[s] = next;
-            for (uint32_t k = c_off[u]; k < c_off[u + 1]; k++) {
-                in_byte[next] = e_byte[c_edge[k]];
-                next++;
-            }
-        }
-        first_child[n_nodes] = next;
-    }
     // own lists (stable: pattern id order)
     A.own_off.assign((size_t)n_nodes + 1, 0);
-    for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_off[newid[term_node[i]] + 1]++;
+    for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_off[term_node[i] + 1]++;
     for (uint32_t s = 0; s < n_nodes; s++) A.own_off[s + 1] += A.own_off[s];
     A.own_pid.assign(n, 0); // (n entries whatever is filed: the C ABI's view has this size)
     {
         std::vector<uint32_t> fill(A.own_off.begin(), A.own_off.end() - 1);
-        for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_pid[fill[newid[term_node[i]]]++] = (uint32_t)i;
+        for (uint64_t i = 0; i < n; i++) if (!dup[i]) A.own_pid[fill[term_node[i]]++] = (uint32_t)i;
     }
     A.own1.assign(n_nodes, OWN1_NONE);
     for (uint32_t s = 0; s < n_nodes; s++) {
@@ -206,10 +243,9 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         if (c == 1) A.own1[s] = A.own_pid[A.own_off[s]];
         else if (c > 1) A.own1[s] = OWN1_MANY;
     }
-    // free construction scratch early (large automata)
-    em = EdgeMap(); e_parent = {}; e_child = {}; e_byte = {}; c_off = {}; c_edge = {};
-    order = {}; newid = {}; term_node = {};
+    term_node = {};
 
+    ACX_PHASE("failure links (classic construction on t");
     // ---- failure links (classic construction on the trie: children of s are the consecutive BFS
     // ids [first_child[s], first_child[s + 1]), bytes ascending)
     auto child_of = [&](uint32_t s, uint8_t b) -> uint32_t {
@@ -221,18 +257,31 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         return lo < first_child[s + 1] && in_byte[lo] == b ? lo : 0u;
     };
     std::vector<uint32_t> fail(n_nodes, 0);
-    for (uint32_t s = 1; s < n_nodes; s++) { // BFS order: fail[s] is final when s is reached
-        for (uint32_t c = first_child[s]; c < first_child[s + 1]; c++) {
-            const uint8_t b = in_byte[c];
-            uint32_t f = fail[s];
-            for (;;) {
-                const uint32_t x = child_of(f, b);
-                if (x) { fail[c] = x; break; }
-                if (f == 0) { fail[c] = 0; break; }
-                f = fail[f];
+    // level by level: the links of a level's children only need the links of the levels above
+    // (a level of a large automaton is cut into ranges for up to 16 threads)
+    auto links_of = [&](uint32_t lo_s, uint32_t hi_s) {
+        for (uint32_t s = lo_s; s < hi_s; s++) {
+            for (uint32_t c = first_child[s]; c < first_child[s + 1]; c++) {
+                const uint8_t b = in_byte[c];
+                uint32_t f = fail[s];
+                for (;;) {
+                    const uint32_t x = child_of(f, b);
+                    if (x) { fail[c] = x; break; }
+                    if (f == 0) { fail[c] = 0; break; }
+                    f = fail[f];
+                }
             }
         }
+    };
+    for (size_t d = 1; d + 1 < A.level_start.size(); d++) { // (the root's children keep 0)
+        const uint32_t lo_s = A.level_start[d], hi_s = A.level_start[d + 1];
+        if (hi_s - lo_s < 65536 || hw_threads == 1) { links_of(lo_s, hi_s); continue; }
+        std::vector<std::thread> th;
+        const uint32_t step = (hi_s - lo_s + hw_threads - 1) / hw_threads;
+        for (uint32_t a0 = lo_s; a0 < hi_s; a0 += step) th.emplace_back(links_of, a0, std::min(hi_s, a0 + step));
+        for (auto &t : th) t.join();
     }
+    ACX_PHASE("dictionary suffix links and output flags");
     // ---- dictionary suffix links and output flags
     A.dlink.assign(n_nodes, NONE);
     std::vector<uint32_t> flags(n_nodes, 0);
@@ -244,6 +293,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         if (own) flags[s] |= FLAG_OWN | FLAG_OUT;
         if (A.dlink[s] != NONE) flags[s] |= FLAG_OUT;
     }
+    ACX_PHASE("the compressed form (always): trie edges");
     // ---- the compressed form (always): trie edges + failure links -- "NFA" rows of a few bytes per
     // state.  K0's anchored walk and the failure-link walk (K1a on automata without a dense table)
     // run on it; K1b needs neither form.
@@ -251,6 +301,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     for (uint32_t c = first_child[0]; c < first_child[1]; c++) A.root_next[in_byte[c]] = c;
     A.sflags.resize(n_nodes);
     for (uint32_t s = 0; s < n_nodes; s++) A.sflags[s] = (uint8_t)(flags[s] >> 30);
+    ACX_PHASE("the dense form: only while it is worth i");
     // ---- the dense form: only while it is worth its memory (the crate's own rule of thumb: a DFA
     // for small sets, an NFA beyond -- /root/reference/README.md:173-177).  One row per state, built
     // level by level: a row is its failure state's row (one level up at least) + its own edges, so
@@ -298,16 +349,27 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     A.in_byte = in_byte;
     A.fail = fail;
 
+    ACX_PHASE("tie-break rank (len desc, pid asc)");
     // ---- tie-break rank (len desc, pid asc)
     {
-        std::vector<uint32_t> idx(n);
-        std::iota(idx.begin(), idx.end(), 0u);
-        std::stable_sort(idx.begin(), idx.end(),
-                         [&](uint32_t a, uint32_t b) { return A.plen[a] > A.plen[b]; });
+        // (a counting sort over the lengths: longest first, pattern ids ascending within a length)
         A.rank.resize(n);
-        for (uint32_t r = 0; r < n; r++) A.rank[idx[r]] = r;
+        if (A.max_len <= (1u << 20)) {
+            std::vector<uint64_t> at((size_t)A.max_len + 2, 0);
+            for (uint64_t i = 0; i < n; i++) at[A.plen[i]]++;
+            uint64_t run = 0;
+            for (size_t L = (size_t)A.max_len + 1; L-- > 0;) { const uint64_t c = at[L]; at[L] = run; run += c; }
+            for (uint64_t i = 0; i < n; i++) A.rank[i] = (uint32_t)at[A.plen[i]]++;
+        } else {
+            std::vector<uint32_t> idx(n);
+            std::iota(idx.begin(), idx.end(), 0u);
+            std::stable_sort(idx.begin(), idx.end(),
+                             [&](uint32_t a, uint32_t b) { return A.plen[a] > A.plen[b]; });
+            for (uint32_t r = 0; r < n; r++) A.rank[idx[r]] = r;
+        }
     }
 
+    ACX_PHASE("K1b prefilter tables");
     // ---- K1b prefilter tables
     A.filter_q = 0; A.filter_q2 = 0;
     if (n > 0) {
@@ -348,10 +410,13 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         std::vector<uint32_t> by_g1; // (without the identical later copies of a pattern: leftmost kinds)
         by_g1.reserve(n);
         for (uint64_t i = 0; i < n; i++) if (!dup[i]) by_g1.push_back((uint32_t)i);
-        std::stable_sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] < g1[b]; });
+        // (sorted by (first Q2 bytes, pattern id); every group then in place by (key bytes, pattern id): the
+        // patterns of a key are a stretch of by_g1 in id order -- no vector per group or per key)
+        std::sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] != g1[b] ? g1[a] < g1[b] : a < b; });
         const size_t n_filed = by_g1.size();
-        struct Key { uint64_t gram; uint32_t K, next, salt; std::vector<uint32_t> pids; };
+        struct Key { uint64_t gram; uint32_t K, next, salt; uint32_t pid0, npid; }; // patterns: by_g1[pid0 .. pid0 + npid)
         std::vector<Key> keys;
+        keys.reserve(n_filed + n_filed / 8);
         for (size_t b = 0; b < n_filed;) {
             size_t e = b;
             uint32_t Lg = FILTER2_MAX_Q;
@@ -359,20 +424,21 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                 Lg = std::min<uint32_t>(Lg, std::min<uint32_t>(A.plen[by_g1[e]], FILTER2_MAX_Q));
                 e++;
             }
-            std::vector<uint32_t> sub(by_g1.begin() + b, by_g1.begin() + e);
-            std::stable_sort(sub.begin(), sub.end(), [&](uint32_t x, uint32_t y) {
-                return gram_of(pb + A.offsets[x], Lg) < gram_of(pb + A.offsets[y], Lg);
-            });
+            if (e - b > 1)
+                std::sort(by_g1.begin() + b, by_g1.begin() + e, [&](uint32_t x, uint32_t y) {
+                    const uint64_t gx = gram_of(pb + A.offsets[x], Lg), gy = gram_of(pb + A.offsets[y], Lg);
+                    return gx != gy ? gx < gy : x < y;
+                });
             const size_t first_key = keys.size();
-            for (size_t j = 0; j < sub.size();) {
-                const uint64_t g2 = gram_of(pb + A.offsets[sub[j]], Lg);
-                Key k{g2, Lg, 0, Q2, {}};
-                while (j < sub.size() && gram_of(pb + A.offsets[sub[j]], Lg) == g2) k.pids.push_back(sub[j++]);
-                keys.push_back(std::move(k));
+            for (size_t j = b; j < e;) {
+                const uint64_t g2 = gram_of(pb + A.offsets[by_g1[j]], Lg);
+                Key k{g2, Lg, 0, Q2, (uint32_t)j, 0};
+                while (j < e && gram_of(pb + A.offsets[by_g1[j]], Lg) == g2) { k.npid++; j++; }
+                keys.push_back(k);
             }
             if (keys.size() - first_key > 1) { // several keys: redirect from the Q2 bytes to the keys' own hash
                 for (size_t k = first_key; k < keys.size(); k++) keys[k].salt = Lg;
-                keys.push_back(Key{g1[by_g1[b]], Q2, Lg, Q2, {}});
+                keys.push_back(Key{g1[by_g1[b]], Q2, Lg, Q2, 0, 0});
             }
             b = e;
         }
@@ -431,20 +497,17 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // looks the entry up, so it must sit in its home slot (a displaced one would turn all of
         // them into HIT_RETRY traffic); then the single keys of the other groups, then the keys
         // behind the redirects.
-        std::stable_sort(keys.begin(), keys.end(), [&](const Key &a, const Key &b) {
-            auto cls = [&](const Key &k) { return k.next ? 0 : (k.salt == Q2 ? 1 : 2); };
-            return cls(a) < cls(b);
-        });
+        for (int pass = 0; pass < 3; pass++)
         for (Key &k : keys) {
+            if ((k.next ? 0 : (k.salt == Q2 ? 1 : 2)) != pass) continue;
             uint32_t code = 0;
-            if (k.next == 0) {
-                std::sort(k.pids.begin(), k.pids.end()); // pattern id order inside every list
-                if (k.pids.size() == 1) {
-                    code = k.pids[0];
+            if (k.next == 0) { // (the patterns of a key are in id order)
+                if (k.npid == 1) {
+                    code = by_g1[k.pid0];
                 } else {
                     code = 0x80000000u | (uint32_t)A.blist.size();
-                    A.blist.push_back((uint32_t)k.pids.size());
-                    A.blist.insert(A.blist.end(), k.pids.begin(), k.pids.end());
+                    A.blist.push_back(k.npid);
+                    A.blist.insert(A.blist.end(), by_g1.begin() + k.pid0, by_g1.begin() + k.pid0 + k.npid);
                 }
             }
             const uint32_t h = hash_of(k.gram, k.salt);
@@ -471,7 +534,9 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             if (hm != e) A.ptab[4 * (size_t)hm + 2] |= prefix_more_bit(hash_at[e]);
         }
     }
+    ACX_PHASE("walk tables");
     build_walk_tables(A);
+    ACX_PHASE("end");
     return std::string();
 }
 
