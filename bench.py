@@ -691,7 +691,7 @@ def cpu_baseline(w, gpu_matches, sample_bytes):
         one = (lambda: o.find_raw(sample, overlapping=True)) if ov else (lambda: o.count(sample))
         med1, ts1 = median_time(one)
         # (64 threads: measured on the 256-core box of round 3 -- 64 / 128 / 256 threads: 1.80 / 1.96 / 1.85 GB/s,
-        # the leg is bound by the merge of the ranges' results, not by cores; ACX_CPU_BASELINE_THREADS overrides)
+        # the leg does not scale beyond that on this host; ACX_CPU_BASELINE_THREADS overrides)
         threads = max(1, min(ncpu, int(os.environ.get("ACX_CPU_BASELINE_THREADS", "64"))))
         medn, tsn = median_time(lambda: oracle_all_cores(o, host, max_len, threads, ov), warm=1, runs=3)
         full = oracle_all_cores(o, host, max_len, threads, ov)
