@@ -66,7 +66,7 @@ def parse_args(argv=None):
                          "after a cold start; 0: none); reported as config.settle_ms")
     ap.add_argument("--ablate", default="", help="measurement only: override the configuration's match kind / "
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
-    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx"], default="auto",
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx", "cfg2b"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U", "Z", "D"], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
@@ -136,6 +136,11 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
     w = {"cfg": cfg, "overlapping": False, "codepoints": False, "n_hay": 0, "uniform_len": 0}
     if cfg in ("cfg2", "cfg3"):
         pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+        w["mk"], impl = capi.MATCH_STANDARD, capi.IMPL_DFA
+    elif cfg == "cfg2b":
+        # SURVEY 8(d)'s stress variant (B) of cfg2: 10 000 patterns over all byte values (seed 2: 74 579 states,
+        # a 72.8 MiB dense table with Implementation.DFA) over iid-uniform bytes
+        pats = gen.gen_patterns(10000, 5, 12, gen.ALL_BYTES, 2)
         w["mk"], impl = capi.MATCH_STANDARD, capi.IMPL_DFA
     elif cfg in ("mixed", "mixedx"):
         # cfg2's set plus a 2-byte and a 1-byte pattern (mixed lengths: K1b cannot take the set).  mixed: the
@@ -231,6 +236,11 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             ac.generate(hay.data_ptr(), nbytes, 0, 12)
             w["desc"] = (f"cfg4: 100k patterns a-z len 5-12 (seed 3), implementation=None, overlapping=True, one "
                          f"{nbytes / GIB:g} GiB uniform a-z haystack (seed 12)")
+        elif cfg == "cfg2b":
+            host = gen.gen_uniform(nbytes, gen.ALL_BYTES, 12)
+            hay = torch.from_numpy(host).to(dev)
+            w["desc"] = (f"cfg2b (stress variant B of cfg2): 10k patterns over all byte values len 5-12 (seed 2), "
+                         f"Implementation.DFA, MatchKind.Standard, one {nbytes / GIB:g} GiB uniform-bytes haystack (seed 12)")
         else:
             host = gen.gen_uniform(nbytes, gen.ALL_BYTES, 12)
             hay = torch.from_numpy(host).to(dev)

@@ -17,7 +17,7 @@ if [ "$PART" = all ] || [ "$PART" = bench ]; then
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_T.json 2> $OUT/bench_T.err
 timeout 300 python bench.py --dist U --no-cpu-baseline > $OUT/bench_U.json 2> $OUT/bench_U.err
 timeout 300 python bench.py --config cfg3 --no-cpu-baseline > $OUT/bench_cfg3_shape_n1.json 2> $OUT/bench_cfg3.err
-for cfg in cfg4 cfg4b cfg5; do
+for cfg in cfg4 cfg4b cfg5 cfg2b; do
   timeout 900 python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
 done
 timeout 900 python bench.py --config large --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_large_1M_patterns.json 2> $OUT/bench_large.err
