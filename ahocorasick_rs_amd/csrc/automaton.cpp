@@ -36,6 +36,21 @@ struct PhaseClock {
 };
 #define ACX_PHASE(N) phase_clock.next(N)
 
+static unsigned build_threads() {
+    unsigned t = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    if (const char *e = std::getenv("ACX_BUILD_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+    return t;
+}
+// fn(lo, hi, thread index) over [0, n) cut into one contiguous range per thread (small n: one call)
+template <typename F> static void parallel_ranges(uint64_t n, unsigned threads, F fn) {
+    if (n < 65536 || threads <= 1) { fn((uint64_t)0, n, 0u); return; }
+    std::vector<std::thread> th;
+    const uint64_t step = (n + threads - 1) / threads;
+    unsigned k = 0;
+    for (uint64_t a0 = 0; a0 < n; a0 += step, k++) th.emplace_back(fn, a0, std::min(n, a0 + step), k);
+    for (auto &t : th) t.join();
+}
+
 namespace {
 
 // open-addressing map (parent << 8 | byte) -> child, for trie construction
@@ -131,8 +146,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     // in: a new state at depth d is simply the next id of its depth.  (Until round 3 the trie was built in
     // creation order through a hash map of edges and renumbered by a queue: 1.9 of the 3.8 s of a 10^6-
     // pattern set; now a sort, two linear passes over the pattern bytes, no hash map.)
-    unsigned hw_threads = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (const char *e = std::getenv("ACX_BUILD_THREADS")) hw_threads = (unsigned)std::max(1, std::atoi(e));
+    const unsigned hw_threads = build_threads();
     std::vector<uint32_t> sorted(n);
     {
         // bucket by first byte, the buckets sorted side by side
@@ -169,19 +183,32 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     std::vector<uint32_t> lcp(n, 0);
     std::vector<uint64_t> per_depth((size_t)A.max_len + 2, 0);
     per_depth[0] = 1;
-    for (uint64_t k = 0; k < n; k++) {
-        const uint32_t i = sorted[k];
-        const uint8_t *x = pb + A.offsets[i];
-        const uint64_t L = A.offsets[i + 1] - A.offsets[i];
-        uint64_t c = 0;
-        if (k) {
-            const uint32_t j = sorted[k - 1];
-            const uint8_t *y = pb + A.offsets[j];
-            const uint64_t Lj = A.offsets[j + 1] - A.offsets[j], m = std::min(L, Lj);
-            while (c < m && x[c] == y[c]) c++;
-        }
-        lcp[k] = (uint32_t)c;
-        for (uint64_t d = c + 1; d <= L; d++) per_depth[d]++;
+    {
+        std::vector<std::vector<uint64_t>> part(hw_threads, std::vector<uint64_t>((size_t)A.max_len + 2, 0));
+        parallel_ranges(n, hw_threads, [&](uint64_t k0, uint64_t k1, unsigned t) {
+            std::vector<uint64_t> &pd = part[t];
+            for (uint64_t k = k0; k < k1; k++) {
+                const uint32_t i = sorted[k];
+                const uint8_t *x = pb + A.offsets[i];
+                const uint64_t L = A.offsets[i + 1] - A.offsets[i];
+                uint64_t c = 0;
+                if (k) {
+                    const uint32_t j = sorted[k - 1];
+                    const uint8_t *y = pb + A.offsets[j];
+                    const uint64_t Lj = A.offsets[j + 1] - A.offsets[j], m = std::min(L, Lj);
+                    while (c < m && x[c] == y[c]) c++;
+                }
+                lcp[k] = (uint32_t)c;
+                // (states c + 1 .. L are new: as a difference, summed up below)
+                pd[c + 1]++;
+                pd[L + 1]--;
+            }
+        });
+        std::vector<int64_t> diff((size_t)A.max_len + 3, 0);
+        for (auto &pd : part)
+            for (size_t d = 0; d < pd.size(); d++) diff[d] += (int64_t)pd[d];
+        int64_t run = 0;
+        for (size_t d = 1; d <= (size_t)A.max_len; d++) { run += diff[d]; per_depth[d] = (uint64_t)run; }
     }
     uint64_t n_nodes64 = 0;
     A.level_start.assign((size_t)A.max_len + 2, 0);
@@ -551,24 +578,32 @@ void build_walk_tables(Automaton &A) {
     std::vector<uint32_t> tail_pid;
     std::vector<uint8_t> tail_len;
     const uint32_t NS = A.n_states;
+    const unsigned threads = build_threads();
     grec.assign((size_t)4 * NS, 0);
-    for (uint32_t s2 = 0; s2 < NS; s2++) {
-        uint32_t bm = 0;
-        for (uint32_t c = A.first_child[s2]; c < A.first_child[s2 + 1]; c++) bm |= 1u << A.classes[A.in_byte[c]];
-        grec[4 * (size_t)s2] = bm;
-        grec[4 * (size_t)s2 + 1] = A.first_child[s2] | ((A.sflags[s2] & 1u) ? GREC_OWN : 0u);
-        grec[4 * (size_t)s2 + 2] = A.own1[s2];
-    }
+    parallel_ranges(NS, threads, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t s2 = lo; s2 < hi; s2++) {
+            uint32_t bm = 0;
+            for (uint32_t c = A.first_child[s2]; c < A.first_child[s2 + 1]; c++) bm |= 1u << A.classes[A.in_byte[c]];
+            grec[4 * (size_t)s2] = bm;
+            grec[4 * (size_t)s2 + 1] = A.first_child[s2] | ((A.sflags[s2] & 1u) ? GREC_OWN : 0u);
+            grec[4 * (size_t)s2 + 2] = A.own1[s2];
+        }
+    });
     // tails: a node without a pattern of its own whose subtree is one chain of at most 8 edges that
-    // ends in a leaf with exactly one pattern (children have higher BFS ids: bottom-up in one pass)
+    // ends in a leaf with exactly one pattern (a node's child lies one level down: bottom-up, level by level)
     {
         std::vector<uint8_t> tl(NS, 0xFF);
         std::vector<uint32_t> tp(NS, 0);
-        for (uint32_t s2 = NS; s2-- > 1;) {
-            const uint32_t c0 = A.first_child[s2], nc = A.first_child[s2 + 1] - c0;
-            const bool own = (A.sflags[s2] & 1u) != 0;
-            if (nc == 0 && own && A.own1[s2] != OWN1_MANY) { tl[s2] = 0; tp[s2] = A.own1[s2]; }
-            else if (nc == 1 && !own && tl[c0] < 8) { tl[s2] = (uint8_t)(tl[c0] + 1); tp[s2] = tp[c0]; }
+        for (size_t d = A.level_start.size() - 1; d-- > 1;) {
+            const uint32_t l0 = A.level_start[d], l1 = A.level_start[d + 1];
+            parallel_ranges(l1 - l0, threads, [&](uint64_t lo, uint64_t hi, unsigned) {
+                for (uint64_t s2 = l0 + lo; s2 < l0 + hi; s2++) {
+                    const uint32_t c0 = A.first_child[s2], nc = A.first_child[s2 + 1] - c0;
+                    const bool own = (A.sflags[s2] & 1u) != 0;
+                    if (nc == 0 && own && A.own1[s2] != OWN1_MANY) { tl[s2] = 0; tp[s2] = A.own1[s2]; }
+                    else if (nc == 1 && !own && tl[c0] < 8) { tl[s2] = (uint8_t)(tl[c0] + 1); tp[s2] = tp[c0]; }
+                }
+            });
         }
         tail_len.swap(tl); tail_pid.swap(tp);
     }
@@ -616,18 +651,20 @@ void build_walk_tables(Automaton &A) {
         }
     }
     // (last: t3r above was filled from the plain records) the tail nodes' records
-    for (uint32_t s2 = 1; s2 < NS; s2++) {
-        if (tail_len[s2] == 0xFF) continue;
-        uint32_t by[2] = {0, 0};
-        for (uint32_t k = 0, n = s2; k < tail_len[s2]; k++) {
-            n = A.first_child[n];
-            by[k >> 2] |= (uint32_t)A.in_byte[n] << (8 * (k & 3));
+    parallel_ranges(NS, threads, [&](uint64_t lo, uint64_t hi, unsigned) {
+        for (uint64_t s2 = std::max<uint64_t>(lo, 1); s2 < hi; s2++) {
+            if (tail_len[s2] == 0xFF) continue;
+            uint32_t by[2] = {0, 0};
+            for (uint32_t k = 0, n = (uint32_t)s2; k < tail_len[s2]; k++) {
+                n = A.first_child[n];
+                by[k >> 2] |= (uint32_t)A.in_byte[n] << (8 * (k & 3));
+            }
+            grec[4 * (size_t)s2] = by[0];
+            grec[4 * (size_t)s2 + 1] = GREC_TAIL | ((uint32_t)tail_len[s2] << 24);
+            grec[4 * (size_t)s2 + 2] = tail_pid[s2];
+            grec[4 * (size_t)s2 + 3] = by[1];
         }
-        grec[4 * (size_t)s2] = by[0];
-        grec[4 * (size_t)s2 + 1] = GREC_TAIL | ((uint32_t)tail_len[s2] << 24);
-        grec[4 * (size_t)s2 + 2] = tail_pid[s2];
-        grec[4 * (size_t)s2 + 3] = by[1];
-    }
+    });
 }
 
 } // namespace acx
