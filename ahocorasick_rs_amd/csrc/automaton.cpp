@@ -439,7 +439,13 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (uint64_t i = 0; i < n; i++) if (!dup[i]) by_g1.push_back((uint32_t)i);
         // (sorted by (first Q2 bytes, pattern id); every group then in place by (key bytes, pattern id): the
         // patterns of a key are a stretch of by_g1 in id order -- no vector per group or per key)
-        std::sort(by_g1.begin(), by_g1.end(), [&](uint32_t a, uint32_t b) { return g1[a] != g1[b] ? g1[a] < g1[b] : a < b; });
+        {   // (pairs sorted in place: no lookup of g1[] per comparison)
+            struct GI { uint64_t g; uint32_t id; };
+            std::vector<GI> gi(by_g1.size());
+            for (size_t k = 0; k < by_g1.size(); k++) gi[k] = GI{g1[by_g1[k]], by_g1[k]};
+            std::sort(gi.begin(), gi.end(), [](const GI &a, const GI &b) { return a.g != b.g ? a.g < b.g : a.id < b.id; });
+            for (size_t k = 0; k < by_g1.size(); k++) by_g1[k] = gi[k].id;
+        }
         const size_t n_filed = by_g1.size();
         struct Key { uint64_t gram; uint32_t K, next, salt; uint32_t pid0, npid; }; // patterns: by_g1[pid0 .. pid0 + npid)
         std::vector<Key> keys;
