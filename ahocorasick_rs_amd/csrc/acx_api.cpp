@@ -768,7 +768,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk) instead of the
     // chunked one (ACX_NO_PFAC: always the chunked walk -- measurements)
     static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
-    const bool pfac = !c.pre && pfac_available(a->dev) && !no_pfac;
+    const bool pfac = !c.pre && pfac_available(a->dev, a->max_lds) && !no_pfac;
     const uint32_t pgrid = pfac ? pfac_scan_grid(c.d_hay, c.len, a->n_cus) : 0;
     // hit counts: contiguous per wave of the scan (K1b, k1a_scan); the chunked walk: plain per-tile
     // arrival counters
@@ -894,7 +894,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
     // K1a: the failureless walk here too (one occurrence region per block of k1a_walk); the chunked walk
     // when the automaton has none, or when its items did not fit
     static const bool no_pfac = std::getenv("ACX_NO_PFAC") != nullptr;
-    const bool pfac = !c.pre && pfac_available(a->dev) && !no_pfac && !c.chunked_walk;
+    const bool pfac = !c.pre && pfac_available(a->dev, a->max_lds) && !no_pfac && !c.chunked_walk;
     const uint32_t pgrid = pfac ? pfac_scan_grid(c.d_hay, c.len, a->n_cus) : 0;
     if (pfac && (rc = ensure_hits(x, (pfac_workspace_words(c.len, pgrid, true) + 3) / 4)) != ACX_OK) return rc;
     const uint32_t grid = c.pre ? walk_hits_grid(hit_grid) : pfac ? pgrid * 16 : c.scan_grid; // occurrence regions
@@ -1105,6 +1105,11 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
         }
         if (len > 0 && a->host.n_patterns > 0) {
             int rc = run_pipeline(c);
+            if (rc) return rc;
+        } else {
+            // nothing to scan (a batch of empty haystacks, or no patterns): the per-haystack counts come
+            // out of the buffer cache uninitialised -- they are this call's to clear
+            int rc = zero_counts(c);
             if (rc) return rc;
         }
         if (c.queued) {
@@ -1699,6 +1704,11 @@ int acx_replicate(const acx_automaton_t *a, int device, acx_automaton_t **out) {
 int acx_automaton_device(const acx_automaton_t *a) { return a ? a->device : -1; }
 
 void acx_shard_range(uint64_t n_items, int shard, int n_shards, uint64_t *lo, uint64_t *hi) {
+    if (n_shards <= 0 || shard < 0 || shard >= n_shards) { // no such shard: the empty range
+        if (lo) *lo = 0;
+        if (hi) *hi = 0;
+        return;
+    }
     const uint64_t base = n_items / (uint64_t)n_shards, extra = n_items % (uint64_t)n_shards;
     const uint64_t s = (uint64_t)shard;
     *lo = s * base + std::min<uint64_t>(s, extra);
@@ -1798,6 +1808,14 @@ int acx_device_download(void *h_dst, const void *d_src, uint64_t bytes) {
     return ACX_OK;
 }
 int acx_device_synchronize(void) { HIPCHK(hipDeviceSynchronize()); return ACX_OK; }
+int acx_device_synchronize_on(int device) {
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail(ACX_EINVAL, "device ordinal out of range");
+    DeviceScope ds(device);
+    HIPCHK(hipDeviceSynchronize());
+    return ACX_OK;
+}
 
 int acx_generate_haystack(acx_automaton_t *a, void *d_dst, uint64_t len, int kind, uint64_t seed,
                           uint64_t stream_offset) {

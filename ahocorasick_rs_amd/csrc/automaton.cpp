@@ -38,7 +38,7 @@ struct PhaseClock {
 
 static unsigned build_threads() {
     unsigned t = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
-    if (const char *e = std::getenv("ACX_BUILD_THREADS")) t = (unsigned)std::max(1, std::atoi(e));
+    if (const char *e = std::getenv("ACX_BUILD_THREADS")) t = (unsigned)std::max(1, std::min(64, std::atoi(e)));
     return t;
 }
 // fn(lo, hi, thread index) over [0, n) cut into one contiguous range per thread (small n: one call)
@@ -180,13 +180,17 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     }
     ACX_PHASE("trie: prefixes, states per depth, ids");
     // pass 1: the longest common prefix with the pattern in front, the states of every depth
+    // (memory: 4 B per unit of max_len for the differences, + 4 B per thread when the pass is cut into
+    // ranges -- which it is only for many patterns whose histograms are small; a single 1 GiB pattern costs
+    // 4 GiB here, not the 24 B x max_len x threads it did)
     std::vector<uint32_t> lcp(n, 0);
-    std::vector<uint64_t> per_depth((size_t)A.max_len + 2, 0);
-    per_depth[0] = 1;
+    std::vector<int32_t> diff((size_t)A.max_len + 3, 0); // states c + 1 .. L of a pattern are new: +1 at c + 1, -1 at L + 1
     {
-        std::vector<std::vector<uint64_t>> part(hw_threads, std::vector<uint64_t>((size_t)A.max_len + 2, 0));
-        parallel_ranges(n, hw_threads, [&](uint64_t k0, uint64_t k1, unsigned t) {
-            std::vector<uint64_t> &pd = part[t];
+        const size_t slots = (size_t)A.max_len + 3;
+        const unsigned ranges = (n >= 65536 && hw_threads > 1 && slots * hw_threads * 4 <= ((size_t)64 << 20)) ? hw_threads : 1;
+        std::vector<std::vector<int32_t>> part(ranges > 1 ? ranges : 0, std::vector<int32_t>(slots, 0));
+        parallel_ranges(n, ranges, [&](uint64_t k0, uint64_t k1, unsigned t) {
+            int32_t *pd = ranges > 1 ? part[t].data() : diff.data();
             for (uint64_t k = k0; k < k1; k++) {
                 const uint32_t i = sorted[k];
                 const uint8_t *x = pb + A.offsets[i];
@@ -199,20 +203,24 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                     while (c < m && x[c] == y[c]) c++;
                 }
                 lcp[k] = (uint32_t)c;
-                // (states c + 1 .. L are new: as a difference, summed up below)
                 pd[c + 1]++;
                 pd[L + 1]--;
             }
         });
-        std::vector<int64_t> diff((size_t)A.max_len + 3, 0);
         for (auto &pd : part)
-            for (size_t d = 0; d < pd.size(); d++) diff[d] += (int64_t)pd[d];
-        int64_t run = 0;
-        for (size_t d = 1; d <= (size_t)A.max_len; d++) { run += diff[d]; per_depth[d] = (uint64_t)run; }
+            for (size_t d = 0; d < pd.size(); d++) diff[d] += pd[d];
     }
     uint64_t n_nodes64 = 0;
     A.level_start.assign((size_t)A.max_len + 2, 0);
-    for (size_t d = 0; d <= (size_t)A.max_len; d++) { A.level_start[d] = (uint32_t)std::min<uint64_t>(n_nodes64, ID_MASK); n_nodes64 += per_depth[d]; }
+    {
+        int64_t run = 0; // states of depth d
+        for (size_t d = 0; d <= (size_t)A.max_len; d++) {
+            run = d == 0 ? 1 : (d == 1 ? (int64_t)diff[1] : run + diff[d]);
+            A.level_start[d] = (uint32_t)std::min<uint64_t>(n_nodes64, ID_MASK);
+            n_nodes64 += (uint64_t)run;
+        }
+    }
+    diff = {};
     if (n_nodes64 >= ID_MASK) { code = ACX_ETOOBIG; return "more than 2^30 states"; }
     const uint32_t n_nodes = (uint32_t)n_nodes64;
     A.level_start[(size_t)A.max_len + 1] = n_nodes;

@@ -112,6 +112,22 @@ static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     return g;
 }
 
+// ---- K1b, short patterns (1 and 2 bytes).  A q-gram prefilter keyed by the set's SHORTEST pattern
+// degenerates when that is 1 or 2 bytes long (Q = 1: every occurrence of a byte is a survivor), and
+// until round 4 such sets left K1b altogether.  Now the set is split: the LONG patterns (>= 3 bytes)
+// build the level-1 / level-2 tables above with Q, Q2 taken from THEIR shortest; the SHORT ones are
+// found by a side test of the same shape as level 1 -- positions j, j+1 share ONE 8-byte LDS read of
+// short_xy[middle byte b(j+1)] = {X, Y}:
+//     position j   survives iff bit (b(j)   & 31) of X:  a 2-byte pattern (b(j), b(j+1)) or a 1-byte pattern b(j)
+//     position j+1 survives iff bit (b(j+2) & 31) of Y:  a 2-byte pattern (b(j+1), b(j+2)) or a 1-byte pattern b(j+1)
+// (a superset where bytes alias in their low five bits) -- and settled exactly by short_codes: [b0] the
+// code of the 1-byte pattern b0, [256 + (b0 | b1 << 8)] of the 2-byte pattern (b0, b1); a code is a
+// pattern id, 0x80000000 | index into blist (duplicates), or SHORT_NONE.
+constexpr uint32_t SHORT_MAX_LEN = 2;
+constexpr uint32_t SHORT_XY_WORDS = 512;
+constexpr uint32_t SHORT_CODES = 256 + 65536;
+constexpr uint32_t SHORT_NONE = 0xFFFFFFFFu;
+
 // K1a's failureless walk: the records of the trie
 // entry of the symbols (s0, s1, s2) in walk_t3b: word ((s0 << 5 | s1) * 33 + s2) -- the odd stride puts the
 // sum of two symbols into the LDS bank (with a stride of 32 every position in front of a space met in ONE bank)
@@ -145,8 +161,14 @@ struct Automaton {
     std::vector<uint32_t> plen;        // n_patterns
     std::vector<uint32_t> rank;        // n_patterns: rank in (len desc, pid asc)
     // prefilter
-    uint32_t filter_q = 0;             // level-1 prefix length Q (1..5), 0 = no patterns
-    uint32_t filter_q2 = 0;            // level-2 prefix length Q2 (1..8)
+    uint32_t filter_q = 0;             // level-1 prefix length Q (3..5; 1..2 only with ACX_NO_SHORT_SPLIT), 0 = no patterns
+    uint32_t filter_q2 = 0;            // level-2 prefix length Q2 (3..8)
+    uint32_t long_min_len = 0;         // shortest LONG pattern (what Q / Q2 are taken from); no long pattern: 5
+    uint32_t n_short = 0;              // patterns of at most SHORT_MAX_LEN bytes: K1b's side test (0: none, the
+                                       // tables below are empty)
+    uint32_t short_min_len = 0;        // the shortest of them (1 or 2)
+    std::vector<uint32_t> short_xy;    // SHORT_XY_WORDS: {X, Y} by middle byte
+    std::vector<uint32_t> short_codes; // SHORT_CODES
     std::vector<uint32_t> filterA;     // FILTER_WORDS: interleaved {X, Y}
     double filter_density = 0.0;       // fraction of X bits set
     // prefix table (K1b level 2): open addressing, 2^ptab_log2 entries of 4 u32:

@@ -1636,7 +1636,9 @@ __global__ __launch_bounds__(256) void k1a_walk(DevAutomaton A, const DevAutomat
     if (threadIdx.x == 0 && GK.block_counts) GK.block_counts[blockIdx.x] = lcount;
 }
 
-bool pfac_available(const DevAutomaton &A) { return A.t3b != nullptr; }
+// (k1a_scan's LDS image is static: on a device with less LDS the launch would fail outright -- such a
+// device walks in chunks)
+bool pfac_available(const DevAutomaton &A, size_t max_lds) { return A.t3b != nullptr && max_lds >= sizeof(K1aLds); }
 uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     const uint64_t total = ((uintptr_t)d_hay & 15) + len;
     uint64_t blocks = ((total + 4095) / 4096 + 15) / 16;

@@ -28,7 +28,7 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 // 16 = the number of occurrence regions, one per block of the walk): everything goes through the walk.
 // work: pfac_workspace_words() u64 words; counts: scan_grid * 16 u64 words.  More items than the
 // regions hold: *K.abort_flag = 1 (both modes).
-bool pfac_available(const DevAutomaton &A);
+bool pfac_available(const DevAutomaton &A, size_t max_lds);
 uint32_t pfac_scan_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
 uint64_t pfac_workspace_words(uint64_t len, uint32_t scan_grid, bool dense);
 hipError_t launch_pfac(const DevAutomaton &A, const DevAutomaton *Ad, const Segments &G, const Sink &K,

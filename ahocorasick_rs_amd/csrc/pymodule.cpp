@@ -625,7 +625,8 @@ PyObject *find_on_device(acx_automaton_t *a, const uint8_t *d_hay, uint64_t len,
     Py_BEGIN_ALLOW_THREADS
     // the producer's kernels may still be writing the tensor on its own stream: the library's
     // streams are non-blocking ones, so order the search behind everything queued on the device
-    rc = acx_device_synchronize();
+    // (on the AUTOMATON's device -- the tensor's: dlpack_view checked that -- not the thread's current one)
+    rc = acx_device_synchronize_on(acx_automaton_device(a));
     if (rc == ACX_OK) rc = acx_find_device(a, d_hay, len, nullptr, 0, 0, overlapping, 0, &r);
     if (rc == ACX_OK) {
         m.resize((size_t)acx_result_count(r));

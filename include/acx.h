@@ -266,6 +266,7 @@ int acx_device_free(void *d_ptr);
 int acx_device_upload(void *d_dst, const void *h_src, uint64_t bytes);
 int acx_device_download(void *h_dst, const void *d_src, uint64_t bytes);
 int acx_device_synchronize(void);
+int acx_device_synchronize_on(int device); /* the same on a given device (the calling thread's current device is left alone) */
 
 /* ---- seeded synthetic haystacks generated in HBM (bench / tests).  Bit-exact
  * twins of tests/gen.py gen_uniform (kind 0, alphabet a-z) and gen_textlike
