@@ -26,7 +26,7 @@ MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
 IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
 KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
 KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
-ABI_VERSION = 4  # ACX_VERSION of include/acx.h this binding was written against
+ABI_VERSION = 5  # ACX_VERSION of include/acx.h this binding was written against
 
 MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
 
@@ -57,7 +57,9 @@ class HostTables(ctypes.Structure):
                 ("prefix_bitmap", ctypes.c_void_p),
                 ("dense", ctypes.c_uint32), ("first_child", ctypes.c_void_p), ("in_byte", ctypes.c_void_p),
                 ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p),
-                ("walk_t3b", ctypes.c_void_p), ("walk_t3r", ctypes.c_void_p), ("walk_grec", ctypes.c_void_p)]
+                ("walk_t3b", ctypes.c_void_p), ("walk_t3r", ctypes.c_void_p), ("walk_grec", ctypes.c_void_p),
+                ("long_min_len", ctypes.c_uint32), ("n_short", ctypes.c_uint32), ("short_min_len", ctypes.c_uint32),
+                ("short_xy", ctypes.c_void_p), ("short_codes", ctypes.c_void_p)]
 
 
 class Profile(ctypes.Structure):
@@ -142,6 +144,7 @@ def lib() -> ctypes.CDLL:
     L.acx_device_upload.argtypes = [vp, vp, u64]
     L.acx_device_download.argtypes = [vp, vp, u64]
     L.acx_device_synchronize.argtypes = []
+    L.acx_device_synchronize_on.argtypes = [i32]
     L.acx_generate_haystack.argtypes = [vp, vp, u64, i32, u64, u64]
     _lib = L
     return L
@@ -238,6 +241,9 @@ class HostAutomaton:
         self.walk_t3b = view(t.walk_t3b, 33 * 1024 if t.walk_t3b else 0, np.uint32)
         self.walk_t3r = view(t.walk_t3r, 2 * nc ** 3 if t.walk_t3r else 0, np.uint32).reshape(-1, 2)
         self.walk_grec = view(t.walk_grec, 4 * self.n_states if t.walk_grec else 0, np.uint32).reshape(-1, 4)
+        # K1b's side test for patterns of 1 and 2 bytes (empty without such patterns)
+        self.short_xy = view(t.short_xy, 512 if t.short_xy else 0, np.uint32).reshape(-1, 2)
+        self.short_codes = view(t.short_codes, 256 + 65536 if t.short_codes else 0, np.uint32)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

@@ -1322,6 +1322,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.n_patterns = H.n_patterns; D.n_states = H.n_states; D.stride2 = H.stride2;
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
     D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
+    D.short_min_len = H.n_short ? H.short_min_len : 0; D.k1b_min_len = H.long_min_len;
     {
         static const char *big_env = std::getenv("ACX_FILTER_BIG"); // measurements: 0 / 1 force the choice
         D.filter_big = big_env ? (uint32_t)std::atoi(big_env) : (H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
@@ -1406,6 +1407,9 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.rbloom, rbloom)
     if (H.pbits.empty()) H.pbits.assign(4, 0);
     UP(H.pbits, pbits)
+    if (H.short_xy.empty()) { H.short_xy.assign(SHORT_XY_WORDS, 0); H.short_codes.assign(4, SHORT_NONE); }
+    UP(H.short_xy, short_xy)
+    UP(H.short_codes, short_codes)
     {
         const uint32_t *pi = nullptr;
         if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
@@ -1490,6 +1494,9 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->filter_density = A.filter_density;
     out->n_prefix_keys = A.n_prefix_keys;
     out->n_prefix_lists = (uint32_t)A.blist.size();
+    out->long_min_len = A.long_min_len; out->n_short = A.n_short; out->short_min_len = A.n_short ? A.short_min_len : 0;
+    out->short_xy = A.n_short ? A.short_xy.data() : nullptr;
+    out->short_codes = A.n_short ? A.short_codes.data() : nullptr;
     return ACX_OK;
 }
 

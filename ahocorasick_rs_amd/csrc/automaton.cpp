@@ -407,13 +407,28 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
     ACX_PHASE("K1b prefilter tables");
     // ---- K1b prefilter tables
     A.filter_q = 0; A.filter_q2 = 0;
+    A.n_short = 0; A.short_min_len = 0; A.long_min_len = 0;
+    A.short_xy.clear(); A.short_codes.clear();
     if (n > 0) {
-        const uint32_t Q = std::min<uint32_t>(FILTER_MAX_Q, A.min_len), g = Q - 1;
-        const uint32_t Q2 = std::min<uint32_t>(FILTER2_MAX_Q, A.min_len);
+        // ---- the split (automaton.hpp): patterns of 1 and 2 bytes go to the side test, the prefilter tables
+        // are built from the others (ACX_NO_SHORT_SPLIT: measurements / the round-3 behaviour -- one set, Q from
+        // the shortest pattern whatever it is)
+        static const bool no_split = std::getenv("ACX_NO_SHORT_SPLIT") != nullptr;
+        const bool split = !no_split && A.min_len <= SHORT_MAX_LEN;
+        auto is_short = [&](uint64_t i) { return split && A.plen[i] <= SHORT_MAX_LEN; };
+        uint32_t long_min = split ? 0xFFFFFFFFu : A.min_len;
+        if (split)
+            for (uint64_t i = 0; i < n; i++)
+                if (!is_short(i)) long_min = std::min(long_min, A.plen[i]);
+        if (long_min == 0xFFFFFFFFu) long_min = FILTER_MAX_Q; // no long pattern at all: empty tables of the usual shape
+        A.long_min_len = long_min;
+        const uint32_t Q = std::min<uint32_t>(FILTER_MAX_Q, long_min), g = Q - 1;
+        const uint32_t Q2 = std::min<uint32_t>(FILTER2_MAX_Q, long_min);
         A.filter_q = Q; A.filter_q2 = Q2;
         const uint32_t gmask = g == 4 ? 0xFFFFFFFFu : ((1u << (8 * g)) - 1);
         A.filterA.assign(FILTER_WORDS, 0);
         for (uint64_t i = 0; i < n; i++) {
+            if (is_short(i)) continue;
             const uint8_t *pp = pb + A.offsets[i];
             uint32_t wx = (uint32_t)gram_of(pp + 1, g) & gmask; // p[1..1+g)
             uint32_t wy = (uint32_t)gram_of(pp, g) & gmask;     // p[0..g)
@@ -441,10 +456,10 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // 0xFFFFFFFF = empty; next = 0: code = the only pattern with this key, or HIT_LIST | index
         // into blist; next = N > K: look the first N bytes up (salt N).
         std::vector<uint64_t> g1(n);              // first Q2 bytes of every pattern
-        for (uint64_t i = 0; i < n; i++) g1[i] = gram_of(pb + A.offsets[i], Q2);
+        for (uint64_t i = 0; i < n; i++) g1[i] = is_short(i) ? 0 : gram_of(pb + A.offsets[i], Q2);
         std::vector<uint32_t> by_g1; // (without the identical later copies of a pattern: leftmost kinds)
         by_g1.reserve(n);
-        for (uint64_t i = 0; i < n; i++) if (!dup[i]) by_g1.push_back((uint32_t)i);
+        for (uint64_t i = 0; i < n; i++) if (!dup[i] && !is_short(i)) by_g1.push_back((uint32_t)i);
         // (sorted by (first Q2 bytes, pattern id); every group then in place by (key bytes, pattern id): the
         // patterns of a key are a stretch of by_g1 in id order -- no vector per group or per key)
         {   // (pairs sorted in place: no lookup of g1[] per comparison)
@@ -505,7 +520,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // (a table of at most 32 MiB), 1/8 beyond; 1/4 otherwise.
         uint64_t multibyte = 0;
         for (uint64_t i = 0; i < n; i++)
-            for (uint32_t k = 0; k < Q2; k++)
+            for (uint32_t k = 0; k < Q2 && !is_short(i); k++)
                 if (pb[A.offsets[i] + k] >= 0xC0) { multibyte++; break; }
         const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
         const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env))
@@ -565,6 +580,43 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             } else { // filed under its first Q2 bytes: what a lookup starts from
                 const uint32_t bit = prefix_bitmap_bit(h, lg);
                 A.pbits[bit >> 5] |= 1u << (bit & 31);
+            }
+        }
+        // ---- the short patterns' side tables (automaton.hpp): exact codes + the {X, Y} pair table
+        if (split) {
+            A.short_xy.assign(SHORT_XY_WORDS, 0);
+            A.short_codes.assign(SHORT_CODES, SHORT_NONE);
+            A.short_min_len = SHORT_MAX_LEN;
+            // the patterns of one short key, in id order, become its code (a list when there are several:
+            // duplicates -- the leftmost kinds keep the first only, like every other table)
+            std::vector<std::vector<uint32_t>> of_key; // (filled sparsely: index into it from short_codes while building)
+            std::vector<uint32_t> key_of;
+            for (uint64_t i = 0; i < n; i++) {
+                if (!is_short(i)) continue;
+                A.n_short++;
+                A.short_min_len = std::min(A.short_min_len, A.plen[i]);
+                if (dup[i]) continue;
+                const uint8_t *pp = pb + A.offsets[i];
+                const uint32_t key = A.plen[i] == 1 ? pp[0] : 256u + (pp[0] | ((uint32_t)pp[1] << 8));
+                if (A.short_codes[key] == SHORT_NONE) { A.short_codes[key] = (uint32_t)of_key.size(); of_key.emplace_back(); key_of.push_back(key); }
+                of_key[A.short_codes[key]].push_back((uint32_t)i);
+                if (A.plen[i] == 1) {
+                    for (uint32_t m = 0; m < 256; m++) A.short_xy[2 * m] |= filter_bit(pp[0]); // even position: any middle byte
+                    A.short_xy[2 * (uint32_t)pp[0] + 1] = 0xFFFFFFFFu;                          // odd position: it IS the middle byte
+                } else {
+                    A.short_xy[2 * (uint32_t)pp[1]] |= filter_bit(pp[0]);     // even position: the middle byte is its second
+                    A.short_xy[2 * (uint32_t)pp[0] + 1] |= filter_bit(pp[1]); // odd position: the middle byte is its first
+                }
+            }
+            for (size_t k = 0; k < of_key.size(); k++) {
+                const std::vector<uint32_t> &v = of_key[k];
+                uint32_t code = v[0];
+                if (v.size() > 1) {
+                    code = 0x80000000u | (uint32_t)A.blist.size();
+                    A.blist.push_back((uint32_t)v.size());
+                    A.blist.insert(A.blist.end(), v.begin(), v.end());
+                }
+                A.short_codes[key_of[k]] = code;
             }
         }
         // the filter of displaced keys on every home slot: without the lookup's own bit a home slot

@@ -44,6 +44,11 @@ struct DevAutomaton {
     uint32_t rank_bits;          // bits of the tie-break field of an occurrence key
     uint32_t ptab_log2;
     uint32_t filter_big;         // the level-1 table is saturated: K1b puts every position to both tests
+    // K1b, short patterns (automaton.hpp): the side test's pair table and exact codes; short_min_len = 0: the
+    // set has none.  k1b_min_len: the shortest pattern the prefilter tables were built from
+    const uint32_t *short_xy;    // SHORT_XY_WORDS (copied to LDS)
+    const uint32_t *short_codes; // SHORT_CODES
+    uint32_t short_min_len, k1b_min_len;
     // K1a, automata of at most 65 535 states: the whole DFA as u16, rows of n_classes entries
     // (no padding: 63 277 states x 28 classes x 2 B = 3.4 MiB fits one XCD's 4 MiB L2), in an
     // order of its own: states that report nothing first (BFS order), the reporting ones after

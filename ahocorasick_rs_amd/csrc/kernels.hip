@@ -587,6 +587,7 @@ struct K1bLds {
     uint4 hb[16][K1B_HB][2];
     uint32_t cb[16][16]; // sparse mode: hit counts of the wave's last tiles, stored 16 at a time
     uint32_t rbloom[REDIRECT_BLOOM_WORDS]; // Bloom filter of the keys behind redirect entries
+    uint32_t sxy[SHORT_XY_WORDS];          // SH: the short patterns' {X, Y} pair table by middle byte
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
 
@@ -775,8 +776,10 @@ struct K1bTables {
     const uint32_t *ptab;
     const uint32_t *rbloom;
     const uint32_t *pbits; // BIG: the bitmap in front of the prefix table
-    uint32_t ptab_log2, filter_q2, min_len;
+    uint32_t ptab_log2, filter_q2, min_len; // min_len: the shortest pattern IN THESE TABLES (DevAutomaton::k1b_min_len)
     uint8_t *cp_sub; // CP: lead (non-continuation) bytes of every 64 bytes of the stream (K3's sub counts)
+    const uint32_t *short_xy, *short_codes; // SH: the side test for patterns of 1 and 2 bytes (automaton.hpp)
+    uint32_t short_min;                     // SH: the shortest of them
 };
 
 // CP (str API, sparse mode, lead == 0): the scan also counts the UTF-8 lead bytes of every 64-byte
@@ -786,7 +789,12 @@ struct K1bTables {
 // of the gram behind it (X): 17 LDS reads per lane-row instead of 8, twice the level-1 VALU, but
 // the false positives multiply (0.18 x 0.07 instead of their mean) and the level-2 gathers, which
 // bound the kernel on such sets, go down by a factor of five.
-template <int Q, bool SLOTS, bool CP, bool BIG>
+// SH (pattern sets with patterns of 1 or 2 bytes; they are NOT in the level-1 / level-2 tables): every pair
+// of positions is also put to the short patterns' pair table (one more 8-byte LDS read per pair, ~6 VALU); its
+// survivors travel through the same queue and pipeline with a flag (bit 15 of the offset) and are settled
+// against the exact codes (two 4-byte gathers: the 1-byte and the 2-byte pattern that may start there)
+// instead of the prefix table.
+template <int Q, bool SLOTS, bool CP, bool BIG, bool SH>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
@@ -808,6 +816,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
         for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) L.rbloom[i] = A.rbloom[i];
+        if (SH && threadIdx.x < SHORT_XY_WORDS) L.sxy[threadIdx.x] = A.short_xy[threadIdx.x];
     }
     __syncthreads();
 
@@ -827,6 +836,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     const uint32_t q2salt = q2len * 0x9E3779B1u; // prefix_key_hash(gram, q2len) = gram_hash2(gram) + q2salt
     const uint32_t ptab_log2 = A.ptab_log2;
     uint32_t q1c = 0; // wave-uniform queue fill
+    constexpr uint32_t OFFMASK = SH ? 0x0FFFu : 0xFFFFu; // a queued offset (12 bits); SH: bit 15 = a survivor of the side test
+    constexpr uint32_t SHFLAG = 0x8000u;
 
     // Prefix hits leave the wave THROUGH an LDS buffer that is stored in bursts of up to K1B_HB
     // records: on this architecture stores count in vmcnt like loads, so a store issued every
@@ -953,7 +964,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // ---- stage C: compare the slots with their windows
         if (stC) {
             if (nC) {
-                const bool act = lane < nC && (!BIG || liveC) && entC.z != PREFIX_EMPTY;
+                const bool shC = SH && lane < nC && (offC & SHFLAG) != 0; // the side test's survivor: entC = {code of byte 0, code of bytes 0-1}
+                const bool act = lane < nC && (!BIG || liveC) && !shC && entC.z != PREFIX_EMPTY;
                 const bool same = act && entry_matches(entC, winC);
                 uint32_t code = entC.w;
                 // a group with several keys: its home slot redirects to the keys' own hash.  These
@@ -971,8 +983,13 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 // the probe sequence in place was measured at +15 % of the kernel on the headline set)
                 // (the four bits of the window's hash that select the filter bit travel in the offset's spare bits)
                 const bool retry = act && !same && ((entC.z >> (8 + (BIG ? prefix_more_index(gram_hash2(winC & q2mask) + q2salt) : offC >> 16))) & 1u);
-                cntC += hit_push((same && code != HIT_NONE) || retry, (uint64_t)tileC * tile_bytes + (offC & 0xFFFFu) - lead,
-                                 same ? code : HIT_RETRY, winC, winC1, tileC, cntC);
+                const uint64_t posC = (uint64_t)tileC * tile_bytes + (offC & OFFMASK) - lead;
+                bool found = (same && code != HIT_NONE) || retry;
+                uint32_t hcode = same ? code : HIT_RETRY;
+                if (SH && shC) { found = entC.x != SHORT_NONE; hcode = entC.x; }
+                cntC += hit_push(found, posC, hcode, winC, winC1, tileC, cntC);
+                // (a 1-byte AND a 2-byte pattern at one position: the second hit)
+                if (SH) cntC += hit_push(shC && entC.y != SHORT_NONE, posC, entC.y, winC, winC1, tileC, cntC);
             }
             if (stC == 2) { // the tile is complete
                 if (SLOTS) { // its count: through LDS, 16 tiles of the wave per store
@@ -990,17 +1007,23 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         if (BIG) {
             // ---- stage M -> C: the windows the bitmap passes fetch their home slots and their second half
             if (nM) {
-                liveC = lane < nM && ((bitM >> (prefix_bitmap_bit(gram_hash2(winM & q2mask) + q2salt, ptab_log2) & 31)) & 1u);
+                const bool shM = SH && (offM & SHFLAG) != 0;
+                liveC = lane < nM && (shM || ((bitM >> (prefix_bitmap_bit(gram_hash2(winM & q2mask) + q2salt, ptab_log2) & 31)) & 1u));
                 if (liveC) {
-                    entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 4);
-                    winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + offM - lead + 8);
+                    if (shM) {
+                        entC.x = A.short_codes[(uint32_t)winM & 0xFFu];
+                        entC.y = A.short_codes[256u + ((uint32_t)winM & 0xFFFFu)];
+                    } else {
+                        entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 4);
+                    }
+                    winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + (offM & OFFMASK) - lead + 8);
                 }
                 offC = offM; winC = winM;
             }
             nC = nM; stC = stM; tileC = tileM;
             // ---- stage B -> M: hash the windows, fetch their bitmap words
             if (nB) {
-                if (lane < nB)
+                if (lane < nB && !(SH && (offB & SHFLAG)))
                     bitM = A.pbits[prefix_bitmap_bit(gram_hash2(winB & q2mask) + q2salt, ptab_log2) >> 5];
                 offM = offB; winM = winB;
             }
@@ -1009,14 +1032,21 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             if (q1c) {
                 if (lane < q1c) {
                     offB = q1[lane];
-                    winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + offB - lead);
+                    winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead);
                 }
             }
         } else {
             // ---- stage B -> C: hash the windows, fetch their home slots
             if (nB) {
                 const uint32_t hB = gram_hash2(winB & q2mask) + q2salt;
-                if (lane < nB) entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
+                if (lane < nB) {
+                    if (SH && (offB & SHFLAG)) { // the side test's survivor: the exact codes instead of the prefix table
+                        entC.x = A.short_codes[(uint32_t)winB & 0xFFu];
+                        entC.y = A.short_codes[256u + ((uint32_t)winB & 0xFFFFu)];
+                    } else {
+                        entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
+                    }
+                }
                 offC = offB | (prefix_more_index(hB) << 16); winC = winB; winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
@@ -1026,7 +1056,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
                 if (lane < q1c) {
                     offB = q1[lane];
-                    const uint64_t p_ = (uint64_t)tileQ * tile_bytes + offB - lead;
+                    const uint64_t p_ = (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead;
                     if (inside) {
                         u32x4 w_;
                         __builtin_memcpy(&w_, stream + p_, 16);
@@ -1156,6 +1186,43 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             K1B_ROW(2, nxt2, __builtin_amdgcn_readfirstlane(nxt3.x), __builtin_amdgcn_readfirstlane(nxt3.y), mrow2)
             K1B_ROW(3, nxt3, nxtL.x, nxtL.y, mrow3)
         }
+        // SH: the side test for patterns of 1 and 2 bytes.  Positions j, j+1 share the read of sxy[byte j+1]:
+        // bit (byte j) of X, bit (byte j+2) of Y (the shifts take the low five bits of their operand by themselves)
+        uint32_t srow0 = 0, srow1 = 0, srow2 = 0, srow3 = 0;
+#define K1B_ROW_SHORT(RI, VR, RX, MROW)                                                          \
+        {                                                                                        \
+            const uint32_t nx_ = __builtin_amdgcn_update_dpp(0u, VR.x, 0x130, 0xf, 0xf, true);   \
+            const uint32_t rx_ = (RX);                                                           \
+            const uint32_t d_[5] = {VR.x, VR.y, VR.z, VR.w, lane == 63 ? rx_ : nx_};             \
+            uint2 e8_[8];                                                                        \
+            _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
+                const uint32_t mid_ = (d_[(j + 1) >> 2] >> (8 * ((j + 1) & 3))) & 0xFFu;         \
+                e8_[j >> 1] = *(const uint2 *)((const uint8_t *)L.sxy + mid_ * 8);               \
+            }                                                                                    \
+            uint32_t m_ = 0;                                                                     \
+            _Pragma("unroll") for (int j = 0; j < 16; j += 2) {                                  \
+                const uint32_t bx_ = d_[j >> 2] >> (8 * (j & 3));                                \
+                const uint32_t by_ = d_[(j + 2) >> 2] >> (8 * ((j + 2) & 3));                    \
+                m_ = __builtin_amdgcn_alignbit(e8_[j >> 1].x >> (bx_ & 31), m_, 1);              \
+                m_ = __builtin_amdgcn_alignbit(e8_[j >> 1].y >> (by_ & 31), m_, 1);              \
+            }                                                                                    \
+            m_ >>= 16;                                                                           \
+            if (!interior) { /* wave-uniform: a scalar branch */                                 \
+                const uint64_t p0_ = tbase + (uint64_t)(RI) * 1024 + lane * 16;                  \
+                uint32_t keep_ = 0;                                                              \
+                _Pragma("unroll") for (int j = 0; j < 16; j++)                                   \
+                    if (p0_ + j >= lead && p0_ + j + A.short_min <= total) keep_ |= 1u << j;     \
+                m_ &= keep_;                                                                     \
+            }                                                                                    \
+            MROW = m_;                                                                           \
+        }
+        if (SH) {
+            K1B_ROW_SHORT(0, nxt0, __builtin_amdgcn_readfirstlane(nxt1.x), srow0)
+            K1B_ROW_SHORT(1, nxt1, __builtin_amdgcn_readfirstlane(nxt2.x), srow1)
+            K1B_ROW_SHORT(2, nxt2, __builtin_amdgcn_readfirstlane(nxt3.x), srow2)
+            K1B_ROW_SHORT(3, nxt3, nxtL.x, srow3)
+        }
+#undef K1B_ROW_SHORT
         if (CP) { // lead bytes of the lane's 16 bytes of every row, summed over the 4 lanes of a 64-byte stretch
 #define K1B_LEADS(RI, VR)                                                                        \
             {                                                                                    \
@@ -1185,20 +1252,24 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
         // (one 64-bit mask per lane; the round is branch-free: the lowest set bit by two v_ffbl, lanes
         // without a survivor compute along and do not store)
-        uint64_t m64 = (uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32);
-        while (true) {
-            const bool has = m64 != 0;
-            const unsigned long long act = __ballot(has);
-            if (!act) break;
-            const uint32_t np = __popcll(act);
-            if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u); // dense survivors: a full batch moves on now
-            const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
-            m64 &= m64 - 1;
-            const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
-                                                                  __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
-            if (has) q1[slot] = (uint16_t)(((pos >> 4) << 10) + lane * 16 + (pos & 15)); // offset in the tile
-            q1c += np;
-        }
+        auto compact = [&](uint64_t m64, uint32_t flag) __attribute__((always_inline)) {
+            while (true) {
+                const bool has = m64 != 0;
+                const unsigned long long act = __ballot(has);
+                if (!act) break;
+                const uint32_t np = __popcll(act);
+                if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u); // dense survivors: a full batch moves on now
+                const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
+                m64 &= m64 - 1;
+                const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+                if (has) q1[slot] = (uint16_t)((((pos >> 4) << 10) + lane * 16 + (pos & 15)) | flag); // offset in the tile
+                q1c += np;
+            }
+        };
+        compact((uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32), 0u);
+        // SH: the side test's survivors, flagged (a position may be queued twice: once for each kind of table)
+        if (SH) compact((uint64_t)(srow0 | (srow1 << 16)) | ((uint64_t)(srow2 | (srow3 << 16)) << 32), SHFLAG);
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
     }
@@ -1249,30 +1320,31 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
-    const K1bTables T{A.filterA, A.ptab, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.min_len, cp_sub};
+    const K1bTables T{A.filterA, A.ptab, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.k1b_min_len, cp_sub,
+                      A.short_xy, A.short_codes, A.short_min_len};
+    const bool sh = A.short_min_len != 0; // the set has patterns of 1 or 2 bytes: the side test runs too
     if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
-#define ACX_K1B_LAUNCH(Q, S, C, B)                                                                         \
-    hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
-#define ACX_K1B(Q)                                                                                         \
-    if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, false);                                                      \
-    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, false);                                              \
-    else ACX_K1B_LAUNCH(Q, false, false, false)
+#define ACX_K1B_LAUNCH(Q, S, C, B, H)                                                                      \
+    hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B, H>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
+#define ACX_K1B(Q, B, H)                                                                                   \
+    if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, B, H);                                                       \
+    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, B, H);                                               \
+    else ACX_K1B_LAUNCH(Q, false, false, B, H)
+#define ACX_K1B_SH(Q, B)                                                                                   \
+    if (sh) { ACX_K1B(Q, B, true); } else { ACX_K1B(Q, B, false); }
     switch (A.filter_q) {
-    case 1: ACX_K1B(1); break;
-    case 2: ACX_K1B(2); break;
-    case 3: ACX_K1B(3); break;
-    case 4: ACX_K1B(4); break;
+    // (Q = 1, 2: only with ACX_NO_SHORT_SPLIT -- the split keeps such patterns out of these tables)
+    case 1: ACX_K1B(1, false, false); break;
+    case 2: ACX_K1B(2, false, false); break;
+    case 3: ACX_K1B_SH(3, false) break;
+    case 4: ACX_K1B_SH(4, false) break;
     default:
-        if (A.filter_big) { // saturated level-1 table: both tests for every position
-            if (cp_sub) ACX_K1B_LAUNCH(5, true, true, true);
-            else if (K.hslots) ACX_K1B_LAUNCH(5, true, false, true);
-            else ACX_K1B_LAUNCH(5, false, false, true);
-        } else {
-            ACX_K1B(5);
-        }
+        if (A.filter_big) { ACX_K1B_SH(5, true) } // saturated level-1 table: both tests for every position
+        else { ACX_K1B_SH(5, false) }
         break;
     }
+#undef ACX_K1B_SH
 #undef ACX_K1B_LAUNCH
 #undef ACX_K1B
     return hipGetLastError();

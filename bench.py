@@ -66,7 +66,7 @@ def parse_args(argv=None):
                          "after a cold start; 0: none); reported as config.settle_ms")
     ap.add_argument("--ablate", default="", help="measurement only: override the configuration's match kind / "
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
-    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx", "cfg2b"], default="auto",
+    ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx", "mixedb", "cfg2b"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
     ap.add_argument("--dist", choices=["T", "U", "Z", "D"], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
@@ -156,9 +156,13 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
         # ~4.9 M states that is kept in its compressed form (no dense table)
         pats = gen.gen_patterns(1000000, 8, 16, gen.AZ, 9)
         w["mk"], impl = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO
-    else:  # cfg5
+    else:  # cfg5 / mixedb
         spats = list(dict.fromkeys(gen.gen_patterns(10000, 5, 12, gen.AZ_UNI, 5)))
         pats = [p.encode() for p in spats]
+        if cfg == "mixedb":
+            # round 3's cliff: cfg5's set (> 32 byte classes) + 1-character patterns of 1 and 2 bytes that are rare
+            # in the haystack ("Q": its low five bits are q's -- the side test's aliasing is part of the number)
+            pats += ["ß".encode(), b"Q"]
         w["mk"], impl, w["codepoints"] = capi.MATCH_LEFTMOST_LONGEST, capi.IMPL_AUTO, True
     t0 = time.perf_counter()
     for kv in filter(None, (args.ablate or "").split(",")):  # measurement switches, never the judged line
@@ -173,7 +177,7 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             raise SystemExit(f"--ablate: unknown switch {k}")
     ac = capi.Automaton(pats, w["mk"], impl, kernel=kern)
     w.update(ac=ac, patterns=pats, build_s=time.perf_counter() - t0)
-    if cfg == "cfg5":
+    if cfg in ("cfg5", "mixedb"):
         # ~1.13 bytes per character at 5 % non-ASCII: generate enough characters, cut at a
         # character boundary at or below --bytes
         host = gen.gen_unicode_textlike_bytes(int(nbytes / 1.12) + 1024, 56, spats,
@@ -186,6 +190,8 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
         w["desc"] = (f"cfg5: 10k patterns over a-z + e-acute/snowman/facepalm (2/3/4-byte), seed 5, MatchKind."
                      f"LeftmostLongest, {nbytes / GIB:.3f} GiB UTF-8 text-like str haystack (~5 % non-ASCII, "
                      "seed 56), code-point indexes (AhoCorasick str path)")
+        if cfg == "mixedb":
+            w["desc"] = "mixedb (not a BASELINE configuration): cfg5's set + the 1-character patterns sharp-s (2 bytes) and Q; " + w["desc"][6:]
     else:
         hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         torch.cuda.synchronize()

@@ -23,11 +23,12 @@
 extern "C" {
 #endif
 
-/* 4: acx_host_tables_t grew (walk_t3b / walk_t3r / walk_grec, round 3);
+/* 5: acx_host_tables_t grew (short-pattern tables), acx_device_synchronize_on, acx_comm_* added (round 4);
+ * 4: acx_host_tables_t grew (walk_t3b / walk_t3r / walk_grec, round 3);
  * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 4
+#define ACX_VERSION 5
 
 /* status codes */
 #define ACX_OK 0
@@ -178,6 +179,16 @@ typedef struct acx_host_tables {
     const uint32_t *walk_grec;    /* n_states x 4: {children bitmap, first child | OWN << 31, own pattern, 0}
                                      or a tail {bytes 0-3, 1 << 30 | n << 24, pattern, bytes 4-7}: the rest
                                      of the only pattern below the node, n <= 8 bytes                         */
+    /* K1b, short patterns (round 4; layouts: csrc/automaton.hpp).  Patterns of 1 and 2 bytes are kept out of
+       the prefilter tables above (filter_q / filter_q2 are taken from the shortest of the OTHER patterns,
+       long_min_len) and found by a side test instead                                                       */
+    uint32_t long_min_len;        /* shortest pattern of 3 bytes or more (5 when there is none)             */
+    uint32_t n_short;             /* patterns of 1 or 2 bytes (0: the two tables below are NULL)             */
+    uint32_t short_min_len;       /* the shortest of them                                                    */
+    const uint32_t *short_xy;     /* 256 x {X, Y} by middle byte b(j+1): bit (b(j) & 31) of X -- a short pattern
+                                     may start at j; bit (b(j+2) & 31) of Y -- one may start at j+1 (superset)  */
+    const uint32_t *short_codes;  /* [b0]: the 1-byte pattern b0; [256 + (b0 | b1 << 8)]: the 2-byte pattern
+                                     (b0, b1): pattern id, 0x80000000 | index into prefix_lists, or 0xFFFFFFFF  */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);

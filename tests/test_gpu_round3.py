@@ -225,21 +225,24 @@ def test_cfg3_full_per_gpu_size_counts_and_samples():
 
 @pytest.mark.parametrize("short", [[b"qz", b"~"], [b"ab", b"x"], [b"b", b"abcd"]], ids=["rare", "frequent", "readme"])
 def test_mixed_length_sets_leave_the_prefilter_for_the_failureless_walk(short):
-    """A dictionary with a 1- or 2-byte pattern in it (VERDICT round 2, item 3): K1b cannot take it;
-    the set runs the failureless walk (k1a_scan marks every triple below a short pattern, k1a_walk
-    starts those positions at the root).  Rare short patterns stay on the sparse path, frequent ones
-    (b"x": every 26th letter) end on the dense path -- every kind equals the oracle either way.
+    """A dictionary with a 1- or 2-byte pattern in it.  Round 3: K1b could not
+    take it, the set ran the failureless walk (k1a_scan marks every triple below a short pattern, k1a_walk
+    starts those positions at the root).  Round 4: K1b takes it after all (the short patterns through its
+    side test, tests/test_gpu_round4.py) -- the failureless walk is still what an explicit dfa_walk runs.
+    Rare short patterns stay on the sparse path, frequent ones (b"x": every 26th letter) end on the dense
+    path -- every kind equals the oracle either way.
     ([b"b", b"abcd"] is the vector of /root/reference/README.md:106-108.)"""
     pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1) + short
     hay = gen.gen_textlike(4 << 20, 11, pats[:10000]).tobytes()
     for mk in (0, 1, 2):
-        a = capi.Automaton(pats, mk)
-        assert capi.KERNEL_NAMES[a.info.kernel] == "dfa_walk"
         o = Oracle(pats, mk, KIND_DFA)
-        for ov in ([False, True] if mk == 0 else [False]):
-            got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
-            assert np.array_equal(got, want), (mk, ov, short)
-        a.close()
+        for kernel, name in ((None, "prefilter"), (capi.KERNEL_DFA_WALK, "dfa_walk")):
+            a = capi.Automaton(pats, mk, kernel=kernel)
+            assert capi.KERNEL_NAMES[a.info.kernel] == name
+            for ov in ([False, True] if mk == 0 else [False]):
+                got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
+                assert np.array_equal(got, want), (mk, ov, short, name)
+            a.close()
 
 
 def test_fuzz_case_long_tail_behind_an_eight_byte_prefix_dense_output():

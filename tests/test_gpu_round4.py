@@ -1,0 +1,161 @@
+"""GPU tests added in round 4 (each one answers an item of VERDICT.md / ADVICE.md, round 3):
+
+  * pattern sets with patterns of 1 and 2 bytes stay on K1b (the side test): every kind, wide alphabets
+    (> 32 byte classes: the sets that used to fall to the chunked walk), saturated level-1 tables, str API,
+    batches (a short pattern never crosses a haystack boundary), unaligned buffers, sets of short patterns only
+  * a batch of empty haystacks after a batch with matches returns zero counts (ADVICE, high)
+"""
+import numpy as np
+import pytest
+
+import gen
+from oracle_lib import KIND_DFA, Oracle
+
+pytestmark = pytest.mark.gpu
+capi = pytest.importorskip("ahocorasick_rs_amd.capi")
+
+
+def cols(a):
+    return np.stack([a["pattern"], a["start"], a["end"]], 1) if len(a) else np.zeros((0, 3), np.uint64)
+
+
+def check_all_kinds(pats, hay, what, kernels=(None,)):
+    for mk in (0, 1, 2):
+        o = Oracle(pats, mk, KIND_DFA)
+        for kernel in kernels:
+            a = capi.Automaton(pats, mk, kernel=kernel)
+            if kernel is None:
+                assert capi.KERNEL_NAMES[a.info.kernel] == "prefilter", what
+            for ov in ([False, True] if mk == 0 else [False]):
+                got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
+                assert np.array_equal(got, want), (what, mk, ov, kernel, len(got), len(want))
+            a.close()
+
+
+SHORT_SETS = {
+    "rare": [b"qz", b"~"],
+    "frequent": [b"ab", b"x"],
+    "readme": [b"b", b"abcd"],
+    "dups": [b"q", b"qz", b"q", b"qz", b"zq"],
+    "nul": [b"\0", b"a\0", b"\0\0"],
+}
+
+
+@pytest.mark.parametrize("name", list(SHORT_SETS))
+def test_short_patterns_ride_the_prefilter(name):
+    """cfg2's set + short patterns: K1b is the default kernel (round 3: the failureless walk), every
+    kind equals the oracle; the haystack ends in a short pattern (the last positions are legal starts)."""
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1) + SHORT_SETS[name]
+    hay = gen.gen_textlike(3 << 20, 11, pats[:10000]).tobytes() + b"qzq\0a\0x~q\0"
+    check_all_kinds(pats, hay, name)
+
+
+def test_short_patterns_with_a_wide_alphabet():
+    """> 32 byte classes AND a short pattern: the case that used to end on the chunked walk (0.5 TB/s with a
+    dense table, 18 GB/s without).  cfg5's alphabet (a-z + 2/3/4-byte characters), mixed case + digits, all
+    byte values."""
+    uni = [p.encode() for p in dict.fromkeys(gen.gen_patterns(3000, 5, 12, gen.AZ_UNI, 5))]
+    hay = gen.gen_unicode_textlike(1 << 20, 56, [p.decode() for p in uni]).encode()
+    check_all_kinds(uni + ["é".encode(), b"Q", b"zq"], hay, "utf8")
+    alnum = bytes(range(48, 58)) + bytes(range(65, 91)) + bytes(range(97, 123))
+    pats = gen.gen_patterns(5000, 4, 10, alnum, 8) + [b"Zz", b"7", b"_"]
+    hay = gen.gen_uniform(2 << 20, alnum + b" _", 9).tobytes()
+    a = capi.Automaton(pats, 0)
+    assert a.info.n_classes > 32 and capi.KERNEL_NAMES[a.info.kernel] == "prefilter"
+    a.close()
+    check_all_kinds(pats, hay, "alnum")
+    pats = gen.gen_patterns(2000, 3, 9, gen.ALL_BYTES, 4) + [b"\xff", b"\x80\x81", b"\0"]
+    hay = gen.gen_uniform(1 << 20, gen.ALL_BYTES, 3).tobytes()
+    check_all_kinds(pats, hay, "bytes")
+
+
+def test_short_patterns_only_and_tiny_sets():
+    """No long pattern at all (empty prefilter tables), and sets whose long patterns are 3 and 4 bytes."""
+    hay = gen.gen_textlike(1 << 20, 3).tobytes()
+    for pats in ([b"q"], [b"qz"], [b"qz", b"zq", b"j", b"j"], [b"qz", b"qzx"], [b"~", b"qzxv", b"abc"]):
+        check_all_kinds(pats, hay, pats, kernels=(None, capi.KERNEL_DFA_WALK))
+
+
+def test_short_patterns_with_a_saturated_filter():
+    """10^5 patterns (the BIG variant of K1b: both tests for every position, the bitmap stage) + short ones."""
+    pats = gen.gen_patterns(100000, 5, 12, gen.AZ, 3) + [b"qz", b"~", b"Q"]
+    hay = gen.gen_uniform(2 << 20, gen.AZ, 12).tobytes() + b"~Qqz"
+    for mk, ov in ((0, True), (0, False), (2, False)):
+        a = capi.Automaton(pats, mk)
+        assert capi.KERNEL_NAMES[a.info.kernel] == "prefilter"
+        got, want = cols(a.find(hay, overlapping=ov)), Oracle(pats, mk, KIND_DFA).find_raw(hay, overlapping=ov)
+        assert np.array_equal(got, want), (mk, ov, len(got), len(want))
+        a.close()
+
+
+def test_short_patterns_in_batches_and_unaligned_buffers():
+    """A 2-byte pattern never matches across two haystacks of a batch; unaligned device buffers shift the
+    parity of the side test's pairs."""
+    pats = gen.gen_patterns(2000, 5, 12, gen.AZ, 1) + [b"qz", b"z"]
+    a = capi.Automaton(pats, 2)
+    o = Oracle(pats, 2, KIND_DFA)
+    rng = np.random.default_rng(5)
+    hs = []
+    for i in range(300):
+        n = int(rng.integers(0, 9000))
+        h = bytearray(gen.gen_textlike(n, 100 + i, pats[:2000]).tobytes())
+        if n:
+            h[-1] = ord("q")  # ... q | z ...: the pair straddles the boundary
+        if n > 1 and i % 2:
+            h[0] = ord("z")
+        hs.append(bytes(h))
+    m, counts = a.find_batch(hs)
+    pos = 0
+    for i, h in enumerate(hs):
+        want = o.find_raw(h)
+        assert np.array_equal(cols(m[pos:pos + int(counts[i])]), want), i
+        pos += int(counts[i])
+    assert pos == len(m)
+    big = gen.gen_textlike((1 << 20) + 64, 7, pats[:2000])
+    buf = capi.DeviceBuffer(len(big) + 64).upload(big)
+    for lead in (0, 1, 2, 7, 15):
+        n = (1 << 20) - 3
+        r = a.find_device(buf.ptr + lead, n)
+        got = cols(r.matches())
+        r.free()
+        assert np.array_equal(got, o.find_raw(big[lead:lead + n].tobytes())), lead
+    buf.free()
+    a.close()
+
+
+def test_short_patterns_str_api():
+    """The str API (code points, the CP variant of the scan) with a 1-character pattern of 1 and of 2 bytes."""
+    import ahocorasick_rs_amd as ac
+    spats = list(dict.fromkeys(gen.gen_patterns(3000, 5, 12, gen.AZ_UNI, 5))) + ["é", "Q", "zq"]
+    hay = gen.gen_unicode_textlike(300000, 56, spats[:3000]) + "Qzqé"
+    bpats = [p.encode() for p in spats]
+    bhay = hay.encode()
+    cp = np.cumsum(np.frombuffer(bhay, dtype=np.uint8) & 0xC0 != 0x80) - 1  # byte offset -> code point of its character
+    cp = np.concatenate([cp, [cp[-1] + 1]])
+    for mk_name, mk in (("Standard", 0), ("LeftmostLongest", 2)):
+        a = ac.AhoCorasick(spats, matchkind=getattr(ac.MatchKind, mk_name))
+        got = a.find_matches_as_indexes(hay)
+        want = Oracle(bpats, mk, KIND_DFA).find_raw(bhay)
+        assert got == [(int(p), int(cp[s]), int(cp[e])) for p, s, e in want], mk_name
+
+
+def test_batch_of_empty_haystacks_after_a_batch_with_matches():
+    """the per-haystack counts of a call that never reaches the pipeline (only empty
+    haystacks) came out of the buffer cache holding the previous call's counts."""
+    import ahocorasick_rs_amd as ac
+    pats = [b"abc", b"bcd", b"zz"]
+    a = capi.Automaton(pats, 0)
+    m, counts = a.find_batch([b"abcd", b"zzz", b"xabc"])
+    assert list(counts) == [1, 1, 1] and len(m) == 3
+    for _ in range(3):
+        m, counts = a.find_batch([b"", b"", b""])
+        assert len(m) == 0 and list(counts) == [0, 0, 0]
+    a.close()
+    b = ac.BytesAhoCorasick(pats)
+    assert b.find_matches_as_indexes_batch([b"abcd", b"zzz", b"xabc"]) == [[(0, 0, 3)], [(2, 0, 2)], [(0, 1, 4)]]
+    for _ in range(3):
+        assert b.find_matches_as_indexes_batch([b"", b""]) == [[], []]
+    e = capi.Automaton([], 0)
+    m, counts = e.find_batch([b"abc", b"", b"zz"])
+    assert len(m) == 0 and list(counts) == [0, 0, 0]
+    e.close()

@@ -205,12 +205,21 @@ def test_prefilter_tables_have_every_pattern_prefix():
                  gen.gen_patterns(500, 6, 9, gen.AZ, 4), gen.gen_patterns(300, 9, 12, gen.AZ, 5),
                  [p.encode() for p in gen.names_like(800, 6)], uni, zeros):
         h = capi.HostAutomaton(pats)
-        minlen = min(len(p) for p in pats)
+        # (round 4: patterns of 1 and 2 bytes are kept out of these tables -- test_short_pattern_side_tables)
+        long_ = [p for p in pats if len(p) >= 3]
+        minlen = min((len(p) for p in long_), default=5)
         q, q2 = int(h.t.filter_q), int(h.t.filter_q2)
-        assert (q, q2) == (min(5, minlen), min(8, minlen))
+        assert (q, q2) == (min(5, minlen), min(8, minlen)) and int(h.t.long_min_len) == minlen
+        assert int(h.t.n_short) == len(pats) - len(long_)
         g = q - 1
         lg = int(h.t.prefix_table_log2)
-        for pid, p in enumerate(pats):
+        all_pats, pats = pats, long_
+        if not pats:
+            assert not np.any(h.filter_xy) and int(h.t.n_prefix_keys) == 0
+            h.close()
+            continue
+        ids = [i for i, p in enumerate(all_pats) if len(p) >= 3]
+        for pid, p in zip(ids, pats):
             # level 1: in the row of p[1..1+g): bit p[0] of X; in the row of p[0..g): bit p[q-1] of Y;
             # in both rows the gate bit (gram & 31) of X
             for gram, byte, col in ((p[1:1 + g], p[0], 0), (p[0:g], p[q - 1], 1)):
@@ -226,8 +235,8 @@ def test_prefilter_tables_have_every_pattern_prefix():
                 cands = prefix_candidates(h, lg, q2, (p + tail)[:16])
                 assert pid in cands, (p, cands)
                 assert cands == sorted(cands)
-                klen = min(min(len(pats[c]) for c in cands), 8)
-                assert all(pats[c][:klen] == p[:klen] for c in cands)
+                klen = min(min(len(all_pats[c]) for c in cands), 8)
+                assert all(all_pats[c][:klen] == p[:klen] for c in cands)
         # the bitmap in front of the table: the first Q2 bytes of every pattern have their bit
         # (bit = the top log2 + 3 bits of the hash the home slot is taken from), and it is as
         # sparse as one bit per group in 8 bits per slot can be
@@ -242,9 +251,9 @@ def test_prefilter_tables_have_every_pattern_prefix():
             w = bytearray((p + bytes(rng.randrange(256) for _ in range(16)))[:16])
             w[rng.randrange(min(len(p), 8))] ^= 1 + rng.randrange(255)
             for c in prefix_candidates(h, lg, q2, bytes(w)):
-                klen = min(len(pats[c]), 8)
-                group = [o for o in pats if o[:q2] == pats[c][:q2]]
-                assert bytes(w[:min(klen, min(min(len(o) for o in group), 8))]) == pats[c][:min(klen, min(min(len(o) for o in group), 8))]
+                klen = min(len(all_pats[c]), 8)
+                group = [o for o in pats if o[:q2] == all_pats[c][:q2]]
+                assert bytes(w[:min(klen, min(min(len(o) for o in group), 8))]) == all_pats[c][:min(klen, min(min(len(o) for o in group), 8))]
         # the MORE filter (bits 23:8 of the meta word) of a home slot holds exactly the bits of the keys
         # that hash there and live elsewhere; redirect entries and single keys sit at the hash of
         # their first Q2 bytes, the keys behind a redirect at the hash of their own bytes
@@ -272,6 +281,69 @@ def test_prefilter_tables_have_every_pattern_prefix():
             assert int(tab[e, 2]) & 0x00FFFF00 == want_more.get(int(e), 0)
         assert 0 < h.t.filter_density <= 3 * len(pats) / (32 << 14)
         h.close()
+
+
+def short_survivor(h, hay: bytes, p: int, lead: int = 0) -> bool:
+    """Python twin of K1b's side test (K1B_ROW_SHORT): the positions with an even / odd INDEX (position + lead)
+    share the read of short_xy[middle byte]; bytes beyond the end are arbitrary (here: 0xAA)."""
+    b = lambda i: hay[i] if i < len(hay) else 0xAA
+    if (p + lead) % 2 == 0:
+        return bool(int(h.short_xy[b(p + 1), 0]) >> (b(p) & 31) & 1)
+    return bool(int(h.short_xy[b(p), 1]) >> (b(p + 1) & 31) & 1)
+
+
+def short_codes_at(h, hay: bytes, p: int):
+    """Python twin of the settle step: the pattern ids of the 1-byte and the 2-byte pattern at p."""
+    out = []
+    keys = [hay[p]] + ([256 + (hay[p] | hay[p + 1] << 8)] if p + 1 < len(hay) else [])
+    for k in keys:
+        code = int(h.short_codes[k])
+        if code == 0xFFFFFFFF:
+            continue
+        if code & 0x80000000:
+            i = code & 0x7FFFFFFF
+            out += [int(x) for x in h.prefix_lists[i + 1:i + 1 + int(h.prefix_lists[i])]]
+        else:
+            out.append(code)
+    return out
+
+
+def test_short_pattern_side_tables():
+    """Round 4: patterns of 1 and 2 bytes are found by K1b's side test.  Its pair table lets every true start
+    through (at both parities of the index, at the very end of the haystack too) and the exact codes name the
+    patterns -- all copies for Standard, the first only for the leftmost kinds."""
+    rng = random.Random(17)
+    for it in range(120):
+        alpha = [b"ab", b"abcdefgh", bytes(range(97, 123)) + b" ", bytes(range(256))][it % 4]
+        pats = [bytes(rng.choice(alpha) for _ in range(rng.choice([1, 1, 2, 2, 2, 3, 5, 7]))) for _ in range(rng.randint(1, 30))]
+        if it % 5 == 0:
+            pats += [pats[0], pats[-1]]  # duplicates
+        hay = bytes(rng.choice(alpha) for _ in range(rng.randint(1, 200)))
+        for mk in (capi.MATCH_STANDARD, capi.MATCH_LEFTMOST_FIRST):
+            h = capi.HostAutomaton(pats, mk)
+            shorts = [i for i, p in enumerate(pats) if len(p) <= 2]
+            assert int(h.t.n_short) == len(shorts)
+            if not shorts:
+                assert len(h.short_codes) == 0
+                h.close()
+                continue
+            assert int(h.t.short_min_len) == min(len(pats[i]) for i in shorts)
+            for p in range(len(hay)):
+                want = [i for i in shorts if hay[p:p + len(pats[i])] == pats[i]]
+                if mk != capi.MATCH_STANDARD:  # identical patterns: only the first can be reported
+                    want = [i for i in want if pats.index(pats[i]) == i]
+                got = short_codes_at(h, hay, p)
+                assert sorted(got) == want, (pats, hay, p)
+                if want:
+                    assert short_survivor(h, hay, p, 0) and short_survivor(h, hay, p, 1), (pats, hay, p)
+            h.close()
+    # a text-like case: the side test is selective where it can be (letters differ in their low five bits)
+    h = capi.HostAutomaton([b"qz", b"~"] + gen.gen_patterns(50, 5, 9, gen.AZ, 3))
+    hay = gen.gen_textlike(20000, 5).tobytes()
+    surv = sum(short_survivor(h, hay, p) for p in range(len(hay)))
+    true = sum(hay[p:p + 2] == b"qz" or hay[p:p + 1] == b"~" for p in range(len(hay)))
+    assert true <= surv <= true + len(hay) // 200
+    h.close()
 
 
 def test_prefix_keys_extend_beyond_the_shortest_pattern():
