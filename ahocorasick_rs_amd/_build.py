@@ -23,7 +23,7 @@ INCLUDE = os.path.join(ROOT, "include")
 LIB = os.path.join(HERE, "libacx_hip.so")
 EXT = os.path.join(HERE, "ahocorasick_rs" + (sysconfig.get_config_var("EXT_SUFFIX") or ".so"))
 
-LIB_SOURCES = ["kernels.hip", "acx_api.cpp", "automaton.cpp"]
+LIB_SOURCES = ["kernels.hip", "acx_api.cpp", "automaton.cpp", "comm.cpp"]
 LIB_HEADERS = ["kernels.hpp", "automaton.hpp", "device_types.hpp", os.path.join(INCLUDE, "acx.h")]
 EXT_SOURCES = ["pymodule.cpp"]
 
@@ -48,7 +48,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
     if not force and _newer(LIB, deps):
         return LIB
     cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-I" + INCLUDE, "-o", LIB] + srcs
+           "-I" + INCLUDE, "-o", LIB] + srcs + ["-ldl"]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.check_call(cmd)

@@ -148,6 +148,16 @@ def lib() -> ctypes.CDLL:
     L.acx_device_download.argtypes = [vp, vp, u64]
     L.acx_device_synchronize.argtypes = []
     L.acx_device_synchronize_on.argtypes = [i32]
+    L.acx_comm_init_all.argtypes = [ctypes.POINTER(i32), i32, ctypes.POINTER(vp)]
+    L.acx_comm_unique_id.argtypes = [vp]
+    L.acx_comm_init_rank.argtypes = [vp, i32, i32, i32, ctypes.POINTER(vp)]
+    L.acx_comm_world.argtypes = [vp]
+    L.acx_comm_local_ranks.argtypes = [vp]
+    L.acx_comm_allgather_counts.argtypes = [vp, vp, vp]
+    L.acx_comm_free.argtypes = [vp]
+    L.acx_comm_free.restype = None
+    L.acx_output_offsets.argtypes = [vp, i32, vp]
+    L.acx_output_offsets.restype = None
     L.acx_generate_haystack.argtypes = [vp, vp, u64, i32, u64, u64]
     _lib = L
     return L
@@ -279,6 +289,72 @@ def prefix_hash(gram: bytes, salt: int) -> int:
 def prefix_slot(gram: bytes, salt: int, log2: int) -> int:
     """home slot of the first `salt` bytes of `gram` in the prefix table."""
     return int(lib().acx_prefix_slot(int.from_bytes(gram[:salt], "little"), salt, log2))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """acx_comm_unique_id: the 128 bytes rank 0 creates and every rank passes to Comm.init_rank."""
+    buf = (ctypes.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().acx_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def output_offsets(counts: Sequence[int]) -> List[int]:
+    """acx_output_offsets: exclusive prefix of the ranks' match counts (+ the total)."""
+    c = np.asarray(counts, dtype=np.uint64)
+    out = np.zeros(len(c) + 1, dtype=np.uint64)
+    lib().acx_output_offsets(c.ctypes.data, len(c), out.ctypes.data)
+    return [int(x) for x in out]
+
+
+class Comm:
+    """acx_comm_t: the count exchange over RCCL, without torch (include/acx.h)."""
+
+    def __init__(self, handle: int):
+        self._h = handle
+
+    @classmethod
+    def init_all(cls, devices: Sequence[int]) -> "Comm":
+        arr = (ctypes.c_int * len(devices))(*devices)
+        h = ctypes.c_void_p()
+        _check(lib().acx_comm_init_all(arr, len(devices), ctypes.byref(h)))
+        return cls(h.value)
+
+    @classmethod
+    def init_rank(cls, uid: bytes, world: int, rank: int, device: int) -> "Comm":
+        assert len(uid) == COMM_ID_BYTES
+        buf = (ctypes.c_uint8 * COMM_ID_BYTES).from_buffer_copy(uid)
+        h = ctypes.c_void_p()
+        _check(lib().acx_comm_init_rank(buf, world, rank, device, ctypes.byref(h)))
+        return cls(h.value)
+
+    @property
+    def world(self) -> int:
+        return int(lib().acx_comm_world(self._h))
+
+    @property
+    def local_ranks(self) -> int:
+        return int(lib().acx_comm_local_ranks(self._h))
+
+    def allgather_counts(self, local_counts: Sequence[int]) -> List[int]:
+        loc = np.asarray(local_counts, dtype=np.uint64)
+        assert len(loc) == self.local_ranks
+        out = np.zeros(self.world, dtype=np.uint64)
+        _check(lib().acx_comm_allgather_counts(self._h, loc.ctypes.data, out.ctypes.data))
+        return [int(x) for x in out]
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib().acx_comm_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class DeviceBuffer:

@@ -362,6 +362,7 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
     uint64_t seq = 0;          // sequence number the scan kernel publishes to h_pinned[7]
+    uint64_t small_seq = 0;    // K0 (host entry point): the number it publishes to h_pinned[11]
 };
 
 } // namespace
@@ -633,16 +634,34 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 
 // One K0 launch + one sync.  hay / out: anything the device can address (HBM or pinned host);
 // out holds SMALL_MAX_OCC records.  *done = false: too many occurrences, use the general path.
+// poll: hay and out are host memory the kernel reads / writes in place: wait for the number the kernel publishes
+// behind its last store instead of synchronising the stream (tools/ubench_roundtrip.hip: 6 us against 11)
 int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
-              acx_match_t *out, uint64_t *n_out, bool *done) {
+              acx_match_t *out, uint64_t *n_out, bool *done, bool poll = false) {
     *done = false;
     int rc = ensure_common(c);
     if (rc) return rc;
     Workspace &w = c->ws;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
+    static const bool no_poll = std::getenv("ACX_SMALL_SYNC") != nullptr; // measurements: always synchronise
+    const uint64_t seq = poll && !no_poll ? ++c->small_seq : 0;
     HIPCHK(launch_small(a->dev, hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        w.h_pinned + 8, c->stream));
-    HIPCHK(hipStreamSynchronize(c->stream));
+                        w.h_pinned + 8, seq, c->stream));
+    if (seq) {
+        volatile uint64_t *p = w.h_pinned;
+        const auto t0 = std::chrono::steady_clock::now();
+        for (uint32_t spins = 0; p[11] != seq; spins++) {
+            cpu_relax();
+            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (p[11] != seq) return fail(ACX_EDEVICE, "K0 did not publish its result");
+                break;
+            }
+        }
+        std::atomic_thread_fence(std::memory_order_acquire);
+    } else {
+        HIPCHK(hipStreamSynchronize(c->stream));
+    }
     if (w.h_pinned[9] == 0) {
         *n_out = w.h_pinned[8];
         *done = true;
@@ -1237,6 +1256,9 @@ int download_matches(const acx_result *r, acx_match_t **out, uint64_t *n_out) {
 // ---------------------------------------------------------------------------
 extern "C" {
 
+// (comm.cpp reports through the same thread-local message)
+int acx_internal_fail(int code, const char *msg) { return fail(code, msg ? msg : ""); }
+
 int acx_version(void) { return ACX_VERSION; }
 const char *acx_last_error(void) { return g_err.c_str(); }
 
@@ -1634,12 +1656,13 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
         Workspace &w = c->ws;
         if (!w.pin_hay) {
             HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_MAX_LEN + 16, hipHostMallocDefault));
-            HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocDefault));
+            // (read by the host as soon as the kernel's sequence number shows up: system-coherent)
+            HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocCoherent));
         }
         std::memcpy(w.pin_hay, hay, len);
         uint64_t n = 0;
         bool done = false;
-        rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done);
+        rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done, true);
         if (rc != ACX_OK) return rc;
         if (done) {
             if (n) {

@@ -2594,10 +2594,13 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 // position on text), rank-sort them by key in LDS, resolve the match kind, convert to code
 // points, write the final records.  `hay`, `out` and `res` may live in pinned host memory
 // (zero-copy): the host-memory entry point then costs one launch and one sync.
-// res[0] = matches written, res[1] = 0, or 1: too many occurrences, nothing written.
+// res[0] = matches written, res[1] = 0, or 1: too many occurrences, nothing written.  seq != 0: res[3] = seq
+// is written LAST, behind a system-scope fence -- a host that polls it (res in coherent pinned memory) has the
+// whole result when it sees the number: one launch and one PCIe read instead of a launch and a stream
+// synchronisation (whose wake-up alone costs 5-10 us).
 __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
                                                  uint32_t len, int key_mode, int overlapping,
-                                                 int codepoints, acx_match_t *out, uint64_t *res) {
+                                                 int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq) {
     __shared__ __attribute__((aligned(16))) uint8_t sh[SMALL_MAX_LEN + 16];
     __shared__ uint8_t cls[256];
     __shared__ uint4 occ[SMALL_MAX_OCC]; // {key lo, key hi, pid, pattern length}
@@ -2647,7 +2650,10 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     __syncthreads();
     const uint32_t n = nocc;
     if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
-        if (t == 0) { res[0] = 0; res[1] = 1; }
+        if (t == 0) {
+            res[0] = 0; res[1] = 1;
+            if (seq) { __threadfence_system(); ((volatile uint64_t *)res)[3] = seq; }
+        }
         return;
     }
     // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
@@ -2725,13 +2731,17 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
         out[dst].pattern = v.z; out[dst].start = s; out[dst].end = e;
     }
     if (t == 1023) { res[0] = dst + mine; res[1] = 0; }
+    if (seq) { // (every thread's records and the totals first: the barrier, then ONE thread's system-scope release)
+        __syncthreads();
+        if (t == 0) { __threadfence_system(); ((volatile uint64_t *)res)[3] = seq; }
+    }
 #undef K0_SPAN
 }
 
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
-                        bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st) {
+                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st) {
     hipLaunchKernelGGL(k0_small, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,
-                       codepoints ? 1 : 0, out, res);
+                       codepoints ? 1 : 0, out, res, seq);
     return hipGetLastError();
 }
 

@@ -71,8 +71,9 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 // SMALL_MAX_OCC occurrences, one haystack).  hay / out / res may be pinned host memory.
 // out: SMALL_MAX_OCC records; res[0] = matches written, res[1] != 0: too dense, nothing written.
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
+// seq != 0: res[3] = seq is written last behind a system-scope fence (res: coherent pinned memory the host polls)
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
-                        bool codepoints, acx_match_t *out, uint64_t *res, hipStream_t st);
+                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write

@@ -54,6 +54,42 @@ def gather_match_counts(local_count: int, group=None, device=None) -> Tuple[List
     return counts, exclusive_offsets(counts)[rank], sum(counts)
 
 
+def capi_comm_from_env(device: int, timeout_s: float = 120.0):
+    """A `capi.Comm` (RCCL behind the C ABI: no torch.distributed) for a process started by any launcher
+    that sets RANK / WORLD_SIZE / MASTER_PORT (torch.distributed.run does).  The 128-byte RCCL id goes from
+    rank 0 to the others through a file next to the rendezvous port -- the host's own means, as
+    include/acx.h puts it; an MPI or socket host would carry it its own way."""
+    import os
+    import tempfile
+    import time
+    from . import capi
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    path = os.path.join(tempfile.gettempdir(), f"acx_comm_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.id")
+    if rank == 0:
+        uid = capi.comm_unique_id()
+        with open(path + ".tmp", "wb") as f:
+            f.write(uid)
+        os.replace(path + ".tmp", path)
+    else:
+        t0 = time.time()
+        while not os.path.exists(path):
+            if time.time() - t0 > timeout_s:
+                raise TimeoutError(f"rank 0 never published the RCCL id at {path}")
+            time.sleep(0.01)
+        with open(path, "rb") as f:
+            uid = f.read()
+    comm = capi.Comm.init_rank(uid, world, rank, device)
+    return comm
+
+
+def gather_match_counts_capi(comm, local_count: int, rank: int) -> Tuple[List[int], int, int]:
+    """gather_match_counts through the C ABI's communicator (acx_comm_allgather_counts + acx_output_offsets)."""
+    from . import capi
+    counts = comm.allgather_counts([int(local_count)])
+    off = capi.output_offsets(counts)
+    return counts, off[rank], off[-1]
+
+
 def find_batch_sharded(automaton, haystacks: Sequence[bytes], overlapping: bool = False,
                        codepoints: bool = False, group=None):
     """Scan this rank's shard of `haystacks` (every rank passes the same list, or at least

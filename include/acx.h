@@ -253,6 +253,28 @@ int acx_find_batch_multi(acx_automaton_t *const *handles, int n_handles, const u
                          const uint64_t *offsets, uint64_t n_hay, int overlapping, int codepoints,
                          acx_match_t **out, uint64_t *n_out, uint64_t *counts);
 
+/* ---- one process PER device: the count exchange over RCCL (north_star: "RCCL over xGMI only to gather
+ * per-shard match counts").  The search itself needs no communicator: every rank scans its own range of
+ * the batch (acx_shard_range) with its own replica of the automaton.  What the ranks exchange is one u64
+ * each -- their match counts -- from which acx_output_offsets gives every rank its place in the global
+ * output.  acx_comm_init_all: one process holding n devices (ncclCommInitAll; local_counts has n entries, one
+ * per device in the order given).  acx_comm_unique_id + acx_comm_init_rank: one process per device
+ * (ncclCommInitRank; the 128-byte id is created on one rank and carried to the others by the host's own
+ * means -- a file, a socket, MPI); local_counts has one entry.  all_counts receives `world` entries on
+ * every caller.  librccl is loaded on first use.  (The torch.distributed form of the same exchange:
+ * ahocorasick_rs_amd/distributed.py.) */
+#define ACX_COMM_ID_BYTES 128
+typedef struct acx_comm acx_comm_t;
+int acx_comm_init_all(const int *devices, int n, acx_comm_t **out);
+int acx_comm_unique_id(uint8_t id[ACX_COMM_ID_BYTES]);
+int acx_comm_init_rank(const uint8_t id[ACX_COMM_ID_BYTES], int world, int rank, int device, acx_comm_t **out);
+int acx_comm_world(const acx_comm_t *c);
+int acx_comm_local_ranks(const acx_comm_t *c);
+int acx_comm_allgather_counts(acx_comm_t *c, const uint64_t *local_counts, uint64_t *all_counts);
+void acx_comm_free(acx_comm_t *c);
+/* offsets[r] = the matches of the ranks in front of r, offsets[world] = their total (exclusive prefix) */
+void acx_output_offsets(const uint64_t *counts, int world, uint64_t *offsets);
+
 /* ---- device-resident form (what bench.py times).  d_hay is a device pointer
  * to `len` bytes on the automaton's device.  Batches: either d_offsets
  * (device, n_hay + 1 u64, ragged) or uniform_len > 0 (n_hay * uniform_len ==

@@ -220,3 +220,30 @@ def test_exact_stage_forced_on_other_sets(monkeypatch, what):
         assert np.array_equal(cols(m[pos:pos + int(counts[i])]), o.find_raw(hh)), i
         pos += int(counts[i])
     a.close()
+
+
+def test_count_exchange_through_the_c_abi_one_rank():
+    """RCCL behind the C ABI, executed on the MI355X at one rank (more needs a node): both ways of making the
+    communicator -- ncclCommInitAll for one process, ncclGetUniqueId + ncclCommInitRank for one process per
+    device -- all-gather a count and turn the counts into output offsets; then a sharded batch call whose
+    count exchange goes through it (no torch.distributed anywhere)."""
+    from ahocorasick_rs_amd import distributed as D
+    c = capi.Comm.init_all([0])
+    assert (c.world, c.local_ranks) == (1, 1)
+    for n in (0, 42, 1 << 40):
+        assert c.allgather_counts([n]) == [n]
+    c.close()
+    uid = capi.comm_unique_id()
+    assert len(uid) == capi.COMM_ID_BYTES
+    c = capi.Comm.init_rank(uid, 1, 0, 0)
+    pats = gen.gen_patterns(2000, 5, 12, gen.AZ, 1)
+    a = capi.Automaton(pats, 0)
+    hs = [gen.gen_textlike(5000, 40 + i, pats).tobytes() for i in range(64)]
+    lo, hi = capi.shard_range(len(hs), 0, c.world)
+    m, counts = a.find_batch(hs[lo:hi])
+    rank_counts, off, total = D.gather_match_counts_capi(c, len(m), 0)
+    assert rank_counts == [len(m)] and off == 0 and total == len(m) == int(counts.sum()) > 0
+    c.close()
+    a.close()
+    with pytest.raises(ValueError):
+        capi.Comm.init_all([0, 0])

@@ -42,6 +42,27 @@ def test_shard_range_twin_of_the_distributed_helper():
             assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
 
 
+def test_count_exchange_behind_the_c_abi_offsets_and_clean_failure():
+    """Round 4: RCCL behind the C ABI (acx_comm_*).  The offset arithmetic is host code; without a HIP device
+    the communicator entry points fail with a message instead of crashing (there is no CPU path)."""
+    assert capi.output_offsets([3, 0, 5]) == [0, 3, 3, 8]
+    assert capi.output_offsets([]) == [0]
+    assert capi.output_offsets([7]) == [0, 7]
+    rng = random.Random(1)
+    for _ in range(50):
+        c = [rng.randrange(1 << 40) for _ in range(rng.randrange(1, 9))]
+        off = capi.output_offsets(c)
+        assert off[0] == 0 and off[-1] == sum(c) and all(off[i + 1] - off[i] == c[i] for i in range(len(c)))
+    if capi.device_count() == 0:
+        with pytest.raises(capi.AcxError) as e:
+            capi.Comm.init_all([0])
+        assert "no HIP device" in str(e.value)
+        with pytest.raises(capi.AcxError):
+            capi.comm_unique_id()
+    with pytest.raises((ValueError, capi.AcxError)):
+        capi.Comm.init_all([])
+
+
 def walk_all_occurrences(h, hay: bytes):
     """Test-side walker over the product's host tables (NOT a product path)."""
     out, s = [], 0
