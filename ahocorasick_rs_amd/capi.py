@@ -59,8 +59,7 @@ class HostTables(ctypes.Structure):
                 ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p),
                 ("walk_t3b", ctypes.c_void_p), ("walk_t3r", ctypes.c_void_p), ("walk_grec", ctypes.c_void_p),
                 ("long_min_len", ctypes.c_uint32), ("n_short", ctypes.c_uint32), ("short_min_len", ctypes.c_uint32),
-                ("short_xy", ctypes.c_void_p), ("short_codes", ctypes.c_void_p),
-                ("key_bloom", ctypes.c_void_p), ("key_lens", ctypes.c_uint32), ("exact_stage", ctypes.c_uint32)]
+                ("short_xy", ctypes.c_void_p), ("short_codes", ctypes.c_void_p)]
 
 
 class Profile(ctypes.Structure):
@@ -113,8 +112,6 @@ def lib() -> ctypes.CDLL:
     L.acx_host_tables.argtypes = [vp, ctypes.POINTER(HostTables)]
     L.acx_filter_hash.argtypes = [ctypes.c_uint32]
     L.acx_filter_hash.restype = ctypes.c_uint32
-    L.acx_key_bloom_hash.argtypes = [u64, ctypes.c_uint32]
-    L.acx_key_bloom_hash.restype = ctypes.c_uint32
     L.acx_prefix_slot.argtypes = [u64, ctypes.c_uint32, ctypes.c_uint32]
     L.acx_prefix_slot.restype = ctypes.c_uint32
     L.acx_free_host.argtypes = [vp]
@@ -257,7 +254,6 @@ class HostAutomaton:
         # K1b's side test for patterns of 1 and 2 bytes (empty without such patterns)
         self.short_xy = view(t.short_xy, 512 if t.short_xy else 0, np.uint32).reshape(-1, 2)
         self.short_codes = view(t.short_codes, 256 + 65536 if t.short_codes else 0, np.uint32)
-        self.key_bloom = view(t.key_bloom, 4096 if t.key_bloom else 0, np.uint32)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -274,11 +270,6 @@ class HostAutomaton:
 def filter_hash(gram: bytes) -> int:
     """level-1 hash H of a (Q-1)-byte gram: entry = H >> 18, signature bits from H >> 9."""
     return int(lib().acx_filter_hash(int.from_bytes(gram[:4], "little")))
-
-
-def key_bloom_hash(key: bytes) -> int:
-    """exact stage: hash of a whole prefix-table key (1..8 bytes)."""
-    return int(lib().acx_key_bloom_hash(int.from_bytes(key[:8], "little"), len(key[:8])))
 
 
 def prefix_hash(gram: bytes, salt: int) -> int:

@@ -1345,7 +1345,6 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
     D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
     D.short_min_len = H.n_short ? H.short_min_len : 0; D.k1b_min_len = H.long_min_len;
-    D.key_lens = H.key_lens; D.exact_stage = H.exact_stage;
     {
         static const char *big_env = std::getenv("ACX_FILTER_BIG"); // measurements: 0 / 1 force the choice
         D.filter_big = big_env ? (uint32_t)std::atoi(big_env) : (H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
@@ -1431,8 +1430,6 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     if (H.pbits.empty()) H.pbits.assign(4, 0);
     UP(H.pbits, pbits)
     if (H.short_xy.empty()) { H.short_xy.assign(SHORT_XY_WORDS, 0); H.short_codes.assign(4, SHORT_NONE); }
-    if (H.key_bloom.empty()) H.key_bloom.assign(KEY_BLOOM_WORDS, 0);
-    UP(H.key_bloom, key_bloom)
     UP(H.short_xy, short_xy)
     UP(H.short_codes, short_codes)
     {
@@ -1519,8 +1516,6 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->filter_density = A.filter_density;
     out->n_prefix_keys = A.n_prefix_keys;
     out->n_prefix_lists = (uint32_t)A.blist.size();
-    out->key_bloom = A.key_bloom.empty() ? nullptr : A.key_bloom.data();
-    out->key_lens = A.key_lens; out->exact_stage = A.exact_stage;
     out->long_min_len = A.long_min_len; out->n_short = A.n_short; out->short_min_len = A.n_short ? A.short_min_len : 0;
     out->short_xy = A.n_short ? A.short_xy.data() : nullptr;
     out->short_codes = A.n_short ? A.short_codes.data() : nullptr;
@@ -1528,7 +1523,6 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
 }
 
 uint32_t acx_filter_hash(uint32_t gram) { return filter_hash(gram); }
-uint32_t acx_key_bloom_hash(uint64_t gram, uint32_t k) { return key_bloom_hash((uint32_t)gram, (uint32_t)(gram >> 32), k); }
 uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2) {
     return prefix_slot(prefix_home_hash(q2 >= 8 ? gram : (gram & ((1ull << (8 * q2)) - 1)), q2), log2);
 }

@@ -522,20 +522,8 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (uint64_t i = 0; i < n; i++)
             for (uint32_t k = 0; k < Q2 && !is_short(i); k++)
                 if (pb[A.offsets[i] + k] >= 0xC0) { multibyte++; break; }
-        // The exact stage (automaton.hpp): for the sets with many true prefix hits -- while the LDS filter can
-        // tell their keys apart (two bits per key in 2^17: ~2 % false positives per probed length at 10^4 keys, 7 %
-        // at 2 x 10^4).  Its survivors start with a whole key, so displaced groups no longer flood level 2 with
-        // retries and the table goes back to load 1/8.  ACX_K1B_EXACT=0 / 1 forces the choice (measurements).
-        {
-            const char *ex_env = std::getenv("ACX_K1B_EXACT");
-            A.exact_stage = ex_env ? (uint32_t)(std::atoi(ex_env) != 0)
-                                   : (20 * multibyte > n && keys.size() <= 24576 && Q == FILTER_MAX_Q &&
-                                      !(A.filter_density > 0.2) ? 1u : 0u);
-            if (Q != FILTER_MAX_Q) A.exact_stage = 0; // (the kernel variant exists for Q = 5 only)
-        }
         const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
         const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env))
-                                        : A.exact_stage                                      ? 8
                                         : 20 * multibyte > n && keys.size() <= 65536         ? 32
                                           : (A.filter_q == 5 && A.filter_density > 0.2) || 20 * multibyte > n ? 8
                                                                                                 : 4;
@@ -560,8 +548,6 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         };
         std::vector<uint32_t> hash_at((size_t)1 << lg, 0); // hash of the entry stored in each slot
         A.rbloom.assign(REDIRECT_BLOOM_WORDS, 0);
-        A.key_bloom.assign(KEY_BLOOM_WORDS, 0);
-        A.key_lens = 0;
         A.pbits.assign(((size_t)1 << (lg + PREFIX_BITMAP_LOG2)) / 32, 0);
         // Redirect entries first: every haystack position that starts like ANY pattern of the group
         // looks the entry up, so it must sit in its home slot (a displaced one would turn all of
@@ -571,11 +557,6 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (Key &k : keys) {
             if ((k.next ? 0 : (k.salt == Q2 ? 1 : 2)) != pass) continue;
             uint32_t code = 0;
-            if (k.next == 0) { // a final key: into the exact stage's filter, under its own K bytes
-                const uint32_t hb = key_bloom_hash((uint32_t)k.gram, (uint32_t)(k.gram >> 32), k.K);
-                A.key_bloom[key_bloom_word(hb)] |= key_bloom_mask(hb);
-                A.key_lens |= 1u << k.K;
-            }
             if (k.next == 0) { // (the patterns of a key are in id order)
                 if (k.npid == 1) {
                     code = by_g1[k.pid0];

@@ -112,25 +112,6 @@ static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     return g;
 }
 
-// ---- K1b, exact stage (EX; round 4).  A set whose level-1 survivors are mostly TRUE Q-byte prefixes (keys
-// that start with a multi-byte UTF-8 character: every occurrence of the character opens ~n/alphabet patterns)
-// drowns level 2 in gathers that level 1 cannot prevent.  For such sets every FINAL prefix-table key (its own
-// K bytes, K = its length) is also filed in a blocked Bloom filter that lives in LDS: KEY_BLOOM_WORDS words,
-// two bits of ONE word per key.  The scan keeps the tile it works on in LDS, takes a survivor's first 8 bytes
-// from there and asks the filter once per key length the set has (key_lens: bit K) -- only positions that start
-// with a whole key (+ ~2 % per length) go on to the gathers.  The hash is multilinear in three 24-bit pieces of
-// the key (v_mul_u32_u24 is full rate, and the pieces of the four lengths share their products).
-constexpr uint32_t KEY_BLOOM_WORDS = 4096; // 16 KiB
-constexpr uint32_t KB_A = 0x9E3779u, KB_B = 0x85EBCBu, KB_C = 0xC2B2AFu, KB_S = 0x27D4EB2Fu;
-ACX_HD static inline uint32_t key_bloom_hash(uint32_t lo, uint32_t hi, uint32_t K) { // the first K (1..8) bytes of lo | hi << 32
-    const uint64_t w = ((uint64_t)hi << 32) | lo;
-    const uint64_t g = K >= 8 ? w : (w & ((1ull << (8 * K)) - 1));
-    const uint32_t p0 = (uint32_t)g & 0xFFFFFFu, p1 = (uint32_t)(g >> 24) & 0xFFFFFFu, p2 = (uint32_t)(g >> 48);
-    return p0 * KB_A + p1 * KB_B + p2 * KB_C + K * KB_S;
-}
-ACX_HD static inline uint32_t key_bloom_word(uint32_t h) { return h >> 20; }
-ACX_HD static inline uint32_t key_bloom_mask(uint32_t h) { return (1u << ((h >> 15) & 31)) | (1u << ((h >> 10) & 31)); }
-
 // ---- K1b, short patterns (1 and 2 bytes).  A q-gram prefilter keyed by the set's SHORTEST pattern
 // degenerates when that is 1 or 2 bytes long (Q = 1: every occurrence of a byte is a survivor), and
 // until round 4 such sets left K1b altogether.  Now the set is split: the LONG patterns (>= 3 bytes)
@@ -182,9 +163,6 @@ struct Automaton {
     // prefilter
     uint32_t filter_q = 0;             // level-1 prefix length Q (3..5; 1..2 only with ACX_NO_SHORT_SPLIT), 0 = no patterns
     uint32_t filter_q2 = 0;            // level-2 prefix length Q2 (3..8)
-    uint32_t exact_stage = 0;          // 1: K1b runs the exact stage (EX) on this set
-    uint32_t key_lens = 0;             // bit K: the prefix table holds a final key of K bytes
-    std::vector<uint32_t> key_bloom;   // KEY_BLOOM_WORDS (always built)
     uint32_t long_min_len = 0;         // shortest LONG pattern (what Q / Q2 are taken from); no long pattern: 5
     uint32_t n_short = 0;              // patterns of at most SHORT_MAX_LEN bytes: K1b's side test (0: none, the
                                        // tables below are empty)

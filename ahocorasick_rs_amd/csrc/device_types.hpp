@@ -49,10 +49,6 @@ struct DevAutomaton {
     const uint32_t *short_xy;    // SHORT_XY_WORDS (copied to LDS)
     const uint32_t *short_codes; // SHORT_CODES
     uint32_t short_min_len, k1b_min_len;
-    // K1b, exact stage (automaton.hpp): Bloom filter of the final prefix-table keys (copied to LDS)
-    const uint32_t *key_bloom;   // KEY_BLOOM_WORDS
-    uint32_t key_lens;           // bit K: a final key of K bytes exists
-    uint32_t exact_stage;        // 1: K1b runs its EX variant on this automaton
     // K1a, automata of at most 65 535 states: the whole DFA as u16, rows of n_classes entries
     // (no padding: 63 277 states x 28 classes x 2 B = 3.4 MiB fits one XCD's 4 MiB L2), in an
     // order of its own: states that report nothing first (BFS order), the reporting ones after

@@ -32,7 +32,6 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
-#include <type_traits>
 
 #include <rocprim/rocprim.hpp>
 
@@ -591,42 +590,6 @@ struct K1bLds {
     uint32_t sxy[SHORT_XY_WORDS];          // SH: the short patterns' {X, Y} pair table by middle byte
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
-// EX (the exact stage, automaton.hpp): the level-1 table folded to 2^13 entries (these sets' survivors are true
-// prefixes, not collisions: the table's size is not what limits them), the 4 KiB tile every wave works on
-// (+ the 8 bytes behind it), a second queue (level-1 survivors -> q1 -> the key filter -> q2 -> level 2), a
-// smaller hit buffer, and the Bloom filter of the keys.
-constexpr uint32_t K1B_HB_EX = 16;
-constexpr uint32_t K1B_STAGE_BYTES = 4096 + 16;
-struct K1bLdsEx {
-    uint32_t xy[FILTER_WORDS / 2];
-    uint8_t stage[16][K1B_STAGE_BYTES];
-    uint16_t q1[16][K1B_Q1CAP];
-    uint16_t q2[16][K1B_Q1CAP];
-    uint4 hb[16][K1B_HB_EX][2];
-    uint32_t cb[16][16];
-    uint32_t kb[KEY_BLOOM_WORDS];
-    uint32_t sxy[SHORT_XY_WORDS];
-};
-static_assert(sizeof(K1bLdsEx) <= 160 * 1024, "K1b (EX) LDS image exceeds 160 KiB");
-static_assert(K1B_STAGE_BYTES % 16 == 0, "rows of the staged tiles are written 16 bytes at a time");
-
-// Does a window (its first 8 bytes: lo, hi) start with a key of the prefix table?  One probe of the Bloom
-// filter per key length the set has (lens: bit K); the hash of automaton.hpp, its three products shared
-// between the lengths (v_mul_u32_u24 takes bits [23:0] of its operands by itself).
-__device__ __forceinline__ bool key_bloom_test(const uint32_t *kb, uint32_t lens, uint32_t lo, uint32_t hi) {
-    const uint32_t p1 = __builtin_amdgcn_alignbyte(hi, lo, 3), p2 = hi >> 16;
-    bool pass = false;
-#pragma unroll
-    for (uint32_t K = 1; K <= 8; K++) {
-        if (!((lens >> K) & 1u)) continue; // (wave-uniform)
-        uint32_t h = __umul24(K >= 3 ? lo : (lo & ((1u << (8 * K)) - 1u)), KB_A) + K * KB_S;
-        if (K > 3) h += __umul24(K >= 6 ? p1 : (p1 & ((1u << (8 * (K - 3))) - 1u)), KB_B);
-        if (K > 6) h += __umul24(K >= 8 ? p2 : (p2 & 0xFFu), KB_C);
-        const uint32_t w = kb[key_bloom_word(h)];
-        pass = pass || (((w >> ((h >> 15) & 31u)) & (w >> ((h >> 10) & 31u)) & 1u) != 0);
-    }
-    return pass;
-}
 
 __device__ __forceinline__ uint32_t hash_mul24(uint32_t a, uint32_t k) {
     return __umul24(a, k); // v_mul_u32_u24: uses bits [23:0] of each operand
@@ -817,8 +780,6 @@ struct K1bTables {
     uint8_t *cp_sub; // CP: lead (non-continuation) bytes of every 64 bytes of the stream (K3's sub counts)
     const uint32_t *short_xy, *short_codes; // SH: the side test for patterns of 1 and 2 bytes (automaton.hpp)
     uint32_t short_min;                     // SH: the shortest of them
-    const uint32_t *key_bloom;              // EX: Bloom filter of the final keys (automaton.hpp)
-    uint32_t key_lens;                      // EX: bit K: a key of K bytes exists
 };
 
 // CP (str API, sparse mode, lead == 0): the scan also counts the UTF-8 lead bytes of every 64-byte
@@ -833,21 +794,15 @@ struct K1bTables {
 // survivors travel through the same queue and pipeline with a flag (bit 15 of the offset) and are settled
 // against the exact codes (two 4-byte gathers: the 1-byte and the 2-byte pattern that may start there)
 // instead of the prefix table.
-// EX (Q = 5, not BIG; sets with many TRUE prefix hits, automaton.hpp): the wave keeps its tile in LDS; the level-1
-// survivors are collected in q1 and put, 64 at a time -- one per lane, every lane busy -- to the Bloom filter
-// of the prefix-table keys with 8 bytes read back from the staged tile; only those that start with a whole key
-// enter level 2 (q2), their windows' first half from LDS again, the second half gathered with the home slot.
-template <int Q, bool SLOTS, bool CP, bool BIG, bool SH, bool EX>
+template <int Q, bool SLOTS, bool CP, bool BIG, bool SH>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
     // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real stream and are
     // never candidates.  Stream position = index - lead.
-    static_assert(!EX || (Q == 5 && !BIG), "the exact stage exists for Q = 5, unsaturated tables");
-    using Lds = std::conditional_t<EX, K1bLdsEx, K1bLds>;
-    __shared__ __attribute__((aligned(16))) Lds L;
-    constexpr uint32_t FLOG = EX ? FILTER_ENTRIES_LOG2 - 1 : FILTER_ENTRIES_LOG2; // entries of the level-1 table in LDS
-    constexpr uint32_t HB = EX ? K1B_HB_EX : K1B_HB;
+    __shared__ __attribute__((aligned(16))) K1bLds L;
+    constexpr uint32_t FLOG = FILTER_ENTRIES_LOG2;
+    constexpr uint32_t HB = K1B_HB;
     // the wave index is wave-uniform: say so, and the tile index, its byte offset, the
     // interior test and most of the prefetch address arithmetic move from VALU to SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -858,16 +813,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     uint4 *const hrec = SLOTS ? GK.hslots : GK.recs + (uint64_t)region * GK.region_cap * 2;
     const uint32_t hcap = SLOTS ? 0u : (uint32_t)(GK.region_cap < 0xFFFFFFFFull ? GK.region_cap : 0xFFFFFFFFull);
     uint32_t hcur = 0;
-    if constexpr (EX) {
-        // entries 2 i and 2 i + 1 (they differ in the lowest bit of the index = bit 18 of the hash) fold into entry i
-        const uint4 *src = (const uint4 *)A.filterA;
-        uint2 *dst = (uint2 *)L.xy;
-        for (uint32_t i = threadIdx.x; i < (1u << FLOG); i += blockDim.x) {
-            const uint4 v = src[i];
-            dst[i] = make_uint2(v.x | v.z, v.y | v.w);
-        }
-        for (uint32_t i = threadIdx.x; i < KEY_BLOOM_WORDS; i += blockDim.x) L.kb[i] = A.key_bloom[i];
-    } else {
+    {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
@@ -892,12 +838,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     const uint32_t q2salt = q2len * 0x9E3779B1u; // prefix_key_hash(gram, q2len) = gram_hash2(gram) + q2salt
     const uint32_t ptab_log2 = A.ptab_log2;
     uint32_t q1c = 0; // wave-uniform queue fill
-    // the queue level 2 takes its batches from: q1 itself, or (EX) q2 behind the key filter
-    // (not EX: qa / qac ARE q1 / q1c)
-    uint16_t *qa;
-    if constexpr (EX) qa = L.q2[wave]; else qa = q1;
-    uint32_t q2c = 0;
-    uint32_t &qac = EX ? q2c : q1c;
     constexpr uint32_t OFFMASK = SH ? 0x0FFFu : 0xFFFFu; // a queued offset (12 bits); SH: bit 15 = a survivor of the side test
     constexpr uint32_t SHFLAG = 0x8000u;
 
@@ -1034,11 +974,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 // dependent gathers are waited for in place (rare unless many patterns share their
                 // first Q2 bytes; the other waves of the SIMD cover them)
                 uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
-                if constexpr (!EX) { // (EX: the key filter has spoken already)
-                    if (next) { // (most such positions end here: the LDS Bloom filter of those keys says no)
-                        const uint32_t bit = redirect_bloom_bit(prefix_home_hash(low_bytes(winC, next), next));
-                        if (!((L.rbloom[bit >> 5] >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
-                    }
+                if (next) { // (most such positions end here: the LDS Bloom filter of those keys says no)
+                    const uint32_t bit = redirect_bloom_bit(prefix_home_hash(low_bytes(winC, next), next));
+                    if (!((L.rbloom[bit >> 5] >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
                 }
                 if (next) code = prefix_walk(A.ptab, ptab_log2, next, winC, nullptr);
                 // a home slot holding another key proves absence unless the slot's filter of
@@ -1098,9 +1036,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             }
             nM = nB; stM = stB; tileM = tileB;
             // ---- stage A -> B: fetch the first 8 bytes of the queued survivors' windows
-            if (qac) {
-                if (lane < qac) {
-                    offB = qa[lane];
+            if (q1c) {
+                if (lane < q1c) {
+                    offB = q1[lane];
                     winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead);
                 }
             }
@@ -1115,30 +1053,18 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                     } else {
                         entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
                     }
-                    // (EX: the window's first half came from the staged tile; its second half -- what the hit record
-                    // carries for the verification -- is gathered here, with the slot, for the few that got this far)
-                    if constexpr (EX) winB1 = load_window(stream, len, (uint64_t)tileB * tile_bytes + (offB & OFFMASK) - lead + 8);
                 }
                 offC = offB | (prefix_more_index(hB) << 16); winC = winB; winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
             // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
-            if (qac) {
+            if (q1c) {
                 // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
                 const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
-                if (lane < qac) {
-                    offB = qa[lane];
+                if (lane < q1c) {
+                    offB = q1[lane];
                     const uint64_t p_ = (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead;
-                    if (EX && inside) { // the first 8 bytes from the staged tile (tileQ is still the one in LDS)
-                        if constexpr (EX) {
-                            const uint32_t o_ = offB & 0xFFFu;
-                            const uint8_t *sp_ = L.stage[wave] + (o_ & ~3u);
-                            const uint32_t d0_ = *(const uint32_t *)sp_, d1_ = *(const uint32_t *)(sp_ + 4), d2_ = *(const uint32_t *)(sp_ + 8);
-                            winB = ((uint64_t)__builtin_amdgcn_alignbyte(d2_, d1_, o_ & 3u) << 32) | __builtin_amdgcn_alignbyte(d1_, d0_, o_ & 3u);
-                        }
-                    } else if (EX) {
-                        winB = load_window(stream, len, p_);
-                    } else if (inside) {
+                    if (inside) {
                         u32x4 w_;
                         __builtin_memcpy(&w_, stream + p_, 16);
                         winB = ((uint64_t)w_.y << 32) | w_.x;
@@ -1149,40 +1075,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 }
             }
         }
-        nB = qac; stB = stQ; tileB = tileQ;
-        qac = 0;
+        nB = q1c; stB = stQ; tileB = tileQ;
+        q1c = 0;
         __builtin_amdgcn_wave_barrier();
-    };
-    // EX: q1 (level-1 survivors, one per lane) -> the key filter -> qa.  The 8 bytes come from the staged tile;
-    // the side test's survivors (SH) pass as they are.
-    auto exact_filter = [&](uint32_t tile32) __attribute__((always_inline)) {
-        if constexpr (EX) {
-            __builtin_amdgcn_wave_barrier();
-            bool pass = false;
-            uint32_t off = 0;
-            if (lane < q1c) {
-                off = q1[lane];
-                if (SH && (off & SHFLAG)) {
-                    pass = true;
-                } else {
-                    const uint32_t o_ = off & 0xFFFu;
-                    const uint8_t *sp_ = L.stage[wave] + (o_ & ~3u);
-                    const uint32_t d0_ = *(const uint32_t *)sp_, d1_ = *(const uint32_t *)(sp_ + 4), d2_ = *(const uint32_t *)(sp_ + 8);
-                    pass = key_bloom_test(L.kb, A.key_lens, __builtin_amdgcn_alignbyte(d1_, d0_, o_ & 3u),
-                                          __builtin_amdgcn_alignbyte(d2_, d1_, o_ & 3u));
-                }
-            }
-            const unsigned long long pm = __ballot(pass);
-            if (pm) {
-                const uint32_t np = (uint32_t)__popcll(pm);
-                if (qac + np > K1B_Q1CAP) advance(tile32, 1u); // (a full batch moves on now)
-                const uint32_t slot = qac + __builtin_amdgcn_mbcnt_hi((uint32_t)(pm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)pm, 0));
-                if (pass) qa[slot] = (uint16_t)off;
-                qac += np;
-            }
-            q1c = 0;
-            __builtin_amdgcn_wave_barrier();
-        }
     };
     constexpr uint64_t DRAIN = BIG ? 4 : 3; // extra iterations that empty the pipeline
 
@@ -1194,12 +1089,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // the previous tile's remaining survivors: its last batch (possibly empty)
         advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
         if (tile >= ntiles) continue;
-        if constexpr (EX) { // the tile goes to LDS (the previous one has been read for the last time just above)
-            uint8_t *sp_ = L.stage[wave] + lane * 16;
-            *(u32x4 *)sp_ = nxt0; *(u32x4 *)(sp_ + 1024) = nxt1; *(u32x4 *)(sp_ + 2048) = nxt2; *(u32x4 *)(sp_ + 3072) = nxt3;
-            if (lane == 0) *(uint2 *)(L.stage[wave] + 4096) = nxtL;
-            __builtin_amdgcn_wave_barrier();
-        }
 
         // ---- level 1 on this tile
         const uint64_t tbase = tile * tile_bytes;
@@ -1370,7 +1259,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
         // (one 64-bit mask per lane; the round is branch-free: the lowest set bit by two v_ffbl, lanes
         // without a survivor compute along and do not store)
-        if constexpr (!SH && !EX) {
+        if constexpr (!SH) {
             uint64_t m64 = (uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32);
             while (true) {
                 const bool has = m64 != 0;
@@ -1392,9 +1281,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                     const unsigned long long act = __ballot(has);
                     if (!act) break;
                     const uint32_t np = __popcll(act);
-                    if (q1c + np > K1B_Q1CAP) { // dense survivors: a full batch moves on now
-                        if (EX) exact_filter((uint32_t)tile); else advance((uint32_t)tile, 1u);
-                    }
+                    if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u); // dense survivors: a full batch moves on now
                     const uint32_t pos = (uint32_t)__builtin_ctzll(m64 | (1ull << 63));
                     m64 &= m64 - 1;
                     const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
@@ -1405,8 +1292,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             };
             compact((uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32), 0u);
             // SH: the side test's survivors, flagged (a position may be queued twice: once for each kind of table)
-            if (SH) compact((uint64_t)(srow0 | (srow1 << 16)) | ((uint64_t)(srow2 | (srow3 << 16)) << 32), SHFLAG);
-            if (EX) exact_filter((uint32_t)tile); // the rest of q1: the tile's (remaining) survivors are in qa now
+            compact((uint64_t)(srow0 | (srow1 << 16)) | ((uint64_t)(srow2 | (srow3 << 16)) << 32), SHFLAG);
         }
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
@@ -1425,7 +1311,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
 #undef K1B_BYTE_REG
 }
 
-size_t prefilter_lds_bytes() { return sizeof(K1bLds) > sizeof(K1bLdsEx) ? sizeof(K1bLds) : sizeof(K1bLdsEx); }
+size_t prefilter_lds_bytes() { return sizeof(K1bLds); }
 
 uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus) {
     uint64_t ntiles = prefilter_tiles(d_hay, len);
@@ -1459,28 +1345,27 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
     const K1bTables T{A.filterA, A.ptab, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.k1b_min_len, cp_sub,
-                      A.short_xy, A.short_codes, A.short_min_len, A.key_bloom, A.key_lens};
+                      A.short_xy, A.short_codes, A.short_min_len};
     const bool sh = A.short_min_len != 0; // the set has patterns of 1 or 2 bytes: the side test runs too
     if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
-#define ACX_K1B_LAUNCH(Q, S, C, B, H, E)                                                                   \
-    hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B, H, E>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
-#define ACX_K1B(Q, B, H, E)                                                                                \
-    if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, B, H, E);                                                    \
-    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, B, H, E);                                            \
-    else ACX_K1B_LAUNCH(Q, false, false, B, H, E)
-#define ACX_K1B_SH(Q, B, E)                                                                                \
-    if (sh) { ACX_K1B(Q, B, true, E); } else { ACX_K1B(Q, B, false, E); }
+#define ACX_K1B_LAUNCH(Q, S, C, B, H)                                                                      \
+    hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B, H>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
+#define ACX_K1B(Q, B, H)                                                                                   \
+    if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, B, H);                                                       \
+    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, B, H);                                               \
+    else ACX_K1B_LAUNCH(Q, false, false, B, H)
+#define ACX_K1B_SH(Q, B)                                                                                   \
+    if (sh) { ACX_K1B(Q, B, true); } else { ACX_K1B(Q, B, false); }
     switch (A.filter_q) {
     // (Q = 1, 2: only with ACX_NO_SHORT_SPLIT -- the split keeps such patterns out of these tables)
-    case 1: ACX_K1B(1, false, false, false); break;
-    case 2: ACX_K1B(2, false, false, false); break;
-    case 3: ACX_K1B_SH(3, false, false) break;
-    case 4: ACX_K1B_SH(4, false, false) break;
+    case 1: ACX_K1B(1, false, false); break;
+    case 2: ACX_K1B(2, false, false); break;
+    case 3: ACX_K1B_SH(3, false) break;
+    case 4: ACX_K1B_SH(4, false) break;
     default:
-        if (A.filter_big) { ACX_K1B_SH(5, true, false) } // saturated level-1 table: both tests for every position
-        else if (A.exact_stage) { ACX_K1B_SH(5, false, true) } // many true prefix hits: the key filter in LDS
-        else { ACX_K1B_SH(5, false, false) }
+        if (A.filter_big) { ACX_K1B_SH(5, true) } // saturated level-1 table: both tests for every position
+        else { ACX_K1B_SH(5, false) }
         break;
     }
 #undef ACX_K1B_SH

@@ -189,18 +189,11 @@ typedef struct acx_host_tables {
                                      may start at j; bit (b(j+2) & 31) of Y -- one may start at j+1 (superset)  */
     const uint32_t *short_codes;  /* [b0]: the 1-byte pattern b0; [256 + (b0 | b1 << 8)]: the 2-byte pattern
                                      (b0, b1): pattern id, 0x80000000 | index into prefix_lists, or 0xFFFFFFFF  */
-    /* K1b, exact stage (round 4; csrc/automaton.hpp): every final key of prefix_table (its own K bytes) in a
-       blocked Bloom filter of 4096 words -- word (h >> 20), bits ((h >> 15) & 31) and ((h >> 10) & 31),
-       h = acx_key_bloom_hash(key, K)                                                                        */
-    const uint32_t *key_bloom;
-    uint32_t key_lens;            /* bit K: a final key of K bytes exists                                    */
-    uint32_t exact_stage;         /* 1: the scan asks the filter before it gathers (sets with many true prefix hits) */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);
 int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out);
 uint32_t acx_filter_hash(uint32_t gram);   /* level-1 hash of a little-endian (Q-1)-gram   */
-uint32_t acx_key_bloom_hash(uint64_t gram, uint32_t k); /* exact stage: hash of the first k (1..8) bytes of gram */
 uint32_t acx_prefix_slot(uint64_t gram, uint32_t salt, uint32_t log2); /* home slot of the `salt` low
                                                                          bytes of gram */
 void acx_free_host(acx_host_automaton_t *h);

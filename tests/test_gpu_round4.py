@@ -4,9 +4,7 @@
     (> 32 byte classes: the sets that used to fall to the chunked walk), saturated level-1 tables, str API,
     batches (a short pattern never crosses a haystack boundary), unaligned buffers, sets of short patterns only
   * a batch of empty haystacks after a batch with matches returns zero counts (ADVICE, high)
-  * K1b's exact stage (EX: the tile in LDS, the Bloom filter of the prefix-table keys in front of the gathers):
-    cfg5's kind of set by the library's own choice, other sets with ACX_K1B_EXACT=1 -- all kinds, str API, dense
-    path, batches, unaligned buffers, the end of the stream, sets that also have short patterns
+  * RCCL behind the C ABI at one rank
 """
 import numpy as np
 import pytest
@@ -162,64 +160,6 @@ def test_batch_of_empty_haystacks_after_a_batch_with_matches():
     m, counts = e.find_batch([b"abc", b"", b"zz"])
     assert len(m) == 0 and list(counts) == [0, 0, 0]
     e.close()
-
-
-def test_exact_stage_cfg5_shape_all_kinds():
-    """The library chooses the exact stage for sets whose keys start with multi-byte characters (cfg5):
-    bytes API all kinds + overlapping, and the str API (CP variant) with code-point indexes."""
-    import ahocorasick_rs_amd as ac
-    spats = list(dict.fromkeys(gen.gen_patterns(4000, 5, 12, gen.AZ_UNI, 5)))
-    bpats = [p.encode() for p in spats]
-    h = capi.HostAutomaton(bpats)
-    assert int(h.t.exact_stage) == 1
-    h.close()
-    hay = gen.gen_unicode_textlike(1500000, 56, spats)
-    bhay = hay.encode()
-    check_all_kinds(bpats, bhay, "cfg5 shape")
-    cp = np.cumsum(np.frombuffer(bhay, dtype=np.uint8) & 0xC0 != 0x80) - 1
-    cp = np.concatenate([cp, [cp[-1] + 1]])
-    a = ac.AhoCorasick(spats, matchkind=ac.MatchKind.LeftmostLongest)
-    want = Oracle(bpats, 2, KIND_DFA).find_raw(bhay)
-    assert a.find_matches_as_indexes(hay) == [(int(p), int(cp[s]), int(cp[e])) for p, s, e in want]
-
-
-@pytest.mark.parametrize("what", ["cfg2", "lengths", "short", "dense"])
-def test_exact_stage_forced_on_other_sets(monkeypatch, what):
-    """ACX_K1B_EXACT=1: the EX variant of the scan on sets the library would not choose it for -- cfg2's set, a
-    set whose keys have every length from 5 to 8 with several keys per group (redirect entries), a set with
-    short patterns (SH + EX), and the dense path (regions instead of hit slots)."""
-    monkeypatch.setenv("ACX_K1B_EXACT", "1")
-    if what == "dense":
-        monkeypatch.setenv("ACX_NO_BUCKET", "1")
-    pats = gen.gen_patterns(6000, 5, 12, gen.AZ, 1)
-    if what == "lengths":
-        rng = np.random.default_rng(3)
-        stems = [bytes(rng.integers(97, 123, 5).astype(np.uint8)) for _ in range(300)]
-        pats = [s + bytes(rng.integers(97, 123, int(rng.integers(0, 8))).astype(np.uint8)) for s in stems for _ in range(6)]
-        pats += [p + b"xyzxyz" for p in pats[:200]]
-    if what == "short":
-        pats = pats + [b"qz", b"~", b"j"]
-    hay = gen.gen_textlike((3 << 20) + 5, 11, pats[:2000], plant_every=256).tobytes()
-    check_all_kinds(pats, hay, what)
-    # unaligned device buffers (the staged tile is the aligned index space), a stream that ends inside a tile
-    a = capi.Automaton(pats, 1)
-    o = Oracle(pats, 1, KIND_DFA)
-    big = np.frombuffer(hay, dtype=np.uint8)
-    buf = capi.DeviceBuffer(len(big) + 64).upload(big)
-    for lead, n in ((1, 100000), (7, 4096 * 3), (15, 4096 * 3 - 15), (3, 4096 * 5 + 4090), (0, 4097), (0, 11)):
-        r = a.find_device(buf.ptr + lead, n)
-        got = cols(r.matches())
-        r.free()
-        assert np.array_equal(got, o.find_raw(big[lead:lead + n].tobytes())), (lead, n)
-    buf.free()
-    # a batch (the windows of a haystack's last bytes reach into the next one: the verification knows the room)
-    hs = [hay[i * 7001:(i + 1) * 7001] for i in range(40)] + [b"", hay[:3]]
-    m, counts = a.find_batch(hs)
-    pos = 0
-    for i, hh in enumerate(hs):
-        assert np.array_equal(cols(m[pos:pos + int(counts[i])]), o.find_raw(hh)), i
-        pos += int(counts[i])
-    a.close()
 
 
 def test_count_exchange_through_the_c_abi_one_rank():

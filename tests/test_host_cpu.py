@@ -367,53 +367,6 @@ def test_short_pattern_side_tables():
     h.close()
 
 
-def key_bloom_pass(h, window: bytes) -> bool:
-    """Python twin of key_bloom_test (K1b's exact stage): one probe per key length the set has."""
-    for K in range(1, 9):
-        if not (int(h.t.key_lens) >> K) & 1:
-            continue
-        x = capi.key_bloom_hash(window[:K])
-        w = int(h.key_bloom[x >> 20])
-        if (w >> ((x >> 15) & 31)) & (w >> ((x >> 10) & 31)) & 1:
-            return True
-    return False
-
-
-def test_exact_stage_filter_holds_every_key(monkeypatch):
-    """Round 4: the Bloom filter of the final prefix-table keys (K1b's exact stage).  Every window that the
-    prefix table resolves to a candidate passes; random windows pass at the rate two bits per key in 2^17
-    allow; the hash is the documented multilinear one; the stage is chosen for cfg5's kind of set only."""
-    assert capi.key_bloom_hash(b"abcdefgh") == (0x636261 * 0x9E3779 + 0x666564 * 0x85EBCB + 0x6867 * 0xC2B2AF + 8 * 0x27D4EB2F) & 0xFFFFFFFF
-    assert capi.key_bloom_hash(b"abcde") == (0x636261 * 0x9E3779 + 0x6564 * 0x85EBCB + 5 * 0x27D4EB2F) & 0xFFFFFFFF
-    uni = [p.encode() for p in dict.fromkeys(gen.gen_patterns(3000, 5, 12, gen.AZ_UNI, 5))]
-    rng = random.Random(4)
-    for pats, want_stage in ((uni, 1), (gen.gen_patterns(3000, 5, 12, gen.AZ, 1), 0), (gen.gen_patterns(500, 3, 9, gen.ALL_BYTES, 3), 0)):
-        h = capi.HostAutomaton(pats)
-        assert int(h.t.exact_stage) == want_stage
-        lens = {min(8, min(len(o) for o in pats if o[:int(h.t.filter_q2)] == p[:int(h.t.filter_q2)])) for p in pats}
-        assert int(h.t.key_lens) == sum(1 << k for k in lens)
-        lg, q2 = int(h.t.prefix_table_log2), int(h.t.filter_q2)
-        for p in pats:
-            w = (p + bytes(rng.randrange(256) for _ in range(16)))[:16]
-            assert prefix_candidates(h, lg, q2, w) and key_bloom_pass(h, w), p
-        fp = 0
-        for _ in range(4000):
-            w = bytes(rng.randrange(97, 123) for _ in range(16))
-            if prefix_candidates(h, lg, q2, w):
-                assert key_bloom_pass(h, w)
-            else:
-                fp += key_bloom_pass(h, w)
-        assert fp <= 4000 * 0.03 * len(lens) + 8, (fp, lens)
-        h.close()
-    monkeypatch.setenv("ACX_K1B_EXACT", "1")
-    h = capi.HostAutomaton(gen.gen_patterns(3000, 5, 12, gen.AZ, 1))
-    assert int(h.t.exact_stage) == 1
-    h.close()
-    h = capi.HostAutomaton(gen.gen_patterns(300, 4, 9, gen.AZ, 1))  # (the kernel variant exists for Q = 5 only)
-    assert int(h.t.exact_stage) == 0
-    h.close()
-
-
 def test_prefix_keys_extend_beyond_the_shortest_pattern():
     """A set that mixes a 5-byte pattern with patterns starting with a 4-byte UTF-8 character: the
     long ones are filed under 8 bytes, so the character followed by an arbitrary byte is NOT a hit."""
