@@ -59,7 +59,8 @@ class HostTables(ctypes.Structure):
                 ("fail", ctypes.c_void_p), ("state_flags", ctypes.c_void_p),
                 ("walk_t3b", ctypes.c_void_p), ("walk_t3r", ctypes.c_void_p), ("walk_grec", ctypes.c_void_p),
                 ("long_min_len", ctypes.c_uint32), ("n_short", ctypes.c_uint32), ("short_min_len", ctypes.c_uint32),
-                ("short_xy", ctypes.c_void_p), ("short_codes", ctypes.c_void_p)]
+                ("short_xy", ctypes.c_void_p), ("short_codes", ctypes.c_void_p),
+                ("max_shift", ctypes.c_uint32), ("pattern_shift", ctypes.c_void_p), ("pattern_head", ctypes.c_void_p)]
 
 
 class Profile(ctypes.Structure):
@@ -254,6 +255,9 @@ class HostAutomaton:
         # K1b's side test for patterns of 1 and 2 bytes (empty without such patterns)
         self.short_xy = view(t.short_xy, 512 if t.short_xy else 0, np.uint32).reshape(-1, 2)
         self.short_codes = view(t.short_codes, 256 + 65536 if t.short_codes else 0, np.uint32)
+        # anchors: where every pattern is filed (a code of the prefix table is pattern id | shift << 24)
+        self.pattern_shift = view(t.pattern_shift, int(t.n_patterns), np.uint8)
+        self.pattern_head = view(t.pattern_head, 4 * int(t.n_patterns) if t.pattern_head else 0, np.uint32).reshape(-1, 4)
 
     def close(self) -> None:
         if getattr(self, "_h", None):

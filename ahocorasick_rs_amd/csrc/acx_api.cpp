@@ -1345,6 +1345,7 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.min_len = H.min_len; D.max_len = H.max_len; D.filter_q = H.filter_q;
     D.ptab_log2 = H.ptab_log2; D.filter_q2 = H.filter_q2;
     D.short_min_len = H.n_short ? H.short_min_len : 0; D.k1b_min_len = H.long_min_len;
+    D.max_shift = H.max_shift;
     {
         static const char *big_env = std::getenv("ACX_FILTER_BIG"); // measurements: 0 / 1 force the choice
         D.filter_big = big_env ? (uint32_t)std::atoi(big_env) : (H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
@@ -1431,6 +1432,13 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.pbits, pbits)
     if (H.short_xy.empty()) { H.short_xy.assign(SHORT_XY_WORDS, 0); H.short_codes.assign(4, SHORT_NONE); }
     UP(H.short_xy, short_xy)
+    if (H.max_shift) {
+        const uint32_t *ph = nullptr;
+        if ((rc = upload(a, st, H.phead.data(), H.phead.size(), &ph)) != ACX_OK) return destroy(rc);
+        D.phead = reinterpret_cast<const uint4 *>(ph);
+    } else {
+        D.phead = nullptr;
+    }
     UP(H.short_codes, short_codes)
     {
         const uint32_t *pi = nullptr;
@@ -1516,6 +1524,8 @@ int acx_host_tables(const acx_host_automaton_t *h, acx_host_tables_t *out) {
     out->filter_density = A.filter_density;
     out->n_prefix_keys = A.n_prefix_keys;
     out->n_prefix_lists = (uint32_t)A.blist.size();
+    out->max_shift = A.max_shift; out->pattern_shift = A.shift.data();
+    out->pattern_head = A.phead.empty() ? nullptr : A.phead.data();
     out->long_min_len = A.long_min_len; out->n_short = A.n_short; out->short_min_len = A.n_short ? A.short_min_len : 0;
     out->short_xy = A.n_short ? A.short_xy.data() : nullptr;
     out->short_codes = A.n_short ? A.short_codes.data() : nullptr;

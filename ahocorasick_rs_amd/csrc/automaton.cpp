@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -426,10 +427,60 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         const uint32_t Q2 = std::min<uint32_t>(FILTER2_MAX_Q, long_min);
         A.filter_q = Q; A.filter_q2 = Q2;
         const uint32_t gmask = g == 4 ? 0xFFFFFFFFu : ((1u << (8 * g)) - 1);
+        // ---- anchors (automaton.hpp): where every long pattern is filed.  How often a Q-gram will turn up in
+        // haystacks is estimated from the pattern set itself -- a first-order model of its bytes, P(b0) x prod
+        // P(b(k) | b(k-1)): the continuation bytes of a multi-byte character, "ttp:/" behind "h" are certain, a
+        // letter behind a letter is 1 in 26 -- and a pattern leaves its beginning for the offset with the
+        // rarest gram when that is at least SHIFT_GAIN times rarer (the first offset within a factor of two of
+        // the rarest: heads stay short).  Random sets have no such offsets and stay as they are.  The suffix
+        // keeps at least long_min bytes, so Q and Q2 are what they were.
+        // ACX_NO_ANCHORS: every pattern under its beginning (measurements / the round-3 tables).
+        A.shift.assign(n, 0);
+        A.max_shift = 0;
+        if (std::getenv("ACX_NO_ANCHORS") == nullptr && long_min >= Q && Q >= 3) {
+            std::vector<uint32_t> uni(256, 1), big((size_t)65536, 0), row(256, 256); // (+1 smoothing per cell)
+            uint64_t total_b = 256;
+            for (uint64_t i = 0; i < n; i++) {
+                if (is_short(i)) continue;
+                const uint8_t *pp = pb + A.offsets[i];
+                for (uint32_t k = 0; k < A.plen[i]; k++) {
+                    uni[pp[k]]++; total_b++;
+                    if (k) { big[(size_t)pp[k - 1] * 256 + pp[k]]++; row[pp[k - 1]]++; }
+                }
+            }
+            std::vector<float> lu(256), lb((size_t)65536);
+            for (uint32_t b = 0; b < 256; b++) lu[b] = std::log2((float)uni[b] / (float)total_b);
+            for (uint32_t a = 0; a < 256; a++)
+                for (uint32_t b = 0; b < 256; b++) lb[(size_t)a * 256 + b] = std::log2((float)(big[(size_t)a * 256 + b] + 1) / (float)row[a]);
+            auto gram_bits = [&](const uint8_t *x) { // -log2 of the gram's estimated probability
+                float v = -lu[x[0]];
+                for (uint32_t k = 1; k < Q; k++) v -= lb[(size_t)x[k - 1] * 256 + x[k]];
+                return v;
+            };
+            const float gain_bits = std::log2((float)SHIFT_GAIN);
+            for (uint64_t i = 0; i < n; i++) {
+                if (is_short(i)) continue;
+                const uint8_t *pp = pb + A.offsets[i];
+                const uint32_t dmax = std::min<uint32_t>(SHIFT_MAX, A.plen[i] - long_min);
+                if (!dmax) continue;
+                const float b0 = gram_bits(pp);
+                float best = b0;
+                for (uint32_t d = 1; d <= dmax; d++) best = std::max(best, gram_bits(pp + d));
+                if (best < b0 + gain_bits) continue;
+                uint32_t pick = 0;
+                for (uint32_t d = 1; d <= dmax; d++)
+                    if (gram_bits(pp + d) >= best - 1.0f) { pick = d; break; }
+                A.shift[i] = (uint8_t)pick;
+                A.max_shift = std::max(A.max_shift, pick);
+            }
+        }
+        // (from here on a long pattern IS its anchored suffix for every table of the prefilter)
+        auto abytes = [&](uint64_t i) { return pb + A.offsets[i] + A.shift[i]; };
+        auto alen = [&](uint64_t i) { return A.plen[i] - A.shift[i]; };
         A.filterA.assign(FILTER_WORDS, 0);
         for (uint64_t i = 0; i < n; i++) {
             if (is_short(i)) continue;
-            const uint8_t *pp = pb + A.offsets[i];
+            const uint8_t *pp = abytes(i);
             uint32_t wx = (uint32_t)gram_of(pp + 1, g) & gmask; // p[1..1+g)
             uint32_t wy = (uint32_t)gram_of(pp, g) & gmask;     // p[0..g)
             A.filterA[2 * filter_entry(filter_hash(wx))] |= filter_bit(pp[0]) | filter_bit(wx);
@@ -456,7 +507,7 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         // 0xFFFFFFFF = empty; next = 0: code = the only pattern with this key, or HIT_LIST | index
         // into blist; next = N > K: look the first N bytes up (salt N).
         std::vector<uint64_t> g1(n);              // first Q2 bytes of every pattern
-        for (uint64_t i = 0; i < n; i++) g1[i] = is_short(i) ? 0 : gram_of(pb + A.offsets[i], Q2);
+        for (uint64_t i = 0; i < n; i++) g1[i] = is_short(i) ? 0 : gram_of(abytes(i), Q2);
         std::vector<uint32_t> by_g1; // (without the identical later copies of a pattern: leftmost kinds)
         by_g1.reserve(n);
         for (uint64_t i = 0; i < n; i++) if (!dup[i] && !is_short(i)) by_g1.push_back((uint32_t)i);
@@ -477,19 +528,19 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             size_t e = b;
             uint32_t Lg = FILTER2_MAX_Q;
             while (e < n_filed && g1[by_g1[e]] == g1[by_g1[b]]) {
-                Lg = std::min<uint32_t>(Lg, std::min<uint32_t>(A.plen[by_g1[e]], FILTER2_MAX_Q));
+                Lg = std::min<uint32_t>(Lg, std::min<uint32_t>(alen(by_g1[e]), FILTER2_MAX_Q));
                 e++;
             }
             if (e - b > 1)
                 std::sort(by_g1.begin() + b, by_g1.begin() + e, [&](uint32_t x, uint32_t y) {
-                    const uint64_t gx = gram_of(pb + A.offsets[x], Lg), gy = gram_of(pb + A.offsets[y], Lg);
+                    const uint64_t gx = gram_of(abytes(x), Lg), gy = gram_of(abytes(y), Lg);
                     return gx != gy ? gx < gy : x < y;
                 });
             const size_t first_key = keys.size();
             for (size_t j = b; j < e;) {
-                const uint64_t g2 = gram_of(pb + A.offsets[by_g1[j]], Lg);
+                const uint64_t g2 = gram_of(abytes(by_g1[j]), Lg);
                 Key k{g2, Lg, 0, Q2, (uint32_t)j, 0};
-                while (j < e && gram_of(pb + A.offsets[by_g1[j]], Lg) == g2) { k.npid++; j++; }
+                while (j < e && gram_of(abytes(by_g1[j]), Lg) == g2) { k.npid++; j++; }
                 keys.push_back(k);
             }
             if (keys.size() - first_key > 1) { // several keys: redirect from the Q2 bytes to the keys' own hash
@@ -521,9 +572,10 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         uint64_t multibyte = 0;
         for (uint64_t i = 0; i < n; i++)
             for (uint32_t k = 0; k < Q2 && !is_short(i); k++)
-                if (pb[A.offsets[i] + k] >= 0xC0) { multibyte++; break; }
+                if (abytes(i)[k] >= 0xC0) { multibyte++; break; }
         const char *inv_env = std::getenv("ACX_PTAB_INV_LOAD"); // measurements: slots per key
         const size_t inv_load = inv_env ? (size_t)std::max(2, std::atoi(inv_env))
+                                        : A.max_shift                                        ? 8 // (anchored sets: the hot beginnings are gone)
                                         : 20 * multibyte > n && keys.size() <= 65536         ? 32
                                           : (A.filter_q == 5 && A.filter_density > 0.2) || 20 * multibyte > n ? 8
                                                                                                 : 4;
@@ -533,13 +585,20 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
         for (size_t e = 0; e < ((size_t)1 << lg); e++) A.ptab[4 * e + 2] = PREFIX_EMPTY;
         const uint32_t pmask = (1u << lg) - 1;
         A.pinfo.assign((size_t)4 * n, 0);
+        // (the 12 bytes that follow the first Q2 of the ANCHORED suffix; the length is the whole pattern's)
         for (uint64_t i = 0; i < n; i++) {
-            const uint8_t *pp = pb + A.offsets[i];
-            uint32_t L = A.plen[i];
+            const uint8_t *pp = abytes(i);
+            const uint32_t L = A.plen[i], La = alen(i);
             uint8_t tail[12] = {0};
-            for (uint32_t k = 0; k < 12 && Q2 + k < L; k++) tail[k] = pp[Q2 + k];
+            for (uint32_t k = 0; k < 12 && Q2 + k < La; k++) tail[k] = pp[Q2 + k];
             A.pinfo[4 * i] = A.rank[i] | (std::min<uint32_t>(L, 255) << 24);
             std::memcpy(&A.pinfo[4 * i + 1], tail, 12);
+        }
+        A.phead.clear();
+        if (A.max_shift) { // the bytes in front of the anchor (at most SHIFT_MAX = 12 of them are ever compared)
+            A.phead.assign((size_t)4 * n, 0);
+            for (uint64_t i = 0; i < n; i++)
+                std::memcpy(&A.phead[4 * i], pb + A.offsets[i], std::min<uint32_t>(A.plen[i], 12));
         }
         A.blist.clear();
         auto hash_of = [&](uint64_t gram, uint32_t salt) { // salt = the number of key bytes hashed
@@ -558,12 +617,13 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
             if ((k.next ? 0 : (k.salt == Q2 ? 1 : 2)) != pass) continue;
             uint32_t code = 0;
             if (k.next == 0) { // (the patterns of a key are in id order)
+                auto coded = [&](uint32_t pid) { return pid | ((uint32_t)A.shift[pid] << CODE_SHIFT_SHIFT); };
                 if (k.npid == 1) {
-                    code = by_g1[k.pid0];
+                    code = coded(by_g1[k.pid0]);
                 } else {
                     code = 0x80000000u | (uint32_t)A.blist.size();
                     A.blist.push_back(k.npid);
-                    A.blist.insert(A.blist.end(), by_g1.begin() + k.pid0, by_g1.begin() + k.pid0 + k.npid);
+                    for (uint32_t q = 0; q < k.npid; q++) A.blist.push_back(coded(by_g1[k.pid0 + q]));
                 }
             }
             const uint32_t h = hash_of(k.gram, k.salt);

@@ -112,6 +112,21 @@ static inline uint64_t gram_of(const uint8_t *p, uint32_t q) {
     return g;
 }
 
+// ---- K1b, anchors (round 4).  The prefilter can only be as selective as the bytes it is keyed by.  When many
+// patterns START alike -- a multi-byte UTF-8 character ("🤦..." opens 345 of cfg5's 10^4 patterns), "http://",
+// a common word stem -- their first Q bytes occur in every haystack at the rate of that beginning, level 1
+// cannot reject a true prefix, and every occurrence costs the whole level-2 pipeline (cfg5, round 3: 53 M
+// survivors per GiB, 5 % of all positions, K1b 2.7x slower than on cfg2).  So a pattern is filed under the
+// bytes at its ANCHOR, an offset d = shift[i] in [0, SHIFT_MAX] chosen by the compiler: the offset whose
+// Q-gram a first-order model of the pattern set's own bytes calls the rarest, when that is at least SHIFT_GAIN
+// times rarer than the beginning (automaton.cpp).  Level 1 and the prefix keys are built from the anchored
+// suffix p[d..]; a prefix-table code carries the shift (pattern id | d << 24); a hit at position i means
+// "pattern id may START at i - d", and the verification compares the d bytes in front of the hit (phead: the
+// pattern's first 12 bytes) as well as the rest.
+constexpr uint32_t SHIFT_MAX = 12;
+constexpr uint32_t SHIFT_GAIN = 16;     // how much rarer (estimated) an offset's gram must be for a pattern to move there
+constexpr uint32_t CODE_PID_MASK = 0x00FFFFFFu, CODE_SHIFT_SHIFT = 24, CODE_SHIFT_MASK = 15u;
+
 // ---- K1b, short patterns (1 and 2 bytes).  A q-gram prefilter keyed by the set's SHORTEST pattern
 // degenerates when that is 1 or 2 bytes long (Q = 1: every occurrence of a byte is a survivor), and
 // until round 4 such sets left K1b altogether.  Now the set is split: the LONG patterns (>= 3 bytes)
@@ -163,6 +178,9 @@ struct Automaton {
     // prefilter
     uint32_t filter_q = 0;             // level-1 prefix length Q (3..5; 1..2 only with ACX_NO_SHORT_SPLIT), 0 = no patterns
     uint32_t filter_q2 = 0;            // level-2 prefix length Q2 (3..8)
+    uint32_t max_shift = 0;            // largest anchor offset in use (0: every pattern is filed under its beginning)
+    std::vector<uint8_t> shift;        // n_patterns: the anchor offset d of every pattern (automaton.hpp, anchors)
+    std::vector<uint32_t> phead;       // n_patterns x 4 (empty when max_shift == 0): {the pattern's first 12 bytes, 0}
     uint32_t long_min_len = 0;         // shortest LONG pattern (what Q / Q2 are taken from); no long pattern: 5
     uint32_t n_short = 0;              // patterns of at most SHORT_MAX_LEN bytes: K1b's side test (0: none, the
                                        // tables below are empty)

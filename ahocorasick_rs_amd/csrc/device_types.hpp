@@ -49,6 +49,10 @@ struct DevAutomaton {
     const uint32_t *short_xy;    // SHORT_XY_WORDS (copied to LDS)
     const uint32_t *short_codes; // SHORT_CODES
     uint32_t short_min_len, k1b_min_len;
+    // K1b, anchors (automaton.hpp): a prefix-table code is pattern id | shift << 24 -- the pattern may START
+    // shift bytes in front of the hit; phead = every pattern's first 12 bytes (null when max_shift == 0)
+    const uint4 *phead;
+    uint32_t max_shift;
     // K1a, automata of at most 65 535 states: the whole DFA as u16, rows of n_classes entries
     // (no padding: 63 277 states x 28 classes x 2 B = 3.4 MiB fits one XCD's 4 MiB L2), in an
     // order of its own: states that report nothing first (BFS order), the reporting ones after

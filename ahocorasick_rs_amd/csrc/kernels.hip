@@ -176,6 +176,13 @@ __device__ __forceinline__ uint64_t segment_end(const Segments &G, uint64_t len,
     return len;
 }
 
+// [*lo, *hi) = the haystack containing stream position x (x < len)
+__device__ __forceinline__ void segment_bounds(const Segments &G, uint64_t len, uint64_t x, uint64_t *lo, uint64_t *hi) {
+    if (G.uniform_len) { *lo = (x / G.uniform_len) * G.uniform_len; *hi = *lo + G.uniform_len; }
+    else if (G.offsets) { const uint64_t h = upper_bound_u64(G.offsets, G.n_hay + 1, x); *lo = G.offsets[h - 1]; *hi = G.offsets[h]; }
+    else { *lo = 0; *hi = len; }
+}
+
 // ---------------------------------------------------------------------------
 // K1a: chunked DFA walk
 // ---------------------------------------------------------------------------
@@ -663,18 +670,33 @@ __device__ __forceinline__ uint32_t prefix_code(const uint32_t *__restrict__ pta
     return next ? prefix_walk(ptab, log2, next, w0, nullptr) : code;
 }
 
-// L3: does pattern `pid` occur at stream position p?  The first Q2 bytes are known to match
-// (the prefix table said so), the rest is compared with the haystack: ONE 16-byte load (pinfo:
-// rank, length and the 12 bytes after the first Q2) settles a pattern of up to Q2 + 12 bytes
-// against the window (w0, w1) = the 16 haystack bytes at p that travel with the hit -- independent
-// loads, no dependent DFA walk, no second touch of the (by now cold) haystack.  Returns the
-// pattern's length (0: no occurrence); *rk = its tie-break rank.  room = bytes from p to the end
-// of its haystack.
+// L3: does the pattern of `code` (pattern id | anchor shift << 24, automaton.hpp) occur with its ANCHOR at stream
+// position p -- i.e. does it start at p - shift?  The first Q2 bytes at the anchor are known to match (the prefix
+// table said so), the rest is compared with the haystack: ONE 16-byte load (pinfo: rank, length and the 12 bytes
+// after the anchor's first Q2) settles a pattern of up to Q2 + 12 bytes behind its anchor against the window
+// (w0, w1) = the 16 haystack bytes at p that travel with the hit -- independent loads, no dependent DFA walk, no
+// second touch of the (by now cold) haystack.  A shifted pattern also has its head compared: its first `shift`
+// bytes (phead) with the haystack bytes in front of the hit -- two more independent loads.  Returns the pattern's
+// length (0: no occurrence); *rk = its tie-break rank, *start = p - shift.  room = bytes from p to the end of
+// its haystack, back = bytes from the start of its haystack to p.
+// (ANCH = false: the automaton files every pattern under its beginning -- the instantiation without anchors is
+// the round-3 code, register for register)
+template <bool ANCH>
 __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, const uint8_t *__restrict__ stream,
-                                                     uint64_t len, uint64_t p, uint32_t pid, uint64_t w0,
-                                                     uint64_t w1, uint64_t room, uint32_t *rk) {
+                                                     uint64_t len, uint64_t p, uint32_t code, uint64_t w0,
+                                                     uint64_t w1, uint64_t room, uint64_t back, uint32_t *rk,
+                                                     uint64_t *start) {
     const uint32_t q = A.filter_q2;
+    const uint32_t pid = code & CODE_PID_MASK;
+    const uint32_t sh = ANCH ? (code >> CODE_SHIFT_SHIFT) & CODE_SHIFT_MASK : 0u;
     const uint4 pi = A.pinfo[pid];
+    // the bytes in front of the anchor: the pattern's and the haystack's, requested together with the info
+    uint4 hd = make_uint4(0, 0, 0, 0);
+    uint64_t hw0 = 0, hw1 = 0;
+    if (ANCH && sh != 0 && sh <= back) {
+        hd = A.phead[pid];
+        load_window16(stream, len, p - sh, &hw0, &hw1);
+    }
     // patterns that can reach beyond the carried window: where the pattern's bytes lie, requested
     // together with its info (uniform branch; the bytes themselves together with the haystack's)
     // (the carried window holds the haystack's first 16 bytes, pinfo the pattern's first filter_q2 + 12: a
@@ -682,11 +704,13 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
     // and let 14..16-byte patterns behind a short prefix through; the first fix of round 3 tested pinfo
     // only -- and let 17..20-byte patterns behind an 8-byte prefix through: found by tools/gpu_fuzz.py)
     const bool far = A.max_len > (A.filter_q2 + 12 < 16 ? A.filter_q2 + 12 : 16);
-    const uint64_t po = far ? A.pat_off[pid] : 0;
+    const uint64_t po = far ? A.pat_off[pid] + sh : 0; // (the anchored suffix's bytes)
     *rk = pi.x & 0xFFFFFFu;
-    uint32_t L = pi.x >> 24;
-    if (L == 255) L = A.plen[pid];
-    bool ok = L <= room;
+    uint32_t Lw = pi.x >> 24;
+    if (Lw == 255) Lw = A.plen[pid];
+    const uint32_t L = Lw - sh; // bytes from the anchor on
+    *start = p - sh;
+    bool ok = L <= room && sh <= back;
     if (ok && L > q) {
         // haystack bytes q.. from the carried window (16 - q of them), pattern bytes from pinfo
         const uint32_t have = 16 - q;                  // carried bytes beyond the prefix
@@ -719,7 +743,12 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
             }
         }
     }
-    return ok ? L : 0;
+    if (ANCH && sh) { // the head (sh <= SHIFT_MAX = 12 bytes)
+        const uint64_t m0 = sh >= 8 ? ~0ull : ((1ull << (8 * sh)) - 1);
+        const uint64_t m1 = sh > 8 ? ((1ull << (8 * (sh - 8))) - 1) : 0;
+        ok = ok && ((((hw0 ^ (((uint64_t)hd.y << 32) | hd.x)) & m0) | ((hw1 ^ (uint64_t)hd.z) & m1)) == 0);
+    }
+    return ok ? Lw : 0;
 }
 
 __device__ __forceinline__ uint64_t occurrence_key(int key_mode, uint32_t rank_bits, uint64_t p, uint32_t L,
@@ -731,6 +760,7 @@ __device__ __forceinline__ uint64_t occurrence_key(int key_mode, uint32_t rank_b
 
 // Dense path: one thread per prefix hit of K1b (region mode).  Hits live in the per-wave regions
 // of the scan's sink (H); occurrences go to the occurrence sink (GK, one region per workgroup).
+template <bool ANCH>
 __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, Sink H, uint32_t h_grid,
                                                    Sink GK, const uint8_t *__restrict__ stream,
                                                    uint64_t len) {
@@ -746,17 +776,21 @@ __global__ __launch_bounds__(256) void k_walk_hits(DevAutomaton A, Segments G, S
             const uint4 h = rec[2 * i], w = rec[2 * i + 1];
             const uint64_t p = ((uint64_t)h.y << 32) | h.x;
             const uint64_t w0 = ((uint64_t)w.y << 32) | w.x, w1 = ((uint64_t)w.w << 32) | w.z;
-            const uint64_t room = segment_end(G, len, p) - p;
+            uint64_t seg_lo, seg_hi;
+            segment_bounds(G, len, p, &seg_lo, &seg_hi);
+            const uint64_t room = seg_hi - p, back = p - seg_lo;
             uint32_t code = h.z;
             if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
             const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
             const uint32_t li = code & ~HIT_LIST;
             const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
             for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t pid = list ? A.blist[li + 1 + k] : code;
+                const uint32_t cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
+                const uint32_t pid = cand & CODE_PID_MASK;
                 uint32_t rk;
-                const uint32_t L = verify_candidate(A, stream, len, p, pid, w0, w1, room, &rk);
-                emit_key_agg(K, L != 0, occurrence_key(K.key_mode, A.rank_bits, p, L, pid, rk), pid, L);
+                uint64_t ps;
+                const uint32_t L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
+                emit_key_agg(K, L != 0, occurrence_key(K.key_mode, A.rank_bits, ps, L, pid, rk), pid, L);
             }
         }
     }
@@ -1325,7 +1359,8 @@ uint32_t walk_hits_grid(uint32_t hit_regions) { return hit_regions < 4096 ? hit_
 hipError_t launch_walk_hits(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
                             const Sink &occ, uint32_t occ_grid, const uint8_t *d_hay, uint64_t len,
                             hipStream_t st) {
-    hipLaunchKernelGGL(k_walk_hits, dim3(occ_grid), dim3(256), 0, st, A, G, hits, hit_grid, occ, d_hay, len);
+    if (A.max_shift) hipLaunchKernelGGL(k_walk_hits<true>, dim3(occ_grid), dim3(256), 0, st, A, G, hits, hit_grid, occ, d_hay, len);
+    else hipLaunchKernelGGL(k_walk_hits<false>, dim3(occ_grid), dim3(256), 0, st, A, G, hits, hit_grid, occ, d_hay, len);
     return hipGetLastError();
 }
 
@@ -2026,6 +2061,7 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
     else { *s = rel; *e = rel + L; }
 }
 
+template <bool ANCH>
 __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
@@ -2040,14 +2076,18 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
     __shared__ uint64_t st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
     __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
     __shared__ int32_t bmax[STAGE_BUCKETS];        // largest end per bucket
-    __shared__ uint32_t hoff[STAGE_BUCKETS + 1];   // exclusive prefix of the tiles' hit counts
+    __shared__ uint32_t hoff[STAGE_BUCKETS + 2];   // exclusive prefix of the tiles' hit counts
     __shared__ uint32_t synm[STAGE_BUCKETS], accm[STAGE_BUCKETS]; // per bucket: sync points / accepted
     __shared__ uint32_t fail, stop, tail_base;
     const uint32_t t = threadIdx.x, g = blockIdx.x;
     const uint32_t tile0 = g * GROUP_TILES;
     const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
     const uint32_t lb = tile0 - first;                               // context tiles in front
-    const uint32_t nb = GROUP_TILES + lb;                            // staged buckets
+    // anchors (automaton.hpp): a hit lies up to SHIFT_MAX bytes BEHIND the start of its occurrence, so an
+    // occurrence that starts in the group's last bytes has its hit in the first tile of the next group: that
+    // tile's hits are read too (the occurrences that start beyond the group are dropped like the context's)
+    const uint32_t la = ANCH ? 1u : 0u;
+    const uint32_t nb = GROUP_TILES + lb + la;                       // tiles whose hits are read
     // ---- hits of the staged tiles: exclusive prefix of the counts (wave 0: 64 tiles, wave 1: the
     // few beyond -- nb <= 68)
     uint32_t c = 0;
@@ -2095,19 +2135,25 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
         const uint4 r0 = rec[0];
         const uint4 w = rec[1]; // (unconditional: in flight together with the first half)
         const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
-        uint64_t w0 = 0, w1 = 0, room = 0;
+        uint64_t w0 = 0, w1 = 0, room = 0, back = 0;
         uint32_t nc = 1, li = 0, code = r0.z;
         const bool verified = code != HIT_RETRY && (code & HIT_VERIFIED) != 0;
         bool list = false;
         if (!verified) {
             w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
-            room = segment_end(G, len, p) - p;
+            if (ANCH) { // the haystack's start matters only to patterns filed behind their beginning
+                uint64_t seg_lo, seg_hi;
+                segment_bounds(G, len, p, &seg_lo, &seg_hi);
+                room = seg_hi - p; back = p - seg_lo;
+            } else {
+                room = segment_end(G, len, p) - p;
+            }
             if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
             if (code == HIT_NONE) nc = 0;
             else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
         }
-        auto stage = [&](uint32_t pid, uint32_t L, uint32_t rk) {
-            const uint64_t kidx = (key_mode == 0 ? p + L : p) + lead;
+        auto stage = [&](uint64_t ps, uint32_t pid, uint32_t L, uint32_t rk) { // ps: where the occurrence starts
+            const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
             if (kidx < complete || kidx >= idx_hi) return; // another group's (or nobody's) business
             const uint32_t rel = (uint32_t)(kidx - first_idx);
             const uint32_t b = rel >> TILE_BITS;
@@ -2118,11 +2164,12 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
         };
         if (verified) {
             const uint32_t pid = code & ~HIT_VERIFIED;
-            stage(pid, r0.w, key_mode == 1 ? 0u : A.rank[pid]);
+            stage(p, pid, r0.w, key_mode == 1 ? 0u : A.rank[pid]);
         } else if (!list) {
             uint32_t rk;
-            const uint32_t L = nc ? verify_candidate(A, stream, len, p, code, w0, w1, room, &rk) : 0;
-            if (L) stage(code, L, rk);
+            uint64_t ps = p;
+            const uint32_t L = nc ? verify_candidate<ANCH>(A, stream, len, p, code, w0, w1, room, back, &rk, &ps) : 0;
+            if (L) stage(ps, code & CODE_PID_MASK, L, rk);
         } else {
             // a list (patterns that share their key): two candidates at a time, their gathers in
             // flight together -- a thread with a long list otherwise holds the whole group back
@@ -2130,10 +2177,11 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 const bool two = k + 1 < nc;
                 const uint32_t pid0 = A.blist[li + 1 + k], pid1 = A.blist[li + 1 + (two ? k + 1 : k)];
                 uint32_t rk0, rk1;
-                const uint32_t L0 = verify_candidate(A, stream, len, p, pid0, w0, w1, room, &rk0);
-                const uint32_t L1 = verify_candidate(A, stream, len, p, pid1, w0, w1, room, &rk1);
-                if (L0) stage(pid0, L0, rk0);
-                if (two && L1) stage(pid1, L1, rk1);
+                uint64_t ps0, ps1;
+                const uint32_t L0 = verify_candidate<ANCH>(A, stream, len, p, pid0, w0, w1, room, back, &rk0, &ps0);
+                const uint32_t L1 = verify_candidate<ANCH>(A, stream, len, p, pid1, w0, w1, room, back, &rk1, &ps1);
+                if (L0) stage(ps0, pid0 & CODE_PID_MASK, L0, rk0);
+                if (two && L1) stage(ps1, pid1 & CODE_PID_MASK, L1, rk1);
             }
         }
     }
@@ -2241,7 +2289,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             T.btot[g] = n;
             uint64_t *sgw = T.sgw + (seq & 1) * 2 * (uint64_t)T.sg_cap;
             __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, ((uint64_t)occ << 32) | (hoff[nb] - hoff[lb]),
+            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, ((uint64_t)occ << 32) | (hoff[lb + GROUP_TILES] - hoff[lb]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
@@ -2455,8 +2503,12 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
-    hipLaunchKernelGGL(k_tile_main, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
-                       lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
+    if (A.max_shift)
+        hipLaunchKernelGGL(k_tile_main<true>, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
+                           lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
+    else
+        hipLaunchKernelGGL(k_tile_main<false>, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
+                           lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
     if (before_write) { // (what the write kernel needs from another stream: the code-point prefix)
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;

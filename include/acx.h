@@ -189,6 +189,13 @@ typedef struct acx_host_tables {
                                      may start at j; bit (b(j+2) & 31) of Y -- one may start at j+1 (superset)  */
     const uint32_t *short_codes;  /* [b0]: the 1-byte pattern b0; [256 + (b0 | b1 << 8)]: the 2-byte pattern
                                      (b0, b1): pattern id, 0x80000000 | index into prefix_lists, or 0xFFFFFFFF  */
+    /* K1b, anchors (round 4; csrc/automaton.hpp): a pattern is filed under the bytes at offset
+       pattern_shift[i] (0 .. 12; crowded beginnings move away from theirs); filter_xy, prefix_table keys and
+       the 12 tail bytes of a pattern's info are taken from that anchored suffix; a code in prefix_table /
+       prefix_lists is pattern id | shift << 24: "the pattern may start `shift` bytes in front of the hit"   */
+    uint32_t max_shift;           /* largest shift in use (0: none, pattern_head is NULL)                    */
+    const uint8_t *pattern_shift; /* n_patterns                                                              */
+    const uint32_t *pattern_head; /* n_patterns x 4: the pattern's first 12 bytes (what lies in front of the anchor) */
 } acx_host_tables_t;
 int acx_compile_host(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                      int match_kind, acx_host_automaton_t **out);

@@ -5,6 +5,9 @@
     batches (a short pattern never crosses a haystack boundary), unaligned buffers, sets of short patterns only
   * a batch of empty haystacks after a batch with matches returns zero counts (ADVICE, high)
   * RCCL behind the C ABI at one rank
+  * anchors: patterns with common beginnings (a multi-byte character, "http://") are filed under a later
+    offset; a hit lies behind the start of its occurrence -- the head is verified, haystack and group boundaries,
+    the dense path, the str API
 """
 import numpy as np
 import pytest
@@ -187,3 +190,81 @@ def test_count_exchange_through_the_c_abi_one_rank():
     a.close()
     with pytest.raises(ValueError):
         capi.Comm.init_all([0, 0])
+
+
+def url_like_patterns(n=3000, seed=3):
+    rng = np.random.default_rng(seed)
+    hosts = [bytes(rng.integers(97, 123, int(rng.integers(3, 9))).astype(np.uint8)) for _ in range(n)]
+    return [b"http://" + h + [b".com", b".org/x", b".net/index", b""][i % 4] for i, h in enumerate(hosts)] + [b"http://", b"https:"]
+
+
+def test_anchored_patterns_cfg5_shape_and_urls():
+    """The library files cfg5's emoji-led patterns and a URL list behind their common beginnings (max_shift > 0
+    in the host tables); every kind equals the oracle, through both scan kernels (the walk does not use anchors)."""
+    import ahocorasick_rs_amd as ac
+    spats = list(dict.fromkeys(gen.gen_patterns(4000, 5, 12, gen.AZ_UNI, 5)))
+    bpats = [p.encode() for p in spats]
+    h = capi.HostAutomaton(bpats)
+    assert int(h.t.max_shift) >= 3
+    h.close()
+    hay = gen.gen_unicode_textlike(1500000, 56, spats)
+    bhay = hay.encode()
+    check_all_kinds(bpats, bhay, "cfg5 shape", kernels=(None, capi.KERNEL_DFA_WALK))
+    cp = np.cumsum(np.frombuffer(bhay, dtype=np.uint8) & 0xC0 != 0x80) - 1
+    cp = np.concatenate([cp, [cp[-1] + 1]])
+    a = ac.AhoCorasick(spats, matchkind=ac.MatchKind.LeftmostLongest)
+    want = Oracle(bpats, 2, KIND_DFA).find_raw(bhay)
+    assert a.find_matches_as_indexes(hay) == [(int(p), int(cp[s]), int(cp[e])) for p, s, e in want]
+    urls = url_like_patterns()
+    h = capi.HostAutomaton(urls)
+    assert int(h.t.max_shift) >= 5
+    h.close()
+    text = bytearray(gen.gen_textlike(3 << 20, 9).tobytes())
+    rng = np.random.default_rng(4)
+    for o in rng.integers(0, len(text) - 40, 20000):
+        u = urls[int(rng.integers(0, len(urls)))]
+        u = u[:len(u) - int(rng.integers(0, 3))]  # (truncated copies: the anchor matches, the rest does not)
+        text[o:o + len(u)] = u
+    text[:len(urls[0])] = urls[0]           # an occurrence at the very start: its anchor lies 7 bytes in
+    text[-len(urls[1]):] = urls[1]          # and one that ends the haystack
+    check_all_kinds(urls, bytes(text), "urls")
+
+
+@pytest.mark.parametrize("dense", [False, True])
+def test_anchored_patterns_at_boundaries(monkeypatch, dense):
+    """A hit lies up to 12 bytes behind the start of its occurrence: occurrences that start in the last bytes
+    of a tile / of a 256 KiB group (their hits are in the next group's first tile), at the start of a haystack of
+    a batch (the head must not reach into the previous haystack), unaligned buffers; sparse and dense path."""
+    if dense:
+        monkeypatch.setenv("ACX_NO_BUCKET", "1")
+    urls = url_like_patterns(800, 5)
+    rng = np.random.default_rng(8)
+    hay = bytearray(gen.gen_textlike((1 << 20) + 4096, 21).tobytes())
+    for edge in list(range(4096, len(hay) - 64, 4096 * 7)) + [262144, 524288, 786432, 1048576]:
+        for back in (1, 3, 6, 7, 8, 11, 13):
+            u = urls[int(rng.integers(0, len(urls)))]
+            o = edge - back
+            hay[o:o + len(u)] = u
+    hay = bytes(hay)
+    for mk in (0, 1, 2):
+        a = capi.Automaton(urls, mk)
+        o = Oracle(urls, mk, KIND_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            assert np.array_equal(cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)), (mk, ov)
+        big = np.frombuffer(hay, dtype=np.uint8)
+        buf = capi.DeviceBuffer(len(big) + 64).upload(big)
+        for lead, n in ((1, 300000), (9, 262144 + 4096), (15, 4096 * 3 - 15)):
+            r = a.find_device(buf.ptr + lead, n)
+            got = cols(r.matches())
+            r.free()
+            assert np.array_equal(got, o.find_raw(big[lead:lead + n].tobytes())), (mk, lead, n)
+        buf.free()
+        # batch: haystacks cut INSIDE planted URLs (the anchor "//xyz" opens a haystack whose head is elsewhere)
+        cuts = sorted(set([0, len(hay)] + [int(x) for x in rng.integers(0, len(hay), 150)] + [4096 * 7 + 4096 - 3 + 7, 262144 - 7 + 5]))
+        hs = [hay[cuts[i]:cuts[i + 1]] for i in range(len(cuts) - 1)]
+        m, counts = a.find_batch(hs)
+        pos = 0
+        for i, hh in enumerate(hs):
+            assert np.array_equal(cols(m[pos:pos + int(counts[i])]), o.find_raw(hh)), (mk, i)
+            pos += int(counts[i])
+        a.close()

@@ -146,10 +146,11 @@ def test_compressed_form_is_the_same_automaton(monkeypatch):
             assert np.array_equal(getattr(c, name), getattr(h, name)), name
 
 
-def test_leftmost_kinds_file_only_the_first_of_identical_patterns():
+def test_leftmost_kinds_file_only_the_first_of_identical_patterns(monkeypatch):
     """Of several identical patterns only the first can be reported by a leftmost kind (lowest index
     wins): the later copies stay out of the own lists and of the prefix table's candidate lists;
     Standard keeps them all (an overlapping search reports every one)."""
+    monkeypatch.setenv("ACX_NO_ANCHORS", "1")  # (every pattern under its beginning: the windows below start with the patterns)
     pats = [b"abcde", b"xyzzy", b"abcde", b"abcdefgh", b"abcde", b"xyzzy", b"q" * 9, b"abcdefgh"]
     for mk in (0, 1, 2):
         h = capi.HostAutomaton(pats, mk)
@@ -201,9 +202,9 @@ def prefix_walk(h, lg, salt, window: bytes, allow_redirect: bool):
         idx = (idx + 1) & ((1 << lg) - 1)
 
 
-def prefix_candidates(h, lg, q2, window: bytes):
+def prefix_candidates(h, lg, q2, window: bytes, coded: bool = False):
     """Python twin of prefix_code + the candidate list: the pattern ids K1b hands on for a
-    haystack window (>= 8 bytes, zero padded)."""
+    haystack window (>= 8 bytes, zero padded).  coded: the codes as they are (pattern id | anchor shift << 24)."""
     got = prefix_walk(h, lg, q2, window, True)
     if got and got[0] == "redirect":
         assert got[1] > q2
@@ -211,14 +212,16 @@ def prefix_candidates(h, lg, q2, window: bytes):
     if not got:
         return []
     code = got[1]
+    codes = [code]
     if code & 0x80000000:
         i = code & 0x7FFFFFFF
         cnt = int(h.prefix_lists[i])
-        return [int(x) for x in h.prefix_lists[i + 1:i + 1 + cnt]]
-    return [code]
+        codes = [int(x) for x in h.prefix_lists[i + 1:i + 1 + cnt]]
+    return codes if coded else [c & 0xFFFFFF for c in codes]
 
 
-def test_prefilter_tables_have_every_pattern_prefix():
+def test_prefilter_tables_have_every_pattern_prefix(monkeypatch):
+    monkeypatch.setenv("ACX_NO_ANCHORS", "1")  # (the tables of patterns filed under their beginnings; anchors: the next test)
     uni = [p.encode() for p in dict.fromkeys(gen.gen_patterns(600, 5, 12, gen.AZ_UNI, 5))]
     zeros = [b"abcde", b"abcde\0", b"abcde\0\0\0", b"abcdefgh", b"abcdefgi", b"abcdefghij", b"abcdf\0x", b"abcdf\0y",
              b"abcde", b"zzzzzzzzzzzz"]
@@ -302,6 +305,89 @@ def test_prefilter_tables_have_every_pattern_prefix():
             assert int(tab[e, 2]) & 0x00FFFF00 == want_more.get(int(e), 0)
         assert 0 < h.t.filter_density <= 3 * len(pats) / (32 << 14)
         h.close()
+
+
+def k1b_twin_occurrences(h, pats, hay: bytes):
+    """Python twin of K1b + the verification over the host tables: level 1 (both positions of a pair), the
+    prefix table, the candidate list, the anchor shift of every candidate, the comparison of the whole
+    pattern at hit - shift.  -> sorted (pattern, start, end) of the LONG patterns (3 bytes or more)."""
+    q, q2, lg = int(h.t.filter_q), int(h.t.filter_q2), int(h.t.prefix_table_log2)
+    g = q - 1
+    out = []
+    pad = hay + bytes(32)
+    for i in range(len(hay)):
+        if i + int(h.t.long_min_len) > len(hay):
+            break
+        # level 1 as the kernel pairs it: position j (even) tests X of the gram at j+1 with byte j, position j+1
+        # tests Y of the same gram with byte j+q; both need the gate bit of X
+        if i % 2 == 0:
+            gram = pad[i + 1:i + 1 + g]
+            H = capi.filter_hash(gram)
+            x = int(h.filter_xy[H >> 18, 0])
+            ok = (x >> (pad[i] & 31)) & (x >> (int.from_bytes(gram, "little") & 31)) & 1
+        else:
+            gram = pad[i:i + g]
+            H = capi.filter_hash(gram)
+            x, y = int(h.filter_xy[H >> 18, 0]), int(h.filter_xy[H >> 18, 1])
+            ok = (y >> (pad[i + q - 1] & 31)) & (x >> (int.from_bytes(gram, "little") & 31)) & 1
+        if not ok:
+            continue
+        for code in prefix_candidates(h, lg, q2, pad[i:i + 16], coded=True):
+            pid, d = code & 0xFFFFFF, (code >> 24) & 15
+            assert d == int(h.pattern_shift[pid]) <= int(h.t.max_shift)
+            if d:
+                assert bytes(np.asarray(h.pattern_head[pid]).astype("<u4").tobytes()[:min(12, len(pats[pid]))]) == pats[pid][:12]
+            s0 = i - d
+            if s0 >= 0 and hay[s0:s0 + len(pats[pid])] == pats[pid]:
+                out.append((pid, s0, s0 + len(pats[pid])))
+    return sorted(out)
+
+
+def test_anchors_move_crowded_beginnings_and_lose_nothing():
+    """Round 4: patterns whose first Q bytes are common by the pattern set's own byte statistics are filed under a
+    later, rarer offset (cfg5's kind of set: hundreds of patterns behind one 4-byte character; URL lists behind
+    "http:").  Whatever
+    the anchors, the twin of the scan + verification over the host tables finds every occurrence of every long
+    pattern -- at the very start of the haystack (the anchor lies behind the start), at its very end, for
+    duplicates, for patterns that are prefixes of one another."""
+    face = "\U0001F926"
+    urls = [b"http://" + w for w in (b"alpha.example/x", b"beta.example", b"gamma.org/abcdef", b"delta", b"epsilon.net", b"ab")]
+    words = [(face + c + t).encode() for c in "abcdef" for t in ("tail", "xy", "longer tail here", "zzz", "tailor")] + ["xyzzy".encode(), (face + face + "q").encode()]
+    for pats in (urls, words, urls + words + [urls[0], words[0], b"http:", b"http://a"]):
+        for mk in (capi.MATCH_STANDARD, capi.MATCH_LEFTMOST_LONGEST):
+            h = capi.HostAutomaton(pats, mk)
+            assert int(h.t.max_shift) > 0
+            shifted = [i for i in range(len(pats)) if h.pattern_shift[i]]
+            assert shifted
+            for i in shifted:  # the suffix behind the anchor keeps the set-wide minimum length
+                assert len(pats[i]) - int(h.pattern_shift[i]) >= int(h.t.long_min_len)
+            rng = random.Random(5)
+            hay = bytearray()
+            for _ in range(60):
+                hay += rng.choice(pats) if rng.random() < 0.7 else bytes(rng.choice(b"htp:/ab\xf0\x9f\xa4\xa6xy") for _ in range(rng.randint(1, 9)))
+                if rng.random() < 0.3:
+                    hay = hay[:-rng.randint(1, 3)]  # truncated copies
+            hay = bytes(hay)
+            want = sorted(m for m in occurrences(pats, hay) if len(pats[m[0]]) >= 3)
+            if mk != capi.MATCH_STANDARD:  # identical patterns: the tables hold the first only
+                want = [m for m in want if pats.index(pats[m[0]]) == m[0]]
+            assert k1b_twin_occurrences(h, pats, hay) == want
+            h.close()
+    # sets without crowded beginnings are filed as they were
+    for pats in (gen.gen_patterns(3000, 5, 12, gen.AZ, 1), gen.gen_patterns(500, 3, 9, gen.ALL_BYTES, 3)):
+        h = capi.HostAutomaton(pats)
+        assert int(h.t.max_shift) == 0 and not np.any(h.pattern_shift) and len(h.pattern_head) == 0
+        h.close()
+    # cfg5's shape: patterns that begin with a multi-byte character are filed behind it
+    uni = [p.encode() for p in dict.fromkeys(gen.gen_patterns(3000, 5, 12, gen.AZ_UNI, 5))]
+    h = capi.HostAutomaton(uni)
+    lead4 = [i for i, p in enumerate(uni) if p[0] == 0xF0 and len(p) >= 12]
+    assert len(lead4) > 30 and sum(h.pattern_shift[i] >= 3 for i in lead4) >= 0.8 * len(lead4)
+    plain = [i for i, p in enumerate(uni) if max(p) < 0x80]
+    assert len(plain) > 300 and not any(h.pattern_shift[i] for i in plain)
+    hay = gen.gen_unicode_textlike(3000, 56, [p.decode() for p in uni], plant_every=64).encode()
+    assert k1b_twin_occurrences(h, uni, hay) == sorted(occurrences(uni, hay))
+    h.close()
 
 
 def short_survivor(h, hay: bytes, p: int, lead: int = 0) -> bool:
