@@ -74,6 +74,9 @@ def parse_args(argv=None):
                          "D dense: one pattern planted every 32 bytes (>= 1 occurrence per 32 B: the region path)")
     ap.add_argument("--no-target-size", action="store_true",
                     help="skip the in-process run at north_star's target size (8 GiB) that fills config.target_8gib")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the secondary lines of the default run (config.secondary: the DFA-walk kernel on the same "
+                         "input, word-shaped text, the reference benchmark's names-over-prose shape)")
     ap.add_argument("--no-cold", action="store_true",
                     help="skip the second timed region without the settle phase (config.value_no_settle)")
     ap.add_argument("--kernel", choices=["auto", "dfa_walk", "prefilter"], default="auto")
@@ -514,6 +517,9 @@ def run(args) -> None:
             if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_target_size
                     and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
                 out["config"]["target_8gib"] = target_size_run(w, torch, dev)
+            if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_secondary
+                    and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
+                out["config"]["secondary"] = secondary_runs(w, capi, gen, torch, dev)
             if world == 1 and not args.no_cpu_baseline:
                 last["keep"] = True
                 step()  # one more pass, keeping the match stream for the SHA-256 comparison
@@ -522,6 +528,89 @@ def run(args) -> None:
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
+    """W warm-up + K timed steps of find_device behind the settled state of the main run -> (ms per step, matches)"""
+    n = 0
+    for _ in range(warmup):
+        r = ac.find_device(ptr, nbytes, **kw)
+        n = r.count
+        r.free()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = ac.find_device(ptr, nbytes, **kw)
+        n = r.count
+        r.free()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / steps * 1e3, int(n)
+
+
+def tile_to_device(period, nbytes, torch, dev):
+    """a device haystack of nbytes made of copies of `period` (host numpy bytes): the scan does not care that the
+    content repeats, and a 1 GiB host array would cost more time than the measurement"""
+    hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    dper = torch.from_numpy(period).to(dev)
+    for off in range(0, nbytes, len(period)):
+        n_ = min(len(period), nbytes - off)
+        hay[off:off + n_] = dper[:n_]
+    torch.cuda.synchronize()
+    return hay
+
+
+def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
+    """Lines that belong next to the headline, same process, same settled GPU:
+      k1a      the kernel north_star describes (the DFA walk, failureless form) on the headline's very input
+      T_words  the headline's set over SURVEY 8d's T as worded: a-z words of 1-10 letters, single spaces
+      prose    the reference benchmark's "long" shape (benchmarks/test_comparison.py:16-53): 4 244 names-like patterns
+               (5 % duplicates) over ~600-byte prose lines, a name in every third line; with the fraction of the
+               positions that survive level 1 of the prefilter (CPU simulation of the kernel's test on the
+               product's own table over the 16 MiB period)
+    Each: {gbps, frac (of 8 TB/s), ms_per_step, matches}.  Device-resident, 10 timed steps."""
+    import numpy as np
+    out = {}
+    try:
+        k1a = capi.Automaton(w["patterns"], w["mk"], capi.IMPL_DFA, kernel=capi.KERNEL_DFA_WALK)
+        ms, n = timed_steps(k1a, w["hay"].data_ptr(), nbytes, torch)
+        out["k1a"] = {"kernel": "k1a_scan+k1a_walk", "gbps": round(nbytes / ms / 1e6, 2), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                      "ms_per_step": round(ms, 4), "matches": n}
+        k1a.close()
+    except Exception as e:
+        out["k1a"] = {"skipped": repr(e)}
+    try:
+        per = gen.gen_words(16 << 20, 11, w["patterns"])
+        hay = tile_to_device(per, nbytes, torch, dev)
+        ms, n = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch)
+        out["T_words"] = {"what": "cfg2's set over a-z words of 1-10 letters, single spaces, one pattern planted per KiB "
+                                  "(16 MiB period)", "gbps": round(nbytes / ms / 1e6, 2),
+                          "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "matches": n}
+        del hay
+    except Exception as e:
+        out["T_words"] = {"skipped": repr(e)}
+    try:
+        names = [p.encode() for p in gen.names_like(4244, 6)]
+        per = np.frombuffer(gen.names_haystack([p.decode() for p in names], 16 << 20, every=3), dtype=np.uint8).copy()
+        ac = capi.Automaton(names, capi.MATCH_STANDARD, capi.IMPL_AUTO)
+        hay = tile_to_device(per, nbytes, torch, dev)
+        ms, n = timed_steps(ac, hay.data_ptr(), nbytes, torch)
+        surv = None
+        try:
+            h = capi.HostAutomaton(names, capi.MATCH_STANDARD)
+            surv = round(100.0 * gen.level1_survivor_rate(np.asarray(h.filter_xy), int(h.t.filter_q), per[: 4 << 20]), 3)
+            h.close()
+        except Exception:
+            pass
+        out["prose"] = {"what": "4 244 names-like patterns (5-12 letters, ~5 % duplicates) over prose lines, a name in every "
+                                "third line (tests/gen.py names_haystack, 16 MiB period): the reference benchmark's long shape",
+                        "kernel": capi.KERNEL_NAMES[ac.info.kernel], "gbps": round(nbytes / ms / 1e6, 2),
+                        "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "matches": n,
+                        "level1_survivor_pct": surv}
+        ac.close()
+        del hay
+    except Exception as e:
+        out["prose"] = {"skipped": repr(e)}
+    return out
 
 
 def target_size_run(w, torch, dev, nbytes: int = 8 * GIB, steps: int = 5, warmup: int = 2):
@@ -562,8 +651,12 @@ def measured_traffic(kernel: str, nbytes: int, dist_name: str, cfg: str):
     (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, gfx950 correction; produced by
     tools/collect_profiles.sh and committed under profiles/).  NOT measured in this run: the
     second value names the file the number comes from; (None, None) when no measurement of this
-    exact configuration is on file."""
+    exact configuration is on file -- or when the file's counters were read from other device code than
+    this tree's (kernel_source_sha256, tools/kernel_hash.py): a figure goes stale the moment a kernel changes."""
     try:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        from kernel_hash import kernel_source_sha256
+        now = kernel_source_sha256()
         best = (None, None)
         for d in sorted(os.listdir(os.path.join(ROOT, "profiles"))):
             f = os.path.join(ROOT, "profiles", d, "pmc_traffic.json")
@@ -572,7 +665,11 @@ def measured_traffic(kernel: str, nbytes: int, dist_name: str, cfg: str):
                 for e in (t if isinstance(t, list) else [t]):  # (round 3: one entry per measured configuration)
                     if (e.get("kernel") == kernel and e.get("workload_bytes") == nbytes
                             and e.get("dist") == dist_name and e.get("config", "cfg2") == cfg):
-                        best = (int(e["traffic_bytes"]), os.path.relpath(f, ROOT))
+                        if e.get("kernel_source_sha256") == now:  # counters of THIS device code only
+                            best = (int(e["traffic_bytes"]), os.path.relpath(f, ROOT))
+                        elif best[0] is None:
+                            best = (None, f"{os.path.relpath(f, ROOT)} is of other device code "
+                                          f"({str(e.get('kernel_source_sha256'))[:12]} != {now[:12]}): stale, not reported")
         return best
     except Exception:
         return (None, None)

@@ -248,3 +248,42 @@ def gen_unicode_textlike_bytes(nchars: int, seed: int, patterns: Sequence[str] =
     else:
         out = [one_chunk(c0) for c0 in starts]
     return np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
+
+
+def gen_words(n: int, seed: int, patterns: Sequence[bytes] = (), plant_every: int = 1024) -> np.ndarray:
+    """(T) as SURVEY.md section 8d words it: a-z words of length 1-10 (uniform) separated by SINGLE spaces, one
+    pattern planted per `plant_every` bytes.  (gen_textlike -- a space with probability 1/6 at every position --
+    is what bench.py's headline haystack has always been; both are reported.)"""
+    z = stream_np(seed, n)
+    out = (97 + ((z >> np.uint64(8)) % np.uint64(26))).astype(np.uint8)
+    # word lengths from a second stream: enough words to cover n bytes (mean length 5.5 + the space)
+    nw = n // 5 + 16
+    lens = (1 + stream_np(seed ^ 0x77, nw) % np.uint64(10)).astype(np.int64)
+    ends = np.cumsum(lens + 1) - 1          # index of the space behind every word
+    out[ends[ends < n]] = 32
+    if len(patterns):
+        nb = n // plant_every
+        zz = stream_np(seed ^ 0x5EED, 2 * nb)
+        for b in range(nb):
+            p = patterns[int(zz[2 * b] % np.uint64(len(patterns)))]
+            if len(p) >= plant_every:
+                continue
+            o = b * plant_every + int(zz[2 * b + 1] % np.uint64(plant_every - len(p)))
+            out[o:o + len(p)] = np.frombuffer(p, dtype=np.uint8)
+    return out
+
+
+def level1_survivor_rate(filter_xy: np.ndarray, q: int, hay: np.ndarray) -> float:
+    """Fraction of the positions of `hay` that survive level 1 of K1b (CPU simulation of the kernel's pair test
+    on the product's own table: positions j, j+1 share the row of the 4-gram at j+1; Q = 5 tables only)."""
+    assert q == 5
+    h = np.asarray(hay, dtype=np.uint8).astype(np.uint64)
+    n = len(h) - 8
+    j = np.arange(0, n - (n & 1), 2)
+    W = h[j + 1] | (h[j + 2] << np.uint64(8)) | (h[j + 3] << np.uint64(16)) | (h[j + 4] << np.uint64(24))
+    e = ((((W & np.uint64(0xFFFFFF)) * np.uint64(0x9E3779) + W) & np.uint64(0xFFFFFFFF)) >> np.uint64(18)).astype(np.int64)
+    X, Y = filter_xy[e, 0].astype(np.uint64), filter_xy[e, 1].astype(np.uint64)
+    gate = (X >> (W & np.uint64(31))) & np.uint64(1)
+    p0 = gate & (X >> (h[j] & np.uint64(31))) & np.uint64(1)
+    p1 = gate & (Y >> (h[j + 5] & np.uint64(31))) & np.uint64(1)
+    return float(p0.sum() + p1.sum()) / float(2 * len(j))

@@ -268,3 +268,25 @@ def test_anchored_patterns_at_boundaries(monkeypatch, dense):
             assert np.array_equal(cols(m[pos:pos + int(counts[i])]), o.find_raw(hh)), (mk, i)
             pos += int(counts[i])
         a.close()
+
+
+def test_prose_and_word_text_64mib_against_the_oracle():
+    """The reference benchmark's long shape at device scale (bench.py's config.secondary.prose): 4 244 names-like
+    patterns over prose lines, and cfg2's set over word-shaped text -- a 64 MiB slice of each against the oracle,
+    element-wise (the bench line tiles a 16 MiB period: four periods here, the seams included)."""
+    names = [p.encode() for p in gen.names_like(4244, 6)]
+    per = np.frombuffer(gen.names_haystack([p.decode() for p in names], 16 << 20, every=3), dtype=np.uint8)
+    hay = np.tile(per, 4)
+    for mk in (0, 2):
+        a = capi.Automaton(names, mk)
+        got = cols(a.find(hay))
+        want = Oracle(names, mk, KIND_DFA).find_raw(hay.tobytes())
+        assert len(want) > 30000 and np.array_equal(got, want), mk
+        a.close()
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+    hay = np.tile(gen.gen_words(16 << 20, 11, pats), 4)
+    a = capi.Automaton(pats, 0, capi.IMPL_DFA)
+    got = cols(a.find(hay))
+    want = Oracle(pats, 0, KIND_DFA).find_raw(hay.tobytes())
+    assert len(want) > 60000 and np.array_equal(got, want)
+    a.close()

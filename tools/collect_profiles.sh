@@ -6,13 +6,26 @@
 #   combined with tracing other than --kernel-trace.  Every command is bounded by `timeout`.
 # usage: tools/collect_profiles.sh [round] [part]   then: python tools/summarize_profiles.py [round]
 #   part: all (default) | bench | trace | pmc
+# usage: tools/collect_profiles.sh --check [round]   (no GPU) fails when profiles/<round> was measured on other
+#        device code than the working tree's (tools/kernel_hash.py), i.e. when the kernels changed since
 set -u
 export TMPDIR=/tmp
-R=${1:-r03}
+if [ "${1:-}" = "--check" ]; then
+  R=${2:-r04}
+  cd "$(dirname "$0")/.."
+  HAVE=$(cat profiles/$R/kernel_source_sha256.txt 2>/dev/null || echo none)
+  NOW=$(python tools/kernel_hash.py)
+  if [ "$HAVE" != "$NOW" ]; then
+    echo "profiles/$R was measured on device code $HAVE, the working tree is $NOW: collect again"; exit 1
+  fi
+  echo "profiles/$R matches the working tree's device code ($NOW)"; exit 0
+fi
+R=${1:-r04}
 PART=${2:-all}
 OUT=/root/repo/gpurun_out/$R
 mkdir -p $OUT
 cd /root/repo
+python tools/kernel_hash.py > $OUT/kernel_source_sha256.txt
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_T.json 2> $OUT/bench_T.err
 timeout 300 python bench.py --dist U --no-cpu-baseline > $OUT/bench_U.json 2> $OUT/bench_U.err

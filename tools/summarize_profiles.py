@@ -44,6 +44,11 @@ for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline 
     open(os.path.join(DST, f"rocprofv3_kernel_summary_bench_{tag}.txt"), "w").write(
         f"# rocprofv3 --kernel-trace --stats -- {cmd}\n" + txt)
 
+# the hash collect_profiles.sh recorded on the GPU box next to its measurements (never today's working tree:
+# a summary written after the kernels changed must not relabel old counters)
+KSHA = open(os.path.join(SRC, "kernel_source_sha256.txt")).read().strip() if os.path.exists(os.path.join(SRC, "kernel_source_sha256.txt")) else None
+if KSHA:
+    open(os.path.join(DST, "kernel_source_sha256.txt"), "w").write(KSHA + "\n")
 pmc = {}
 for d in sorted(os.listdir(SRC)):
     f = os.path.join(SRC, d, "r_counter_collection.csv")
@@ -92,6 +97,7 @@ def entry(kernel, kernels, cfg, dist, bench_file, fetch_pass, write_pass, zero_p
             e["traffic_bytes_gathers_1to1"] = int((2 * zero + max(fetch - zero, 0) + write) * 1024)
             e["traffic_over_algorithmic_gathers_1to1"] = round(e["traffic_bytes_gathers_1to1"] / e["algorithmic_bytes"], 3)
         e["traffic_over_algorithmic"] = round(e["traffic_bytes"] / e["algorithmic_bytes"], 3)
+        e["kernel_source_sha256"] = KSHA  # the device code these counters were read from (tools/kernel_hash.py)
         entries.append(e)
     except (KeyError, FileNotFoundError, ZeroDivisionError) as ex:
         print("no traffic entry for", kernel, cfg, ":", repr(ex))
