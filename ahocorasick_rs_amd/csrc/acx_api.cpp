@@ -608,7 +608,7 @@ int ensure_blocks(Ctx *c, uint64_t nblocks_plus1) {
         w.blockcnt = w.blockpre = nullptr; w.blocksub = nullptr; w.block_cap = 0;
         HIPCHK(hipMalloc((void **)&w.blockcnt, nblocks_plus1 * 8));
         HIPCHK(hipMalloc((void **)&w.blockpre, nblocks_plus1 * 8));
-        HIPCHK(hipMalloc((void **)&w.blocksub, nblocks_plus1 * 16));
+        HIPCHK(hipMalloc((void **)&w.blocksub, nblocks_plus1 * 64)); // one lead-byte count per 16 bytes
         w.block_cap = nblocks_plus1;
     }
     size_t need = scan_temp_bytes(nblocks_plus1) + 256; // the scan temp storage must cover this size too

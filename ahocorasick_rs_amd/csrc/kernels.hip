@@ -685,7 +685,7 @@ template <bool ANCH>
 __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, const uint8_t *__restrict__ stream,
                                                      uint64_t len, uint64_t p, uint32_t code, uint64_t w0,
                                                      uint64_t w1, uint64_t room, uint64_t back, uint32_t *rk,
-                                                     uint64_t *start) {
+                                                     uint64_t *start, uint64_t *sw0 = nullptr, uint64_t *sw1 = nullptr) {
     const uint32_t q = A.filter_q2;
     const uint32_t pid = code & CODE_PID_MASK;
     const uint32_t sh = ANCH ? (code >> CODE_SHIFT_SHIFT) & CODE_SHIFT_MASK : 0u;
@@ -710,6 +710,7 @@ __device__ __forceinline__ uint32_t verify_candidate(const DevAutomaton &A, cons
     if (Lw == 255) Lw = A.plen[pid];
     const uint32_t L = Lw - sh; // bytes from the anchor on
     *start = p - sh;
+    if (sw0) { *sw0 = sh ? hw0 : w0; *sw1 = sh ? hw1 : w1; } // (the 16 haystack bytes at the START of the occurrence)
     bool ok = L <= room && sh <= back;
     if (ok && L > q) {
         // haystack bytes q.. from the carried window (16 - q of them), pattern bytes from pinfo
@@ -1264,7 +1265,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             K1B_ROW_SHORT(3, nxt3, nxtL.x, srow3)
         }
 #undef K1B_ROW_SHORT
-        if (CP) { // lead bytes of the lane's 16 bytes of every row, summed over the 4 lanes of a 64-byte stretch
+        if (CP) { // lead bytes of the lane's 16 bytes of every row: one count byte per lane, 64 per row (coalesced)
 #define K1B_LEADS(RI, VR)                                                                        \
             {                                                                                    \
                 uint32_t c_ = lead_bytes_in_word(VR.x) + lead_bytes_in_word(VR.y) +              \
@@ -1278,9 +1279,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                             if (p0_ + k_ < total && ((w_[k_ >> 2] >> (8 * (k_ & 3))) & 0xC0) != 0x80) c_++; \
                     }                                                                            \
                 }                                                                                \
-                c_ += __shfl_xor(c_, 1);                                                         \
-                c_ += __shfl_xor(c_, 2);                                                         \
-                if ((lane & 3) == 0) A.cp_sub[(tile * 4 + (RI)) * 16 + (lane >> 2)] = (uint8_t)c_; \
+                A.cp_sub[(tile * 4 + (RI)) * 64 + lane] = (uint8_t)c_;                           \
             }
             K1B_LEADS(0, nxt0) K1B_LEADS(1, nxt1) K1B_LEADS(2, nxt2) K1B_LEADS(3, nxt3)
 #undef K1B_LEADS
@@ -2018,6 +2017,19 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // up.  If there is none (a chain of overlapping occurrences longer than the context: periodic
 // patterns on periodic text), or a bucket overflows, the group raises the abort flag and the
 // host redoes the call on the dense path, whose resolve is global.
+// lead (non-continuation) bytes among the bytes of w selected by `valid` (0x80 per byte kept)
+__device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
+    const uint64_t HI = 0x8080808080808080ull;
+    const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
+    return __popcll(valid & HI & ~cont);
+}
+
+// str API: how many of the lead bytes of the 16-byte chunk that holds a match's start lie AT OR BEHIND the start
+// (0 .. 16) -- k_tile_main has the 16 haystack bytes at the start in registers (the hit's window, or the head it
+// compared), so the write kernel turns the offset into a code point from the counts alone and never touches the
+// haystack again.  CP_UNKNOWN: no window came with the occurrence (the DFA walk's hits).
+constexpr uint32_t CP_UNKNOWN = 31, CP_BITS = 5;
+
 #ifndef ACX_MAIN_THREADS
 #define ACX_MAIN_THREADS 256
 #endif
@@ -2054,14 +2066,15 @@ __device__ __forceinline__ void span_of(uint32_t rank_bits, int key_mode, uint4 
 }
 
 // span of a staged occurrence, relative to the first staged tile (a start may lie in front of it)
+template <bool CP>
 __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, uint64_t r, int32_t *s, int32_t *e) {
-    const uint32_t lb = 64 - REL_BITS - rank_bits;
+    const uint32_t lb = 64 - REL_BITS - rank_bits - (CP ? CP_BITS : 0); // (CP: the carried count sits above the length)
     const int32_t rel = (int32_t)(r >> (64 - REL_BITS)), L = (int32_t)(r & ((1ull << lb) - 1));
     if (key_mode == 0) { *e = rel; *s = rel - L; }
     else { *s = rel; *e = rel + L; }
 }
 
-template <bool ANCH>
+template <bool ANCH, bool CP>
 __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
@@ -2152,24 +2165,36 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             if (code == HIT_NONE) nc = 0;
             else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
         }
-        auto stage = [&](uint64_t ps, uint32_t pid, uint32_t L, uint32_t rk) { // ps: where the occurrence starts
+        // (cin -- CP only: lead bytes of the start's 16-byte chunk at or behind the start, or CP_UNKNOWN)
+        auto stage = [&](uint64_t ps, uint32_t pid, uint32_t L, uint32_t rk, uint32_t cin) { // ps: where the occurrence starts
             const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
             if (kidx < complete || kidx >= idx_hi) return; // another group's (or nobody's) business
             const uint32_t rel = (uint32_t)(kidx - first_idx);
             const uint32_t b = rel >> TILE_BITS;
             const uint32_t r = atomicAdd(&bn[b], 1u);
-            if (r < STAGE_SLOTS)
-                st[b][r] = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
-            else fail = 1;
+            if (r < STAGE_SLOTS) {
+                uint64_t word = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
+                if constexpr (CP) word |= (uint64_t)cin << (len_bits - CP_BITS);
+                st[b][r] = word;
+            } else fail = 1;
+        };
+        // lead bytes among the first (16 - (ps & 15)) bytes of the window (x0, x1) at ps, not beyond the stream's end
+        auto leads_in_chunk = [&](uint64_t ps, uint64_t x0, uint64_t x1) -> uint32_t {
+            uint32_t n_in = 16 - (uint32_t)(ps & 15);
+            if (len - ps < n_in) n_in = (uint32_t)(len - ps);
+            const uint64_t v0 = n_in >= 8 ? ~0ull : (n_in ? ~0ull >> (8 * (8 - n_in)) : 0);
+            const uint64_t v1 = n_in > 8 ? (n_in >= 16 ? ~0ull : ~0ull >> (8 * (16 - n_in))) : 0;
+            return lead_in_word(x0, v0) + lead_in_word(x1, v1);
         };
         if (verified) {
             const uint32_t pid = code & ~HIT_VERIFIED;
-            stage(p, pid, r0.w, key_mode == 1 ? 0u : A.rank[pid]);
+            stage(p, pid, r0.w, key_mode == 1 ? 0u : A.rank[pid], CP_UNKNOWN);
         } else if (!list) {
             uint32_t rk;
-            uint64_t ps = p;
-            const uint32_t L = nc ? verify_candidate<ANCH>(A, stream, len, p, code, w0, w1, room, back, &rk, &ps) : 0;
-            if (L) stage(ps, code & CODE_PID_MASK, L, rk);
+            uint64_t ps = p, x0 = w0, x1 = w1;
+            const uint32_t L = nc ? verify_candidate<ANCH>(A, stream, len, p, code, w0, w1, room, back, &rk, &ps,
+                                                           CP && ANCH ? &x0 : nullptr, CP && ANCH ? &x1 : nullptr) : 0;
+            if (L) stage(ps, code & CODE_PID_MASK, L, rk, CP ? leads_in_chunk(ps, x0, x1) : 0u);
         } else {
             // a list (patterns that share their key): two candidates at a time, their gathers in
             // flight together -- a thread with a long list otherwise holds the whole group back
@@ -2177,11 +2202,13 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 const bool two = k + 1 < nc;
                 const uint32_t pid0 = A.blist[li + 1 + k], pid1 = A.blist[li + 1 + (two ? k + 1 : k)];
                 uint32_t rk0, rk1;
-                uint64_t ps0, ps1;
-                const uint32_t L0 = verify_candidate<ANCH>(A, stream, len, p, pid0, w0, w1, room, back, &rk0, &ps0);
-                const uint32_t L1 = verify_candidate<ANCH>(A, stream, len, p, pid1, w0, w1, room, back, &rk1, &ps1);
-                if (L0) stage(ps0, pid0 & CODE_PID_MASK, L0, rk0);
-                if (two && L1) stage(ps1, pid1 & CODE_PID_MASK, L1, rk1);
+                uint64_t ps0, ps1, a0 = w0, a1 = w1, b0 = w0, b1 = w1;
+                const uint32_t L0 = verify_candidate<ANCH>(A, stream, len, p, pid0, w0, w1, room, back, &rk0, &ps0,
+                                                           CP && ANCH ? &a0 : nullptr, CP && ANCH ? &a1 : nullptr);
+                const uint32_t L1 = verify_candidate<ANCH>(A, stream, len, p, pid1, w0, w1, room, back, &rk1, &ps1,
+                                                           CP && ANCH ? &b0 : nullptr, CP && ANCH ? &b1 : nullptr);
+                if (L0) stage(ps0, pid0 & CODE_PID_MASK, L0, rk0, CP ? leads_in_chunk(ps0, a0, a1) : 0u);
+                if (two && L1) stage(ps1, pid1 & CODE_PID_MASK, L1, rk1, CP ? leads_in_chunk(ps1, b0, b1) : 0u);
             }
         }
     }
@@ -2197,7 +2224,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             while (j > 0 && st[t][j - 1] > v) { st[t][j] = st[t][j - 1]; j--; }
             st[t][j] = v;
             int32_t s, e;
-            staged_span(rank_bits, key_mode, v, &s, &e);
+            staged_span<CP>(rank_bits, key_mode, v, &s, &e);
             mx = max(mx, e);
         }
         bmax[t] = mx;
@@ -2217,7 +2244,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
             uint32_t sm = 0;
             for (uint32_t i = 0; i < n; i++) {
                 int32_t s, e;
-                staged_span(rank_bits, key_mode, st[t][i], &s, &e);
+                staged_span<CP>(rank_bits, key_mode, st[t][i], &s, &e);
                 if (s >= wlow && m <= s) sm |= 1u << i;
                 m = max(m, e);
             }
@@ -2242,7 +2269,7 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 int32_t pos = INT32_MIN;
                 for (;;) { // forward again, to the end of bucket ob
                     int32_t s, e;
-                    staged_span(rank_bits, key_mode, st[b][i], &s, &e);
+                    staged_span<CP>(rank_bits, key_mode, st[b][i], &s, &e);
                     const bool take = s >= pos;
                     if (take) pos = e;
                     if ((uint32_t)b == ob && take) { accepted |= 1u << i; cnt++; }
@@ -2278,8 +2305,14 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 const uint64_t r = st[lb + t][i];
                 const uint64_t x = r >> len_bits; // rel << rank_bits | tie
                 const uint64_t key = x + (base << rank_bits);
-                dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
-                                    (uint32_t)(r & ((1ull << len_bits) - 1)));
+                if constexpr (CP) { // length | carried count << 24 (k_tile_write takes it apart)
+                    const uint32_t lc = (uint32_t)(r & ((1ull << len_bits) - 1));
+                    dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
+                                        (lc & ((1u << (len_bits - CP_BITS)) - 1)) | ((lc >> (len_bits - CP_BITS)) << 24));
+                } else {
+                    dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
+                                        (uint32_t)(r & ((1ull << len_bits) - 1)));
+                }
             }
         }
         if (t == 0) {
@@ -2293,13 +2326,6 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-}
-
-// lead (non-continuation) bytes among the bytes of w selected by `valid` (0x80 per byte kept)
-__device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
-    const uint64_t HI = 0x8080808080808080ull;
-    const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
-    return __popcll(valid & HI & ~cont);
 }
 
 // non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
@@ -2326,46 +2352,41 @@ __device__ __forceinline__ uint64_t lead_bytes_between(const uint8_t *p, const u
     return c;
 }
 
-// lead bytes in [base, base + n), base 64-byte aligned, n < 64: the stretch is loaded whole (four
-// 16-byte loads in flight together; it cannot leave the page of its first byte)
-__device__ __forceinline__ uint32_t lead_bytes_in_stretch(const uint8_t *base, uint32_t n) {
-    const uint4 *b = (const uint4 *)base;
-    uint4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) v[k] = (uint32_t)(16 * k) < n ? b[k] : make_uint4(0, 0, 0, 0);
-    uint32_t c = 0;
-#pragma unroll
-    for (int k = 0; k < 8; k++) {
-        const uint64_t w = k & 1 ? ((uint64_t)v[k >> 1].w << 32 | v[k >> 1].z) : ((uint64_t)v[k >> 1].y << 32 | v[k >> 1].x);
-        const int32_t left = (int32_t)n - 8 * k;
-        const uint64_t valid = left >= 8 ? ~0ull : left > 0 ? ~0ull >> (8 * (8 - left)) : 0;
-        c += lead_in_word(w, valid);
-    }
-    return c;
-}
-
-// code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of
-// its 1 KiB block + the counts of the whole 64-byte stretches before it inside the block (ONE
-// 16-byte load, byte sums by v_sad_u8) + at most 63 bytes counted in place.  Every load's address
-// depends on x only: they are all in flight together.
+// code-point index of byte offset x = number of non-continuation bytes in [0, x): the prefix of its 1 KiB block
+// + the counts of the 16-byte chunks in front of it inside the block (64 count bytes: ONE line, byte sums by
+// v_sad_u8) + the lead bytes of its own chunk in front of x: that chunk's count minus `carried` (how many of
+// them lie at or behind x -- the caller had those bytes in registers), or, carried == CP_UNKNOWN, at most 15
+// bytes counted in place.  Every load's address depends on x only: they are all in flight together.
 __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
-                                                  const uint8_t *__restrict__ sub, uint64_t x) {
+                                                  const uint8_t *__restrict__ sub, uint64_t x, uint32_t carried) {
     const uint64_t blk = x >> 10;
-    const uint32_t q = (uint32_t)(x & 1023) >> 6; // whole 64-byte stretches before x
-    const uint4 sv = *(const uint4 *)(sub + blk * 16);
+    const uint32_t i = (uint32_t)(x & 1023) >> 4; // whole 16-byte chunks before x inside the block
+    const uint4 *sp = (const uint4 *)(sub + blk * 64);
+    const uint4 sv[4] = {sp[0], sp[1], sp[2], sp[3]};
     const uint64_t pre = blockpre[blk];
-    // (uniform branch: a haystack that is not 16-byte aligned takes the word-wise count)
-    const uint32_t tail = ((uintptr_t)hay & 15) == 0 ? lead_bytes_in_stretch(hay + (x & ~63ull), (uint32_t)(x & 63))
-                                                     : (uint32_t)lead_bytes_between(hay + (x & ~63ull), hay + x);
-    const uint32_t w[4] = {sv.x, sv.y, sv.z, sv.w};
+    uint32_t tail = 0;
+    if (carried == CP_UNKNOWN && (x & 15)) {
+        // (uniform branch: a haystack that is not 16-byte aligned takes the word-wise count)
+        if (((uintptr_t)hay & 15) == 0) {
+            const uint4 v = *(const uint4 *)(hay + (x & ~15ull));
+            const uint32_t n = (uint32_t)(x & 15);
+            const uint64_t v0 = n >= 8 ? ~0ull : ~0ull >> (8 * (8 - n)), v1 = n > 8 ? ~0ull >> (8 * (16 - n)) : 0;
+            tail = lead_in_word(((uint64_t)v.y << 32) | v.x, v0) + lead_in_word(((uint64_t)v.w << 32) | v.z, v1);
+        } else {
+            tail = (uint32_t)lead_bytes_between(hay + (x & ~15ull), hay + x);
+        }
+    }
+    const uint32_t upto = carried == CP_UNKNOWN ? i : i + 1; // count bytes summed: the chunks in front (+ x's own)
+    const uint32_t w[16] = {sv[0].x, sv[0].y, sv[0].z, sv[0].w, sv[1].x, sv[1].y, sv[1].z, sv[1].w,
+                            sv[2].x, sv[2].y, sv[2].z, sv[2].w, sv[3].x, sv[3].y, sv[3].z, sv[3].w};
     uint32_t acc = 0;
 #pragma unroll
-    for (uint32_t d = 0; d < 4; d++) {
-        const uint32_t nb = q > 4 * d ? (q - 4 * d < 4 ? q - 4 * d : 4) : 0;
+    for (uint32_t d = 0; d < 16; d++) {
+        const uint32_t nb = upto > 4 * d ? (upto - 4 * d < 4 ? upto - 4 * d : 4) : 0;
         const uint32_t m = nb >= 4 ? 0xFFFFFFFFu : ((1u << (8 * nb)) - 1);
         acc = __builtin_amdgcn_sad_u8(w[d] & m, 0u, acc);
     }
-    return pre + acc + tail;
+    return carried == CP_UNKNOWN ? pre + acc + tail : pre + acc - carried;
 }
 
 // The groups' reported occurrences -> final records.  A workgroup takes one group: its output is
@@ -2394,6 +2415,7 @@ struct PostOut {
     uint32_t *next_flag;         // the abort flag of the NEXT call: left clear
     uint64_t seq;                // this call's sequence number
 };
+template <bool CPW> // CPW: cp.blockpre != null (the instantiation without code points is the round-3 kernel)
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode,
                                                               const uint32_t *__restrict__ by_rank, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
@@ -2450,7 +2472,9 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     for (uint32_t c0 = 0; c0 < n; c0 += WRITE_CHUNK) {
         const uint32_t m = n - c0 < WRITE_CHUNK ? n - c0 : WRITE_CHUNK;
         for (uint32_t i = t; i < m; i += WRITE_THREADS) {
-            const uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + c0 + i];
+            uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + c0 + i];
+            uint32_t carried = CP_UNKNOWN;
+            if constexpr (CPW) { carried = v.w >> 24; v.w &= 0xFFFFFFu; } // (str API: k_tile_main<.., CP> packed the count above the length)
             uint64_t s, e;
             span_of(rank_bits, key_mode, v, &s, &e);
             if (seg_counts) {
@@ -2461,8 +2485,8 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
                 hs[i] = (uint32_t)h;
             }
             const uint32_t pid = key_mode == 1 ? v.z : by_rank[v.z];
-            if (cp.blockpre) { // (a match is as many code points as its pattern: nothing of the span is read)
-                const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s);
+            if constexpr (CPW) { // (a match is as many code points as its pattern: nothing of the span is read)
+                const uint64_t cs = code_point_of(cp.hay, cp.blockpre, cp.sub, s, carried);
                 e = cs + cp.pchars[pid];
                 s = cs;
             }
@@ -2503,19 +2527,25 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
-    if (A.max_shift)
-        hipLaunchKernelGGL(k_tile_main<true>, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
-                           lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
-    else
-        hipLaunchKernelGGL(k_tile_main<false>, dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback,
-                           lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0);
+    const bool cpw = cp_blockpre != nullptr; // the write kernel converts to code points: the occurrences carry their chunk counts
+#define ACX_TILE_MAIN(AN, CPW)                                                                                        \
+    hipLaunchKernelGGL((k_tile_main<AN, CPW>), dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback, \
+                       lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0)
+    if (A.max_shift) { if (cpw) ACX_TILE_MAIN(true, true); else ACX_TILE_MAIN(true, false); }
+    else { if (cpw) ACX_TILE_MAIN(false, true); else ACX_TILE_MAIN(false, false); }
+#undef ACX_TILE_MAIN
     if (before_write) { // (what the write kernel needs from another stream: the code-point prefix)
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_tile_write, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
-                       T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
-                       PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
+    if (cpw)
+        hipLaunchKernelGGL(k_tile_write<true>, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
+                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
+    else
+        hipLaunchKernelGGL(k_tile_write<false>, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
+                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
     return hipGetLastError();
 }
 
@@ -2685,7 +2715,7 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // ---------------------------------------------------------------------------
 // K3: UTF-8 code-point indexes
 // ---------------------------------------------------------------------------
-// one wave per 1 KiB block: cnt[blk] = its lead bytes, sub[blk * 16 + q] = those of its q-th 64 bytes
+// one wave per 1 KiB block: cnt[blk] = its lead bytes, sub[blk * 64 + q] = those of its q-th 16 bytes
 __global__ __launch_bounds__(256) void k_count_leads(const uint8_t *__restrict__ hay,
                                                      uint64_t len, uint64_t *cnt, uint8_t *sub,
                                                      uint64_t nblocks) {
@@ -2703,9 +2733,7 @@ __global__ __launch_bounds__(256) void k_count_leads(const uint8_t *__restrict__
         for (uint32_t k = 0; k < 16; k++)
             if (base + k < len && (hay[base + k] & 0xC0) != 0x80) c++;
     }
-    uint32_t q = c + __shfl_xor(c, 1);
-    q += __shfl_xor(q, 2); // the four lanes of a 64-byte stretch
-    if ((lane & 3) == 0) sub[blk * 16 + (lane >> 2)] = (uint8_t)q;
+    sub[blk * 64 + lane] = (uint8_t)c; // one count per 16 bytes
     for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
     if (lane == 0) cnt[blk] = c;
 }
@@ -2725,9 +2753,12 @@ __global__ void k_block_totals(const uint8_t *__restrict__ sub, uint64_t *cnt, u
     if (blk > nblocks) return;
     uint32_t acc = 0;
     if (blk < nblocks) {
-        const uint4 v = *(const uint4 *)(sub + blk * 16);
-        acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
-        acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const uint4 v = *(const uint4 *)(sub + blk * 64 + 16 * k);
+            acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
+            acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+        }
     }
     cnt[blk] = acc;
 }
@@ -2749,7 +2780,7 @@ __global__ void k_to_code_points(const uint8_t *__restrict__ hay, const uint64_t
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t s = m[i].start, e = m[i].end;
-    const uint64_t cs = code_point_of(hay, blockpre, sub, s);
+    const uint64_t cs = code_point_of(hay, blockpre, sub, s, CP_UNKNOWN);
     m[i].start = cs;
     m[i].end = cs + lead_bytes_between(hay + s, hay + e);
 }
@@ -2777,7 +2808,7 @@ __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t
     else { h = upper_bound_u64(G.offsets, G.n_hay + 1, s) - 1; base = G.offsets[h]; }
     (void)len;
     if (codepoints) {
-        const uint64_t cs = code_point_of(hay, blockpre, sub, s) - code_point_of(hay, blockpre, sub, base);
+        const uint64_t cs = code_point_of(hay, blockpre, sub, s, CP_UNKNOWN) - code_point_of(hay, blockpre, sub, base, CP_UNKNOWN);
         m[i].start = cs;
         m[i].end = cs + lead_bytes_between(hay + s, hay + e);
     } else {

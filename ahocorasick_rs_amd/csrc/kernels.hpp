@@ -41,8 +41,8 @@ uint32_t prefilter_grid(const uint8_t *d_hay, uint64_t len, int n_cus);
 uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len); // 4 KiB tiles of the aligned index space
 uint32_t prefilter_hit_regions(uint32_t grid);
 // cp_sub != null (sparse mode, 16-byte aligned d_hay only): the scan also writes the lead-byte
-// counts of every 64 bytes it streams (16 per 1 KiB block; 4 KiB-tile granularity: the array
-// holds 64 * prefilter_tiles() bytes) -- block_totals() then replaces count_lead_bytes()
+// counts of every 16 bytes it streams (64 per 1 KiB block; 4 KiB-tile granularity: the array
+// holds 256 * prefilter_tiles() bytes) -- block_totals() then replaces count_lead_bytes()
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
                             uint32_t grid, hipStream_t st, hipEvent_t ev_start = nullptr,
                             hipEvent_t ev_stop = nullptr, uint8_t *cp_sub = nullptr);
@@ -85,7 +85,8 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
 // into seg_counts (cleared by k_tile_main).  Automata with tile_lookback(max_len) > MAX_LOOKBACK
 // cannot take this path.  cp_blockpre != null (one haystack): the write kernel turns the byte
-// offsets into code-point indexes on the way out (prefix of the 1 KiB blocks + 64-byte sub counts).
+// offsets into code-point indexes on the way out (prefix of the 1 KiB blocks + the counts of the 16-byte
+// chunks + what k_tile_main carried over of the start's own chunk: no haystack access).
 uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
@@ -112,8 +113,8 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
                          uint64_t n, hipStream_t st);
 
 // ---- UTF-8 code-point fix-up (reference: get_byte_to_code_point)
-// lead-byte count of every 1 KiB block -> cnt[nblocks + 1] (last = 0), of every 64 bytes of a
-// block -> sub[16 * nblocks]
+// lead-byte count of every 1 KiB block -> cnt[nblocks + 1] (last = 0), of every 16 bytes of a
+// block -> sub[64 * nblocks]
 hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt, uint8_t *sub,
                             hipStream_t st);
 hipError_t block_totals(const uint8_t *sub, uint64_t *cnt, uint64_t nblocks, hipStream_t st);
