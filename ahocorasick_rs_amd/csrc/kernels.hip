@@ -2034,6 +2034,18 @@ constexpr uint32_t CP_UNKNOWN = 31, CP_BITS = 5;
 #define ACX_MAIN_THREADS 256
 #endif
 constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
+// How many groups a CU works on at once is what this latency-bound kernel lives on.  LDS (14.7 KiB) and VGPRs
+// (63) allow 8 workgroups of four waves per CU, but 256-thread workgroups are admitted up to
+// floor(800 / (ceil(sgpr / 16) * 16 + 16)) per CU (MI355X guide): the 106 SGPRs the compiler takes by itself
+// admit 6, 80 admit 8 -- the few values that do not fit ride in VGPR lanes.
+#ifndef ACX_MAIN_SGPR_LIMIT
+#define ACX_MAIN_SGPR_LIMIT 80
+#endif
+#if ACX_MAIN_SGPR_LIMIT > 0
+#define ACX_MAIN_SGPR __attribute__((amdgpu_num_sgpr(ACX_MAIN_SGPR_LIMIT)))
+#else
+#define ACX_MAIN_SGPR
+#endif
 constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 // occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
 constexpr uint32_t STAGE_SLOTS = 24;
@@ -2075,7 +2087,7 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 }
 
 template <bool ANCH, bool CP>
-__global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+__global__ __launch_bounds__(MAIN_THREADS) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
@@ -2306,9 +2318,9 @@ __global__ __launch_bounds__(MAIN_THREADS) void k_tile_main(DevAutomaton A, Segm
                 const uint64_t x = r >> len_bits; // rel << rank_bits | tie
                 const uint64_t key = x + (base << rank_bits);
                 if constexpr (CP) { // length | carried count << 24 (k_tile_write takes it apart)
-                    const uint32_t lc = (uint32_t)(r & ((1ull << len_bits) - 1));
+                    const uint64_t lc = r & ((1ull << len_bits) - 1); // (len_bits can exceed 32: few patterns, short ranks)
                     dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
-                                        (lc & ((1u << (len_bits - CP_BITS)) - 1)) | ((lc >> (len_bits - CP_BITS)) << 24));
+                                        (uint32_t)(lc & ((1ull << (len_bits - CP_BITS)) - 1)) | ((uint32_t)(lc >> (len_bits - CP_BITS)) << 24));
                 } else {
                     dst[k] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), (uint32_t)(x & ((1u << rank_bits) - 1)),
                                         (uint32_t)(r & ((1ull << len_bits) - 1)));

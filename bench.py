@@ -514,12 +514,13 @@ def run(args) -> None:
                 "kernel_ms_samples": int(prof.scan_launches),
                 "algorithmic_bytes": int(algo_bytes),
             }
+            if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_secondary
+                    and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
+                # (before the 8 GiB run: the lines that sit next to the headline are taken in the headline's own state)
+                out["config"]["secondary"] = secondary_runs(w, capi, gen, torch, dev)
             if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_target_size
                     and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
                 out["config"]["target_8gib"] = target_size_run(w, torch, dev)
-            if (world == 1 and cfg == "cfg2" and args.dist == "T" and nbytes == GIB and not args.no_secondary
-                    and not args.host and args.callers == 1 and not args.ablate and args.kernel == "auto"):
-                out["config"]["secondary"] = secondary_runs(w, capi, gen, torch, dev)
             if world == 1 and not args.no_cpu_baseline:
                 last["keep"] = True
                 step()  # one more pass, keeping the match stream for the SHA-256 comparison
@@ -531,12 +532,15 @@ def run(args) -> None:
 
 
 def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
-    """W warm-up + K timed steps of find_device behind the settled state of the main run -> (ms per step, matches)"""
+    """W warm-up + K timed steps of find_device behind the settled state of the main run
+    -> (ms per step, matches, ms of the scan stage from the event pair on every 4th step)"""
     n = 0
     for _ in range(warmup):
         r = ac.find_device(ptr, nbytes, **kw)
         n = r.count
         r.free()
+    ac.profile_enable(4)
+    ac.profile_read(reset=True)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
@@ -544,7 +548,10 @@ def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
         n = r.count
         r.free()
     torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / steps * 1e3, int(n)
+    dt = (time.perf_counter() - t0) / steps * 1e3
+    pr = ac.profile_read(reset=True)
+    ac.profile_enable(False)
+    return dt, int(n), round(pr.scan_ms / max(pr.scan_launches, 1), 4)
 
 
 def tile_to_device(period, nbytes, torch, dev):
@@ -572,19 +579,19 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
     out = {}
     try:
         k1a = capi.Automaton(w["patterns"], w["mk"], capi.IMPL_DFA, kernel=capi.KERNEL_DFA_WALK)
-        ms, n = timed_steps(k1a, w["hay"].data_ptr(), nbytes, torch)
+        ms, n, kms = timed_steps(k1a, w["hay"].data_ptr(), nbytes, torch)
         out["k1a"] = {"kernel": "k1a_scan+k1a_walk", "gbps": round(nbytes / ms / 1e6, 2), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                      "ms_per_step": round(ms, 4), "matches": n}
+                      "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
         k1a.close()
     except Exception as e:
         out["k1a"] = {"skipped": repr(e)}
     try:
         per = gen.gen_words(16 << 20, 11, w["patterns"])
         hay = tile_to_device(per, nbytes, torch, dev)
-        ms, n = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch)
+        ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch)
         out["T_words"] = {"what": "cfg2's set over a-z words of 1-10 letters, single spaces, one pattern planted per KiB "
                                   "(16 MiB period)", "gbps": round(nbytes / ms / 1e6, 2),
-                          "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "matches": n}
+                          "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
         del hay
     except Exception as e:
         out["T_words"] = {"skipped": repr(e)}
@@ -593,7 +600,7 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
         per = np.frombuffer(gen.names_haystack([p.decode() for p in names], 16 << 20, every=3), dtype=np.uint8).copy()
         ac = capi.Automaton(names, capi.MATCH_STANDARD, capi.IMPL_AUTO)
         hay = tile_to_device(per, nbytes, torch, dev)
-        ms, n = timed_steps(ac, hay.data_ptr(), nbytes, torch)
+        ms, n, kms = timed_steps(ac, hay.data_ptr(), nbytes, torch)
         surv = None
         try:
             h = capi.HostAutomaton(names, capi.MATCH_STANDARD)
@@ -604,7 +611,7 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
         out["prose"] = {"what": "4 244 names-like patterns (5-12 letters, ~5 % duplicates) over prose lines, a name in every "
                                 "third line (tests/gen.py names_haystack, 16 MiB period): the reference benchmark's long shape",
                         "kernel": capi.KERNEL_NAMES[ac.info.kernel], "gbps": round(nbytes / ms / 1e6, 2),
-                        "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "matches": n,
+                        "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n,
                         "level1_survivor_pct": surv}
         ac.close()
         del hay
