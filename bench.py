@@ -205,7 +205,7 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             elif args.dist == "D":
                 # dense output: uniform a-z with a pattern planted at every multiple of 32 bytes (chunks built
                 # on the host from one 16 MiB period: the content repeats, the scan does not care)
-                per = gen.gen_uniform(16 << 20, gen.AZ, 12)
+                per = gen.gen_uniform(PERIOD_BYTES, gen.AZ, 12)  # (not 16 MiB: tile_to_device)
                 rng = gen.SplitMix64(77)
                 for k in range(0, len(per) - 32, 32):
                     p = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
@@ -221,7 +221,7 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
             what = {"T": "text-like (T, seed 11: iid a-z letters, a space with probability 43/256 at every "
                          "position -- geometric word lengths, not a natural-language word model -- one pattern planted per KiB)", "U": "uniform a-z (U, seed 12)",
                     "Z": "ALL-ZERO (calibration only, not a benchmark)",
-                    "D": "DENSE (uniform a-z, one pattern planted every 32 bytes, 16 MiB period: the region path, "
+                    "D": "DENSE (uniform a-z, one pattern planted every 32 bytes, period 4093 x 4 KiB: the dense path, "
                          "not the headline)"}[args.dist]
             w["desc"] = ("cfg2: 10k patterns a-z len 5-12 (seed 1), Implementation.DFA, one "
                          f"{nbytes / GIB:g} GiB {what} bytes haystack, MatchKind.Standard, non-overlapping")
@@ -554,9 +554,15 @@ def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
     return dt, int(n), round(pr.scan_ms / max(pr.scan_launches, 1), 4)
 
 
+PERIOD_BYTES = 4093 * 4096  # (see tile_to_device)
+
+
 def tile_to_device(period, nbytes, torch, dev):
-    """a device haystack of nbytes made of copies of `period` (host numpy bytes): the scan does not care that the
-    content repeats, and a 1 GiB host array would cost more time than the measurement"""
+    """a device haystack of nbytes made of copies of `period` (host numpy bytes): a 1 GiB host array would cost
+    more time than the measurement.  The period is 4093 tiles of 4 KiB -- NOT the 16 MiB it was at first: a K1b
+    wave scans the tiles gw, gw + 4096, gw + 8192, ...; with a period of 4096 tiles every one of them had the
+    SAME content, a wave with an expensive tile kept it for the whole launch, and the kernel ran at the pace of
+    the unluckiest wave (measured: 333 us against 284 us on the same text unrepeated)."""
     hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
     dper = torch.from_numpy(period).to(dev)
     for off in range(0, nbytes, len(period)):
@@ -586,18 +592,18 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
     except Exception as e:
         out["k1a"] = {"skipped": repr(e)}
     try:
-        per = gen.gen_words(16 << 20, 11, w["patterns"])
+        per = gen.gen_words(16 << 20, 11, w["patterns"])[:PERIOD_BYTES]
         hay = tile_to_device(per, nbytes, torch, dev)
         ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch)
         out["T_words"] = {"what": "cfg2's set over a-z words of 1-10 letters, single spaces, one pattern planted per KiB "
-                                  "(16 MiB period)", "gbps": round(nbytes / ms / 1e6, 2),
+                                  "(period: 4093 tiles of 4 KiB)", "gbps": round(nbytes / ms / 1e6, 2),
                           "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
         del hay
     except Exception as e:
         out["T_words"] = {"skipped": repr(e)}
     try:
         names = [p.encode() for p in gen.names_like(4244, 6)]
-        per = np.frombuffer(gen.names_haystack([p.decode() for p in names], 16 << 20, every=3), dtype=np.uint8).copy()
+        per = np.frombuffer(gen.names_haystack([p.decode() for p in names], PERIOD_BYTES, every=3), dtype=np.uint8).copy()
         ac = capi.Automaton(names, capi.MATCH_STANDARD, capi.IMPL_AUTO)
         hay = tile_to_device(per, nbytes, torch, dev)
         ms, n, kms = timed_steps(ac, hay.data_ptr(), nbytes, torch)
@@ -609,7 +615,7 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
         except Exception:
             pass
         out["prose"] = {"what": "4 244 names-like patterns (5-12 letters, ~5 % duplicates) over prose lines, a name in every "
-                                "third line (tests/gen.py names_haystack, 16 MiB period): the reference benchmark's long shape",
+                                "third line (tests/gen.py names_haystack, period: 4093 tiles of 4 KiB): the reference benchmark's long shape",
                         "kernel": capi.KERNEL_NAMES[ac.info.kernel], "gbps": round(nbytes / ms / 1e6, 2),
                         "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n,
                         "level1_survivor_pct": surv}
