@@ -326,6 +326,9 @@ struct Workspace {
     uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
     uint8_t *blocksub = nullptr;                        // lead bytes per 64 bytes of a block
     uint64_t block_cap = 0;
+    DenseTiles dt{};                  // dense path, tile-ordered: occurrence buckets by key tile
+    TileSpace TD{};                   //   its groups' reported occurrences (64-bit words), counts, supergroup words
+    uint64_t dt_cap = 0;              //   tiles both are allocated for
     TileSpace T{};                    // sparse path (hit slots + tile kernels)
     uint64_t tile_cap = 0;            // tiles T is allocated for
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
@@ -437,7 +440,16 @@ void free_tiles(Workspace &w) {
     w.group_cap = 0;
 }
 
+void free_dense_tiles(Workspace &w) {
+    (void)hipFree(w.dt.words); (void)hipFree(w.dt.counts);
+    (void)hipFree(w.TD.trecs); (void)hipFree(w.TD.btot); (void)hipFree(w.TD.sgw);
+    w.dt = DenseTiles{};
+    w.TD = TileSpace{};
+    w.dt_cap = 0;
+}
+
 void free_ws(Workspace &w, int device) {
+    free_dense_tiles(w);
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
@@ -598,6 +610,29 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
     }
     T.n_tiles = (uint32_t)tiles;
     T.n_groups = (uint32_t)groups;
+    return ACX_OK;
+}
+
+// dense path, tile-ordered: buckets of DT_SLOTS words per key tile (tiles + 1 of them), DT_GMAX words per group
+int ensure_dense_tiles(Ctx *c, uint64_t tiles) {
+    Workspace &w = c->ws;
+    const uint64_t key_tiles = tiles + 1;
+    if (key_tiles > w.dt_cap) {
+        free_dense_tiles(w);
+        const uint64_t cap = key_tiles + key_tiles / 8 + DT_GROUP;
+        const uint64_t cap_groups = (cap + DT_GROUP - 1) / DT_GROUP, cap_super = (cap_groups + 63) / 64;
+        HIPCHK(hipMalloc((void **)&w.dt.words, cap * DT_SLOTS * 8));
+        HIPCHK(hipMalloc((void **)&w.dt.counts, (cap + 16) * 4));
+        HIPCHK(hipMalloc((void **)&w.TD.trecs, cap_groups * DT_GMAX * 8));
+        HIPCHK(hipMalloc((void **)&w.TD.btot, cap_groups * 4));
+        HIPCHK(hipMalloc((void **)&w.TD.sgw, 4 * cap_super * 8));
+        HIPCHK(hipMemset(w.TD.sgw, 0, 4 * cap_super * 8));
+        w.TD.sg_cap = (uint32_t)cap_super;
+        w.dt_cap = cap;
+    }
+    w.dt.n_tiles = (uint32_t)key_tiles;
+    w.TD.n_tiles = (uint32_t)key_tiles;
+    w.TD.n_groups = (uint32_t)((key_tiles + DT_GROUP - 1) / DT_GROUP);
     return ACX_OK;
 }
 
@@ -763,6 +798,7 @@ struct FindCall {
     uint64_t n_raw = 0, n_final = 0, n_hits = 0;
     bool exact_regions = false; // dense path, second pass: regions at the exclusive prefix of the first pass's counts
     bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
+    bool no_dense_tiles = false; // dense path: the tile-ordered form gave up on this call (the radix-sort form takes it)
     bool counts_zeroed = false; // batch: the per-haystack counts are zero or being accumulated into
     uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
@@ -900,12 +936,82 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     return ACX_OK;
 }
 
+int zero_counts(FindCall &c);
+
+// ---- dense output, tile-ordered (K1b sets whose patterns fit the context tiles): prefix hits in per-wave regions ->
+// occurrence words in the bucket of their key tile -> per group: sort + match kind in LDS -> the sparse path's write
+// kernel.  One round trip for the totals (the output buffer is sized exactly), a second pass only when the hit
+// regions were too small.  Gives up (Attempt::Again with no_dense_tiles) when a bucket overflows -- more than one
+// occurrence per 8 bytes -- or a chain of overlapping occurrences is longer than the context.
+int attempt_dense_tiles(FindCall &c, Attempt *what) {
+    acx_automaton *a = c.a;
+    Ctx *x = c.c;
+    Workspace &w = x->ws;
+    hipStream_t st = x->stream;
+    int rc = ensure_hits(x, std::max<uint64_t>(1u << 16, c.len / 64));
+    if (rc) return rc;
+    if ((rc = ensure_dense_tiles(x, c.tiles)) != ACX_OK) return rc;
+    const uint32_t hit_grid = prefilter_hit_regions(c.scan_grid);
+    const uint64_t hit_cap = w.hit_total / hit_grid;
+    const Sink H{w.hrecs, w.hit_counts, hit_cap, c.key_mode, nullptr, nullptr, nullptr, c.lead, 1, 0};
+    uint32_t *abort_flag = (uint32_t *)(w.summary + 10), *zero_flag = (uint32_t *)(w.summary + 11);
+    HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
+    HIPCHK_RC(hipMemsetAsync(w.TD.sgw, 0, 2 * (uint64_t)w.TD.sg_cap * 8, st));
+    HIPCHK_RC(hipMemsetAsync(w.summary + 10, 0, 16, st));
+    const bool prof = c.timed;
+    HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
+                               prof ? scan_stop_ev(x) : nullptr));
+    HIPCHK_RC(dense_tiles_verify(a->dev, c.G, H, hit_grid, w.dt, c.key_mode, c.lead, c.d_hay, c.len, abort_flag, st));
+    // (the hit regions' fill: summary[2] = hits kept, [3] = the fullest region)
+    HIPCHK_RC(sink_summary(w.hit_counts, hit_grid, hit_cap, w.hit_counts, hit_grid, hit_cap, w.summary, w.region_off, st));
+    HIPCHK_RC(dense_tiles_main(a->dev, c.key_mode, c.overlapping, w.dt, w.TD, c.lead, abort_flag, w.summary, st));
+    // ([0..3]: the hit regions' fill; [8] matches, [9] occurrences, [10] the abort flag -- not [7], [11]: the words the
+    // sparse path and K0 publish their sequence numbers in)
+    HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
+    HIPCHK_RC(hipMemcpyAsync(w.h_pinned + 8, w.summary + 8, 24, hipMemcpyDeviceToHost, st));
+    HIPCHK_RC(hipStreamSynchronize(st));
+    add_scan_profile(a, x, c.len, c.timed);
+    const uint64_t hit_max = w.h_pinned[3];
+    if (hit_max > hit_cap) { // hits were dropped: more room, again (the regions are balanced: a wave's tiles are spread over the stream)
+        if ((rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
+        *what = Attempt::Again;
+        return ACX_OK;
+    }
+    if ((uint32_t)w.h_pinned[10] != 0) { // a bucket overflowed / a chain left its context: the radix-sort form
+        c.no_dense_tiles = true;
+        *what = Attempt::Again;
+        return ACX_OK;
+    }
+    const uint64_t n_final = w.h_pinned[8], n_raw = w.h_pinned[9];
+    if (n_raw > 8 * c.tiles) x->dense_hold = 8;
+    else if (x->dense_hold > 0) x->dense_hold--;
+    c.n_raw = n_raw;
+    c.n_hits = w.h_pinned[2];
+    c.n_final = n_final;
+    *what = Attempt::Done;
+    if (n_final == 0) return ACX_OK;
+    HIPCHK_RC(g_bufs.get((void **)&c.r->d_matches, n_final * sizeof(acx_match_t), a->device));
+    // batch with byte offsets: the write kernel localises and counts per haystack itself
+    uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
+    if (seg_counts && (rc = zero_counts(c)) != ACX_OK) return rc;
+    HIPCHK_RC(dense_tiles_write(a->dev, c.key_mode, w.TD, c.d_hay, c.r->d_matches, w.summary, zero_flag, w.h_pinned, c.lead,
+                                c.G, seg_counts, nullptr, nullptr, st));
+    c.localized = seg_counts != nullptr;
+    c.queued = true;
+    return ACX_OK;
+}
+
 // ---- dense output: region mode -> compact -> radix sort -> resolve (two round trips)
 int attempt_dense(FindCall &c, Attempt *what) {
     acx_automaton *a = c.a;
     Ctx *x = c.c;
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
+    {
+        const bool no_tiles_env = std::getenv("ACX_NO_DENSE_TILES") != nullptr; // tests / measurements: the radix-sort form (read per call)
+        if (c.pre && a->sparse_ok && !c.no_dense_tiles && !no_tiles_env && c.tiles < (1ull << 26))
+            return attempt_dense_tiles(c, what);
+    }
     int rc = ensure_occ_capacity(x, std::max<uint64_t>(1u << 16, c.len / 64));
     if (rc) return rc;
     if (c.pre && (rc = ensure_hits(x, std::max<uint64_t>(1u << 16, c.len / 64))) != ACX_OK) return rc;

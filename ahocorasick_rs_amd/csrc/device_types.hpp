@@ -132,6 +132,18 @@ struct Sink {
     uint32_t cnt_nw, cnt_iters;
 };
 
+// Dense outputs, tile-ordered (round 4; kernels.hip: k_dense_verify / k_dense_main): occurrences are filed by
+// the 4 KiB tile of their KEY position -- DT_SLOTS words per tile (one occurrence per 8 bytes: denser inputs
+// take the radix-sort path) -- and a workgroup orders and resolves DT_GROUP tiles in LDS.
+constexpr uint32_t DT_SLOTS = 512;
+constexpr uint32_t DT_GROUP = 4;
+constexpr uint32_t DT_GMAX = DT_GROUP * DT_SLOTS; // reported occurrences per group
+struct DenseTiles {
+    uint64_t *words;   // (n_tiles + 1) * DT_SLOTS: [rel : 12 | tie : rank_bits | length], rel = key index & 4095
+    uint32_t *counts;  // n_tiles + 1 (atomic arrival counters; cleared before every call)
+    uint32_t n_tiles;  // key tiles: tiles of the stream + 1 (an occurrence may END at the very end)
+};
+
 // Storage of the sparse path, sized by the number of tiles / groups of the stream.
 struct TileSpace {
     uint4 *hslots;      // n_tiles * HIT_SLOTS * 2

@@ -2426,8 +2426,12 @@ struct PostOut {
     volatile uint64_t *host_out; // pinned host memory the host polls
     uint32_t *next_flag;         // the abort flag of the NEXT call: left clear
     uint64_t seq;                // this call's sequence number
+    uint32_t lead;               // DENSE: index = stream position + lead
 };
-template <bool CPW> // CPW: cp.blockpre != null (the instantiation without code points is the round-3 kernel)
+// CPW: cp.blockpre != null (the instantiation without code points is the round-3 kernel); GMAX: records a group
+// of T.trecs holds (GROUP_MAX: the sparse path; DT_GMAX: the tile-ordered dense path)
+// DENSE: T.trecs holds the tile-ordered dense path's 64-bit words (k_dense_main) instead of 16-byte records
+template <bool CPW, uint32_t GMAX, bool DENSE = false>
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode,
                                                               const uint32_t *__restrict__ by_rank, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
@@ -2484,7 +2488,17 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     for (uint32_t c0 = 0; c0 < n; c0 += WRITE_CHUNK) {
         const uint32_t m = n - c0 < WRITE_CHUNK ? n - c0 : WRITE_CHUNK;
         for (uint32_t i = t; i < m; i += WRITE_THREADS) {
-            uint4 v = T.trecs[(uint64_t)g * GROUP_MAX + c0 + i];
+            uint4 v;
+            if constexpr (DENSE) {
+                const uint64_t w_ = ((const uint64_t *)T.trecs)[(uint64_t)g * GMAX + c0 + i];
+                const uint32_t lenb = 50 - rank_bits;
+                const uint64_t pos_ = (((uint64_t)g * DT_GROUP) << TILE_BITS) + (w_ >> 50) - O.lead; // key position in the stream
+                const uint64_t tie_ = (w_ >> lenb) & ((1ull << rank_bits) - 1);
+                const uint64_t key_ = (pos_ << rank_bits) | tie_;
+                v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), (uint32_t)tie_, (uint32_t)(w_ & ((1ull << lenb) - 1)));
+            } else {
+                v = T.trecs[(uint64_t)g * GMAX + c0 + i];
+            }
             uint32_t carried = CP_UNKNOWN;
             if constexpr (CPW) { carried = v.w >> 24; v.w &= 0xFFFFFFu; } // (str API: k_tile_main<.., CP> packed the count above the length)
             uint64_t s, e;
@@ -2551,13 +2565,281 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
         if (e != hipSuccess) return e;
     }
     if (cpw)
-        hipLaunchKernelGGL(k_tile_write<true>, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+        hipLaunchKernelGGL((k_tile_write<true, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
                            T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
-                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
+                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq, 0});
     else
-        hipLaunchKernelGGL(k_tile_write<false>, dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+        hipLaunchKernelGGL((k_tile_write<false, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
                            T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
-                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq});
+                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq, 0});
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// dense outputs, tile-ordered (round 4)
+// ---------------------------------------------------------------------------
+// Until round 4 every input that did not fit the hit slots went through a global radix sort (rocPRIM, six passes
+// over 16-byte pairs: 41 % of a dense step) although its occurrences are born almost in order: a hit's key lies
+// within max_len bytes of the hit.  Now:
+//   k_dense_verify  one thread per prefix hit of K1b's regions (as k_walk_hits): the occurrences go, as ONE 64-bit
+//                   word each, into the bucket of the 4 KiB tile their KEY position lies in (an arrival counter
+//                   per tile: ~130 atomics per address on the densest inputs this path takes)
+//   k_dense_main    one workgroup per DT_GROUP tiles + the context tiles in front: loads their buckets into LDS,
+//                   a wave sorts a bucket (bitonic: words of a bucket compare like their keys), then the staged
+//                   array -- buckets in order = key order -- gets the running maximum of the ends (block scan), the
+//                   certified sync points, the greedy chains from them (as k_resolve, but in LDS), and the reported
+//                   occurrences of the group's own tiles are written, in order, as records k_tile_write takes
+//   k_tile_write    (the sparse path's own, with DT_GMAX records per group): output offsets, totals, final records,
+//                   local offsets + per-haystack counts, code points
+// A bucket that overflows (more than one occurrence per 8 bytes), or a chain that enters a group from beyond its
+// context: the abort flag, and the call takes the radix-sort path after all.
+constexpr uint32_t DT_STAGE = DT_GROUP + MAX_LOOKBACK;
+constexpr uint32_t DT_THREADS = 256;
+
+template <bool ANCH>
+__global__ __launch_bounds__(256) void k_dense_verify(DevAutomaton A, Segments G, Sink H, uint32_t h_grid, DenseTiles D,
+                                                      int key_mode, uint32_t lead, const uint8_t *__restrict__ stream,
+                                                      uint64_t len, uint32_t *abort_flag) {
+    const uint32_t rank_bits = A.rank_bits, len_bits = 52 - rank_bits;
+    for (uint32_t b = blockIdx.x; b < h_grid; b += gridDim.x) {
+        uint64_t n = H.block_counts[b];
+        if (n > H.region_cap) n = H.region_cap; // hits were dropped: the host sees the count and redoes the call
+        const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
+        for (uint64_t i = threadIdx.x; i < n; i += 256) {
+            const uint4 h = rec[2 * i], w = rec[2 * i + 1];
+            const uint64_t p = ((uint64_t)h.y << 32) | h.x;
+            const uint64_t w0 = ((uint64_t)w.y << 32) | w.x, w1 = ((uint64_t)w.w << 32) | w.z;
+            uint64_t seg_lo, seg_hi;
+            segment_bounds(G, len, p, &seg_lo, &seg_hi);
+            const uint64_t room = seg_hi - p, back = p - seg_lo;
+            uint32_t code = h.z;
+            if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
+            const uint32_t li = code & ~HIT_LIST;
+            const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
+            for (uint32_t k = 0; k < nc; k++) {
+                const uint32_t cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
+                uint32_t rk;
+                uint64_t ps;
+                const uint32_t L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
+                if (!L) continue;
+                const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
+                const uint64_t tile = kidx >> TILE_BITS;
+                const uint32_t slot = atomicAdd(&D.counts[tile], 1u);
+                if (slot < DT_SLOTS)
+                    D.words[tile * DT_SLOTS + slot] =
+                        (((((uint64_t)kidx & ((1u << TILE_BITS) - 1)) << rank_bits) | (key_mode == 1 ? (cand & CODE_PID_MASK) : rk)) << len_bits) | L;
+                else
+                    *abort_flag = 1; // denser than one occurrence per 8 bytes: the radix-sort path
+            }
+        }
+    }
+}
+
+// LDS: static part below + dynamic: arr[nb_max][DT_SLOTS] (the staged buckets), syn[], acc[] (one byte per staged
+// occurrence, by virtual index = position in the staged array without its gaps), nb_max = DT_GROUP + lookback --
+// sized by the automaton's lookback so that sets with short patterns get 5 workgroups per CU, not 3
+struct DtLds {
+    uint32_t cnt[DT_STAGE], voff[DT_STAGE + 1];
+    int32_t part[DT_THREADS];         // partial results of the block scans
+    uint32_t upart[DT_THREADS];
+    uint32_t first_sync;
+};
+static size_t dense_main_lds(uint32_t lookback) { return (size_t)(DT_GROUP + lookback) * DT_SLOTS * (8 + 2); }
+
+__global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, uint32_t max_len, int key_mode, int overlapping,
+                                                           DenseTiles D, TileSpace T, uint32_t lookback, uint32_t lead,
+                                                           uint32_t *abort_flag) {
+    __shared__ DtLds L;
+    extern __shared__ __attribute__((aligned(16))) uint8_t dt_dyn[];
+    const uint32_t t = threadIdx.x, g = blockIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t nb_max = DT_GROUP + lookback;
+    uint64_t (*const arr)[DT_SLOTS] = (uint64_t (*)[DT_SLOTS])dt_dyn;
+    uint8_t *const syn = dt_dyn + (size_t)nb_max * DT_SLOTS * 8, *const acc = syn + (size_t)nb_max * DT_SLOTS;
+    const uint32_t tile0 = g * DT_GROUP;
+    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
+    const uint32_t lb = tile0 - first, nb = DT_GROUP + lb;
+    const uint32_t len_bits = 52 - rank_bits;
+    if (t < DT_STAGE) {
+        uint32_t c = 0;
+        if (t < nb && first + t < D.n_tiles) c = D.counts[first + t];
+        L.cnt[t] = c < DT_SLOTS ? c : DT_SLOTS; // (overfull: the producer raised the abort flag)
+    }
+    if (t == 0) L.first_sync = 0xFFFFFFFFu;
+    __syncthreads();
+    if (t == 0) {
+        uint32_t run = 0;
+        for (uint32_t b = 0; b < DT_STAGE; b++) { L.voff[b] = run; run += b < nb ? L.cnt[b] : 0; }
+        L.voff[DT_STAGE] = run;
+    }
+    __syncthreads();
+    const uint32_t N = L.voff[DT_STAGE], out0 = L.voff[lb]; // staged occurrences; the first one of the group's own tiles
+    if (N == out0 || *abort_flag) { // nothing to report (or the call is lost already)
+        if (t == 0) T.btot[g] = 0;
+        return;
+    }
+    // ---- load + sort: a wave takes the buckets wave, wave + 4 (words are unique and compare like their keys)
+    for (uint32_t b = wave; b < nb; b += DT_THREADS / 64) {
+        const uint32_t n = L.cnt[b];
+        uint32_t P = 1;
+        while (P < n) P <<= 1;
+        const uint64_t *src = D.words + (uint64_t)(first + b) * DT_SLOTS;
+        for (uint32_t i = lane; i < P; i += 64) arr[b][i] = i < n ? src[i] : ~0ull;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t k = 2; k <= P; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t i = lane; i < P; i += 64) {
+                    const uint32_t x = i ^ j;
+                    if (x > i) {
+                        const uint64_t a = arr[b][i], c = arr[b][x];
+                        if ((a > c) == ((i & k) == 0)) { arr[b][i] = c; arr[b][x] = a; }
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+    }
+    __syncthreads();
+    // virtual index v -> its bucket and word; spans relative to the first staged tile (position = bucket << 12 | rel)
+    auto locate = [&](uint32_t v, uint32_t *b_) -> uint64_t {
+        uint32_t b = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < DT_STAGE; q++) b += (q < nb && v >= L.voff[q]) ? 1u : 0u;
+        *b_ = b;
+        return arr[b][v - L.voff[b]];
+    };
+    auto span = [&](uint32_t b, uint64_t w, int32_t *s_, int32_t *e_) {
+        const int32_t rel = (int32_t)((b << TILE_BITS) | (uint32_t)(w >> 52)), Ln = (int32_t)(w & ((1ull << len_bits) - 1));
+        if (key_mode == 0) { *e_ = rel; *s_ = rel - Ln; } else { *s_ = rel; *e_ = rel + Ln; }
+    };
+    auto span_at = [&](uint32_t v, int32_t *s_, int32_t *e_) { uint32_t b; const uint64_t w = locate(v, &b); span(b, w, s_, e_); };
+    const uint32_t C = (N + DT_THREADS - 1) / DT_THREADS; // elements per thread (<= 16)
+    const uint32_t v0 = t * C, v1 = v0 + C < N ? v0 + C : N;
+    if (overlapping) {
+        for (uint32_t v = v0; v < v1; v++) acc[v] = 1;
+    } else {
+        // ---- running maximum of the ends (chunks of C, block scan of the chunk maxima), certified sync points
+        const int32_t margin = max_len ? (int32_t)max_len - 1 : 0;
+        const int32_t wlow = first == 0 ? 0 : margin; // occurrences that start at or beyond it have all their company staged
+        int32_t mine = INT32_MIN;
+        for (uint32_t v = v0; v < v1; v++) { int32_t s_, e_; span_at(v, &s_, &e_); mine = max(mine, e_); }
+        L.part[t] = mine;
+        __syncthreads();
+        for (uint32_t o = 1; o < DT_THREADS; o <<= 1) { // inclusive max-scan (Hillis-Steele)
+            const int32_t other = t >= o ? L.part[t - o] : INT32_MIN;
+            __syncthreads();
+            L.part[t] = max(L.part[t], other);
+            __syncthreads();
+        }
+        int32_t m = t ? L.part[t - 1] : INT32_MIN; // maximum end in front of the chunk
+        uint32_t fs = 0xFFFFFFFFu;
+        for (uint32_t v = v0; v < v1; v++) {
+            int32_t s_, e_;
+            span_at(v, &s_, &e_);
+            const bool sy = s_ >= wlow && m <= s_;
+            syn[v] = sy;
+            if (sy && fs == 0xFFFFFFFFu) fs = v;
+            m = max(m, e_);
+        }
+        if (fs != 0xFFFFFFFFu) atomicMin(&L.first_sync, fs);
+        __syncthreads();
+        // an occurrence of the group's own tiles in front of every certified sync point: its chain enters from
+        // beyond the context (periodic patterns on periodic text): the radix-sort path resolves globally
+        if (L.first_sync > out0) { if (t == 0) *abort_flag = 1; return; }
+        // ---- greedy chains: every sync point walks to the next one
+        for (uint32_t v = t; v < N; v += DT_THREADS) {
+            if (!syn[v]) continue;
+            int32_t s_, pos;
+            span_at(v, &s_, &pos);
+            acc[v] = 1;
+            for (uint32_t u = v + 1; u < N && !syn[u]; u++) {
+                int32_t su, eu;
+                span_at(u, &su, &eu);
+                const bool take = su >= pos;
+                acc[u] = take;
+                if (take) pos = eu;
+            }
+        }
+    }
+    __syncthreads();
+    // ---- the reported occurrences of the group's own tiles, in order, to its stretch
+    uint32_t cntm = 0;
+    for (uint32_t v = v0 > out0 ? v0 : out0; v < v1; v++) cntm += acc[v];
+    L.upart[t] = cntm;
+    __syncthreads();
+    for (uint32_t o = 1; o < DT_THREADS; o <<= 1) {
+        const uint32_t other = t >= o ? L.upart[t - o] : 0;
+        __syncthreads();
+        L.upart[t] += other;
+        __syncthreads();
+    }
+    const uint32_t total = L.upart[DT_THREADS - 1];
+    uint32_t at = L.upart[t] - cntm;
+    // (ONE 64-bit word per reported occurrence: [key position relative to the group's first tile : 14 | tie | length];
+    // k_tile_write<.., DENSE> turns it back into a span)
+    uint64_t *dst = (uint64_t *)T.trecs + (uint64_t)g * DT_GMAX;
+    for (uint32_t v = v0 > out0 ? v0 : out0; v < v1; v++) {
+        if (!acc[v]) continue;
+        uint32_t b;
+        const uint64_t w = locate(v, &b);
+        const uint64_t relg = ((uint64_t)(b - lb) << TILE_BITS) | (w >> 52);
+        dst[at++] = (relg << 50) | (((w >> len_bits) & ((1ull << rank_bits) - 1)) << (50 - rank_bits)) | (w & ((1ull << len_bits) - 1));
+    }
+    if (t == 0) {
+        T.btot[g] = total;
+        uint64_t *sgw = T.sgw; // (the dense path uses set 0; k_tile_write leaves the other clear)
+        __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, (uint64_t)(N - out0) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// the totals of the tile-ordered dense path before its write kernel: summary[8] = matches, [9] = occurrences
+__global__ void k_dense_totals(TileSpace T, uint64_t *summary) {
+    uint64_t m = 0, occ = 0;
+    const uint32_t n_super = (T.n_groups + SUPER - 1) / SUPER;
+    for (uint32_t k = threadIdx.x; k < n_super; k += 256) { m += T.sgw[k]; occ += T.sgw[T.sg_cap + k] >> 32; }
+    for (int o = 32; o > 0; o >>= 1) { m += __shfl_xor(m, o); occ += __shfl_xor(occ, o); }
+    __shared__ uint64_t red[2][4];
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = m; red[1][threadIdx.x >> 6] = occ; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        summary[8] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        summary[9] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+    }
+}
+
+hipError_t dense_tiles_verify(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
+                              const DenseTiles &D, int key_mode, uint32_t lead, const uint8_t *d_hay, uint64_t len,
+                              uint32_t *abort_flag, hipStream_t st) {
+    const uint32_t grid = walk_hits_grid(hit_grid);
+    if (A.max_shift) hipLaunchKernelGGL(k_dense_verify<true>, dim3(grid), dim3(256), 0, st, A, G, hits, hit_grid, D, key_mode, lead, d_hay, len, abort_flag);
+    else hipLaunchKernelGGL(k_dense_verify<false>, dim3(grid), dim3(256), 0, st, A, G, hits, hit_grid, D, key_mode, lead, d_hay, len, abort_flag);
+    return hipGetLastError();
+}
+
+hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlapping, const DenseTiles &D, const TileSpace &T,
+                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, hipStream_t st) {
+    const uint32_t lookback = tile_lookback(A.max_len);
+    if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(k_dense_main, dim3(T.n_groups), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len, key_mode,
+                       overlapping ? 1 : 0, D, T, lookback, lead, abort_flag);
+    hipLaunchKernelGGL(k_dense_totals, dim3(1), dim3(256), 0, st, T, summary);
+    return hipGetLastError();
+}
+
+hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpace &T, const uint8_t *d_hay, acx_match_t *out,
+                             uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
+                             uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
+    const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead};
+    if (cp_blockpre)
+        hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
+                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O);
+    else
+        hipLaunchKernelGGL((k_tile_write<false, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
+                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O);
     return hipGetLastError();
 }
 

@@ -93,6 +93,19 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
                      const uint8_t *cp_sub, hipEvent_t before_write, hipStream_t st);
+// dense outputs, tile-ordered (kernels.hip): K1b's prefix hits (per-wave regions) -> occurrence words in the
+// bucket of their key tile (D.counts must be zero) -> per group of DT_GROUP tiles: sort + match kind in LDS, the
+// reported occurrences in T.trecs (DT_GMAX per group), T.btot, the supergroup words of set 0 (must be zero); summary[8]
+// = matches, [9] = occurrences; *abort_flag != 0: a bucket overflowed or a chain left its context (the caller
+// takes the radix-sort path).  dense_tiles_write: the sparse path's write kernel over T (out: capacity = matches).
+hipError_t dense_tiles_verify(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
+                              const DenseTiles &D, int key_mode, uint32_t lead, const uint8_t *d_hay, uint64_t len,
+                              uint32_t *abort_flag, hipStream_t st);
+hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlapping, const DenseTiles &D, const TileSpace &T,
+                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, hipStream_t st);
+hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpace &T, const uint8_t *d_hay, acx_match_t *out,
+                             uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
+                             uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st);
 // spans from sorted (key,pid): S[i], E[i]
 hipError_t make_spans(const DevAutomaton &A, int key_mode, const uint64_t *keys,
                       const uint32_t *pids, uint64_t *S, uint64_t *E, uint64_t n,

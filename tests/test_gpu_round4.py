@@ -8,6 +8,8 @@
   * anchors: patterns with common beginnings (a multi-byte character, "http://") are filed under a later
     offset; a hit lies behind the start of its occurrence -- the head is verified, haystack and group boundaries,
     the dense path, the str API
+  * the tile-ordered dense path (occurrence buckets by key tile, sort + match kind in LDS) against the oracle and
+    against the radix-sort form it replaces; its give-up cases (a bucket overflows, a chain leaves its context)
 """
 import numpy as np
 import pytest
@@ -290,3 +292,85 @@ def test_prose_and_word_text_64mib_against_the_oracle():
     want = Oracle(pats, 0, KIND_DFA).find_raw(hay.tobytes())
     assert len(want) > 60000 and np.array_equal(got, want)
     a.close()
+
+
+def dense_haystack(pats, n, every=32, seed=12):
+    """uniform a-z with a pattern planted every `every` bytes (bench.py --dist D's shape)"""
+    hay = gen.gen_uniform(n, gen.AZ, seed).copy()
+    rng = gen.SplitMix64(77)
+    for k in range(0, n - 32, every):
+        p = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
+        hay[k:k + len(p)] = p
+    return hay
+
+
+@pytest.mark.parametrize("form", ["tiles", "radix"])
+def test_dense_output_tile_ordered_and_radix_forms(monkeypatch, form):
+    """Dense outputs (an occurrence every 32 bytes; cfg2's set + b"ab" + b"x": one every ~22 bytes) through the
+    tile-ordered dense path and through the radix-sort form (ACX_NO_DENSE_TILES=1): every kind, overlapping,
+    batches, unaligned buffers -- element-wise equal to the oracle."""
+    if form == "radix":
+        monkeypatch.setenv("ACX_NO_DENSE_TILES", "1")
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+    hay = dense_haystack(pats, (6 << 20) + 77).tobytes()
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk)
+        o = Oracle(pats, mk, KIND_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            got, want = cols(a.find(hay, overlapping=ov)), o.find_raw(hay, overlapping=ov)
+            assert len(want) > 150000 and np.array_equal(got, want), (form, mk, ov, len(got), len(want))
+        if mk == 2:
+            big = np.frombuffer(hay, dtype=np.uint8)
+            buf = capi.DeviceBuffer(len(big) + 64).upload(big)
+            for lead, n in ((3, 1 << 20), (15, 4096 * 5 + 1)):
+                r = a.find_device(buf.ptr + lead, n)
+                got = cols(r.matches())
+                r.free()
+                assert np.array_equal(got, o.find_raw(big[lead:lead + n].tobytes())), (form, lead)
+            buf.free()
+            hs = [hay[i * 50001:(i + 1) * 50001] for i in range(40)] + [b"", hay[:9]]
+            m, counts = a.find_batch(hs)
+            pos = 0
+            for i, hh in enumerate(hs):
+                assert np.array_equal(cols(m[pos:pos + int(counts[i])]), o.find_raw(hh)), (form, i)
+                pos += int(counts[i])
+        a.close()
+    mixedx = pats + [b"ab", b"x"]
+    text = gen.gen_textlike(4 << 20, 11, pats).tobytes()
+    for mk in (0, 2):
+        a = capi.Automaton(mixedx, mk)
+        got, want = cols(a.find(text)), Oracle(mixedx, mk, KIND_DFA).find_raw(text)
+        assert len(want) > 100000 and np.array_equal(got, want), (form, mk)
+        a.close()
+
+
+def test_dense_tiles_str_api_and_give_up_cases():
+    """Code points on the dense path (the str API over a dense haystack), and the inputs the tile-ordered form
+    hands to the radix-sort form: more than one occurrence per 8 bytes (a bucket overflows), a chain of
+    overlapping occurrences longer than the context tiles (periodic patterns on periodic text)."""
+    import ahocorasick_rs_amd as ac
+    spats = list(dict.fromkeys(gen.gen_patterns(3000, 5, 12, gen.AZ_UNI, 5)))
+    hay = "".join(spats[(i * 7) % len(spats)] + "xé"[i % 2] for i in range(60000))
+    bpats, bhay = [p.encode() for p in spats], hay.encode()
+    cp = np.cumsum(np.frombuffer(bhay, dtype=np.uint8) & 0xC0 != 0x80) - 1
+    cp = np.concatenate([cp, [cp[-1] + 1]])
+    a = ac.AhoCorasick(spats, matchkind=ac.MatchKind.LeftmostLongest)
+    want = Oracle(bpats, 2, KIND_DFA).find_raw(bhay)
+    assert len(want) >= 60000
+    assert a.find_matches_as_indexes(hay) == [(int(p), int(cp[s]), int(cp[e])) for p, s, e in want]
+    # a bucket overflows: every second byte starts a match
+    pats = [b"ab", b"abab", b"ba"]
+    hay = b"ab" * (1 << 20)
+    for mk in (0, 1, 2):
+        a2 = capi.Automaton(pats, mk)
+        for ov in ([False, True] if mk == 0 else [False]):
+            assert np.array_equal(cols(a2.find(hay, overlapping=ov)), Oracle(pats, mk, KIND_DFA).find_raw(hay, overlapping=ov)), (mk, ov)
+        a2.close()
+    # a chain longer than the context: 3000-byte periodic patterns over the same period
+    per = bytes(gen.gen_uniform(7, gen.AZ, 5))
+    pats = [(per * 500)[i:i + 3000] for i in range(7)] + [per * 3]
+    hay = per * 60000
+    for mk in (1, 2):
+        a3 = capi.Automaton(pats, mk)
+        assert np.array_equal(cols(a3.find(hay)), Oracle(pats, mk, KIND_DFA).find_raw(hay)), mk
+        a3.close()
