@@ -2601,39 +2601,111 @@ __global__ __launch_bounds__(256) void k_dense_verify(DevAutomaton A, Segments G
                                                       int key_mode, uint32_t lead, const uint8_t *__restrict__ stream,
                                                       uint64_t len, uint32_t *abort_flag) {
     const uint32_t rank_bits = A.rank_bits, len_bits = 52 - rank_bits;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below_me = (1ull << lane) - 1;
     for (uint32_t b = blockIdx.x; b < h_grid; b += gridDim.x) {
         uint64_t n = H.block_counts[b];
         if (n > H.region_cap) n = H.region_cap; // hits were dropped: the host sees the count and redoes the call
         const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
-        for (uint64_t i = threadIdx.x; i < n; i += 256) {
-            const uint4 h = rec[2 * i], w = rec[2 * i + 1];
-            const uint64_t p = ((uint64_t)h.y << 32) | h.x;
-            const uint64_t w0 = ((uint64_t)w.y << 32) | w.x, w1 = ((uint64_t)w.w << 32) | w.z;
-            uint64_t seg_lo, seg_hi;
-            segment_bounds(G, len, p, &seg_lo, &seg_hi);
-            const uint64_t room = seg_hi - p, back = p - seg_lo;
-            uint32_t code = h.z;
-            if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+        // (wave-uniform loops: the lanes of a wave take their bucket slots together -- a region holds a wave's hits tile
+        // after tile, so the 64 occurrences of one step mostly share ONE bucket: one atomic per distinct tile and step
+        // instead of 64 on the same address; measured before: 6.3 ms for 33 M occurrences, the atomics serialised)
+        for (uint64_t i0 = 0; i0 < n; i0 += 256) {
+            const uint64_t i = i0 + threadIdx.x;
+            const bool live = i < n;
+            uint64_t p = 0, w0 = 0, w1 = 0, room = 0, back = 0;
+            uint32_t code = HIT_NONE;
+            if (live) {
+                const uint4 h = rec[2 * i], w = rec[2 * i + 1];
+                p = ((uint64_t)h.y << 32) | h.x;
+                w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
+                uint64_t seg_lo, seg_hi;
+                segment_bounds(G, len, p, &seg_lo, &seg_hi);
+                room = seg_hi - p; back = p - seg_lo;
+                code = h.z;
+                if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            }
             const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
             const uint32_t li = code & ~HIT_LIST;
             const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
-            for (uint32_t k = 0; k < nc; k++) {
-                const uint32_t cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
-                uint32_t rk;
-                uint64_t ps;
-                const uint32_t L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
-                if (!L) continue;
+            for (uint32_t k = 0; __ballot(k < nc); k++) {
+                uint32_t L = 0, rk = 0, cand = 0;
+                uint64_t ps = 0;
+                if (k < nc) {
+                    cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
+                    L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
+                }
+                const bool have = L != 0;
                 const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
-                const uint64_t tile = kidx >> TILE_BITS;
-                const uint32_t slot = atomicAdd(&D.counts[tile], 1u);
-                if (slot < DT_SLOTS)
-                    D.words[tile * DT_SLOTS + slot] =
-                        (((((uint64_t)kidx & ((1u << TILE_BITS) - 1)) << rank_bits) | (key_mode == 1 ? (cand & CODE_PID_MASK) : rk)) << len_bits) | L;
-                else
-                    *abort_flag = 1; // denser than one occurrence per 8 bytes: the radix-sort path
+                const uint32_t tile = (uint32_t)(kidx >> TILE_BITS);
+                uint32_t slot = 0;
+                unsigned long long todo = __ballot(have);
+                while (todo) {
+                    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+                    const uint32_t t0 = __shfl(tile, leader);
+                    const unsigned long long same = __ballot(have && tile == t0);
+                    uint32_t base = 0;
+                    if (lane == leader) base = atomicAdd(&D.counts[t0], (uint32_t)__popcll(same));
+                    base = __shfl(base, leader);
+                    if (have && tile == t0) slot = base + (uint32_t)__popcll(same & below_me);
+                    todo &= ~same;
+                }
+                if (have) {
+                    if (slot < DT_SLOTS)
+                        D.words[(uint64_t)tile * DT_SLOTS + slot] =
+                            (((((uint64_t)kidx & ((1u << TILE_BITS) - 1)) << rank_bits) | (key_mode == 1 ? (cand & CODE_PID_MASK) : rk)) << len_bits) | L;
+                    else
+                        *abort_flag = 1; // denser than one occurrence per 8 bytes: the radix-sort path
+                }
             }
         }
     }
+}
+
+// One wave sorts P = 64 * EPL words (ascending; the words are unique, the padding ~0): lane l holds the elements
+// l * EPL .. l * EPL + EPL - 1 in registers; partners inside a lane swap in place, partners in other lanes come by
+// ds_bpermute (two per 64-bit word).  (The first version of k_dense_main sorted in LDS: read, compare, write back,
+// 36 dependent passes for 256 words -- 12 us per bucket.)
+template <int EPL>
+__device__ __forceinline__ void wave_bitonic_sort(uint64_t (&v)[EPL], uint32_t lane) {
+    constexpr uint32_t P = 64 * EPL;
+#pragma unroll
+    for (uint32_t k = 2; k <= P; k <<= 1) {
+#pragma unroll
+        for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+            if (j >= (uint32_t)EPL) {
+                const uint32_t lj = j / EPL;
+                const bool lower = (lane & lj) == 0;
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    const uint32_t lo = __shfl_xor((uint32_t)v[e], lj), hi = __shfl_xor((uint32_t)(v[e] >> 32), lj);
+                    const uint64_t other = ((uint64_t)hi << 32) | lo;
+                    const bool up = ((lane * EPL + e) & k) == 0;
+                    const uint64_t mn = v[e] < other ? v[e] : other, mx = v[e] < other ? other : v[e];
+                    v[e] = (up == lower) ? mn : mx;
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < EPL; e++) {
+                    if (e & j) continue;
+                    const bool up = ((lane * EPL + e) & k) == 0;
+                    const uint64_t a = v[e], c = v[e | j];
+                    const uint64_t mn = a < c ? a : c, mx = a < c ? c : a;
+                    v[e] = up ? mn : mx;
+                    v[e | j] = up ? mx : mn;
+                }
+            }
+        }
+    }
+}
+template <int EPL>
+__device__ __forceinline__ void sort_bucket(uint64_t *bucket, const uint64_t *src, uint32_t n, uint32_t lane) {
+    uint64_t v[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) { const uint32_t i = lane * EPL + e; v[e] = i < n ? src[i] : ~0ull; }
+    wave_bitonic_sort<EPL>(v, lane);
+#pragma unroll
+    for (int e = 0; e < EPL; e++) bucket[lane * EPL + e] = v[e];
 }
 
 // LDS: static part below + dynamic: arr[nb_max][DT_SLOTS] (the staged buckets), syn[], acc[] (one byte per staged
@@ -2678,28 +2750,16 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         if (t == 0) T.btot[g] = 0;
         return;
     }
-    // ---- load + sort: a wave takes the buckets wave, wave + 4 (words are unique and compare like their keys)
+    // ---- load + sort: a wave takes the buckets wave, wave + 4 (words are unique and compare like their keys); the
+    // sort runs in registers (wave_bitonic_sort), sized by the bucket's fill
     for (uint32_t b = wave; b < nb; b += DT_THREADS / 64) {
         const uint32_t n = L.cnt[b];
-        uint32_t P = 1;
-        while (P < n) P <<= 1;
         const uint64_t *src = D.words + (uint64_t)(first + b) * DT_SLOTS;
-        for (uint32_t i = lane; i < P; i += 64) arr[b][i] = i < n ? src[i] : ~0ull;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (uint32_t k = 2; k <= P; k <<= 1)
-            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-                for (uint32_t i = lane; i < P; i += 64) {
-                    const uint32_t x = i ^ j;
-                    if (x > i) {
-                        const uint64_t a = arr[b][i], c = arr[b][x];
-                        if ((a > c) == ((i & k) == 0)) { arr[b][i] = c; arr[b][x] = a; }
-                    }
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            }
+        if (n == 0) continue;
+        if (n <= 64) sort_bucket<1>(arr[b], src, n, lane);
+        else if (n <= 128) sort_bucket<2>(arr[b], src, n, lane);
+        else if (n <= 256) sort_bucket<4>(arr[b], src, n, lane);
+        else sort_bucket<8>(arr[b], src, n, lane);
     }
     __syncthreads();
     // virtual index v -> its bucket and word; spans relative to the first staged tile (position = bucket << 12 | rel)
