@@ -2711,11 +2711,12 @@ __device__ __forceinline__ void sort_bucket(uint64_t *bucket, const uint64_t *sr
 // LDS: static part below + dynamic: arr[nb_max][DT_SLOTS] (the staged buckets), syn[], acc[] (one byte per staged
 // occurrence, by virtual index = position in the staged array without its gaps), nb_max = DT_GROUP + lookback --
 // sized by the automaton's lookback so that sets with short patterns get 5 workgroups per CU, not 3
+using dt_scan_max = rocprim::block_scan<int32_t, DT_THREADS>;
+using dt_scan_sum = rocprim::block_scan<uint32_t, DT_THREADS>;
 struct DtLds {
     uint32_t cnt[DT_STAGE], voff[DT_STAGE + 1];
-    int32_t part[DT_THREADS];         // partial results of the block scans
-    uint32_t upart[DT_THREADS];
-    uint32_t first_sync;
+    union { typename dt_scan_max::storage_type mx; typename dt_scan_sum::storage_type sum; } scan;
+    uint32_t first_sync, total;
 };
 static size_t dense_main_lds(uint32_t lookback) { return (size_t)(DT_GROUP + lookback) * DT_SLOTS * (8 + 2); }
 
@@ -2763,12 +2764,15 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
     }
     __syncthreads();
     // virtual index v -> its bucket and word; spans relative to the first staged tile (position = bucket << 12 | rel)
-    auto locate = [&](uint32_t v, uint32_t *b_) -> uint64_t {
-        uint32_t b = 0;
+    uint32_t vo[DT_STAGE]; // (the buckets' first virtual indexes, in registers: locate() runs for every element and pass)
 #pragma unroll
-        for (uint32_t q = 1; q < DT_STAGE; q++) b += (q < nb && v >= L.voff[q]) ? 1u : 0u;
+    for (uint32_t q = 0; q < DT_STAGE; q++) vo[q] = q < nb ? L.voff[q] : 0xFFFFFFFFu;
+    auto locate = [&](uint32_t v, uint32_t *b_) -> uint64_t {
+        uint32_t b = 0, off = 0;
+#pragma unroll
+        for (uint32_t q = 1; q < DT_STAGE; q++) { const bool in = v >= vo[q]; b += in ? 1u : 0u; off = in ? vo[q] : off; }
         *b_ = b;
-        return arr[b][v - L.voff[b]];
+        return arr[b][v - off];
     };
     auto span = [&](uint32_t b, uint64_t w, int32_t *s_, int32_t *e_) {
         const int32_t rel = (int32_t)((b << TILE_BITS) | (uint32_t)(w >> 52)), Ln = (int32_t)(w & ((1ull << len_bits) - 1));
@@ -2785,15 +2789,8 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         const int32_t wlow = first == 0 ? 0 : margin; // occurrences that start at or beyond it have all their company staged
         int32_t mine = INT32_MIN;
         for (uint32_t v = v0; v < v1; v++) { int32_t s_, e_; span_at(v, &s_, &e_); mine = max(mine, e_); }
-        L.part[t] = mine;
-        __syncthreads();
-        for (uint32_t o = 1; o < DT_THREADS; o <<= 1) { // inclusive max-scan (Hillis-Steele)
-            const int32_t other = t >= o ? L.part[t - o] : INT32_MIN;
-            __syncthreads();
-            L.part[t] = max(L.part[t], other);
-            __syncthreads();
-        }
-        int32_t m = t ? L.part[t - 1] : INT32_MIN; // maximum end in front of the chunk
+        int32_t m = INT32_MIN; // maximum end in front of the chunk
+        dt_scan_max().exclusive_scan(mine, m, INT32_MIN, L.scan.mx, rocprim::maximum<int32_t>());
         uint32_t fs = 0xFFFFFFFFu;
         for (uint32_t v = v0; v < v1; v++) {
             int32_t s_, e_;
@@ -2827,16 +2824,11 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
     // ---- the reported occurrences of the group's own tiles, in order, to its stretch
     uint32_t cntm = 0;
     for (uint32_t v = v0 > out0 ? v0 : out0; v < v1; v++) cntm += acc[v];
-    L.upart[t] = cntm;
+    uint32_t at = 0;
+    dt_scan_sum().exclusive_scan(cntm, at, 0u, L.scan.sum);
+    if (t == DT_THREADS - 1) L.total = at + cntm;
     __syncthreads();
-    for (uint32_t o = 1; o < DT_THREADS; o <<= 1) {
-        const uint32_t other = t >= o ? L.upart[t - o] : 0;
-        __syncthreads();
-        L.upart[t] += other;
-        __syncthreads();
-    }
-    const uint32_t total = L.upart[DT_THREADS - 1];
-    uint32_t at = L.upart[t] - cntm;
+    const uint32_t total = L.total;
     // (ONE 64-bit word per reported occurrence: [key position relative to the group's first tile : 14 | tie | length];
     // k_tile_write<.., DENSE> turns it back into a span)
     uint64_t *dst = (uint64_t *)T.trecs + (uint64_t)g * DT_GMAX;

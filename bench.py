@@ -333,14 +333,33 @@ def run(args) -> None:
             m = w["ac"].find(w["host_hay"], overlapping=w["overlapping"], codepoints=w["codepoints"])
             n = len(m)
             last["matches"] = m
-        else:
+        elif last.get("keep"):
             r = w["ac"].find_device(w["hay"].data_ptr(), nbytes, n_hay=w["n_hay"], uniform_len=w["uniform_len"],
                                     overlapping=w["overlapping"], codepoints=w["codepoints"])
             n = r.count
-            if last.get("keep"):
-                last["matches"] = r.matches()
+            last["matches"] = r.matches()
             r.free()
+        else:
+            # the same three C-ABI calls as capi.Automaton.find_device + DeviceResult.count / free, without the Python
+            # objects in between (a step is ~350 us: ten microseconds of interpreter per step are three percent)
+            n = fast_step()
         return n
+
+    fast_step = None
+    if not args.dry_run and not args.host:
+        import ctypes
+        L_ = capi.lib()
+        h_, out_ = w["ac"]._h, ctypes.c_void_p()
+        ptr_, ref_ = w["hay"].data_ptr(), ctypes.byref(out_)
+        nh_, ul_, ov_, cp_ = w["n_hay"], w["uniform_len"], int(w["overlapping"]), int(w["codepoints"])
+
+        def fast_step() -> int:
+            rc = L_.acx_find_device(h_, ptr_, nbytes, None, nh_, ul_, ov_, cp_, ref_)
+            if rc:
+                capi._check(rc)
+            n_ = L_.acx_result_count(out_)
+            L_.acx_free_result(out_)
+            return n_
 
     def gather_wait() -> None:
         if gather_q is not None:
