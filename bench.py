@@ -554,10 +554,13 @@ def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
     """W warm-up + K timed steps of find_device behind the settled state of the main run
     -> (ms per step, matches, ms of the scan stage from the event pair on every 4th step)"""
     n = 0
-    for _ in range(warmup):
+    t_end = time.perf_counter() + 0.03  # (untimed: the same settle phase as the headline's, scaled down: another kernel
+    k = 0                               # mix goes through its own power transient)
+    while k < warmup or time.perf_counter() < t_end:
         r = ac.find_device(ptr, nbytes, **kw)
         n = r.count
         r.free()
+        k += 1
     ac.profile_enable(4)
     ac.profile_read(reset=True)
     torch.cuda.synchronize()

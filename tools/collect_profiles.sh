@@ -28,7 +28,7 @@ cd /root/repo
 python tools/kernel_hash.py > $OUT/kernel_source_sha256.txt
 if [ "$PART" = all ] || [ "$PART" = bench ]; then
 timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_T.json 2> $OUT/bench_T.err
-timeout 300 python bench.py --dist U --no-cpu-baseline > $OUT/bench_U.json 2> $OUT/bench_U.err
+timeout 300 python bench.py --dist U --no-cpu-baseline --no-secondary > $OUT/bench_U.json 2> $OUT/bench_U.err
 timeout 300 python bench.py --config cfg3 --no-cpu-baseline > $OUT/bench_cfg3_shape_n1.json 2> $OUT/bench_cfg3.err
 for cfg in cfg4 cfg4b cfg5 cfg2b; do
   timeout 900 python bench.py --config $cfg --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
@@ -39,32 +39,39 @@ for d in T U; do
   timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --dist $d --kernel dfa_walk > $OUT/bench_${d}_dfa_walk.json 2> $OUT/bench_${d}_dfa_walk.err
   ACX_NO_PFAC=1 timeout 300 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target-size --no-cold --dist $d --kernel dfa_walk > $OUT/bench_${d}_dfa_walk_chunked.json 2> $OUT/bench_${d}_dfa_walk_chunked.err
 done
-# mixed-length sets (K1a by the library's own choice): rare short patterns, and the round-2 VERDICT's example
-for cfg in mixed mixedx; do
-  timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
+# mixed-length sets (round 4: K1b with its side test): rare short patterns, the round-2 VERDICT's example (dense
+# output), cfg5's set + short patterns (> 32 byte classes: the round-3 cliff); and the round-3 path for comparison
+for cfg in mixed mixedx mixedb; do
+  timeout 400 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --config $cfg > $OUT/bench_$cfg.json 2> $OUT/bench_$cfg.err
 done
-# the dense (region) path: a dense input, and the headline input forced onto it
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --dist D > $OUT/bench_dense_D.json 2> $OUT/bench_dense_D.err
-ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_forced_dense_path.json 2> $OUT/bench_T_forced_dense_path.err
+ACX_NO_SHORT_SPLIT=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --config mixed > $OUT/bench_mixed_round3_path_k1a.json 2> $OUT/bench_mixed_round3_path_k1a.err
+# anchors off: cfg5 on the round-3 tables
+ACX_NO_ANCHORS=1 timeout 600 python bench.py --config cfg5 --steps 10 --warmup 2 --no-cpu-baseline > $OUT/bench_cfg5_no_anchors.json 2> $OUT/bench_cfg5_no_anchors.err
+# the dense paths: a dense input through the tile-ordered form and through the radix-sort form, the headline input forced onto it
+timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-target-size --dist D > $OUT/bench_dense_D.json 2> $OUT/bench_dense_D.err
+ACX_NO_DENSE_TILES=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-secondary --no-target-size --dist D > $OUT/bench_dense_D_radix_form.json 2> $OUT/bench_dense_D_radix_form.err
+ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-secondary > $OUT/bench_T_forced_dense_path.json 2> $OUT/bench_T_forced_dense_path.err
 # one rank under the launcher: RCCL init + the count all-gather on the device
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_one_rank_rccl.json 2> $OUT/bench_T_one_rank_rccl.err
 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison.txt 2>&1
+ACX_SMALL_SYNC=1 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison_stream_sync.txt 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 [ -x tools/ubench_stream.bin ] && timeout 120 tools/ubench_stream.bin > $OUT/ubench_stream.txt 2>&1
 fi
 if [ "$PART" = all ] || [ "$PART" = trace ]; then
 cd /tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold > $OUT/trace_T.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary > $OUT/trace_T.log 2>&1
 for cfg in cfg4 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config $cfg > $OUT/trace_$cfg.log 2>&1
 done
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dfa_walk -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target-size --no-cold --kernel dfa_walk > $OUT/trace_dfa_walk.log 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense_D -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --dist D > $OUT/trace_dense_D.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_dense_D -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist D > $OUT/trace_dense_D.log 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_mixed -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-target-size --config mixed > $OUT/trace_mixed.log 2>&1
 cd /root/repo
 fi
 if [ "$PART" = all ] || [ "$PART" = pmc ]; then
 cd /tmp
-P="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-size --no-cold"
+P="python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-size --no-cold --no-secondary"
 timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o r -- $P > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o r -- $P > $OUT/pmc_write.log 2>&1
 # calibration of FETCH_SIZE on this access pattern: the same kernels over a haystack of zero bytes

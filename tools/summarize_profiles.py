@@ -11,7 +11,7 @@ usage: summarize_profiles.py [round]"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r03"
+R = sys.argv[1] if len(sys.argv) > 1 else "r04"
 SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 
@@ -21,7 +21,7 @@ def short(n):
 
 
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
-                                                                  ("smoke.log", "bench_comparison.txt", "ubench_stream.txt")]:
+                                                                  ("smoke.log", "bench_comparison.txt", "bench_comparison_stream_sync.txt", "ubench_stream.txt")]:
     if os.path.exists(f) and os.path.getsize(f):
         if f.endswith(".json"):  # (only the JSON line: RCCL prints its banner to stdout)
             lines = [l for l in open(f) if l.startswith("{")]
@@ -29,12 +29,13 @@ for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SR
                 open(os.path.join(DST, os.path.basename(f)), "w").write(lines[-1])
         else:
             shutil.copy(f, os.path.join(DST, os.path.basename(f)))
-P = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-size --no-cold"
-for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold"),
+P = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-size --no-cold --no-secondary"
+for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary"),
+                 ("mixed", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-target-size --config mixed"),
                  ("cfg4", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg4"),
                  ("cfg5", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg5"),
                  ("dfa_walk", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target-size --no-cold --kernel dfa_walk"),
-                 ("dense_D", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --dist D")):
+                 ("dense_D", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist D")):
     src = os.path.join(SRC, f"trace_{tag}")
     if not os.path.exists(os.path.join(src, "bench_kernel_stats.csv")):
         continue
@@ -60,7 +61,8 @@ for d in sorted(os.listdir(SRC)):
     dur = collections.OrderedDict()
     for r in csv.DictReader(open(os.path.join(SRC, d, "r_kernel_trace.csv"))):
         dur.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
-    keep = ("k1b_prefilter", "k1a_scan", "k1a_walk", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_write", "k_walk_hits")
+    keep = ("k1b_prefilter", "k1a_scan", "k1a_walk", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_write", "k_walk_hits",
+            "k_dense_verify", "k_dense_main")
     pmc[d] = {k: {"dispatches": len(dur.get(k, [])), "mean_duration_us": round(sum(dur[k]) / len(dur[k]), 1) if k in dur else None,
                   "mean_counters": {c: round(sum(v) / len(v)) for c, v in cs.items()}}
               for k, cs in acc.items() if k in keep}
