@@ -136,7 +136,10 @@ struct Sink {
 // the 4 KiB tile of their KEY position -- DT_SLOTS words per tile (one occurrence per 8 bytes: denser inputs
 // take the radix-sort path) -- and a workgroup orders and resolves DT_GROUP tiles in LDS.
 constexpr uint32_t DT_SLOTS = 512;
-constexpr uint32_t DT_GROUP = 4;
+#ifndef ACX_DT_GROUP
+#define ACX_DT_GROUP 4
+#endif
+constexpr uint32_t DT_GROUP = ACX_DT_GROUP;
 constexpr uint32_t DT_GMAX = DT_GROUP * DT_SLOTS; // reported occurrences per group
 struct DenseTiles {
     uint64_t *words;   // (n_tiles + 1) * DT_SLOTS: [rel : 12 | tie : rank_bits | length], rel = key index & 4095

@@ -586,6 +586,7 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 // All LDS is ONE static object with the L1 table at offset 0.
 constexpr int K1B_ROWS = 4;
 static_assert(K1B_ROWS * 1024 == (1 << TILE_BITS), "a K1b tile is a tile of the hit slots");
+static_assert((DT_GROUP << TILE_BITS) <= (1u << 16), "group-relative key positions of the dense path's words");
 constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors settled per round (1 per lane)
 constexpr uint32_t K1B_HB = 40;     // prefix hits a wave collects in LDS before one burst store
 struct K1bLds {
@@ -2041,6 +2042,12 @@ constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 #ifndef ACX_MAIN_SGPR_LIMIT
 #define ACX_MAIN_SGPR_LIMIT 80
 #endif
+// (at least 6 waves per SIMD: the instantiation with anchors AND code points would take 87 VGPRs -- 5 waves -- by itself)
+#ifdef ACX_NO_MAIN_BOUND
+#define ACX_MAIN_BOUNDS __launch_bounds__(MAIN_THREADS)
+#else
+#define ACX_MAIN_BOUNDS __launch_bounds__(MAIN_THREADS, 6)
+#endif
 #if ACX_MAIN_SGPR_LIMIT > 0
 #define ACX_MAIN_SGPR __attribute__((amdgpu_num_sgpr(ACX_MAIN_SGPR_LIMIT)))
 #else
@@ -2087,7 +2094,7 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 }
 
 template <bool ANCH, bool CP>
-__global__ __launch_bounds__(MAIN_THREADS) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+__global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
@@ -2491,8 +2498,8 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             uint4 v;
             if constexpr (DENSE) {
                 const uint64_t w_ = ((const uint64_t *)T.trecs)[(uint64_t)g * GMAX + c0 + i];
-                const uint32_t lenb = 50 - rank_bits;
-                const uint64_t pos_ = (((uint64_t)g * DT_GROUP) << TILE_BITS) + (w_ >> 50) - O.lead; // key position in the stream
+                const uint32_t lenb = 48 - rank_bits;
+                const uint64_t pos_ = (((uint64_t)g * DT_GROUP) << TILE_BITS) + (w_ >> 48) - O.lead; // key position in the stream
                 const uint64_t tie_ = (w_ >> lenb) & ((1ull << rank_bits) - 1);
                 const uint64_t key_ = (pos_ << rank_bits) | tie_;
                 v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), (uint32_t)tie_, (uint32_t)(w_ & ((1ull << lenb) - 1)));
@@ -2829,7 +2836,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
     if (t == DT_THREADS - 1) L.total = at + cntm;
     __syncthreads();
     const uint32_t total = L.total;
-    // (ONE 64-bit word per reported occurrence: [key position relative to the group's first tile : 14 | tie | length];
+    // (ONE 64-bit word per reported occurrence: [key position relative to the group's first tile : 16 | tie | length];
     // k_tile_write<.., DENSE> turns it back into a span)
     uint64_t *dst = (uint64_t *)T.trecs + (uint64_t)g * DT_GMAX;
     for (uint32_t v = v0 > out0 ? v0 : out0; v < v1; v++) {
@@ -2837,7 +2844,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         uint32_t b;
         const uint64_t w = locate(v, &b);
         const uint64_t relg = ((uint64_t)(b - lb) << TILE_BITS) | (w >> 52);
-        dst[at++] = (relg << 50) | (((w >> len_bits) & ((1ull << rank_bits) - 1)) << (50 - rank_bits)) | (w & ((1ull << len_bits) - 1));
+        dst[at++] = (relg << 48) | (((w >> len_bits) & ((1ull << rank_bits) - 1)) << (48 - rank_bits)) | (w & ((1ull << len_bits) - 1));
     }
     if (t == 0) {
         T.btot[g] = total;
