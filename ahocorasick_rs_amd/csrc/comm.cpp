@@ -11,8 +11,10 @@
 //                               ranks by whatever the host has (a file, a socket, MPI), then
 //                               acx_comm_init_rank everywhere (ncclCommInitRank)
 //   * acx_comm_allgather_counts (ncclAllGather of one u64 per rank, over xGMI inside a node)
-// librccl is loaded on first use (dlopen): a host that never calls these functions needs no RCCL,
-// and a process that has PyTorch's copy loaded already shares it (same SONAME).
+// librccl is loaded on first use (dlopen): a host that never calls these functions needs no RCCL.  (A process
+// that has imported a PyTorch wheel holds the wheel's own HIP / HSA runtime and RCCL under other SONAMEs next
+// to /opt/rocm's; this communicator is for the hosts that have no torch -- tests/test_gpu_round4.py runs it in
+// a process of its own.)
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>

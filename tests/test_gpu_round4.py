@@ -171,27 +171,49 @@ def test_count_exchange_through_the_c_abi_one_rank():
     """RCCL behind the C ABI, executed on the MI355X at one rank (more needs a node): both ways of making the
     communicator -- ncclCommInitAll for one process, ncclGetUniqueId + ncclCommInitRank for one process per
     device -- all-gather a count and turn the counts into output offsets; then a sharded batch call whose
-    count exchange goes through it (no torch.distributed anywhere)."""
-    from ahocorasick_rs_amd import distributed as D
-    c = capi.Comm.init_all([0])
-    assert (c.world, c.local_ranks) == (1, 1)
-    for n in (0, 42, 1 << 40):
-        assert c.allgather_counts([n]) == [n]
-    c.close()
-    uid = capi.comm_unique_id()
-    assert len(uid) == capi.COMM_ID_BYTES
-    c = capi.Comm.init_rank(uid, 1, 0, 0)
-    pats = gen.gen_patterns(2000, 5, 12, gen.AZ, 1)
-    a = capi.Automaton(pats, 0)
-    hs = [gen.gen_textlike(5000, 40 + i, pats).tobytes() for i in range(64)]
-    lo, hi = capi.shard_range(len(hs), 0, c.world)
-    m, counts = a.find_batch(hs[lo:hi])
-    rank_counts, off, total = D.gather_match_counts_capi(c, len(m), 0)
-    assert rank_counts == [len(m)] and off == 0 and total == len(m) == int(counts.sum()) > 0
-    c.close()
-    a.close()
-    with pytest.raises(ValueError):
-        capi.Comm.init_all([0, 0])
+    count exchange goes through it.  In a process of its own, WITHOUT torch: that is the host this form exists
+    for (a PyO3 shim) -- and a process into which a PyTorch wheel has been imported holds a second HIP / HSA
+    runtime (the wheel bundles its own, under another SONAME), next to which /opt/rocm's RCCL does not initialise."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys
+sys.path[:0] = [%r, %r]
+import gen
+from ahocorasick_rs_amd import capi, distributed as D
+assert "torch" not in sys.modules
+c = capi.Comm.init_all([0])
+assert (c.world, c.local_ranks) == (1, 1)
+for n in (0, 42, 1 << 40):
+    assert c.allgather_counts([n]) == [n]
+c.close()
+uid = capi.comm_unique_id()
+assert len(uid) == capi.COMM_ID_BYTES
+c = capi.Comm.init_rank(uid, 1, 0, 0)
+pats = gen.gen_patterns(2000, 5, 12, gen.AZ, 1)
+a = capi.Automaton(pats, 0)
+hs = [gen.gen_textlike(5000, 40 + i, pats).tobytes() for i in range(64)]
+lo, hi = capi.shard_range(len(hs), 0, c.world)
+m, counts = a.find_batch(hs[lo:hi])
+rank_counts, off, total = D.gather_match_counts_capi(c, len(m), 0)
+assert rank_counts == [len(m)] and off == 0 and total == len(m) == int(counts.sum()) > 0
+c.close()
+a.close()
+try:
+    capi.Comm.init_all([0, 0])
+    raise SystemExit("a device listed twice was accepted")
+except ValueError:
+    pass
+assert "torch" not in sys.modules
+print("RCCL_C_ABI_OK", total)
+""" % (root, os.path.join(root, "tests"))
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "RCCL_C_ABI_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
 
 
 def url_like_patterns(n=3000, seed=3):
