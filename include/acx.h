@@ -65,8 +65,10 @@ extern "C" {
 
 /* scan kernels (acx_info.kernel, acx_set_kernel).  Haystacks of at most 16 KiB are
  * answered by K0 -- one workgroup does the whole call (anchored walk from every position,
- * sort, resolve, output; one launch) -- unless a scan kernel was chosen explicitly with
- * acx_set_kernel / ACX_KERNEL or the output is too dense for it. */
+ * sort, resolve, output; one launch, the result polled from pinned memory) -- unless a scan
+ * kernel was chosen explicitly with acx_set_kernel / ACX_KERNEL or the output is too dense for it.
+ * Since round 4 the library's own choice is the prefilter for EVERY pattern set (patterns of 1 and
+ * 2 bytes through its side test); the DFA walk runs when it is asked for. */
 #define ACX_KERNEL_AUTO 0
 #define ACX_KERNEL_DFA_WALK 1   /* K1a: the DFA walk -- failureless form, first four levels in LDS;
                                  * chunked walk for automata of more than 32 byte classes */
