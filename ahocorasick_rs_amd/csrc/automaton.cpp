@@ -457,7 +457,8 @@ std::string compile(const uint8_t *blob, const uint64_t *offsets, uint64_t n,
                 for (uint32_t k = 1; k < Q; k++) v -= lb[(size_t)x[k - 1] * 256 + x[k]];
                 return v;
             };
-            const float gain_bits = std::log2((float)SHIFT_GAIN);
+            const char *gain_env = std::getenv("ACX_SHIFT_GAIN"); // measurements: how much rarer an offset must be
+            const float gain_bits = std::log2(gain_env ? std::max(1.0f, (float)std::atof(gain_env)) : (float)SHIFT_GAIN);
             for (uint64_t i = 0; i < n; i++) {
                 if (is_short(i)) continue;
                 const uint8_t *pp = pb + A.offsets[i];
