@@ -112,6 +112,34 @@ def find_batch_sharded(automaton, haystacks: Sequence[bytes], overlapping: bool 
 # ---------------------------------------------------------------------------
 # one large haystack cut into byte ranges
 # ---------------------------------------------------------------------------
+class DeviceHaystack:
+    """A haystack resident in HBM on THIS rank's device: a device pointer and its length (e.g.
+    `torch.Tensor.data_ptr()`, `capi.DeviceBuffer.ptr`).  find_single_sharded / simulate_single_sharded take it in
+    place of a bytes-like object: every range is then scanned where it lies (automaton.find_device), only the
+    match records travel to the host.  (Round 3 had the host form only: Python slices of a host bytes object.)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+
+    def __len__(self) -> int:
+        return self.nbytes
+
+
+def _as_hay(haystack):
+    return haystack if isinstance(haystack, DeviceHaystack) else memoryview(haystack).cast("B")
+
+
+def _scan(automaton, hay, a: int, b: int, overlapping: bool):
+    """The matches of hay[a:b], offsets local to a."""
+    if isinstance(hay, DeviceHaystack):
+        r = automaton.find_device(hay.ptr + a, max(b - a, 0), overlapping=overlapping)
+        try:
+            return r.matches()
+        finally:
+            r.free()
+    return automaton.find(hay[a:b], overlapping=overlapping)
+
+
 def _shift(matches, by: int):
     if by and len(matches):
         matches = matches.copy()
@@ -124,7 +152,7 @@ def _local_overlapping(automaton, hay, lo: int, hi: int, m: int):
     """All occurrences that END in (lo, hi] (rank 0: in (0, hi]); global offsets.  An occurrence
     that ends in the range starts at most m = max_pattern_len - 1 bytes before it."""
     w = max(0, lo - m)
-    got = _shift(automaton.find(hay[w:hi], overlapping=True), w)
+    got = _shift(_scan(automaton, hay, w, hi, True), w)
     return got[got["end"] > lo] if lo > 0 else got
 
 
@@ -134,8 +162,45 @@ def _local_greedy(automaton, hay, carry: int, hi: int, m: int, last: bool):
     range, or the range's own start).  A match that starts before hi ends at most m bytes
     after it, and no occurrence the truncated window hides can beat one that it shows."""
     n = len(hay)
-    got = _shift(automaton.find(hay[carry:n if last else min(n, hi + m)], overlapping=False), carry)
+    got = _shift(_scan(automaton, hay, carry, n if last else min(n, hi + m), False), carry)
     return got if last else got[got["start"] < hi]
+
+
+RESYNC_WINDOW = 1 << 16
+
+
+def _resume_greedy(automaton, hay, carry: int, hi: int, m: int, last: bool, old, window: int = RESYNC_WINDOW):
+    """_local_greedy(carry) when `old` = _local_greedy(some other carry) of the same range is at hand: the
+    non-overlapping iteration is a function of the position it resumes at, so as soon as the new iteration
+    reports a match the old one reported too, the two coincide from there on.  Scans windows from `carry`
+    until that happens (one window unless matches pile up) and splices the old tail on -- instead of
+    rescanning the whole range (round 3).  Returns (matches, bytes scanned)."""
+    import numpy as np
+    n = len(hay)
+    end = n if last else min(n, hi + m)
+    stop = n if last else hi
+    old = old[old["start"] >= carry] if len(old) else old
+    parts, scanned, c = [], 0, carry
+    while c < stop:
+        w_end = min(end, c + window + m)
+        got = _shift(_scan(automaton, hay, c, w_end, False), c)
+        scanned += w_end - c
+        if w_end < end:  # (a match that starts in the window's last m bytes may be cut short: leave it to the next window)
+            got = got[got["start"] < c + window]
+        got = got[got["start"] < stop] if not last else got
+        if len(got) and len(old):
+            # the first new match that is also an old one
+            key_old = {(int(s_), int(e_), int(p_)) for p_, s_, e_ in zip(old["pattern"], old["start"], old["end"])}
+            for i in range(len(got)):
+                if (int(got["start"][i]), int(got["end"][i]), int(got["pattern"][i])) in key_old:
+                    tail = old[old["start"] > got["start"][i]]
+                    parts.append(got[:i + 1])
+                    parts.append(tail)
+                    return np.concatenate(parts), scanned
+        parts.append(got)
+        c = max(c + window, int(got["end"][-1]) if len(got) else 0) if w_end < end else stop
+        old = old[old["start"] >= c] if len(old) else old
+    return (np.concatenate(parts) if parts else old[:0]), scanned
 
 
 def _carry_out(matches, hi: int, carry_in: int) -> int:
@@ -147,7 +212,7 @@ def simulate_single_sharded(automaton, haystack, world: int, overlapping: bool =
     """What find_single_sharded returns on every rank of a `world`-rank job, computed
     sequentially in one process (tests, single-GPU validation).  List of per-rank match arrays;
     their concatenation equals automaton.find(haystack, overlapping)."""
-    hay = memoryview(haystack).cast("B")
+    hay = _as_hay(haystack)
     m = max(int(automaton.max_pattern_len) - 1, 0)
     out, carry = [], 0
     for rank in range(world):
@@ -176,11 +241,13 @@ def find_single_sharded(automaton, haystack, overlapping: bool = False, group=No
     a cut, at most `world` rounds).  Offsets are global byte offsets.
 
     `automaton`: find(bytes-like, overlapping=) -> structured array (pattern, start, end) and
-    max_pattern_len, e.g. ahocorasick_rs_amd.capi.Automaton.
+    max_pattern_len, e.g. ahocorasick_rs_amd.capi.Automaton.  `haystack`: a bytes-like object, or a
+    DeviceHaystack (the haystack -- at least this rank's range plus max_pattern_len - 1 bytes either side --
+    resident on this rank's device: the ranges are scanned in HBM, automaton.find_device).
     Returns dict(lo, hi, matches, rank_counts, global_offset, global_total, rounds)."""
     import torch
     import torch.distributed as dist
-    hay = memoryview(haystack).cast("B")
+    hay = _as_hay(haystack)
     on = dist.is_initialized()
     rank = dist.get_rank(group) if on else 0
     world = dist.get_world_size(group) if on else 1
@@ -204,9 +271,9 @@ def find_single_sharded(automaton, haystack, overlapping: bool = False, group=No
             outs = [int(x) for x in every.cpu().tolist()]
             want = lo if rank == 0 else max(lo, outs[rank - 1])
             changed = want != carry
-            if changed:
+            if changed:  # resume at the true carry and stop as soon as the iteration is back on the old track
                 carry = want
-                got = _local_greedy(automaton, hay, carry, hi, m, last)
+                got, _ = _resume_greedy(automaton, hay, carry, hi, m, last, got)
             flag = torch.tensor([1 if changed else 0], dtype=torch.int64, device=device)
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=group)
             if int(flag.item()) == 0:
