@@ -2234,7 +2234,10 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     __syncthreads();
     if (fail) { if (t == 0) *abort_flag = 1; return; }
     // ---- order every bucket (words are unique), largest end per bucket
-    if (t < nb) {
+    // (buckets, not tiles read: the look-ahead tile of an anchored set has no bucket -- with four context tiles,
+    // patterns longer than 10 KiB, `t < nb` reached one row beyond the stage)
+    const uint32_t nbk = GROUP_TILES + lb;
+    if (t < nbk) {
         const uint32_t n = bn[t];
         int32_t mx = 0;
         for (uint32_t i = 0; i < n; i++) {
@@ -2256,7 +2259,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         // ---- certified sync points.  Only occurrences of the last (lookback + 1) buckets can end
         // beyond the start of one in bucket t (an occurrence spans at most max_len - 1 bytes
         // besides its key position, and lookback tiles are longer than that).
-        if (t < nb) {
+        if (t < nbk) {
             int32_t m = 0;
             for (uint32_t b = t > lookback + 1 ? t - lookback - 1 : 0; b < t; b++) m = max(m, bmax[b]);
             const uint32_t n = bn[t];

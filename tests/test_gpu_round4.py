@@ -421,3 +421,71 @@ def test_single_haystack_cut_into_rank_ranges_device_resident(mk):
     finally:
         buf.free()
         a.close()
+
+
+def test_byte_offsets_and_code_points_agree_on_ascii_and_contexts_survive_reuse():
+    """The bytes API and the str API take different instantiations of the post kernels (offsets straight out /
+    code points from the lead-byte counts); on ASCII text they must report the same numbers.  One handle, inputs of
+    changing sizes, a call that leaves the sparse path in between: nothing of an older call may leak into a newer
+    one (supergroup words, abort flags, hit counts)."""
+    pats = gen.gen_patterns(3000, 3, 12, gen.AZ, 77) + [b"abab", b"bab", b"ababab"]
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk)
+        o = Oracle(pats, mk, KIND_DFA)
+        sizes = [(8 << 20) + 123, 1 << 20, (24 << 20) + 5, 300_000, 8 << 20]
+        for k, n in enumerate(sizes):
+            hay = gen.gen_textlike(n, 1000 + k, pats).tobytes()
+            for ov in ([False, True] if mk == 0 else [False]):
+                plain = a.find(hay, overlapping=ov)
+                cps = a.find(hay, overlapping=ov, codepoints=True)  # ASCII: a code point is a byte
+                assert plain.tolist() == cps.tolist(), (mk, n, ov)
+                if n <= (1 << 20):
+                    raw = o.find_raw(hay, ov)
+                    assert np.stack([plain["pattern"], plain["start"], plain["end"]], 1).tolist() == raw.tolist()
+            if k == 1:  # a call that leaves the sparse path (every byte a match) in between
+                dense = a.find(b"ab" * (1 << 20), overlapping=False)
+                assert len(dense) > 0
+        a.close()
+
+
+def test_groups_in_every_state():
+    """Empty groups, full groups next to empty ones, matches across group borders (256 KiB) and in the very last
+    bytes: the output offsets of the groups have to add up to the oracle's order."""
+    pats = [b"needle", b"needles", b"edle", b"zzzz"]
+    G = 64 * 4096
+    for mk in (0, 1, 2):
+        a = capi.Automaton(pats, mk)
+        o = Oracle(pats, mk, KIND_DFA)
+        hay = bytearray(b"." * (9 * G + 777))
+        for pos in (0, 5, G - 3, G, 2 * G - 6, 2 * G + 1, 5 * G - 1, 7 * G + 4000, len(hay) - 7, len(hay) - 6):
+            hay[pos:pos + 7] = b"needles"[:min(7, len(hay) - pos)]
+        hay[3 * G:3 * G + 4000] = b"needle" * 666 + b"need"  # one busy group between empty ones
+        hay = bytes(hay)
+        for ov in ([False, True] if mk == 0 else [False]):
+            got = a.find(hay, overlapping=ov)
+            raw = o.find_raw(hay, ov)
+            assert np.stack([got["pattern"], got["start"], got["end"]], 1).tolist() == raw.tolist(), (mk, ov)
+        a.close()
+
+
+def test_anchored_set_with_a_pattern_longer_than_ten_kib():
+    """Four context tiles in front of a group (patterns longer than 10 241 bytes) AND a look-ahead tile behind it
+    (anchors): 69 tiles are read, but only 68 buckets exist -- k_tile_main once walked one row beyond its stage
+    here (found reading the code in round 4; the ordering and sync-point phases now stop at the buckets)."""
+    rng = np.random.default_rng(12)
+    urls = url_like_patterns(600, 5)
+    long_pat = bytes(rng.integers(97, 123, 11000, dtype=np.uint8))
+    long2 = urls[3] + bytes(rng.integers(97, 123, 10500, dtype=np.uint8))  # a long one behind a crowded beginning
+    pats = urls + [long_pat, long2]
+    h = capi.HostAutomaton(pats)
+    assert int(h.t.max_shift) > 0
+    h.close()
+    text = bytearray(gen.gen_textlike(6 << 20, 19).tobytes())
+    for o in rng.integers(0, len(text) - 12000, 3000):
+        u = pats[int(rng.integers(0, len(urls)))]
+        text[o:o + len(u)] = u
+    G = 64 * 4096
+    for o in (G - 5000, 3 * G - 11000 - 3, 5 * G + 17, 7 * G - 10, len(text) - 11000):
+        text[o:o + 11000] = long_pat
+    text[9 * G - 40:9 * G - 40 + len(long2)] = long2
+    check_all_kinds(pats, bytes(text), "anchors + 11 000-byte pattern")
