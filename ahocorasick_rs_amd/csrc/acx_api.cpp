@@ -320,7 +320,8 @@ struct Workspace {
                                       // hits, [4] matches written, [5..6] abort flags of the sparse path
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
-    uint64_t *h_pinned = nullptr;     // pinned host scratch (16 x u64; [8], [9] = result of K0; [7] = seq)
+    uint64_t *h_pinned = nullptr;     // pinned host scratch (32 x u64; [8], [9] = result of K0; [7] = seq; [16 .. 23] = K0's
+                                      // polled result line, 64-byte aligned)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
@@ -365,7 +366,7 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
     uint64_t seq = 0;          // sequence number the scan kernel publishes to h_pinned[7]
-    uint64_t small_seq = 0;    // K0 (host entry point): the number it publishes to h_pinned[11]
+    uint64_t small_seq = 0;    // K0 (host entry point): the number it puts at both ends of its result line (h_pinned[16 .. 23])
 };
 
 } // namespace
@@ -532,8 +533,8 @@ int ensure_common(Ctx *c) {
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
         // polled by the host while kernels still run: system-coherent
-        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 128, hipHostMallocCoherent));
-        std::memset(w.h_pinned, 0, 128);
+        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 256, hipHostMallocCoherent));
+        std::memset(w.h_pinned, 0, 256);
         w.flags_dirty = true;
     }
     return ACX_OK;
@@ -671,6 +672,12 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 // out holds SMALL_MAX_OCC records.  *done = false: too many occurrences, use the general path.
 // poll: hay and out are host memory the kernel reads / writes in place: wait for the number the kernel publishes
 // behind its last store instead of synchronising the stream (tools/ubench_roundtrip.hip: 6 us against 11)
+// (ACX_SMALL_SYNC, measurements: always synchronise the stream -- and then the records are plain acx_match_t)
+bool small_polls() {
+    static const bool no_poll = std::getenv("ACX_SMALL_SYNC") != nullptr;
+    return !no_poll;
+}
+
 int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
               acx_match_t *out, uint64_t *n_out, bool *done, bool poll = false) {
     *done = false;
@@ -678,25 +685,32 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     if (rc) return rc;
     Workspace &w = c->ws;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
-    static const bool no_poll = std::getenv("ACX_SMALL_SYNC") != nullptr; // measurements: always synchronise
-    const uint64_t seq = poll && !no_poll ? ++c->small_seq : 0;
+    const uint64_t seq = poll && small_polls() ? ++c->small_seq : 0;
     HIPCHK(launch_small(a->dev, hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        w.h_pinned + 8, seq, c->stream));
+                        seq ? w.h_pinned + 16 : w.h_pinned + 8, seq, c->stream));
     if (seq) {
-        volatile uint64_t *p = w.h_pinned;
+        // the result line (kernels.hpp): complete when BOTH ends carry this call's number
+        volatile uint64_t *p = w.h_pinned + 16;
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0; p[11] != seq; spins++) {
+        for (uint32_t spins = 0; p[K0_LINE_WORDS - 1] != seq || p[0] != seq; spins++) {
             cpu_relax();
             if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
                 HIPCHK(hipStreamSynchronize(c->stream));
-                if (p[11] != seq) return fail(ACX_EDEVICE, "K0 did not publish its result");
+                if (p[K0_LINE_WORDS - 1] != seq || p[0] != seq) return fail(ACX_EDEVICE, "K0 did not publish its result");
                 break;
             }
         }
         std::atomic_thread_fence(std::memory_order_acquire);
-    } else {
-        HIPCHK(hipStreamSynchronize(c->stream));
+        const uint64_t w1 = p[1];
+        if ((w1 >> 32) == 0) {
+            *n_out = w1 & 0xFFFFFFFFull;
+            *done = true;
+            std::lock_guard<std::mutex> lk(a->prof_mu);
+            a->profile.small_calls++;
+        }
+        return ACX_OK;
     }
+    HIPCHK(hipStreamSynchronize(c->stream));
     if (w.h_pinned[9] == 0) {
         *n_out = w.h_pinned[8];
         *done = true;
@@ -1778,7 +1792,13 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             if (n) {
                 acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
                 if (!m) return fail(ACX_ENOMEM, "out of memory");
-                std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
+                // (polled K0: the first matches ride in the result line, the others are in pin_out; all packed)
+                const uint64_t *line = w.h_pinned + 16 + 2, *rest = (const uint64_t *)w.pin_out;
+                if (!small_polls()) std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
+                else for (uint64_t i = 0; i < n; i++) {
+                    const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
+                    m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = v >> 48;
+                }
                 *out = m;
             }
             *n_out = n;

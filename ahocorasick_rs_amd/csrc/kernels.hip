@@ -2905,6 +2905,13 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
     return hipGetLastError();
 }
 
+// lead (non-continuation) bytes among the first n (0 .. 16) bytes of a 16-byte slice
+__device__ __forceinline__ uint32_t leads_in_first(const uint4 v, uint32_t n) {
+    const uint64_t v0 = n >= 8 ? ~0ull : (n ? ~0ull >> (8 * (8 - n)) : 0);
+    const uint64_t v1 = n > 8 ? (n >= 16 ? ~0ull : ~0ull >> (8 * (16 - n))) : 0;
+    return lead_in_word(((uint64_t)v.y << 32) | v.x, v0) + lead_in_word(((uint64_t)v.w << 32) | v.z, v1);
+}
+
 // ---------------------------------------------------------------------------
 // K0: the whole call in ONE workgroup, for small haystacks
 // ---------------------------------------------------------------------------
@@ -2921,29 +2928,131 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
 // is written LAST, behind a system-scope fence -- a host that polls it (res in coherent pinned memory) has the
 // whole result when it sees the number: one launch and one PCIe read instead of a launch and a stream
 // synchronisation (whose wake-up alone costs 5-10 us).
+// LT (small automata: the dense table is at most K0_LT_ENTRIES words, at most K0_LT_IDS states and patterns, patterns
+// shorter than 256 bytes -- the reference's "short" benchmark: 10 patterns): the table, the levels, own1 and the
+// ranks are staged in LDS while the haystack crosses PCIe (the loads are in flight together: the staging costs no
+// time of its own), and the anchored walks run at LDS latency -- a walk of depth 8 is ~1 us instead of ~5 (eight
+// dependent L2 round trips), which was most of what a call on a 75-byte haystack with 4-5 matches cost beyond the launch.
+constexpr uint32_t K0_LT_ENTRIES = 8192, K0_LT_IDS = 2048;
+// The polled result of a K0 call (seq != 0): ONE aligned 64-byte line of coherent pinned host memory, written by ONE store
+// instruction (four lanes x 16 bytes): [ seq | matches + too dense << 32 | the first K0_LINE_MATCHES matches, packed
+// | seq ].  Every separate write to host memory the kernel had to wait for before it may publish -- the records, then the
+// totals behind a system-scope fence, then the number -- was a PCIe round trip of its own (measured, rocprofv3: 6.8 us
+// for the kernel without matches, 8.8 with one, 12.9 with four on 75-byte haystacks); a line that carries its own
+// sequence number at both ends needs none: the host takes it when both ends show the call's number.  A packed match:
+// pattern : 32 | start : 16 | end : 16 (a K0 haystack has at most 16 384 bytes).  More matches than the line holds go,
+// packed, to out[] first, behind a system-scope fence.
+constexpr uint32_t K0_LINE_MATCHES = ACX_K0_LINE_MATCHES;
+static_assert(K0_LINE_MATCHES + 3 == K0_LINE_WORDS, "seq, totals, matches, seq");
+__device__ __forceinline__ void k0_publish_line(uint64_t *line, uint32_t t, uint64_t seq, uint64_t word1, const uint64_t *pk,
+                                                uint32_t npk) {
+    if (t >= 4) return;
+    uint64_t w[2];
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t i = 2 * t + k;
+        w[k] = i == 0 || i == 7 ? seq : i == 1 ? word1 : (i - 2 < npk ? pk[i - 2] : 0);
+    }
+    ((ulonglong2 *)line)[t] = make_ulonglong2(w[0], w[1]);
+}
+// MODE 2, direct comparison (a handful of short patterns on a short haystack: at most K0_DC_PATTERNS patterns of at most
+// 16 bytes, haystack bytes x patterns <= K0_DC_WORK): one thread per (position, pattern) compares the pattern with the
+// 16-byte window at the position -- two masked 64-bit XORs -- instead of one thread per position walking the trie level
+// by level.  A walk is a chain of dependent lookups as long as the match (15 for "arbitrarymonkey" in the reference's
+// short benchmark), and between calls that are 10-20 us apart the shader clock idles low: a dependent LDS round trip
+// costs ~0.3 us there (measured: the kernel took 6.8 us without matches, 8.8 with one 4-byte match, 12.9 with four).
+// MODE 0: the automaton's tables in global memory; MODE 1 (LT above): staged in LDS.
+constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
+template <int MODE>
 __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
                                                  uint32_t len, int key_mode, int overlapping,
                                                  int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq) {
     __shared__ __attribute__((aligned(16))) uint8_t sh[SMALL_MAX_LEN + 16];
+    constexpr bool LT = MODE == 1, DC = MODE == 2;
+    __shared__ uint32_t ltab[LT ? K0_LT_ENTRIES : 1], lown1[LT ? K0_LT_IDS : 1], lrank[LT ? K0_LT_IDS : 1], llevel[LT ? 258 : 1];
+    __shared__ uint64_t plo[DC ? K0_DC_PATTERNS : 1], phi[DC ? K0_DC_PATTERNS : 1]; // DC: the patterns' bytes, masked to their length
+    __shared__ uint32_t pl[DC ? K0_DC_PATTERNS : 1], prk[DC ? K0_DC_PATTERNS : 1];  // their lengths and ranks
     __shared__ uint8_t cls[256];
     __shared__ uint4 occ[SMALL_MAX_OCC]; // {key lo, key hi, pid, pattern length}
     __shared__ uint16_t order[SMALL_MAX_OCC];
     __shared__ uint8_t syn[SMALL_MAX_OCC], acc[SMALL_MAX_OCC];
     __shared__ uint32_t cpre[1025]; // code points before every 16-byte slice
-    __shared__ uint32_t nocc;
+    __shared__ uint32_t nocc, s_total;
+    // the records, assembled here and written as a flat run of dwords: `out` may be pinned HOST memory, where every
+    // store instruction's every lane is a transaction of its own -- 4 matches written field by field were 12 partial
+    // writes over PCIe (measured: the kernel took 12 us on 75-byte haystacks with 4 matches, ~6 without matches)
+    __shared__ uint32_t img[SMALL_MAX_OCC * 6];
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     const uint32_t t = threadIdx.x;
+    // (haystacks of at most 1 KiB -- one position per thread, at most 64 slices of 16 bytes: the prefix sums below are
+    // one wave's shuffles instead of block scans, and an LT walk has its 16 class bytes in registers before it starts)
+    const bool tiny = len <= 1024;
     if (t == 0) nocc = 0;
     if (t < 256) cls[t] = A.classes[t];
     for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
+    if constexpr (LT) {
+        const uint32_t ne = A.n_states << A.stride2;
+        for (uint32_t i = t; i < ne; i += 1024) ltab[i] = A.table[i];
+        for (uint32_t i = t; i < A.n_states; i += 1024) lown1[i] = A.own1[i];
+        for (uint32_t i = t; i < (uint32_t)A.n_patterns; i += 1024) lrank[i] = A.rank[i];
+        if (t < A.max_len + 2) llevel[t] = A.level_start[t];
+    }
+    if constexpr (DC) {
+        if (t < (uint32_t)A.n_patterns) {
+            const uint32_t L = A.plen[t];
+            uint64_t b0, b1;
+            __builtin_memcpy(&b0, A.pat_blob + A.pat_off[t], 8); // (pat_blob is padded by 16 bytes)
+            __builtin_memcpy(&b1, A.pat_blob + A.pat_off[t] + 8, 8);
+            plo[t] = L >= 8 ? b0 : b0 & ((1ull << (8 * L)) - 1);
+            phi[t] = L > 8 ? (L >= 16 ? b1 : b1 & ((1ull << (8 * (L - 8))) - 1)) : 0;
+            pl[t] = L;
+            prk[t] = A.rank[t];
+        }
+    }
     __syncthreads();
+    if constexpr (DC) {
+        const uint32_t np = (uint32_t)A.n_patterns, work = len * np;
+        const uint64_t *sh64 = (const uint64_t *)sh;
+        for (uint32_t idx = t; idx < work; idx += 1024) {
+            const uint32_t pos = idx / np, pid = idx - pos * np;
+            const uint32_t L = pl[pid];
+            if (pos + L > len) continue;
+            const uint32_t q = pos >> 3, r = (pos & 7) * 8;
+            const uint64_t a = sh64[q], b = sh64[q + 1], c = sh64[q + 2];
+            const uint64_t w0 = r ? (a >> r) | (b << (64 - r)) : a, w1 = r ? (b >> r) | (c << (64 - r)) : b;
+            const uint64_t m0 = L >= 8 ? ~0ull : (1ull << (8 * L)) - 1;
+            const uint64_t m1 = L > 8 ? (L >= 16 ? ~0ull : (1ull << (8 * (L - 8))) - 1) : 0;
+            if ((((w0 & m0) ^ plo[pid]) | ((w1 & m1) ^ phi[pid])) != 0) continue;
+            const uint32_t rk = prk[pid];
+            const uint64_t key = key_mode == 0   ? ((uint64_t)(pos + L) << A.rank_bits) | rk
+                                 : key_mode == 1 ? ((uint64_t)pos << A.rank_bits) | pid
+                                                 : ((uint64_t)pos << A.rank_bits) | rk;
+            const uint32_t slot = atomicAdd(&nocc, 1u);
+            if (slot < SMALL_MAX_OCC) occ[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
+        }
+    }
     // ---- all occurrences: anchored walk from every position
-    for (uint32_t pos = t; pos < len; pos += 1024) {
+    for (uint32_t pos = t; !DC && pos < len; pos += 1024) {
         uint32_t s = 0;
+        uint64_t c0 = 0, c1 = 0; // LT, tiny: the classes of the 16 bytes at pos (independent LDS reads, all in flight)
+        if (LT && tiny) {
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint64_t c = pos + k < len ? cls[sh[pos + k]] : 0;
+                if (k < 8) c0 |= c << (8 * k); else c1 |= c << (8 * (k - 8));
+            }
+        }
         for (uint32_t d = 0; pos + d < len;) {
             uint32_t id, own;
-            if (A.table) {
+            if constexpr (LT) {
+                const uint32_t cb = !tiny || d >= 16 ? cls[sh[pos + d]] : (uint32_t)((d < 8 ? c0 >> (8 * d) : c1 >> (8 * (d - 8))) & 0xFF);
+                const uint32_t e = ltab[(s << A.stride2) + cb];
+                id = e & ID_MASK;
+                d++;
+                if (id < llevel[d]) break;
+                own = e & FLAG_OWN;
+            } else if (A.table) {
                 const uint32_t e = A.table[((size_t)s << A.stride2) + cls[sh[pos + d]]];
                 id = e & ID_MASK;
                 d++;
@@ -2957,14 +3066,15 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
             }
             s = id;
             if (!own) continue;
-            const uint32_t one = A.own1[s];
+            const uint32_t one = LT ? lown1[s] : A.own1[s];
             uint32_t b = 0, en = 1;
             if (one == OWN1_MANY) { b = A.own_off[s]; en = A.own_off[s + 1]; }
             for (uint32_t k = b; k < en; k++) { // the patterns that are exactly hay[pos, pos + d)
                 const uint32_t pid = one == OWN1_MANY ? A.own_pid[k] : one;
-                const uint64_t key = key_mode == 0   ? ((uint64_t)(pos + d) << A.rank_bits) | A.rank[pid]
+                const uint32_t rk = key_mode == 1 ? 0u : (LT ? lrank[pid] : A.rank[pid]);
+                const uint64_t key = key_mode == 0   ? ((uint64_t)(pos + d) << A.rank_bits) | rk
                                      : key_mode == 1 ? ((uint64_t)pos << A.rank_bits) | pid
-                                                     : ((uint64_t)pos << A.rank_bits) | A.rank[pid];
+                                                     : ((uint64_t)pos << A.rank_bits) | rk;
                 const uint32_t slot = atomicAdd(&nocc, 1u);
                 if (slot < SMALL_MAX_OCC) occ[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, d);
             }
@@ -2973,10 +3083,8 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     __syncthreads();
     const uint32_t n = nocc;
     if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
-        if (t == 0) {
-            res[0] = 0; res[1] = 1;
-            if (seq) { __threadfence_system(); ((volatile uint64_t *)res)[3] = seq; }
-        }
+        if (seq) k0_publish_line(res, t, seq, 1ull << 32, nullptr, 0);
+        else if (t == 0) { res[0] = 0; res[1] = 1; }
         return;
     }
     // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
@@ -3030,41 +3138,92 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
         mine = t < n ? acc[t] : 0u;
     }
     // ---- byte offset -> code point index (src/lib.rs:73-88): lead bytes before the offset
+    // (a slice is one aligned 16-byte LDS read and two popcounts -- rounds 1-4 read it byte by byte)
     if (codepoints) {
         uint32_t leads = 0;
-        for (uint32_t i = t * 16; i < t * 16 + 16 && i < len; i++) leads += (sh[i] & 0xC0) != 0x80;
-        uint32_t before = 0;
-        scan_t().exclusive_scan(leads, before, 0u, scan_tmp);
-        cpre[t] = before;
-        if (t == 1023) cpre[1024] = before + leads;
+        if (t * 16 < len) leads = leads_in_first(*(const uint4 *)(sh + t * 16), len - t * 16 < 16 ? len - t * 16 : 16);
+        if (tiny) {
+            if (t < 64) {
+                uint32_t incl = leads;
+                for (int o = 1; o < 64; o <<= 1) {
+                    const uint32_t v = __shfl_up(incl, o);
+                    if ((int)t >= o) incl += v;
+                }
+                cpre[t] = incl - leads;
+                if (t == 63) cpre[64] = incl;
+            }
+        } else {
+            uint32_t before = 0;
+            scan_t().exclusive_scan(leads, before, 0u, scan_tmp);
+            cpre[t] = before;
+            if (t == 1023) cpre[1024] = before + leads;
+        }
         __syncthreads();
     }
-    uint32_t dst = 0;
-    scan_t().exclusive_scan(mine, dst, 0u, scan_tmp);
+    uint32_t dst = 0, total = 0;
+    if (n <= 64) { // (mine != 0 only in wave 0)
+        if (t < 64) {
+            uint32_t incl = mine;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t v = __shfl_up(incl, o);
+                if ((int)t >= o) incl += v;
+            }
+            dst = incl - mine;
+            total = __shfl(incl, 63);
+        }
+    } else {
+        scan_t().exclusive_scan(mine, dst, 0u, scan_tmp);
+        total = dst + mine; // (thread 1023's)
+    }
     if (mine) {
         const uint4 v = occ[order[t]];
         uint64_t s, e;
         K0_SPAN(t, s, e)
         if (codepoints) {
-            uint32_t cs = cpre[s >> 4], ce = cpre[e >> 4];
-            for (uint32_t i = (uint32_t)s & ~15u; i < s; i++) cs += (sh[i] & 0xC0) != 0x80;
-            for (uint32_t i = (uint32_t)e & ~15u; i < e; i++) ce += (sh[i] & 0xC0) != 0x80;
+            const uint32_t cs = cpre[s >> 4] + leads_in_first(*(const uint4 *)(sh + (s & ~15ull)), (uint32_t)s & 15u);
+            const uint32_t ce = cpre[e >> 4] + leads_in_first(*(const uint4 *)(sh + (e & ~15ull)), (uint32_t)e & 15u);
             s = cs; e = ce;
         }
-        out[dst].pattern = v.z; out[dst].start = s; out[dst].end = e;
+        if (seq) {
+            ((uint64_t *)img)[dst] = (uint64_t)v.z | (s << 32) | (e << 48);
+        } else {
+            uint32_t *d = img + dst * 6;
+            d[0] = v.z; d[1] = 0;
+            d[2] = (uint32_t)s; d[3] = (uint32_t)(s >> 32); d[4] = (uint32_t)e; d[5] = (uint32_t)(e >> 32);
+        }
     }
-    if (t == 1023) { res[0] = dst + mine; res[1] = 0; }
-    if (seq) { // (every thread's records and the totals first: the barrier, then ONE thread's system-scope release)
-        __syncthreads();
-        if (t == 0) { __threadfence_system(); ((volatile uint64_t *)res)[3] = seq; }
+    if (n <= 64 ? t == 63 : t == 1023) s_total = total;
+    __syncthreads();
+    const uint32_t tot = s_total;
+    if (seq) {
+        const uint64_t *pk = (const uint64_t *)img;
+        if (tot > K0_LINE_MATCHES) { // (uniform)
+            for (uint32_t k = t; k < tot - K0_LINE_MATCHES; k += 1024) ((uint64_t *)out)[k] = pk[K0_LINE_MATCHES + k];
+            __threadfence_system();
+            __syncthreads();
+        }
+        k0_publish_line(res, t, seq, tot, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+    } else {
+        for (uint32_t k = t; k < tot * 6; k += 1024) ((uint32_t *)out)[k] = img[k];
+        if (t == 0) *(ulonglong2 *)res = make_ulonglong2(tot, 0); // res[0] = matches, res[1] = 0: one store
     }
 #undef K0_SPAN
 }
 
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
                         bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st) {
-    hipLaunchKernelGGL(k0_small, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,
-                       codepoints ? 1 : 0, out, res, seq);
+    // (ACX_K0_NO_LDS_TABLE: measurements)
+    static const bool no_lt = std::getenv("ACX_K0_NO_LDS_TABLE") != nullptr;
+    static const bool no_dc = std::getenv("ACX_K0_NO_DIRECT") != nullptr;
+    const bool lt = A.table && ((uint64_t)A.n_states << A.stride2) <= K0_LT_ENTRIES && A.n_states <= K0_LT_IDS &&
+                    A.n_patterns <= K0_LT_IDS && A.max_len < 256 && !no_lt;
+    const bool dc = A.n_patterns <= K0_DC_PATTERNS && A.min_len >= 1 && A.max_len <= 16 && A.pat_blob && A.pat_off &&
+                    (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc;
+#define ACX_K0(M)                                                                                                      \
+    hipLaunchKernelGGL(k0_small<M>, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,            \
+                       codepoints ? 1 : 0, out, res, seq)
+    if (dc) ACX_K0(2); else if (lt) ACX_K0(1); else ACX_K0(0);
+#undef ACX_K0
     return hipGetLastError();
 }
 

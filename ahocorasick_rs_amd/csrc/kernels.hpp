@@ -71,7 +71,12 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 // SMALL_MAX_OCC occurrences, one haystack).  hay / out / res may be pinned host memory.
 // out: SMALL_MAX_OCC records; res[0] = matches written, res[1] != 0: too dense, nothing written.
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
-// seq != 0: res[3] = seq is written last behind a system-scope fence (res: coherent pinned memory the host polls)
+// seq != 0 (the host polls): res is the call's RESULT LINE -- 64 aligned bytes of coherent pinned host memory, written by one
+// store instruction: [0] seq, [1] matches | too dense << 32, [2 .. 6] the first K0_LINE_MATCHES matches packed as
+// pattern | start << 32 | end << 48, [7] seq -- and out[] takes the matches beyond those, packed the same way, first.
+// seq == 0: out[] = acx_match_t records, res[0] / res[1] as above (device memory, read behind a stream synchronisation)
+#define ACX_K0_LINE_MATCHES 5
+constexpr uint32_t K0_LINE_WORDS = 8;
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
                         bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write

@@ -489,3 +489,61 @@ def test_anchored_set_with_a_pattern_longer_than_ten_kib():
         text[o:o + 11000] = long_pat
     text[9 * G - 40:9 * G - 40 + len(long2)] = long2
     check_all_kinds(pats, bytes(text), "anchors + 11 000-byte pattern")
+
+
+def _k0_sets():
+    """Automata that take each of K0's three ways of finding the occurrences (kernels.hip, k0_small<MODE>)."""
+    few = [b"abc", b"hello", b"b", b"aardvark", b"fish", b"whatwhat", b"sixteen-bytes-xy", b"ninebytes", b"host7", b"host76", b"b"]
+    return {
+        "direct comparison": few,                                   # <= 64 patterns of <= 16 bytes
+        "table in LDS": few + [b"seventeen-bytes-xy"],              # a longer pattern: the walk, small tables
+        "tables in global memory": few + gen.gen_patterns(3000, 4, 12, gen.AZ, 3),
+    }
+
+
+@pytest.mark.parametrize("which", ["direct comparison", "table in LDS", "tables in global memory"])
+def test_k0_every_mode_every_kind_result_line_and_overflow(which):
+    """One call on a small host haystack = K0.  0, 1, 5 (the result line is full), 6 and 7 (the first packed
+    records beyond the line), hundreds of matches (SMALL_MAX_OCC is 1024: beyond it the general pipeline), matches
+    at the very start and end, windows at every alignment, a haystack of one byte and the empty one -- bytes
+    and code points, every kind, against the oracle."""
+    import ahocorasick_rs_amd as ac
+    pats = _k0_sets()[which]
+    hays = [b"", b"b", b"x", b"hello", b"xhellox", b"fish host76 abc", b"abc" * 2, b"b" * 5, b"b" * 6, b"b" * 7,
+            b"hello fish abc b host7 host76 whatwhat sixteen-bytes-xy ninebytes aardvark",
+            b"b" * 300, b"ab" * 600, b"sixteen-bytes-xy" * 20 + b"sixteen-bytes-x", b"q" * 407 + b"ninebytes"]
+    hays += [b"z" * k + b"seventeen-bytes-xy" + b"z" * (9 - k) + b"aardvark" for k in range(9)]
+    kinds = [(ac.MatchKind.Standard, 0), (ac.MatchKind.LeftmostFirst, 1), (ac.MatchKind.LeftmostLongest, 2)]
+    for mkind, mk in kinds:
+        o = Oracle(pats, mk, KIND_DFA)
+        a = ac.BytesAhoCorasick(pats, matchkind=mkind)
+        for hay in hays:
+            for ov in ([False, True] if mk == 0 else [False]):
+                want = [tuple(int(x) for x in r) for r in o.find_raw(hay, ov)]
+                assert a.find_matches_as_indexes(hay, overlapping=ov) == want, (which, mk, ov, hay[:40])
+    # code points: the same through the str API with two- and four-byte characters in front of and between the matches
+    spats = [p.decode() for p in pats] + ["é", "🤦b"]
+    bpats = [p.encode() for p in spats]
+    text = "é🤦b hello ☃ fish é abc 🤦 host76 ééé b" + "é" * 40 + "whatwhat"
+    bts = text.encode()
+    cp = np.cumsum(np.frombuffer(bts, dtype=np.uint8) & 0xC0 != 0x80) - 1
+    cp = np.concatenate([cp, [cp[-1] + 1]])
+    for mkind, mk in kinds:
+        a = ac.AhoCorasick(spats, matchkind=mkind)
+        want = [(int(p), int(cp[s]), int(cp[e])) for p, s, e in Oracle(bpats, mk, KIND_DFA).find_raw(bts)]
+        assert a.find_matches_as_indexes(text) == want, (which, mk)
+
+
+def test_k0_direct_comparison_work_limit():
+    """haystack bytes x patterns <= 4096 takes the direct comparison, one byte more the walk: the same answers on
+    both sides of the limit (64 patterns: haystacks of 64 and 65 bytes; 10 patterns: 409 and 410)."""
+    import ahocorasick_rs_amd as ac
+    rng = np.random.default_rng(5)
+    for npat in (64, 10):
+        pats = list(dict.fromkeys(bytes(rng.integers(97, 101, int(rng.integers(1, 17))).astype(np.uint8)) for _ in range(npat * 3)))[:npat]
+        o = Oracle(pats, 2, KIND_DFA)
+        a = ac.BytesAhoCorasick(pats, matchkind=ac.MatchKind.LeftmostLongest)
+        for n in (4096 // npat - 1, 4096 // npat, 4096 // npat + 1, 4096 // npat + 17):
+            hay = bytes(rng.integers(97, 101, n).astype(np.uint8))
+            want = [tuple(int(x) for x in r) for r in o.find_raw(hay, False)]
+            assert a.find_matches_as_indexes(hay) == want, (npat, n)

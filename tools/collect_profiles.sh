@@ -55,6 +55,10 @@ ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-basel
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_one_rank_rccl.json 2> $OUT/bench_T_one_rank_rccl.err
 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison.txt 2>&1
 ACX_SMALL_SYNC=1 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison_stream_sync.txt 2>&1
+# K0's ways of finding the occurrences, same box: the walks only (no direct comparison), and the walks over global tables only
+ACX_K0_NO_DIRECT=1 timeout 300 python benchmarks/bench_comparison.py < /dev/null > $OUT/exp_k0_walk_lds_bench_comparison.txt 2>&1
+ACX_K0_NO_DIRECT=1 ACX_K0_NO_LDS_TABLE=1 timeout 300 python benchmarks/bench_comparison.py < /dev/null > $OUT/exp_k0_walk_global_bench_comparison.txt 2>&1
+for ds in short short_nomatch short_onematch long; do timeout 60 python tools/k0_probe.py $ds indexes 2000 < /dev/null; done > $OUT/k0_probe.txt 2>&1
 timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1
 [ -x tools/ubench_stream.bin ] && timeout 120 tools/ubench_stream.bin > $OUT/ubench_stream.txt 2>&1
 fi
