@@ -2923,13 +2923,14 @@ __device__ __forceinline__ uint32_t leads_in_first(const uint4 v, uint32_t n) {
 // comparison -- and report the patterns that end on the way: 2-3 dependent loads per
 // position on text), rank-sort them by key in LDS, resolve the match kind, convert to code
 // points, write the final records.  `hay`, `out` and `res` may live in pinned host memory
-// (zero-copy): the host-memory entry point then costs one launch and one sync.
-// res[0] = matches written, res[1] = 0, or 1: too many occurrences, nothing written.  seq != 0: res[3] = seq
-// is written LAST, behind a system-scope fence -- a host that polls it (res in coherent pinned memory) has the
-// whole result when it sees the number: one launch and one PCIe read instead of a launch and a stream
-// synchronisation (whose wake-up alone costs 5-10 us).
+// (zero-copy): the host-memory entry point then costs one launch and one poll.
+// seq == 0 (device-resident callers, read behind a stream synchronisation): out[] = acx_match_t records, res[0] =
+// matches written, res[1] = 0, or 1: too many occurrences, nothing written.  seq != 0 (the host polls -- one launch and
+// one PCIe read instead of a launch and a stream synchronisation, whose wake-up alone costs 5-10 us): the result is the
+// 64-byte line described at k0_publish_line below.
+// How the occurrences are found: MODE 0 = the walk over the tables in global memory, MODE 1 (LT) and MODE 2 (DC) below.
 // LT (small automata: the dense table is at most K0_LT_ENTRIES words, at most K0_LT_IDS states and patterns, patterns
-// shorter than 256 bytes -- the reference's "short" benchmark: 10 patterns): the table, the levels, own1 and the
+// shorter than 256 bytes): the table, the levels, own1 and the
 // ranks are staged in LDS while the haystack crosses PCIe (the loads are in flight together: the staging costs no
 // time of its own), and the anchored walks run at LDS latency -- a walk of depth 8 is ~1 us instead of ~5 (eight
 // dependent L2 round trips), which was most of what a call on a 75-byte haystack with 4-5 matches cost beyond the launch.

@@ -21,7 +21,8 @@ def short(n):
 
 
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
-                                                                  ("smoke.log", "bench_comparison.txt", "bench_comparison_stream_sync.txt", "ubench_stream.txt")]:
+                                                                  ("smoke.log", "bench_comparison.txt", "bench_comparison_stream_sync.txt", "ubench_stream.txt", "k0_probe.txt",
+                                                                   "exp_k0_walk_lds_bench_comparison.txt", "exp_k0_walk_global_bench_comparison.txt")]:
     if os.path.exists(f) and os.path.getsize(f):
         if f.endswith(".json"):  # (only the JSON line: RCCL prints its banner to stdout)
             lines = [l for l in open(f) if l.startswith("{")]
