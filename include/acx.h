@@ -64,8 +64,10 @@ extern "C" {
 #define ACX_IMPL_DFA 2
 
 /* scan kernels (acx_info.kernel, acx_set_kernel).  Haystacks of at most 16 KiB are
- * answered by K0 -- one workgroup does the whole call (anchored walk from every position,
- * sort, resolve, output; one launch, the result polled from pinned memory) -- unless a scan
+ * answered by K0 -- one workgroup does the whole call (the occurrences by direct comparison for a
+ * handful of short patterns, else by an anchored walk from every position, over tables staged in LDS
+ * when they are small; sort, resolve, output; one launch, the result -- one 64-byte line that carries
+ * the call's number at both ends -- polled from pinned memory) -- unless a scan
  * kernel was chosen explicitly with acx_set_kernel / ACX_KERNEL or the output is too dense for it.
  * Since round 4 the library's own choice is the prefilter for EVERY pattern set (patterns of 1 and
  * 2 bytes through its side test); the DFA walk runs when it is asked for. */
