@@ -376,6 +376,16 @@ struct acx_automaton {
     int device = 0;
     DevAutomaton dev{};
     const DevAutomaton *d_dev = nullptr; // the same struct, resident in HBM
+    // Copies of a pattern (Standard automata keep them: an overlapping search reports every copy).  A NON-overlapping
+    // search can only ever report the lowest id of a string, and the device enumerates every occurrence it is given --
+    // hundreds of copies of every pattern on text where every position matches were hundreds of times the work
+    // (tools/gpu_fuzz.py, seed 40404).  dev_nov = dev with two tables replaced: own1 holds the lowest id of every
+    // state's string (all patterns that end in a trie state ARE one string: never OWN1_MANY), and blist has every
+    // candidate list's first-of-their-string ids in front and counts only those (same list indexes: the prefix table
+    // and the short patterns' codes are shared).  Taken by the kernels that read those tables on the default path
+    // (K0, k_tile_main, k_walk_hits, k_dense_verify) when the call is not overlapping; has_nov = false: no copies.
+    DevAutomaton dev_nov{};
+    bool has_nov = false;
     std::vector<void *> allocs;
     int kernel = ACX_KERNEL_DFA_WALK;
     int implementation = ACX_IMPL_AUTO; // the caller's hint (replicas are built with the same one)
@@ -672,6 +682,11 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 // out holds SMALL_MAX_OCC records.  *done = false: too many occurrences, use the general path.
 // poll: hay and out are host memory the kernel reads / writes in place: wait for the number the kernel publishes
 // behind its last store instead of synchronising the stream (tools/ubench_roundtrip.hip: 6 us against 11)
+// the device tables a call takes: a non-overlapping search never needs the later copies of a string (acx_automaton::dev_nov)
+inline const DevAutomaton &view(const acx_automaton *a, bool overlapping) {
+    return !overlapping && a->has_nov ? a->dev_nov : a->dev;
+}
+
 // (ACX_SMALL_SYNC, measurements: always synchronise the stream -- and then the records are plain acx_match_t)
 bool small_polls() {
     static const bool no_poll = std::getenv("ACX_SMALL_SYNC") != nullptr;
@@ -686,7 +701,7 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     Workspace &w = c->ws;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     const uint64_t seq = poll && small_polls() ? ++c->small_seq : 0;
-    HIPCHK(launch_small(a->dev, hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
+    HIPCHK(launch_small(view(a, overlapping != 0), hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
                         seq ? w.h_pinned + 16 : w.h_pinned + 8, seq, c->stream));
     if (seq) {
         // the result line (kernels.hpp): complete when BOTH ends carry this call's number
@@ -912,7 +927,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         cp_pre = w.blockpre;
     }
     const uint64_t seq = ++x->seq;
-    HIPCHK_RC(tile_post(a->dev, c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
+    HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
                         next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, st));
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
@@ -975,7 +990,7 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
     const bool prof = c.timed;
     HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
                                prof ? scan_stop_ev(x) : nullptr));
-    HIPCHK_RC(dense_tiles_verify(a->dev, c.G, H, hit_grid, w.dt, c.key_mode, c.lead, c.d_hay, c.len, abort_flag, st));
+    HIPCHK_RC(dense_tiles_verify(view(a, c.overlapping), c.G, H, hit_grid, w.dt, c.key_mode, c.lead, c.d_hay, c.len, abort_flag, st));
     // (the hit regions' fill: summary[2] = hits kept, [3] = the fullest region)
     HIPCHK_RC(sink_summary(w.hit_counts, hit_grid, hit_cap, w.hit_counts, hit_grid, hit_cap, w.summary, w.region_off, st));
     HIPCHK_RC(dense_tiles_main(a->dev, c.key_mode, c.overlapping, w.dt, w.TD, c.lead, abort_flag, w.summary, st));
@@ -1048,7 +1063,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
     if (c.pre) {
         HIPCHK_RC(launch_prefilter(a->dev, H, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
                                    prof ? scan_stop_ev(x) : nullptr));
-        HIPCHK_RC(launch_walk_hits(a->dev, c.G, H, hit_grid, K, grid, c.d_hay, c.len, st));
+        HIPCHK_RC(launch_walk_hits(view(a, c.overlapping), c.G, H, hit_grid, K, grid, c.d_hay, c.len, st));
     } else {
         if (pfac) HIPCHK_RC(hipMemsetAsync(w.summary + 4, 0, 8, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
@@ -1571,6 +1586,35 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
 #undef UP
     if ((rc = upload(a, st, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
     if ((rc = upload(a, st, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
+    {
+        // the view of a non-overlapping search (struct acx_automaton): only when some string is there more than once
+        static const bool no_nov = std::getenv("ACX_NO_COPY_VIEW") != nullptr; // measurements
+        std::vector<uint8_t> later(H.n_patterns, 0); // a copy of a string with a lower id
+        uint64_t n_later = 0;
+        for (uint32_t s2 = 0; s2 < H.n_states && H.match_kind == ACX_MATCH_STANDARD; s2++)
+            for (uint32_t k = H.own_off[s2] + 1; k < H.own_off[s2 + 1]; k++) { later[H.own_pid[k]] = 1; n_later++; }
+        if (n_later && !no_nov) {
+            std::vector<uint32_t> own1_nov(H.n_states, OWN1_NONE);
+            for (uint32_t s2 = 0; s2 < H.n_states; s2++)
+                if (H.own_off[s2 + 1] > H.own_off[s2]) own1_nov[s2] = H.own_pid[H.own_off[s2]]; // (lists are in id order)
+            std::vector<uint32_t> blist_nov(H.blist);
+            for (size_t i = 0; i < blist_nov.size();) { // [count, codes ...] records, back to back
+                const uint32_t cnt = H.blist[i];
+                uint32_t kept = 0;
+                for (uint32_t k = 0; k < cnt; k++)
+                    if (!later[H.blist[i + 1 + k] & CODE_PID_MASK]) blist_nov[i + 1 + kept++] = H.blist[i + 1 + k];
+                uint32_t rest = kept;
+                for (uint32_t k = 0; k < cnt; k++)
+                    if (later[H.blist[i + 1 + k] & CODE_PID_MASK]) blist_nov[i + 1 + rest++] = H.blist[i + 1 + k];
+                blist_nov[i] = kept;
+                i += (size_t)cnt + 1;
+            }
+            a->dev_nov = a->dev;
+            if ((rc = upload(a, st, own1_nov.data(), own1_nov.size(), &a->dev_nov.own1)) != ACX_OK) return destroy(rc);
+            if ((rc = upload(a, st, blist_nov.data(), blist_nov.size(), &a->dev_nov.blist)) != ACX_OK) return destroy(rc);
+            a->has_nov = true;
+        }
+    }
     HIPCHK_A(hipStreamSynchronize(st));
     a->table_bytes = H.table.size() * 4;
     // the big host copy of the table is no longer needed

@@ -547,3 +547,35 @@ def test_k0_direct_comparison_work_limit():
             hay = bytes(rng.integers(97, 101, n).astype(np.uint8))
             want = [tuple(int(x) for x in r) for r in o.find_raw(hay, False)]
             assert a.find_matches_as_indexes(hay) == want, (npat, n)
+
+
+def test_copies_of_a_pattern_cost_a_non_overlapping_search_nothing():
+    """Hundreds of copies of every string (tools/gpu_fuzz.py seed 40404: 22 264 patterns = 30 distinct strings) on
+    text where every position matches: a non-overlapping search reports the lowest id of a string and must not pay
+    for the others (acx_api.cpp: dev_nov, the view without the later copies); an overlapping one reports every copy.
+    Short strings (own lists / K0), longer ones (K1b's candidate lists), 1- and 2-byte ones (the side test's lists)."""
+    import random
+    import time
+    rng = random.Random(7)
+    sets = {
+        "1-4 bytes": [bytes(rng.choice(b"ab") for _ in range(rng.randint(1, 4))) for _ in range(6000)],
+        "5-8 bytes": [bytes(rng.choice(b"ab") for _ in range(rng.randint(5, 8))) for _ in range(20000)],
+        "3-6 bytes": [bytes(rng.choice(b"abc") for _ in range(rng.randint(3, 6))) for _ in range(30000)],
+    }
+    hay = bytes(rng.choice(b"ab") for _ in range(300_000)) + bytes(rng.choice(b"abc") for _ in range(300_000))
+    for name, pats in sets.items():
+        copies = len(pats) / len(set(pats))
+        assert copies > 20, (name, copies)
+        o = Oracle(pats, 0, KIND_DFA)
+        a = capi.Automaton(pats, 0)
+        for h in (hay, hay[:3000], hay[299_000:301_500]):  # the pipeline; K0; K0 across the alphabet change
+            want = o.find_raw(h, False)
+            got = cols(a.find(h))
+            t0 = time.time()
+            got2 = cols(a.find(h))
+            dt = time.time() - t0
+            assert np.array_equal(got, want) and np.array_equal(got2, want), (name, len(h), len(got), len(want))
+            assert dt < 1.0, (name, len(h), dt)  # (the forced DFA walk took 28 s for 20 000 bytes of this)
+        small = hay[:1500]
+        assert np.array_equal(cols(a.find(small, overlapping=True)), o.find_raw(small, True)), name  # every copy
+        a.close()
