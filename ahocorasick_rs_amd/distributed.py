@@ -189,14 +189,16 @@ def _resume_greedy(automaton, hay, carry: int, hi: int, m: int, last: bool, old,
             got = got[got["start"] < c + window]
         got = got[got["start"] < stop] if not last else got
         if len(got) and len(old):
-            # the first new match that is also an old one
-            key_old = {(int(s_), int(e_), int(p_)) for p_, s_, e_ in zip(old["pattern"], old["start"], old["end"])}
-            for i in range(len(got)):
-                if (int(got["start"][i]), int(got["end"][i]), int(got["pattern"][i])) in key_old:
-                    tail = old[old["start"] > got["start"][i]]
-                    parts.append(got[:i + 1])
-                    parts.append(tail)
-                    return np.concatenate(parts), scanned
+            # the first new match that is also an old one (both are sorted by start, a start occurs once in either)
+            j = np.searchsorted(old["start"], got["start"])
+            jc = np.minimum(j, len(old) - 1)
+            same = (j < len(old)) & (old["start"][jc] == got["start"]) & (old["end"][jc] == got["end"]) & \
+                   (old["pattern"][jc] == got["pattern"])
+            if same.any():
+                i = int(np.argmax(same))
+                parts.append(got[:i + 1])
+                parts.append(old[int(j[i]) + 1:])
+                return np.concatenate(parts), scanned
         parts.append(got)
         c = max(c + window, int(got["end"][-1]) if len(got) else 0) if w_end < end else stop
         old = old[old["start"] >= c] if len(old) else old
