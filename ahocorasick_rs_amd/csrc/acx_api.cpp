@@ -382,9 +382,12 @@ struct acx_automaton {
     // (tools/gpu_fuzz.py, seed 40404).  dev_nov = dev with two tables replaced: own1 holds the lowest id of every
     // state's string (all patterns that end in a trie state ARE one string: never OWN1_MANY), and blist has every
     // candidate list's first-of-their-string ids in front and counts only those (same list indexes: the prefix table
-    // and the short patterns' codes are shared).  Taken by the kernels that read those tables on the default path
-    // (K0, k_tile_main, k_walk_hits, k_dense_verify) when the call is not overlapping; has_nov = false: no copies.
+    // and the short patterns' codes are shared).  The DFA walk reports through the own lists (own_off / own_pid: one
+    // entry per state in the view) and through its trie records (grec: own1 in their third word).  Taken by the
+    // kernels that read those tables (K0, k_tile_main, k_walk_hits, k_dense_verify; k1a_walk, the walks' emit
+    // paths through the device-resident copy d_dev_nov) when the call is not overlapping; has_nov = false: no copies.
     DevAutomaton dev_nov{};
+    const DevAutomaton *d_dev_nov = nullptr;
     bool has_nov = false;
     std::vector<void *> allocs;
     int kernel = ACX_KERNEL_DFA_WALK;
@@ -686,6 +689,9 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 inline const DevAutomaton &view(const acx_automaton *a, bool overlapping) {
     return !overlapping && a->has_nov ? a->dev_nov : a->dev;
 }
+inline const DevAutomaton *d_view(const acx_automaton *a, bool overlapping) { // (the same, resident in HBM)
+    return !overlapping && a->has_nov ? a->d_dev_nov : a->d_dev;
+}
 
 // (ACX_SMALL_SYNC, measurements: always synchronise the stream -- and then the records are plain acx_match_t)
 bool small_polls() {
@@ -903,10 +909,10 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         }
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
         if (pfac)
-            HIPCHK_RC(launch_pfac(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
+            HIPCHK_RC(launch_pfac(view(a, c.overlapping), d_view(a, c.overlapping), c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
                                   pgrid * 16, false, st));
         else
-            HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+            HIPCHK_RC(launch_dfa_walk(view(a, c.overlapping), d_view(a, c.overlapping), c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     // str API, one haystack: the prefix of the lead-byte counts is ready before the write kernel
@@ -1068,10 +1074,10 @@ int attempt_dense(FindCall &c, Attempt *what) {
         if (pfac) HIPCHK_RC(hipMemsetAsync(w.summary + 4, 0, 8, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_start_ev(x), st));
         if (pfac)
-            HIPCHK_RC(launch_pfac(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
+            HIPCHK_RC(launch_pfac(view(a, c.overlapping), d_view(a, c.overlapping), c.G, K, c.d_hay, c.len, pgrid, (uint64_t *)w.hrecs, w.hit_counts,
                                   grid, true, st));
         else
-            HIPCHK_RC(launch_dfa_walk(a->dev, a->d_dev, c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
+            HIPCHK_RC(launch_dfa_walk(view(a, c.overlapping), d_view(a, c.overlapping), c.G, K, c.d_hay, c.len, c.scan_grid, a->max_lds, st));
         if (prof) HIPCHK_RC(hipEventRecord(scan_stop_ev(x), st));
     }
     HIPCHK_RC(sink_summary(w.block_counts, grid, c.exact_regions ? ~0ull : region_cap, c.pre ? w.hit_counts : nullptr,
@@ -1609,9 +1615,26 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                 blist_nov[i] = kept;
                 i += (size_t)cnt + 1;
             }
+            std::vector<uint32_t> own_off_nov((size_t)H.n_states + 1, 0), own_pid_nov(H.own_pid.size(), 0);
+            for (uint32_t s2 = 0; s2 < H.n_states; s2++) {
+                own_off_nov[s2 + 1] = own_off_nov[s2];
+                if (own1_nov[s2] != OWN1_NONE) own_pid_nov[own_off_nov[s2 + 1]++] = own1_nov[s2];
+            }
             a->dev_nov = a->dev;
             if ((rc = upload(a, st, own1_nov.data(), own1_nov.size(), &a->dev_nov.own1)) != ACX_OK) return destroy(rc);
             if ((rc = upload(a, st, blist_nov.data(), blist_nov.size(), &a->dev_nov.blist)) != ACX_OK) return destroy(rc);
+            if ((rc = upload(a, st, own_off_nov.data(), own_off_nov.size(), &a->dev_nov.own_off)) != ACX_OK) return destroy(rc);
+            if ((rc = upload(a, st, own_pid_nov.data(), own_pid_nov.size(), &a->dev_nov.own_pid)) != ACX_OK) return destroy(rc);
+            if (!H.walk_grec.empty()) { // the failureless walk's trie records: {children bitmap, first child | OWN, own1, ..}
+                std::vector<uint32_t> grec_nov(H.walk_grec);
+                // (only the records that say "several": a tail record's third word is its leaf's pattern, not own1)
+                for (uint32_t s2 = 0; s2 < H.n_states; s2++)
+                    if (grec_nov[4 * (size_t)s2 + 2] == OWN1_MANY) grec_nov[4 * (size_t)s2 + 2] = own1_nov[s2];
+                const uint32_t *p2 = nullptr;
+                if ((rc = upload(a, st, grec_nov.data(), grec_nov.size(), &p2)) != ACX_OK) return destroy(rc);
+                a->dev_nov.grec = reinterpret_cast<const uint4 *>(p2);
+            }
+            if ((rc = upload(a, st, &a->dev_nov, (size_t)1, &a->d_dev_nov)) != ACX_OK) return destroy(rc);
             a->has_nov = true;
         }
     }

@@ -549,7 +549,8 @@ def test_k0_direct_comparison_work_limit():
             assert a.find_matches_as_indexes(hay) == want, (npat, n)
 
 
-def test_copies_of_a_pattern_cost_a_non_overlapping_search_nothing():
+@pytest.mark.parametrize("kernel", [None, capi.KERNEL_DFA_WALK])
+def test_copies_of_a_pattern_cost_a_non_overlapping_search_nothing(kernel):
     """Hundreds of copies of every string (tools/gpu_fuzz.py seed 40404: 22 264 patterns = 30 distinct strings) on
     text where every position matches: a non-overlapping search reports the lowest id of a string and must not pay
     for the others (acx_api.cpp: dev_nov, the view without the later copies); an overlapping one reports every copy.
@@ -567,7 +568,7 @@ def test_copies_of_a_pattern_cost_a_non_overlapping_search_nothing():
         copies = len(pats) / len(set(pats))
         assert copies > 20, (name, copies)
         o = Oracle(pats, 0, KIND_DFA)
-        a = capi.Automaton(pats, 0)
+        a = capi.Automaton(pats, 0, kernel=kernel)  # (a forced scan kernel also keeps K0 out: every size through the pipeline)
         for h in (hay, hay[:3000], hay[299_000:301_500]):  # the pipeline; K0; K0 across the alphabet change
             want = o.find_raw(h, False)
             got = cols(a.find(h))

@@ -84,8 +84,8 @@ def fuzz(budget: float, seed: int, max_size_log2: float = 25.5, save_failures: b
             continue
         # hundreds of copies of every pattern on text where every position matches: the device enumerates every copy's
         # occurrence (seed 40404, case 23: 22 264 patterns over {a, b} of 1-4 bytes = 30 distinct strings, 256 KiB of
-        # a/b -> ~8 * 10^8 occurrences for 262 144 matches; DESIGN.md section 8, "copies of a pattern": the default path
-        # no longer pays for the copies of a non-overlapping search, the forced DFA walk and overlapping searches do).  Minutes per
+        # a/b -> ~8 * 10^8 occurrences for 262 144 matches; DESIGN.md section 8, "copies of a pattern": non-overlapping
+        # searches no longer pay for the copies -- tests/test_gpu_round4.py covers that --, overlapping ones report them all).  Minutes per
         # case: skipped here, like the outputs beyond 2 * 10^7 matches below (the rng stream is not disturbed)
         copies = len(pats) / max(len(set(pats)), 1)
         if copies > 50 and len(hay) * copies > 2e7:
