@@ -26,7 +26,7 @@ MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
 IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
 KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
 KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
-ABI_VERSION = 5  # ACX_VERSION of include/acx.h this binding was written against
+ABI_VERSION = 6  # ACX_VERSION of include/acx.h this binding was written against
 
 MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
 
@@ -140,6 +140,7 @@ def lib() -> ctypes.CDLL:
     L.acx_free_result.restype = None
     L.acx_profile_enable.argtypes = [vp, i32]
     L.acx_profile_read.argtypes = [vp, ctypes.POINTER(Profile), i32]
+    L.acx_path_stats.argtypes = [vp, ctypes.POINTER(u64), i32]
     L.acx_device_alloc.argtypes = [ctypes.POINTER(vp), u64]
     L.acx_device_free.argtypes = [vp]
     L.acx_device_upload.argtypes = [vp, vp, u64]
@@ -536,6 +537,15 @@ class Automaton:
     def profile_enable(self, on=True) -> None:
         """True / 1: time every call's scan kernel; N > 1: every N-th call; False / 0: off."""
         _check(lib().acx_profile_enable(self._h, int(on)))
+
+    PATH_STATS = ("sparse", "hot_calls", "hot_groups", "overflow_hits", "dense_tiles", "dense_radix", "overflow_regrown", "k0")
+
+    def path_stats(self, reset: bool = True) -> dict:
+        """which way this handle's calls went (acx_path_stats): {sparse, hot_calls, hot_groups, overflow_hits,
+        dense_tiles, dense_radix, overflow_regrown, k0}"""
+        out = (ctypes.c_uint64 * 8)()
+        _check(lib().acx_path_stats(self._h, out, int(reset)))
+        return dict(zip(self.PATH_STATS, [int(v) for v in out]))
 
     def profile_read(self, reset: bool = True) -> Profile:
         p = Profile()

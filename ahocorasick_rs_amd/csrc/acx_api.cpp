@@ -322,6 +322,7 @@ struct Workspace {
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
     uint64_t *h_pinned = nullptr;     // pinned host scratch (32 x u64; [8], [9] = result of K0; [7] = seq; [16 .. 23] = K0's
                                       // polled result line, 64-byte aligned)
+    uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
@@ -333,7 +334,11 @@ struct Workspace {
     TileSpace T{};                    // sparse path (hit slots + tile kernels)
     uint64_t tile_cap = 0;            // tiles T is allocated for
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
-    bool flags_dirty = true;          // the abort flags are not known to be zero
+    bool flags_dirty = true;          // the control blocks' counters are not known to be zero
+    uint32_t *ctl = nullptr;          // device: the sparse path's two control blocks (device_types.hpp), used by the calls in turn
+    uint4 *ovf_recs = nullptr;        // K1b's hits beyond a tile's slots (ovf_cap records of 32 B)
+    uint64_t ovf_cap = 0;
+    uint32_t *hot_list = nullptr;     // groups left to the hot pipeline (group_cap ids)
     acx_match_t *final = nullptr;     // sparse path: output buffer the next call writes into
     uint64_t final_cap = 0;
     uint8_t *hay = nullptr;           // device staging buffer of the host-memory entry points
@@ -407,6 +412,7 @@ struct acx_automaton {
     std::atomic<bool> prof{false};
     std::atomic<int> prof_every{1}; // profiling events on every N-th call of a context
     acx_profile_t profile{};
+    std::atomic<uint64_t> path[ACX_PATH_STATS] = {}; // acx_path_stats
 };
 
 struct acx_host_automaton {
@@ -449,6 +455,8 @@ int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
     (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
+    (void)hipFree(w.hot_list); (void)hipFree(w.ovf_recs);
+    w.hot_list = nullptr; w.ovf_recs = nullptr; w.ovf_cap = 0;
     T = TileSpace{};
     w.tile_cap = 0;
     w.group_cap = 0;
@@ -467,7 +475,7 @@ void free_ws(Workspace &w, int device) {
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
-    (void)hipFree(w.summary); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
+    (void)hipFree(w.summary); (void)hipFree(w.ctl); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     free_tiles(w);
     g_bufs.put(w.final, device);
@@ -541,7 +549,9 @@ struct Lease {
 int ensure_common(Ctx *c) {
     Workspace &w = c->ws;
     if (!w.summary) {
-        HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [5], [6] abort flags, [8], [9] scratch
+        HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline
+        HIPCHK(hipMalloc((void **)&w.ctl, 2 * CTL_WORDS * 4));
+        HIPCHK(hipMemset(w.ctl, 0, 2 * CTL_WORDS * 4));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 16400)); // counts of <= 8192 regions + their exact bases
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
@@ -600,6 +610,32 @@ int ensure_occ_capacity(Ctx *c, uint64_t want) {
     return ACX_OK;
 }
 
+// sparse path: the list of K1b's hits beyond their tiles' slots (dense stretches of the input; device_types.hpp: control
+// block) -- room for `want` records; both control blocks learn where it is (and where the hot list is).  The stream is idle.
+constexpr uint64_t OVF_PER_TILE = 16; // records per tile to start with (a quarter of the slots; grown when an input needs more)
+int set_overflow_room(Ctx *c, uint64_t want) {
+    Workspace &w = c->ws;
+    want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
+    if (want > w.ovf_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(w.ovf_recs); w.ovf_recs = nullptr; w.ovf_cap = 0;
+        HIPCHK(hipMalloc((void **)&w.ovf_recs, want * 32));
+        w.ovf_cap = want;
+    }
+    uint32_t h[2 * CTL_WORDS] = {};
+    for (int b = 0; b < 2; b++) {
+        uint32_t *blk = h + b * CTL_WORDS;
+        blk[CTL_OVF_CAP] = (uint32_t)w.ovf_cap;
+        const uint64_t recs = (uint64_t)(uintptr_t)w.ovf_recs, list = (uint64_t)(uintptr_t)w.hot_list;
+        std::memcpy(blk + CTL_OVF_RECS, &recs, 8);
+        std::memcpy(blk + CTL_HOT_LIST, &list, 8);
+    }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(w.ctl, h, sizeof h, hipMemcpyHostToDevice)); // (the counters with them: clear)
+    w.flags_dirty = false;
+    return ACX_OK;
+}
+
 // sparse path: hit slots for `tiles` tiles of index space, group arrays.  One bucket beyond the
 // last tile exists (an occurrence may END exactly at the end of the last tile).
 int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
@@ -621,6 +657,9 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
         T.sg_cap = (uint32_t)cap_super;
         w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
+        HIPCHK(hipMalloc((void **)&w.hot_list, cap_groups * 4));
+        int rc = set_overflow_room(c, std::max<uint64_t>(4096, cap_tiles * OVF_PER_TILE));
+        if (rc) return rc;
     }
     T.n_tiles = (uint32_t)tiles;
     T.n_groups = (uint32_t)groups;
@@ -710,24 +749,33 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     HIPCHK(launch_small(view(a, overlapping != 0), hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
                         seq ? w.h_pinned + 16 : w.h_pinned + 8, seq, c->stream));
     if (seq) {
-        // the result line (kernels.hpp): complete when BOTH ends carry this call's number
+        // the result line (kernels.hpp): complete when its first word carries this call's number and its last word
+        // agrees with the six in between AS READ HERE (a copy is checked and used: nothing is read twice)
         volatile uint64_t *p = w.h_pinned + 16;
+        uint64_t line[K0_LINE_WORDS];
+        auto complete = [&]() -> bool {
+            if (p[0] != seq) return false;
+            std::atomic_thread_fence(std::memory_order_acquire);
+            for (uint32_t i = 1; i < K0_LINE_WORDS; i++) line[i] = p[i];
+            return line[K0_LINE_WORDS - 1] == (seq ^ k0_line_check(line + 1));
+        };
         const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0; p[K0_LINE_WORDS - 1] != seq || p[0] != seq; spins++) {
+        for (uint32_t spins = 0; !complete(); spins++) {
             cpu_relax();
             if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
                 HIPCHK(hipStreamSynchronize(c->stream));
-                if (p[K0_LINE_WORDS - 1] != seq || p[0] != seq) return fail(ACX_EDEVICE, "K0 did not publish its result");
+                if (!complete()) return fail(ACX_EDEVICE, "K0 did not publish its result");
                 break;
             }
         }
-        std::atomic_thread_fence(std::memory_order_acquire);
-        const uint64_t w1 = p[1];
+        for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i]; // (what the caller unpacks the matches from)
+        const uint64_t w1 = line[1];
         if ((w1 >> 32) == 0) {
             *n_out = w1 & 0xFFFFFFFFull;
             *done = true;
             std::lock_guard<std::mutex> lk(a->prof_mu);
             a->profile.small_calls++;
+            a->path[7]++;
         }
         return ACX_OK;
     }
@@ -737,6 +785,7 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
         *done = true;
         std::lock_guard<std::mutex> lk(a->prof_mu);
         a->profile.small_calls++;
+        a->path[7]++;
     }
     return ACX_OK;
 }
@@ -783,15 +832,15 @@ void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len, bool timed) {
 // Wait until the scan kernel has published sequence number `seq` to pinned host memory.  The
 // wake-up of a blocking stream synchronisation costs 10-20 us; polling the word the kernel
 // writes costs one PCIe round trip.  Falls back to the stream after a few milliseconds.
-int wait_published(Ctx *c, uint64_t seq) {
+int wait_published(Ctx *c, uint64_t seq, int word = 7) {
     volatile uint64_t *p = c->ws.h_pinned;
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; p[7] != seq; spins++) {
+    for (uint32_t spins = 0; p[word] != seq; spins++) {
         cpu_relax();
         if ((spins & 1023) == 1023 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
             HIPCHK(hipStreamSynchronize(c->stream));
-            if (p[7] != seq) return fail(ACX_EDEVICE, "the scan kernel did not publish its totals");
+            if (p[word] != seq) return fail(ACX_EDEVICE, "the scan kernel did not publish its totals");
             break;
         }
     }
@@ -834,6 +883,7 @@ struct FindCall {
     bool exact_regions = false; // dense path, second pass: regions at the exclusive prefix of the first pass's counts
     bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
     bool no_dense_tiles = false; // dense path: the tile-ordered form gave up on this call (the radix-sort form takes it)
+    bool ovf_grown = false;      // sparse path: the overflow list was grown for this call (one more attempt)
     bool counts_zeroed = false; // batch: the per-haystack counts are zero or being accumulated into
     uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
@@ -845,6 +895,62 @@ struct FindCall {
     bool localized = false; // batch: offsets are already local and the counts taken
 };
 enum class Attempt { Done, GoDense, Again };
+
+// ---- sparse output, groups the tile kernels could not finish (a dense stretch of the input: more hits than a tile's
+// slots, a full bucket, more matches than a group's stretch, an uncertifiable chain): the HOT pipeline -- the hot
+// groups' hits (slots + overflow list) through the tile-ordered dense machinery, their counts credited to the sparse
+// path's groups, then the write kernel again.  One dense region costs the groups it lies in, not the call (it used to
+// send the whole call to the dense path and keep the handle there for eight more calls).  *lost: the hot pipeline gave
+// up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
+constexpr uint64_t HOT_INLINE = 64; // hot groups whose capacity the output buffer has room for anyway
+int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t n_ovf, uint64_t *seg_counts,
+            const uint64_t *cp_pre, bool *lost) {
+    acx_automaton *a = c.a;
+    Ctx *x = c.c;
+    Workspace &w = x->ws;
+    hipStream_t st = x->stream;
+    TileSpace &T = w.T;
+    *lost = false;
+    if (ensure_dense_tiles(x, c.tiles) != ACX_OK) { // (no room for the buckets: the radix-sort form needs less)
+        (void)hipGetLastError();
+        free_dense_tiles(w);
+        c.no_dense_tiles = true;
+        *lost = true;
+        return ACX_OK;
+    }
+    uint32_t *hot_abort = (uint32_t *)(w.summary + 10);
+    HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
+    HIPCHK_RC(hipMemsetAsync(w.summary + 10, 0, 16, st));
+    HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, n_hot, w.ovf_recs, n_ovf,
+                              w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, st));
+    // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
+    // instead (one more round trip, next to that much hot work)
+    const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * GROUP_MAX + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
+    if (bound > w.final_cap) {
+        const uint64_t pub_t = seq | (1ull << 62);
+        HIPCHK_RC(hot_totals(T, seq, w.h_pinned, pub_t, st));
+        int rc = wait_published(x, pub_t, 15);
+        if (rc) return rc;
+        const uint64_t n = std::min<uint64_t>(w.h_pinned[14], bound); // (meaningless when the pipeline gave up: bounded all the same)
+        if (n >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+        HIPCHK_RC(hipStreamSynchronize(st));
+        g_bufs.put(w.final, a->device);
+        w.final = nullptr; w.final_cap = 0;
+        HIPCHK_RC(g_bufs.get((void **)&w.final, std::max<uint64_t>(n, 1) * sizeof(acx_match_t), a->device));
+        w.final_cap = std::max<uint64_t>(n, 1);
+    }
+    const uint64_t pub = seq | (1ull << 63);
+    HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, w.final, w.summary,
+                        abort_flag, hot_abort, w.h_pinned, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
+    if (c.early_event && c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st)); // (again: behind the kernels queued since)
+    int rc = wait_published(x, pub);
+    if (rc) return rc;
+    if (w.h_pinned[5] != 0) {
+        c.no_dense_tiles = true;
+        *lost = true;
+    }
+    return ACX_OK;
+}
 
 // ---- sparse output: hit slots + tile kernels; returns when the totals are known
 int attempt_sparse(FindCall &c, Attempt *what) {
@@ -864,17 +970,22 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // arrival counters
     T.cnt_nw = c.pre ? c.scan_grid * 16 : pfac ? pgrid * 16 : 1;
     T.cnt_iters = T.cnt_nw > 1 ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
-    const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX;
+    // (room for every group's capacity + what a few hot groups can report beyond it: run_hot)
+    const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX +
+                             (c.pre ? std::min<uint64_t>(T.n_groups, HOT_INLINE) * HOT_SUB * DT_GMAX : 0);
     if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
     if (!w.final) {
         HIPCHK_RC(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
         w.final_cap = out_cap;
     }
-    if (w.flags_dirty) HIPCHK_RC(hipMemsetAsync(w.summary + 5, 0, 16, st));
+    if (w.flags_dirty) {
+        HIPCHK_RC(hipMemsetAsync(w.ctl, 0, 12, st));
+        HIPCHK_RC(hipMemsetAsync(w.ctl + CTL_WORDS, 0, 12, st));
+    }
     w.flags_dirty = true;
-    // two abort flags used in turn: this attempt's scan kernel clears the other one
-    uint32_t *abort_flag = (uint32_t *)(w.summary + 5 + x->flag_idx);
-    uint32_t *next_flag = (uint32_t *)(w.summary + 5 + (x->flag_idx ^ 1));
+    // two control blocks used in turn: this attempt's write kernel clears the other one
+    uint32_t *abort_flag = w.ctl + CTL_WORDS * x->flag_idx;
+    uint32_t *next_flag = w.ctl + CTL_WORDS * (x->flag_idx ^ 1);
     x->flag_idx ^= 1;
     const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
@@ -934,7 +1045,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     }
     const uint64_t seq = ++x->seq;
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, st));
+                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, st));
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
     // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
@@ -945,9 +1056,34 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         c.event_at_post = c.r->done != nullptr;
     }
     if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
-    w.flags_dirty = false; // the scan kernel left the next flag clean
+    w.flags_dirty = false; // the write kernel left the next control block clean
     add_scan_profile(a, x, c.len, c.timed);
-    if (w.h_pinned[5] != 0) { // the slots could not hold the output: dense path
+    uint64_t gave_up = w.h_pinned[5];
+    const uint64_t n_hot = w.h_pinned[12], n_ovf = w.h_pinned[13];
+    if (gave_up == 2 && !c.ovf_grown && n_ovf <= 3 * c.tiles * HIT_SLOTS) {
+        // K1b found more hits beyond their tiles' slots than the overflow list holds (nothing else is wrong): with a
+        // list of the size this input needs the sparse kernels + the hot pipeline take it -- again, once
+        HIPCHK_RC(hipStreamSynchronize(st));
+        HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
+        if ((rc = set_overflow_room(x, n_ovf + n_ovf / 4 + 4096)) == ACX_OK) {
+            c.ovf_grown = true;
+            c.leads_counted = false;
+            c.event_at_post = false;
+            *what = Attempt::Again;
+            return ACX_OK;
+        }
+        (void)hipGetLastError(); // (no room for it: the dense path)
+    }
+    if (c.ovf_grown && gave_up != 2) a->path[6]++;
+    if (!gave_up && n_hot) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
+        bool lost = false;
+        if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)n_ovf, seg_counts, cp_pre, &lost)) != ACX_OK) return rc;
+        if (lost) gave_up = 1;
+        else { a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf; }
+    } else if (!gave_up) {
+        a->path[0]++;
+    }
+    if (gave_up != 0) { // the slots could not hold the output: dense path
         HIPCHK_RC(hipStreamSynchronize(st));
         c.event_at_post = false; // (the dense path queues more: the event is recorded again at the end)
         // (both sets of supergroup words clear again, whatever made the call give up)
@@ -1024,6 +1160,7 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
     c.n_hits = w.h_pinned[2];
     c.n_final = n_final;
     *what = Attempt::Done;
+    a->path[4]++;
     if (n_final == 0) return ACX_OK;
     HIPCHK_RC(g_bufs.get((void **)&c.r->d_matches, n_final * sizeof(acx_match_t), a->device));
     // batch with byte offsets: the write kernel localises and counts per haystack itself
@@ -1129,6 +1266,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
     c.n_raw = n_raw;
     c.n_hits = c.pre ? w.h_pinned[2] : 0;
     *what = Attempt::Done;
+    a->path[5]++;
     if (n_raw == 0) return ACX_OK;
     HIPCHK_RC(sink_compact(w.recs, w.region_off, grid, region_cap, w.keys[1], w.pids[1], st));
     const int end_bit = std::min(64, (int)a->dev.rank_bits + bits_for(c.len));
@@ -1860,7 +1998,8 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                 acx_match_t *m = (acx_match_t *)std::malloc(n * sizeof(acx_match_t));
                 if (!m) return fail(ACX_ENOMEM, "out of memory");
                 // (polled K0: the first matches ride in the result line, the others are in pin_out; all packed)
-                const uint64_t *line = w.h_pinned + 16 + 2, *rest = (const uint64_t *)w.pin_out;
+                // (the line: the copy run_small checked, not the pinned words themselves)
+                const uint64_t *line = w.h_line + 2, *rest = (const uint64_t *)w.pin_out;
                 if (!small_polls()) std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
                 else for (uint64_t i = 0; i < n; i++) {
                     const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
@@ -2023,6 +2162,12 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset) {
     std::lock_guard<std::mutex> lk(a->prof_mu);
     *out = a->profile;
     if (reset) a->profile = acx_profile_t{};
+    return ACX_OK;
+}
+
+int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset) {
+    if (!a || !out) return fail(ACX_EINVAL, "null argument");
+    for (int i = 0; i < ACX_PATH_STATS; i++) out[i] = reset ? a->path[i].exchange(0) : a->path[i].load();
     return ACX_OK;
 }
 

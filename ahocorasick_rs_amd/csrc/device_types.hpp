@@ -111,7 +111,10 @@ constexpr uint32_t HIT_SLOTS = 64;    // hit records per tile (HBM is 288 GB: ha
 #define ACX_GROUP_TILES 64
 #endif
 constexpr uint32_t GROUP_TILES = ACX_GROUP_TILES;  // tiles per workgroup of k_tile_main (64: 256 KiB)
-constexpr uint32_t GROUP_MAX = 1024;  // reported matches per group
+#ifndef ACX_GROUP_MAX
+#define ACX_GROUP_MAX 1024
+#endif
+constexpr uint32_t GROUP_MAX = ACX_GROUP_MAX;  // reported matches per group
 constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group
 // Where a tile's hit count lives: the counts of the tiles ONE K1b wave scans (tile, tile + nw,
 // tile + 2 nw, ...) are contiguous, so that the wave writes them 16 at a time with one store
@@ -120,6 +123,20 @@ constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in 
 __host__ __device__ inline uint64_t hcnt_index(uint64_t tile, uint32_t nw, uint32_t iters) {
     return nw <= 1 ? tile : (tile % nw) * iters + tile / nw;
 }
+// Sparse path, per-call control words: ONE 64-byte block per call, two blocks used by the calls in turn (k_tile_write
+// leaves the other one clear for the next call).  Sink::abort_flag / the kernels' abort_flag parameter point at the
+// block's first word; the others are reached from there (u32 indexes):
+//   [CTL_ABORT]     the call cannot be finished on the sparse path at all (K1a's slots overflowed, ...)
+//   [CTL_OVF_COUNT] K1b: prefix hits beyond a tile's HIT_SLOTS -- appended to the overflow list, nothing is lost
+//   [CTL_HOT_COUNT] groups k_tile_main left to the HOT pipeline (a staged tile with overflow hits, a full bucket,
+//                   more than GROUP_MAX matches, an uncertifiable chain): their ids are in the hot list
+//   [CTL_OVF_CAP]   records the overflow list holds;  [CTL_OVF_RECS] (u64) the list;  [CTL_HOT_LIST] (u64) n_groups ids
+// One dense region no longer costs the whole call the dense path: the sparse kernels finish every other group, the
+// hot groups (+ their context tiles) go through the tile-ordered dense machinery, k_tile_write splices both by the
+// groups' counts (reference behaviour: the cost per byte does not depend on where the matches are, src/lib.rs:59).
+constexpr uint32_t CTL_ABORT = 0, CTL_OVF_COUNT = 1, CTL_HOT_COUNT = 2, CTL_OVF_CAP = 4, CTL_OVF_RECS = 6, CTL_HOT_LIST = 8;
+constexpr uint32_t CTL_WORDS = 16;         // u32 words per block
+constexpr uint32_t HOT_BIT = 0x80000000u;  // TileSpace::btot[g]: the group is the hot pipeline's (low bits: its matches)
 struct Sink {
     uint4 *recs;            // region mode: region_cap * quads uint4 per region
     uint64_t *block_counts; // region mode: one per region
@@ -127,7 +144,7 @@ struct Sink {
     int key_mode;
     uint4 *hslots;          // hit-slot mode: n_tiles * HIT_SLOTS records of two quads
     uint32_t *hcnt;         // hit-slot mode: hits of every tile, at hcnt_index(tile, cnt_nw, cnt_iters)
-    uint32_t *abort_flag;   // hit-slot mode: set when the slots cannot hold the output
+    uint32_t *abort_flag;   // hit-slot mode: the call's control block (above); [0] set when the slots cannot hold the output
     uint32_t lead;          // index = stream position + lead
     uint32_t cnt_nw, cnt_iters;
 };
@@ -141,6 +158,8 @@ constexpr uint32_t DT_SLOTS = 512;
 #endif
 constexpr uint32_t DT_GROUP = ACX_DT_GROUP;
 constexpr uint32_t DT_GMAX = DT_GROUP * DT_SLOTS; // reported occurrences per group
+constexpr uint32_t HOT_SUB = GROUP_TILES / DT_GROUP; // dense groups of one (hot) group of the sparse path
+static_assert(GROUP_TILES % DT_GROUP == 0, "a hot group is a whole number of dense groups");
 struct DenseTiles {
     uint64_t *words;   // (n_tiles + 1) * DT_SLOTS: [rel : 12 | tie : rank_bits | length], rel = key index & 4095
     uint32_t *counts;  // n_tiles + 1 (atomic arrival counters; cleared before every call)

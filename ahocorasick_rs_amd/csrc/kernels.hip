@@ -913,12 +913,22 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         if (SLOTS) {
             const uint32_t slot = cnt + rk;
             keep = found && slot < HIT_SLOTS;
-            if (found && !keep) *GK.abort_flag = 1; // more hits than the tile holds: dense input
             dst = (uint32_t)tile * HIT_SLOTS + slot;
         }
-        // (sparse mode: a dropped hit still takes its place in the buffer; its slot word says "nowhere")
+        // (sparse mode: a hit beyond the slots still takes its place in the buffer; its slot word says "nowhere")
         const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, keep ? dst : 0xFFFFFFFFu);
         const uint4 r1 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+        if (SLOTS && found && !keep) {
+            // more hits than the tile holds (a dense stretch of the input): the hit goes to the call's overflow list --
+            // the tile's count says "overfull", k_tile_main leaves its group to the hot pipeline (device_types.hpp: control block)
+            uint32_t *ctl = GK.abort_flag;
+            const uint32_t i = atomicAdd(ctl + CTL_OVF_COUNT, 1u);
+            if (i < ctl[CTL_OVF_CAP]) {
+                uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * (uint64_t)i;
+                o[0] = make_uint4(r0.x, r0.y, r0.z, 0);
+                o[1] = r1;
+            }
+        }
         if (np > HB) { // more hits at once than the buffer holds: straight to HBM
             if (SLOTS) {
                 if (keep) { hrec[2 * (uint64_t)dst] = make_uint4(r0.x, r0.y, r0.z, 0); hrec[2 * (uint64_t)dst + 1] = r1; }
@@ -998,7 +1008,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     uint32_t stM = 0, tileM = 0, nM = 0, offM = 0, bitM = 0;
     uint64_t winM = 0;
     bool liveC = true; // BIG: the lane's survivor of the batch in C passed the bitmap
-    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
+    // (advance = advance_front + advance_ab; ACX_K1B_EARLY: the windows of a tile's last batch are requested at the END of
+    // the tile's own iteration -- one iteration of the XCD's other waves less between a tile's load and the re-read of its
+    // survivors' windows, which then still hit the L2 -- and the front stages run at the top of the next one)
+    auto advance_front = [&]() __attribute__((always_inline)) {
         // ---- stage C: compare the slots with their windows
         if (stC) {
             if (nC) {
@@ -1036,7 +1049,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             }
             if (stC == 2) { // the tile is complete
                 if (SLOTS) { // its count: through LDS, 16 tiles of the wave per store
-                    if (lane == 0) L.cb[wave][kC & 15] = cntC < HIT_SLOTS ? cntC : HIT_SLOTS;
+                    if (lane == 0) L.cb[wave][kC & 15] = cntC <= HIT_SLOTS ? cntC : HIT_SLOTS + 1; // (HIT_SLOTS + 1: overfull)
                     if ((kC & 15) == 15) {
                         __builtin_amdgcn_wave_barrier();
                         if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kC - 15) + lane] = L.cb[wave][lane];
@@ -1071,13 +1084,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 offM = offB; winM = winB;
             }
             nM = nB; stM = stB; tileM = tileB;
-            // ---- stage A -> B: fetch the first 8 bytes of the queued survivors' windows
-            if (q1c) {
-                if (lane < q1c) {
-                    offB = q1[lane];
-                    winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead);
-                }
-            }
         } else {
             // ---- stage B -> C: hash the windows, fetch their home slots
             if (nB) {
@@ -1093,6 +1099,19 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 offC = offB | (prefix_more_index(hB) << 16); winC = winB; winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
+        }
+        nB = 0; stB = 0;
+    };
+    auto advance_ab = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
+        if (BIG) {
+            // ---- stage A -> B: fetch the first 8 bytes of the queued survivors' windows
+            if (q1c) {
+                if (lane < q1c) {
+                    offB = q1[lane];
+                    winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead);
+                }
+            }
+        } else {
             // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
             if (q1c) {
                 // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
@@ -1115,7 +1134,15 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         q1c = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    constexpr uint64_t DRAIN = BIG ? 4 : 3; // extra iterations that empty the pipeline
+    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
+        advance_front();
+        advance_ab(tileQ, stQ);
+    };
+#ifndef ACX_K1B_EARLY
+#define ACX_K1B_EARLY 0
+#endif
+    constexpr bool EARLY = ACX_K1B_EARLY != 0;
+    constexpr uint64_t DRAIN = (BIG ? 4 : 3) - (EARLY ? 1 : 0); // extra iterations that empty the pipeline
 
     for (uint64_t tile = gw; tile < ntiles + DRAIN * nw; tile += nw) {
         // Everything loaded during the previous iteration (the tile prefetch and the level-2
@@ -1123,7 +1150,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // the compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
         asm volatile("" : "+v"(nxt0), "+v"(nxt1), "+v"(nxt2), "+v"(nxt3), "+v"(nxtL.x), "+v"(nxtL.y));
         // the previous tile's remaining survivors: its last batch (possibly empty)
-        advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
+        if constexpr (EARLY) advance_front();
+        else advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
         if (tile >= ntiles) continue;
 
         // ---- level 1 on this tile
@@ -1330,6 +1358,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         }
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
+        if constexpr (EARLY) { // ... and their windows are requested at once
+            if (stB) advance_front(); // (a batch that moved on in the middle of the compaction still sits in B)
+            advance_ab((uint32_t)tile, 2u);
+        }
     }
     hit_flush();
     if (SLOTS && (kC & 15)) { // the counts of the wave's last tiles
@@ -2055,7 +2087,10 @@ constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 #endif
 constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 // occurrences a bucket can stage (LDS per group decides how many groups a CU works on at once)
-constexpr uint32_t STAGE_SLOTS = 24;
+#ifndef ACX_STAGE_SLOTS
+#define ACX_STAGE_SLOTS 24
+#endif
+constexpr uint32_t STAGE_SLOTS = ACX_STAGE_SLOTS;
 static_assert(GROUP_TILES <= 64, "one wave owns the output buckets of a group");
 static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit mask");
 // A staged occurrence is ONE 64-bit word (the group's LDS footprint decides how many groups a CU
@@ -2098,7 +2133,11 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
-                                                            uint64_t *seg_counts, uint64_t n_seg) {
+                                                            uint64_t *seg_counts, uint64_t n_seg, int hot_ok) {
+    // abort_flag: the call's control block (device_types.hpp).  hot_ok (K1b's hits): a group that cannot be finished here
+    // -- a staged tile with more hits than its slots, a full bucket, more than GROUP_MAX matches, a chain that no
+    // certified sync point cuts -- is handed to the hot pipeline (its id in the hot list, T.btot[g] = HOT_BIT) and costs
+    // the CALL nothing; without it such a group raises the abort flag and the call is redone on the dense path.
     // (batch: the per-haystack counts k_tile_write adds to -- cleared here, no memset in front of the scan)
     if (seg_counts)
         for (uint64_t i = (uint64_t)blockIdx.x * MAIN_THREADS + threadIdx.x; i < n_seg; i += (uint64_t)gridDim.x * MAIN_THREADS)
@@ -2123,12 +2162,26 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     // ---- hits of the staged tiles: exclusive prefix of the counts (wave 0: 64 tiles, wave 1: the
     // few beyond -- nb <= 68)
     uint32_t c = 0;
+    bool overfull = false; // the tile's hits did not fit its slots (K1b: the rest is in the overflow list)
     if (t < nb && first + t < T.n_tiles) {
         c = T.hcnt[hcnt_index(first + t, T.cnt_nw, T.cnt_iters)];
-        c = c < HIT_SLOTS ? c : HIT_SLOTS; // overfull: the producer raised the abort flag
+        overfull = c > HIT_SLOTS;
+        c = c < HIT_SLOTS ? c : HIT_SLOTS;
     }
     if (t < STAGE_BUCKETS) { bn[t] = 0; bmax[t] = 0; }
     if (t == 0) { fail = 0; stop = *abort_flag; }
+    // the group gives up: all threads get here together
+    auto give_up = [&]() {
+        if (t == 0) {
+            if (hot_ok) {
+                T.btot[g] = HOT_BIT;
+                const uint32_t i = atomicAdd(abort_flag + CTL_HOT_COUNT, 1u);
+                (*(uint32_t *const *)(abort_flag + CTL_HOT_LIST))[i] = g; // (the list holds n_groups ids: a group enters once)
+            } else {
+                *abort_flag = 1;
+            }
+        }
+    };
     uint32_t incl = c;
     if (t < 128) { // (lanes beyond nb carry zeros)
         for (int o = 1; o < 64; o <<= 1) {
@@ -2140,9 +2193,11 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     __syncthreads();
     if (t >= 64 && t < 128) incl += tail_base;
     if (t <= nb) hoff[t] = incl - c;
+    if (overfull) fail = 1;
     __syncthreads();
     const uint32_t H = hoff[nb];
     if (stop) return;
+    if (fail) { give_up(); return; }
     if (H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
         if (t == 0) T.btot[g] = 0;
         return;
@@ -2232,7 +2287,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         }
     }
     __syncthreads();
-    if (fail) { if (t == 0) *abort_flag = 1; return; }
+    if (fail) { give_up(); return; }
     // ---- order every bucket (words are unique), largest end per bucket
     // (buckets, not tiles read: the look-ahead tile of an anchored set has no bucket -- with four context tiles,
     // patterns longer than 10 KiB, `t < nb` reached one row beyond the stage)
@@ -2304,7 +2359,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             }
         }
         __syncthreads();
-        if (fail) { if (t == 0) *abort_flag = 1; return; }
+        if (fail) { give_up(); return; }
     }
     // ---- compact the reported occurrences of the 64 output buckets into the group's stretch
     if (t < 64) {
@@ -2316,7 +2371,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         const uint32_t total = __shfl(incl, 63);
         for (int o = 32; o > 0; o >>= 1) occ += __shfl_down(occ, o);
         if (total > GROUP_MAX) {
-            if (t == 0) *abort_flag = 1;
+            give_up(); // (wave 0 is here as a whole)
         } else {
             // records {key lo, key hi, tie, length} in stream coordinates (k_tile_write maps a rank to its pattern)
             uint4 *dst = T.trecs + (uint64_t)g * GROUP_MAX + (incl - cnt);
@@ -2337,10 +2392,10 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
                 }
             }
         }
-        if (t == 0) {
+        if (t == 0 && total <= GROUP_MAX) {
             // the group's count, and count and statistics added into the words of its supergroup
             // (k_tile_write, which starts when every group is done, places the output with them)
-            const uint32_t n = total > GROUP_MAX ? 0 : total;
+            const uint32_t n = total;
             T.btot[g] = n;
             uint64_t *sgw = T.sgw + (seq & 1) * 2 * (uint64_t)T.sg_cap;
             __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -2434,28 +2489,62 @@ struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uin
 struct PostOut {
     uint64_t *summary;           // device mirror of the totals
     volatile uint64_t *host_out; // pinned host memory the host polls
-    uint32_t *next_flag;         // the abort flag of the NEXT call: left clear
-    uint64_t seq;                // this call's sequence number
+    uint32_t *next_flag;         // the control block of the NEXT call: left clear
+    uint64_t seq;                // this call's sequence number (its parity selects the set of supergroup words)
     uint32_t lead;               // DENSE: index = stream position + lead
+    uint64_t pub;                // what group 0 writes to host_out[7] behind the totals (pass 0: seq)
+    // pass 0: the call's first (normally only) write kernel -- when k_tile_main left groups to the hot pipeline it only
+    // publishes {[12] hot groups, [13] overflow hits} and writes nothing; pass 1: the write kernel behind the hot
+    // pipeline -- the hot groups' counts are in T.btot / the supergroup words by then, their records are written by
+    // the HOT instantiation; hot_abort (pass 1 / HOT): the hot pipeline's own abort flag
+    int pass;
+    const uint32_t *hot_abort;
+};
+// HOT instantiation: one workgroup per dense group (DT_GROUP tiles) of a hot group of the sparse path
+struct HotWrite {
+    const uint32_t *list;  // hot groups (ids of the sparse path's groups)
+    const uint64_t *trecs; // the dense groups' reported occurrences (DT_GMAX words each, k_dense_main)
+    const uint32_t *btot;  // ... and their counts
+    uint32_t n_dense;      // dense groups there are
 };
 // CPW: cp.blockpre != null (the instantiation without code points is the round-3 kernel); GMAX: records a group
 // of T.trecs holds (GROUP_MAX: the sparse path; DT_GMAX: the tile-ordered dense path)
 // DENSE: T.trecs holds the tile-ordered dense path's 64-bit words (k_dense_main) instead of 16-byte records
-template <bool CPW, uint32_t GMAX, bool DENSE = false>
+template <bool CPW, uint32_t GMAX, bool DENSE = false, bool HOT = false>
 __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits, int key_mode,
                                                               const uint32_t *__restrict__ by_rank, TileSpace T,
                                                               acx_match_t *out, const uint32_t *abort_flag,
                                                               Segments G, uint64_t *seg_counts, CodePointTables cp,
-                                                              PostOut O) {
+                                                              PostOut O, HotWrite W) {
     __shared__ uint32_t img[WRITE_CHUNK * 6];
     __shared__ uint32_t hs[WRITE_CHUNK]; // haystack index of the matches, in output order
     __shared__ uint64_t red[4];
     __shared__ uint64_t s_base;
-    const uint32_t t = threadIdx.x, g = blockIdx.x;
-    const bool stop = *abort_flag != 0; // stable by now: its writers completed
+    const uint32_t t = threadIdx.x;
+    // g: the group of T whose place in the output this workgroup computes; gi: the group its records are read from
+    // (HOT: dense group `sub` of the hot group g)
+    uint32_t g = blockIdx.x, gi = blockIdx.x, sub = 0;
+    if constexpr (HOT) {
+        g = W.list[blockIdx.x / HOT_SUB];
+        sub = blockIdx.x % HOT_SUB;
+        gi = g * HOT_SUB + sub;
+    }
+    // (the flags are stable by now: their writers completed)
+    bool stop;
+    uint32_t n_hot = 0, n_ovf = 0, why = 0; // why (host_out[5]): 1 the call gave up, 2 only the overflow list was too small
+    if (HOT || O.pass == 1) {
+        stop = *O.hot_abort != 0;
+        why = stop ? 1 : 0;
+    } else {
+        // sparse path: more overflow hits than their list holds = hits were lost (the host grows the list or takes the dense path)
+        n_hot = DENSE ? 0u : abort_flag[CTL_HOT_COUNT];
+        n_ovf = DENSE ? 0u : abort_flag[CTL_OVF_COUNT];
+        why = abort_flag[CTL_ABORT] != 0 ? 1u : (!DENSE && n_ovf > abort_flag[CTL_OVF_CAP]) ? 2u : 0u;
+        stop = why != 0;
+    }
     const uint64_t *sgw = T.sgw + (O.seq & 1) * 2 * (uint64_t)T.sg_cap;
     const uint32_t n_super = (T.n_groups + SUPER - 1) / SUPER;
-    if (g == 0) { // the call's totals, as early as they can be known
+    if (!HOT && g == 0) { // the call's totals, as early as they can be known
         uint64_t m = 0, occ = 0, hit = 0;
         for (uint32_t k = t; k < n_super; k += WRITE_THREADS) {
             m += sgw[k];
@@ -2476,20 +2565,32 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         for (uint32_t k = t; k < 2 * T.sg_cap; k += WRITE_THREADS) other[k] = 0;
         if (t == 0) {
             O.summary[0] = tot[1]; O.summary[2] = tot[2]; O.summary[4] = tot[0];
-            if (O.next_flag) *O.next_flag = 0;
+            if (O.next_flag) { O.next_flag[CTL_ABORT] = 0; O.next_flag[CTL_OVF_COUNT] = 0; O.next_flag[CTL_HOT_COUNT] = 0; }
             O.host_out[0] = tot[1]; O.host_out[2] = tot[2]; O.host_out[4] = tot[0];
-            O.host_out[5] = stop ? 1 : 0;
+            O.host_out[5] = why;
+            O.host_out[12] = n_hot; O.host_out[13] = n_ovf;
             __threadfence_system();
-            O.host_out[7] = O.seq;
+            O.host_out[7] = O.pub;
         }
     }
     if (stop) return;
-    const uint32_t n = T.btot[g];
+    if (!HOT && !DENSE && O.pass == 0 && n_hot) return; // (the hot pipeline first: this kernel runs again behind it)
+    uint32_t n;
+    if constexpr (HOT) {
+        if (gi >= W.n_dense) return;
+        n = W.btot[gi];
+    } else {
+        n = T.btot[g];
+        if (!DENSE && (n & HOT_BIT)) return; // the HOT instantiation writes this group's records
+    }
     if (n == 0) return;
     if (t < 64) { // the stretch's place: the groups in front
-        const uint32_t sg = g / SUPER, gi = g % SUPER;
-        uint64_t sum = t < gi ? T.btot[sg * SUPER + t] : 0;
+        const uint32_t sg = g / SUPER, gq = g % SUPER;
+        uint64_t sum = t < gq ? (T.btot[sg * SUPER + t] & ~HOT_BIT) : 0;
         for (uint32_t k = t; k < sg; k += 64) sum += sgw[k];
+        if constexpr (HOT) { // ... and the dense groups in front inside the hot group
+            if (t < sub) sum += W.btot[g * HOT_SUB + t];
+        }
         for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
         if (t == 0) s_base = sum;
     }
@@ -2500,9 +2601,10 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         for (uint32_t i = t; i < m; i += WRITE_THREADS) {
             uint4 v;
             if constexpr (DENSE) {
-                const uint64_t w_ = ((const uint64_t *)T.trecs)[(uint64_t)g * GMAX + c0 + i];
+                const uint64_t *words = HOT ? W.trecs : (const uint64_t *)T.trecs;
+                const uint64_t w_ = words[(uint64_t)gi * GMAX + c0 + i];
                 const uint32_t lenb = 48 - rank_bits;
-                const uint64_t pos_ = (((uint64_t)g * DT_GROUP) << TILE_BITS) + (w_ >> 48) - O.lead; // key position in the stream
+                const uint64_t pos_ = (((uint64_t)gi * DT_GROUP) << TILE_BITS) + (w_ >> 48) - O.lead; // key position in the stream
                 const uint64_t tie_ = (w_ >> lenb) & ((1ull << rank_bits) - 1);
                 const uint64_t key_ = (pos_ << rank_bits) | tie_;
                 v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), (uint32_t)tie_, (uint32_t)(w_ & ((1ull << lenb) - 1)));
@@ -2510,7 +2612,8 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
                 v = T.trecs[(uint64_t)g * GMAX + c0 + i];
             }
             uint32_t carried = CP_UNKNOWN;
-            if constexpr (CPW) { carried = v.w >> 24; v.w &= 0xFFFFFFu; } // (str API: k_tile_main<.., CP> packed the count above the length)
+            // (str API: k_tile_main<.., CP> packed the count above the length; the dense path's words carry none)
+            if constexpr (CPW && !DENSE) { carried = v.w >> 24; v.w &= 0xFFFFFFu; }
             uint64_t s, e;
             span_of(rank_bits, key_mode, v, &s, &e);
             if (seg_counts) {
@@ -2559,14 +2662,14 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipEvent_t before_write, hipStream_t st) {
+                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     const bool cpw = cp_blockpre != nullptr; // the write kernel converts to code points: the occurrences carry their chunk counts
 #define ACX_TILE_MAIN(AN, CPW)                                                                                        \
     hipLaunchKernelGGL((k_tile_main<AN, CPW>), dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback, \
-                       lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0)
+                       lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0, hot_ok ? 1 : 0)
     if (A.max_shift) { if (cpw) ACX_TILE_MAIN(true, true); else ACX_TILE_MAIN(true, false); }
     else { if (cpw) ACX_TILE_MAIN(false, true); else ACX_TILE_MAIN(false, false); }
 #undef ACX_TILE_MAIN
@@ -2574,14 +2677,14 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;
     }
+    const PostOut O{summary, (volatile uint64_t *)host_out, next_flag, seq, 0, seq, 0, nullptr};
+    const HotWrite W0{nullptr, nullptr, nullptr, 0};
     if (cpw)
         hipLaunchKernelGGL((k_tile_write<true, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
-                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
-                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq, 0});
+                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars}, O, W0);
     else
         hipLaunchKernelGGL((k_tile_write<false, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
-                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars},
-                           PostOut{summary, (volatile uint64_t *)host_out, next_flag, seq, 0});
+                           T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars}, O, W0);
     return hipGetLastError();
 }
 
@@ -2606,70 +2709,130 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 constexpr uint32_t DT_STAGE = DT_GROUP + MAX_LOOKBACK;
 constexpr uint32_t DT_THREADS = 256;
 
+// One wave files the occurrences of (up to) 64 prefix hits, one per lane (live: the lane has one -- h = {position lo, hi,
+// code, -}, w = the 16 haystack bytes at the position): verification as k_tile_main's, every occurrence ONE 64-bit word
+// [key position & 4095 : 12 | tie : rank_bits | length] in the bucket of the tile its KEY position lies in.  The lanes of
+// a wave take their bucket slots together: a wave's hits mostly share ONE bucket, so one atomic per distinct tile and step
+// instead of 64 on the same address (measured before: 6.3 ms for 33 M occurrences, the atomics serialised).  All 64 lanes
+// must call (wave-uniform loops).
+template <bool ANCH>
+__device__ __forceinline__ void dense_file_hits(const DevAutomaton &A, const Segments &G, const DenseTiles &D, int key_mode,
+                                                uint32_t lead, const uint8_t *__restrict__ stream, uint64_t len,
+                                                uint32_t *abort_flag, bool live, const uint4 h, const uint4 w) {
+    const uint32_t rank_bits = A.rank_bits, len_bits = 52 - rank_bits;
+    const uint32_t lane = threadIdx.x & 63;
+    const unsigned long long below_me = (1ull << lane) - 1;
+    uint64_t p = 0, w0 = 0, w1 = 0, room = 0, back = 0;
+    uint32_t code = HIT_NONE;
+    if (live) {
+        p = ((uint64_t)h.y << 32) | h.x;
+        w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
+        uint64_t seg_lo, seg_hi;
+        segment_bounds(G, len, p, &seg_lo, &seg_hi);
+        room = seg_hi - p; back = p - seg_lo;
+        code = h.z;
+        if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+    }
+    const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
+    const uint32_t li = code & ~HIT_LIST;
+    const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
+    for (uint32_t k = 0; __ballot(k < nc); k++) {
+        uint32_t L = 0, rk = 0, cand = 0;
+        uint64_t ps = 0;
+        if (k < nc) {
+            cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
+            L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
+        }
+        const bool have = L != 0;
+        const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
+        const uint32_t tile = (uint32_t)(kidx >> TILE_BITS);
+        uint32_t slot = 0;
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
+            const uint32_t t0 = __shfl(tile, leader);
+            const unsigned long long same = __ballot(have && tile == t0);
+            uint32_t base = 0;
+            if (lane == leader) base = atomicAdd(&D.counts[t0], (uint32_t)__popcll(same));
+            base = __shfl(base, leader);
+            if (have && tile == t0) slot = base + (uint32_t)__popcll(same & below_me);
+            todo &= ~same;
+        }
+        if (have) {
+            if (slot < DT_SLOTS)
+                D.words[(uint64_t)tile * DT_SLOTS + slot] =
+                    (((((uint64_t)kidx & ((1u << TILE_BITS) - 1)) << rank_bits) | (key_mode == 1 ? (cand & CODE_PID_MASK) : rk)) << len_bits) | L;
+            else
+                *abort_flag = 1; // denser than one occurrence per 8 bytes: the radix-sort path
+        }
+    }
+}
+
 template <bool ANCH>
 __global__ __launch_bounds__(256) void k_dense_verify(DevAutomaton A, Segments G, Sink H, uint32_t h_grid, DenseTiles D,
                                                       int key_mode, uint32_t lead, const uint8_t *__restrict__ stream,
                                                       uint64_t len, uint32_t *abort_flag) {
-    const uint32_t rank_bits = A.rank_bits, len_bits = 52 - rank_bits;
-    const uint32_t lane = threadIdx.x & 63;
-    const unsigned long long below_me = (1ull << lane) - 1;
     for (uint32_t b = blockIdx.x; b < h_grid; b += gridDim.x) {
         uint64_t n = H.block_counts[b];
         if (n > H.region_cap) n = H.region_cap; // hits were dropped: the host sees the count and redoes the call
         const uint4 *rec = H.recs + (uint64_t)b * H.region_cap * 2;
-        // (wave-uniform loops: the lanes of a wave take their bucket slots together -- a region holds a wave's hits tile
-        // after tile, so the 64 occurrences of one step mostly share ONE bucket: one atomic per distinct tile and step
-        // instead of 64 on the same address; measured before: 6.3 ms for 33 M occurrences, the atomics serialised)
+        // (a region holds a wave's hits tile after tile)
         for (uint64_t i0 = 0; i0 < n; i0 += 256) {
             const uint64_t i = i0 + threadIdx.x;
             const bool live = i < n;
-            uint64_t p = 0, w0 = 0, w1 = 0, room = 0, back = 0;
-            uint32_t code = HIT_NONE;
-            if (live) {
-                const uint4 h = rec[2 * i], w = rec[2 * i + 1];
-                p = ((uint64_t)h.y << 32) | h.x;
-                w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
-                uint64_t seg_lo, seg_hi;
-                segment_bounds(G, len, p, &seg_lo, &seg_hi);
-                room = seg_hi - p; back = p - seg_lo;
-                code = h.z;
-                if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
-            }
-            const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
-            const uint32_t li = code & ~HIT_LIST;
-            const uint32_t nc = code == HIT_NONE ? 0 : list ? A.blist[li] : 1;
-            for (uint32_t k = 0; __ballot(k < nc); k++) {
-                uint32_t L = 0, rk = 0, cand = 0;
-                uint64_t ps = 0;
-                if (k < nc) {
-                    cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
-                    L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
-                }
-                const bool have = L != 0;
-                const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
-                const uint32_t tile = (uint32_t)(kidx >> TILE_BITS);
-                uint32_t slot = 0;
-                unsigned long long todo = __ballot(have);
-                while (todo) {
-                    const uint32_t leader = (uint32_t)__builtin_ctzll(todo);
-                    const uint32_t t0 = __shfl(tile, leader);
-                    const unsigned long long same = __ballot(have && tile == t0);
-                    uint32_t base = 0;
-                    if (lane == leader) base = atomicAdd(&D.counts[t0], (uint32_t)__popcll(same));
-                    base = __shfl(base, leader);
-                    if (have && tile == t0) slot = base + (uint32_t)__popcll(same & below_me);
-                    todo &= ~same;
-                }
-                if (have) {
-                    if (slot < DT_SLOTS)
-                        D.words[(uint64_t)tile * DT_SLOTS + slot] =
-                            (((((uint64_t)kidx & ((1u << TILE_BITS) - 1)) << rank_bits) | (key_mode == 1 ? (cand & CODE_PID_MASK) : rk)) << len_bits) | L;
-                    else
-                        *abort_flag = 1; // denser than one occurrence per 8 bytes: the radix-sort path
-                }
-            }
+            uint4 h = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+            if (live) { h = rec[2 * i]; w = rec[2 * i + 1]; }
+            dense_file_hits<ANCH>(A, G, D, key_mode, lead, stream, len, abort_flag, live, h, w);
         }
     }
+}
+
+// HOT pipeline (device_types.hpp: control block): the hits of the hot groups' staged tiles -- the tiles of the group, the
+// context tiles in front, the look-ahead tile of an anchored set -- from their hit slots, and the hits beyond the slots
+// from the call's overflow list, filed like the dense path's.  One wave per tile.  A tile is filed ONCE: by its own group
+// when that is hot, else by the (one) hot neighbour that stages it as context (the last tiles of a group) or looks
+// ahead into it (its first tile).  Workgroups beyond the hot groups' take the overflow list (its hits belong to
+// overfull tiles, whose groups are always hot).
+static_assert(HIT_SLOTS <= 64, "one wave reads a tile's hit slots in one step");
+constexpr uint32_t HV_TILES = GROUP_TILES + MAX_LOOKBACK + 1;        // tiles a hot group stages at most
+constexpr uint32_t HV_BLOCKS = (HV_TILES + 3) / 4;                   // workgroups (of four waves) per hot group
+template <bool ANCH>
+__global__ __launch_bounds__(256) void k_hot_verify(DevAutomaton A, Segments G, TileSpace T, const uint32_t *hot_list, uint32_t n_hot,
+                                                    const uint4 *ovf, uint32_t n_ovf, uint32_t lookback, DenseTiles D, int key_mode,
+                                                    uint32_t lead, const uint8_t *__restrict__ stream, uint64_t len,
+                                                    uint32_t *abort_flag) {
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (blockIdx.x >= n_hot * HV_BLOCKS) { // the overflow list
+        const uint32_t b0 = blockIdx.x - n_hot * HV_BLOCKS, nb = gridDim.x - n_hot * HV_BLOCKS;
+        for (uint64_t i0 = (uint64_t)b0 * 256; i0 < n_ovf; i0 += (uint64_t)nb * 256) { // (block-uniform bounds: whole waves loop together)
+            const uint64_t i = i0 + threadIdx.x;
+            const bool live = i < n_ovf;
+            uint4 h = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+            if (live) { h = ovf[2 * i]; w = ovf[2 * i + 1]; }
+            dense_file_hits<ANCH>(A, G, D, key_mode, lead, stream, len, abort_flag, live, h, w);
+        }
+        return;
+    }
+    const uint32_t g = hot_list[blockIdx.x / HV_BLOCKS];
+    const uint32_t tile0 = g * GROUP_TILES;
+    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0;
+    const uint32_t nb = GROUP_TILES + (tile0 - first) + (ANCH ? 1u : 0u);
+    const uint32_t j = (blockIdx.x % HV_BLOCKS) * 4 + wave; // (wave-uniform)
+    if (j >= nb) return;
+    const uint32_t tile = first + j;
+    if (tile >= T.n_tiles) return;
+    const uint32_t owner = tile / GROUP_TILES;
+    if (owner != g && (T.btot[owner] & HOT_BIT)) return; // a hot group files its own tiles
+    uint32_t c = T.hcnt[hcnt_index(tile, T.cnt_nw, T.cnt_iters)];
+    c = c < HIT_SLOTS ? c : HIT_SLOTS;
+    if (c == 0) return;
+    const bool live = lane < c;
+    uint4 h = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
+    if (live) {
+        const uint4 *rec = T.hslots + ((uint64_t)tile * HIT_SLOTS + lane) * 2;
+        h = rec[0]; w = rec[1];
+    }
+    dense_file_hits<ANCH>(A, G, D, key_mode, lead, stream, len, abort_flag, live, h, w);
 }
 
 // One wave sorts P = 64 * EPL words (ascending; the words are unique, the padding ~0): lane l holds the elements
@@ -2726,16 +2889,27 @@ using dt_scan_sum = rocprim::block_scan<uint32_t, DT_THREADS>;
 struct DtLds {
     uint32_t cnt[DT_STAGE], voff[DT_STAGE + 1];
     union { typename dt_scan_max::storage_type mx; typename dt_scan_sum::storage_type sum; } scan;
-    uint32_t first_sync, total;
+    uint32_t first_sync, total, stop;
 };
 static size_t dense_main_lds(uint32_t lookback) { return (size_t)(DT_GROUP + lookback) * DT_SLOTS * (8 + 2); }
 
+// HOT pipeline (hot.list != null): the workgroups take the dense groups of the hot groups of the sparse path (HOT_SUB each),
+// and a group's count is credited to ITS hot group in the sparse path's TileSpace (hot.S: btot keeps its HOT_BIT, the
+// supergroup words of the call's set) -- the sparse path's write kernel then places every group of the call.
+struct HotMain {
+    const uint32_t *list; // hot groups, null: every dense group of the stream (the dense path proper)
+    TileSpace S;          // the sparse path's groups
+    uint64_t seq;         // the call's sequence number (its set of supergroup words)
+};
 __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, uint32_t max_len, int key_mode, int overlapping,
                                                            DenseTiles D, TileSpace T, uint32_t lookback, uint32_t lead,
-                                                           uint32_t *abort_flag) {
+                                                           uint32_t *abort_flag, HotMain hot) {
     __shared__ DtLds L;
     extern __shared__ __attribute__((aligned(16))) uint8_t dt_dyn[];
-    const uint32_t t = threadIdx.x, g = blockIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    const uint32_t gs = hot.list ? hot.list[blockIdx.x / HOT_SUB] : 0u;
+    const uint32_t g = hot.list ? gs * HOT_SUB + blockIdx.x % HOT_SUB : blockIdx.x;
+    if (g >= T.n_groups) return; // (hot: the last group of the sparse path may reach beyond the stream's tiles)
     const uint32_t nb_max = DT_GROUP + lookback;
     uint64_t (*const arr)[DT_SLOTS] = (uint64_t (*)[DT_SLOTS])dt_dyn;
     uint8_t *const syn = dt_dyn + (size_t)nb_max * DT_SLOTS * 8, *const acc = syn + (size_t)nb_max * DT_SLOTS;
@@ -2754,10 +2928,13 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         uint32_t run = 0;
         for (uint32_t b = 0; b < DT_STAGE; b++) { L.voff[b] = run; run += b < nb ? L.cnt[b] : 0; }
         L.voff[DT_STAGE] = run;
+        // (other workgroups of this launch may raise the flag while this one runs: ONE read per workgroup, so that all its
+        // waves take the same way past the barriers below)
+        L.stop = *abort_flag;
     }
     __syncthreads();
     const uint32_t N = L.voff[DT_STAGE], out0 = L.voff[lb]; // staged occurrences; the first one of the group's own tiles
-    if (N == out0 || *abort_flag) { // nothing to report (or the call is lost already)
+    if (N == out0 || L.stop) { // nothing to report (or the call is lost already)
         if (t == 0) T.btot[g] = 0;
         return;
     }
@@ -2851,9 +3028,16 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
     }
     if (t == 0) {
         T.btot[g] = total;
-        uint64_t *sgw = T.sgw; // (the dense path uses set 0; k_tile_write leaves the other clear)
-        __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, (uint64_t)(N - out0) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (hot.list) {
+            atomicAdd(&hot.S.btot[gs], total); // (below HOT_BIT: a hot group reports at most HOT_SUB * DT_GMAX occurrences)
+            uint64_t *sgw = hot.S.sgw + (hot.seq & 1) * 2 * (uint64_t)hot.S.sg_cap;
+            __hip_atomic_fetch_add(sgw + gs / SUPER, (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sgw + hot.S.sg_cap + gs / SUPER, (uint64_t)(N - out0) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            uint64_t *sgw = T.sgw; // (the dense path uses set 0; k_tile_write leaves the other clear)
+            __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, (uint64_t)(N - out0) << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -2886,7 +3070,7 @@ hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlappin
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue;
     hipLaunchKernelGGL(k_dense_main, dim3(T.n_groups), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len, key_mode,
-                       overlapping ? 1 : 0, D, T, lookback, lead, abort_flag);
+                       overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
     hipLaunchKernelGGL(k_dense_totals, dim3(1), dim3(256), 0, st, T, summary);
     return hipGetLastError();
 }
@@ -2895,13 +3079,80 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
                              uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
                              uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
     const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
-    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead, 0, 0, nullptr};
+    const HotWrite W{nullptr, nullptr, nullptr, 0};
     if (cp_blockpre)
         hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
-                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O);
+                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O, W);
     else
         hipLaunchKernelGGL((k_tile_write<false, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
-                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O);
+                           A.by_rank, T, out, zero_flag, G, seg_counts, cp, O, W);
+    return hipGetLastError();
+}
+
+// ---- the HOT pipeline's launches (kernels.hpp)
+hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
+                           const uint32_t *hot_list, uint32_t n_hot, const uint4 *ovf, uint32_t n_ovf, const DenseTiles &D,
+                           const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
+                           uint64_t seq, hipStream_t st) {
+    const uint32_t lookback = tile_lookback(A.max_len);
+    if (lookback > MAX_LOOKBACK || n_hot == 0) return hipErrorInvalidValue;
+    const uint32_t ovb = n_ovf ? std::min<uint32_t>((n_ovf + 255) / 256, 2048u) : 0u;
+    const uint32_t grid = n_hot * HV_BLOCKS + ovb;
+    if (A.max_shift)
+        hipLaunchKernelGGL(k_hot_verify<true>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ovf, n_ovf, lookback, D, key_mode,
+                           lead, d_hay, len, hot_abort);
+    else
+        hipLaunchKernelGGL(k_hot_verify<false>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ovf, n_ovf, lookback, D, key_mode,
+                           lead, d_hay, len, hot_abort);
+    hipLaunchKernelGGL(k_dense_main, dim3(n_hot * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
+                       key_mode, overlapping ? 1 : 0, D, TD, lookback, lead, hot_abort, HotMain{hot_list, S, seq});
+    return hipGetLastError();
+}
+
+// the call's matches once the hot groups' counts are in (the supergroup words of the call's set), for a caller that sizes
+// the output exactly: host_out[14] = matches, then host_out[15] = pub behind a system-scope fence
+__global__ void k_hot_totals(TileSpace S, uint64_t seq, volatile uint64_t *host_out, uint64_t pub) {
+    uint64_t m = 0;
+    const uint64_t *sgw = S.sgw + (seq & 1) * 2 * (uint64_t)S.sg_cap;
+    const uint32_t n_super = (S.n_groups + SUPER - 1) / SUPER;
+    for (uint32_t k = threadIdx.x; k < n_super; k += 256) m += sgw[k];
+    for (int o = 32; o > 0; o >>= 1) m += __shfl_xor(m, o);
+    __shared__ uint64_t red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        host_out[14] = red[0] + red[1] + red[2] + red[3];
+        __threadfence_system();
+        host_out[15] = pub;
+    }
+}
+hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint64_t pub, hipStream_t st) {
+    hipLaunchKernelGGL(k_hot_totals, dim3(1), dim3(256), 0, st, S, seq, (volatile uint64_t *)host_out, pub);
+    return hipGetLastError();
+}
+
+// the records of the hot groups (one workgroup per dense group), then the sparse path's write kernel again (pass 1):
+// it places every other group with the hot groups' counts in and publishes the totals ([5] = *hot_abort, [7] = pub)
+hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, const TileSpace &TD, const uint32_t *hot_list,
+                     uint32_t n_hot, uint32_t lead, const uint8_t *d_hay, acx_match_t *out, uint64_t *summary,
+                     const uint32_t *abort_flag, const uint32_t *hot_abort, uint64_t *host_out, uint64_t seq, uint64_t pub,
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
+    const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, seq, lead, pub, 1, hot_abort};
+    const HotWrite W{hot_list, (const uint64_t *)TD.trecs, TD.btot, TD.n_groups};
+    const HotWrite W0{nullptr, nullptr, nullptr, 0};
+    if (cp_blockpre) {
+        hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true, true>), dim3(n_hot * HOT_SUB), dim3(WRITE_THREADS), 0, st, A.rank_bits,
+                           key_mode, A.by_rank, S, out, abort_flag, G, seg_counts, cp, O, W);
+        hipLaunchKernelGGL((k_tile_write<true, GROUP_MAX>), dim3(S.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+                           S, out, abort_flag, G, seg_counts, cp, O, W0);
+    } else {
+        hipLaunchKernelGGL((k_tile_write<false, DT_GMAX, true, true>), dim3(n_hot * HOT_SUB), dim3(WRITE_THREADS), 0, st, A.rank_bits,
+                           key_mode, A.by_rank, S, out, abort_flag, G, seg_counts, cp, O, W);
+        hipLaunchKernelGGL((k_tile_write<false, GROUP_MAX>), dim3(S.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
+                           S, out, abort_flag, G, seg_counts, cp, O, W0);
+    }
     return hipGetLastError();
 }
 
@@ -2937,10 +3188,12 @@ __device__ __forceinline__ uint32_t leads_in_first(const uint4 v, uint32_t n) {
 constexpr uint32_t K0_LT_ENTRIES = 8192, K0_LT_IDS = 2048;
 // The polled result of a K0 call (seq != 0): ONE aligned 64-byte line of coherent pinned host memory, written by ONE store
 // instruction (four lanes x 16 bytes): [ seq | matches + too dense << 32 | the first K0_LINE_MATCHES matches, packed
-// | seq ].  Every separate write to host memory the kernel had to wait for before it may publish -- the records, then the
+// | seq ^ check(the six words in the middle) ].  Every separate write to host memory the kernel had to wait for before it may publish -- the records, then the
 // totals behind a system-scope fence, then the number -- was a PCIe round trip of its own (measured, rocprofv3: 6.8 us
 // for the kernel without matches, 8.8 with one, 12.9 with four on 75-byte haystacks); a line that carries its own
-// sequence number at both ends needs none: the host takes it when both ends show the call's number.  A packed match:
+// sequence number in front and a checksum of its middle keyed with that number at the end needs none: the host takes it
+// when the first word shows the call's number and the last one agrees with the middle as the host read it (no assumption
+// about the order in which the line's four 16-byte pieces become visible).  A packed match:
 // pattern : 32 | start : 16 | end : 16 (a K0 haystack has at most 16 384 bytes).  More matches than the line holds go,
 // packed, to out[] first, behind a system-scope fence.
 constexpr uint32_t K0_LINE_MATCHES = ACX_K0_LINE_MATCHES;
@@ -2948,11 +3201,16 @@ static_assert(K0_LINE_MATCHES + 3 == K0_LINE_WORDS, "seq, totals, matches, seq")
 __device__ __forceinline__ void k0_publish_line(uint64_t *line, uint32_t t, uint64_t seq, uint64_t word1, const uint64_t *pk,
                                                 uint32_t npk) {
     if (t >= 4) return;
+    uint64_t mid[6]; // words 1 .. 6, the same in all four lanes
+    mid[0] = word1;
+#pragma unroll
+    for (uint32_t i = 0; i < K0_LINE_MATCHES; i++) mid[1 + i] = i < npk ? pk[i] : 0;
+    const uint64_t last = seq ^ k0_line_check(mid); // (the host accepts the line on word 0 AND this word: kernels.hpp)
     uint64_t w[2];
 #pragma unroll
     for (uint32_t k = 0; k < 2; k++) {
         const uint32_t i = 2 * t + k;
-        w[k] = i == 0 || i == 7 ? seq : i == 1 ? word1 : (i - 2 < npk ? pk[i - 2] : 0);
+        w[k] = i == 0 ? seq : i == 7 ? last : mid[i - 1 > 5 ? 5 : i - 1];
     }
     ((ulonglong2 *)line)[t] = make_ulonglong2(w[0], w[1]);
 }

@@ -73,10 +73,21 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
 // seq != 0 (the host polls): res is the call's RESULT LINE -- 64 aligned bytes of coherent pinned host memory, written by one
 // store instruction: [0] seq, [1] matches | too dense << 32, [2 .. 6] the first K0_LINE_MATCHES matches packed as
-// pattern | start << 32 | end << 48, [7] seq -- and out[] takes the matches beyond those, packed the same way, first.
+// pattern | start << 32 | end << 48, [7] seq ^ k0_line_check(words 1 .. 6) -- and out[] takes the matches beyond those, packed the same way, first.
 // seq == 0: out[] = acx_match_t records, res[0] / res[1] as above (device memory, read behind a stream synchronisation)
 #define ACX_K0_LINE_MATCHES 5
 constexpr uint32_t K0_LINE_WORDS = 8;
+// the line's last word = seq ^ k0_line_check(words 1 .. 6): the host takes the line when word 0 carries the call's number AND
+// the last word agrees with the six in the middle as it read them -- whatever order the line's four 16-byte pieces arrive in,
+// a line with a stale or half-written middle is not accepted (it is polled again)
+__host__ __device__ inline uint64_t k0_line_check(const uint64_t *mid /* words 1 .. 6 */) {
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int i = 0; i < 6; i++) {
+        h ^= mid[i] + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2);
+        h *= 0xFF51AFD7ED558CCDull;
+    }
+    return h ^ (h >> 32);
+}
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
                         bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
@@ -92,12 +103,35 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // cannot take this path.  cp_blockpre != null (one haystack): the write kernel turns the byte
 // offsets into code-point indexes on the way out (prefix of the 1 KiB blocks + the counts of the 16-byte
 // chunks + what k_tile_main carried over of the start's own chunk: no haystack access).
+// abort_flag / next_flag: the control blocks of this call and of the next one (device_types.hpp).  hot_ok (K1b's prefix
+// hits): groups the sparse kernels cannot finish are listed for the HOT pipeline instead of aborting the call; the write
+// kernel then publishes host_out[12] = hot groups, [13] = overflow hits and -- when there are hot groups -- writes nothing:
+// the caller runs hot_verify_main + hot_write (below) and waits for the second publication.
 uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipEvent_t before_write, hipStream_t st);
+                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, hipStream_t st);
+// HOT pipeline: a dense stretch of the input costs the groups it lies in, not the call (reference behaviour: the cost
+// per byte does not depend on where the matches are, /root/reference/src/lib.rs:59).
+//   hot_verify_main  k_hot_verify: the hits of the hot groups' staged tiles (their slots + the overflow list) -> occurrence
+//                    words in the buckets of their key tiles (D.counts must be zero); k_dense_main over the hot groups'
+//                    dense groups (HOT_SUB each): records in TD.trecs, counts in TD.btot AND credited to the hot group in
+//                    S.btot / the supergroup words of the call's set.  *hot_abort != 0: a bucket overflowed or a chain left
+//                    its context (the caller redoes the call on the radix-sort form of the dense path)
+//   hot_totals       host_out[14] = the call's matches, [15] = pub (for a caller that sizes the output exactly)
+//   hot_write        the hot groups' records, then the sparse path's write kernel again: every group placed with all
+//                    counts in; host_out {[0], [2], [4] totals, [5] = *hot_abort, [7] = pub}
+hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
+                           const uint32_t *hot_list, uint32_t n_hot, const uint4 *ovf, uint32_t n_ovf, const DenseTiles &D,
+                           const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
+                           uint64_t seq, hipStream_t st);
+hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint64_t pub, hipStream_t st);
+hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, const TileSpace &TD, const uint32_t *hot_list,
+                     uint32_t n_hot, uint32_t lead, const uint8_t *d_hay, acx_match_t *out, uint64_t *summary,
+                     const uint32_t *abort_flag, const uint32_t *hot_abort, uint64_t *host_out, uint64_t seq, uint64_t pub,
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st);
 // dense outputs, tile-ordered (kernels.hip): K1b's prefix hits (per-wave regions) -> occurrence words in the
 // bucket of their key tile (D.counts must be zero) -> per group of DT_GROUP tiles: sort + match kind in LDS, the
 // reported occurrences in T.trecs (DT_GMAX per group), T.btot, the supergroup words of set 0 (must be zero); summary[8]

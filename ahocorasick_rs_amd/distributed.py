@@ -64,21 +64,40 @@ def capi_comm_from_env(device: int, timeout_s: float = 120.0):
     import time
     from . import capi
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    path = os.path.join(tempfile.gettempdir(), f"acx_comm_{os.environ.get('MASTER_PORT', '0')}_{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}.id")
+    # the name carries the launcher's pid (the ranks of one job on a node are children of one launcher), so the file
+    # of an earlier job with the same port is another file; rank 0 also removes what it finds before it creates the
+    # id and what it wrote once every rank holds the communicator
+    path = os.path.join(tempfile.gettempdir(), f"acx_comm_{os.environ.get('MASTER_PORT', '0')}_"
+                        f"{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.getppid()}.id")
     if rank == 0:
+        for stale in (path, path + ".tmp"):
+            try:
+                os.unlink(stale)
+            except FileNotFoundError:
+                pass
         uid = capi.comm_unique_id()
         with open(path + ".tmp", "wb") as f:
             f.write(uid)
         os.replace(path + ".tmp", path)
     else:
         t0 = time.time()
-        while not os.path.exists(path):
+        uid = b""
+        while len(uid) != 128:  # (the id is written to a temporary name and renamed: a short read means another writer)
             if time.time() - t0 > timeout_s:
                 raise TimeoutError(f"rank 0 never published the RCCL id at {path}")
-            time.sleep(0.01)
-        with open(path, "rb") as f:
-            uid = f.read()
-    comm = capi.Comm.init_rank(uid, world, rank, device)
+            try:
+                with open(path, "rb") as f:
+                    uid = f.read()
+            except FileNotFoundError:
+                uid = b""
+            if len(uid) != 128:
+                time.sleep(0.01)
+    comm = capi.Comm.init_rank(uid, world, rank, device)  # (collective: returns when every rank has joined)
+    if rank == 0:
+        try:
+            os.unlink(path)
+        except FileNotFoundError:
+            pass
     return comm
 
 

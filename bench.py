@@ -68,7 +68,7 @@ def parse_args(argv=None):
                     "index kind / overlapping, e.g. mk=standard,cp=0,ov=1 (the line says so in config.workload)")
     ap.add_argument("--config", choices=["auto", "cfg2", "cfg3", "cfg4", "cfg4b", "cfg5", "large", "mixed", "mixedx", "mixedb", "cfg2b"], default="auto",
                     help="auto: cfg2 at N=1, cfg3 at N>1")
-    ap.add_argument("--dist", choices=["T", "U", "Z", "D"], default="T",
+    ap.add_argument("--dist", choices=["T", "U", "Z", "D", "H1", "H100"] + ["P%d" % n for n in DENSITIES], default="T",
                     help="cfg2 haystack: T text-like (headline), U iid-uniform a-z, Z all zero bytes "
                          "(calibration of the PMC traffic counters only: the scan reads, nothing else happens), "
                          "D dense: one pattern planted every 32 bytes (>= 1 occurrence per 32 B: the region path)")
@@ -215,10 +215,22 @@ def build_workload(cfg: str, args, rank: int, capi, gen, torch, dev):
                     n_ = min(len(per), nbytes - off)
                     hay[off:off + n_] = dper[:n_]
                 torch.cuda.synchronize()
+            elif args.dist in ("H1", "H100") or args.dist.startswith("P"):
+                # the headline's text with dense stretches / a denser plant on top (the hot pipeline: DESIGN.md)
+                ac.generate(hay.data_ptr(), nbytes, 1, 11)
+                torch.cuda.synchronize()
+                if args.dist.startswith("P"):
+                    overlay_planted(hay, pats, int(args.dist[1:]), None, torch, dev)
+                else:
+                    overlay_planted(hay, pats, 32, hot_regions(args.dist, nbytes), torch, dev)
             else:
                 kind, seed = (1, 11) if args.dist == "T" else (0, 12)
                 ac.generate(hay.data_ptr(), nbytes, kind, seed)
-            what = {"T": "text-like (T, seed 11: iid a-z letters, a space with probability 43/256 at every "
+            what = {"H1": "text-like T (seed 11) with ONE 64 KiB region that holds a pattern every 32 bytes (not the headline)",
+                    "H100": "text-like T (seed 11) with every 100th 256 KiB group holding a pattern every 32 bytes -- 1 % of the groups (not the headline)",
+                    **{"P%d" % n: "text-like T (seed 11) + a pattern planted every %d bytes everywhere (density sweep, not the headline)" % n
+                       for n in DENSITIES},
+                    "T": "text-like (T, seed 11: iid a-z letters, a space with probability 43/256 at every "
                          "position -- geometric word lengths, not a natural-language word model -- one pattern planted per KiB)", "U": "uniform a-z (U, seed 12)",
                     "Z": "ALL-ZERO (calibration only, not a benchmark)",
                     "D": "DENSE (uniform a-z, one pattern planted every 32 bytes, period 4093 x 4 KiB: the dense path, "
@@ -579,6 +591,47 @@ def timed_steps(ac, ptr, nbytes, torch, steps=10, warmup=4, **kw):
 PERIOD_BYTES = 4093 * 4096  # (see tile_to_device)
 
 
+def overlay_planted(hay, pats, every: int, regions, torch, dev, seed: int = 77):
+    """plant a pattern of `pats` at every multiple of `every` bytes (>= 32) inside the byte ranges `regions` of the device
+    haystack `hay` (None: everywhere), on top of what is there: the planted bytes of one period are built on the host
+    (values + mask), the overlay itself is a device-side select.  -> planted slots"""
+    import numpy as np
+    import gen
+    span = PERIOD_BYTES if regions is None else min(PERIOD_BYTES, max(b - a for a, b in regions))
+    val = np.zeros(span, dtype=np.uint8)
+    msk = np.zeros(span, dtype=np.bool_)
+    rng = gen.SplitMix64(seed)
+    for k in range(0, span - 32, every):
+        p_ = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
+        val[k:k + len(p_)] = p_
+        msk[k:k + len(p_)] = True
+    dval, dmsk = torch.from_numpy(val).to(dev), torch.from_numpy(msk).to(dev)
+    nbytes = hay.numel()
+    slots = 0
+    for a, b in (regions if regions is not None else [(0, nbytes)]):
+        for off in range(a, b, span):
+            n_ = min(span, b - off)
+            seg = hay[off:off + n_]
+            seg.copy_(torch.where(dmsk[:n_], dval[:n_], seg))
+            slots += n_ // every
+    torch.cuda.synchronize()
+    return slots
+
+
+DENSITIES = (1024, 512, 256, 128, 64, 32)  # --dist P<n>: T + a pattern planted every n bytes, everywhere
+GROUP_BYTES = 64 * 4096                    # the sparse path's group: 64 tiles of 4 KiB
+
+
+def hot_regions(dist: str, nbytes: int):
+    """H1: ONE 64 KiB region (a third of the way in) holds a pattern every 32 bytes; H100: every 100th 256 KiB group does,
+    whole (1 % of the groups, scattered: none is another's neighbour)"""
+    if dist == "H1":
+        a = (nbytes // 3) & ~(GROUP_BYTES - 1)
+        return [(a + 8 * 4096, a + 8 * 4096 + (64 << 10))] if nbytes >= a + GROUP_BYTES else [(0, min(nbytes, 64 << 10))]
+    groups = nbytes // GROUP_BYTES
+    return [(g * GROUP_BYTES, (g + 1) * GROUP_BYTES) for g in range(50, groups, 100)] or [(0, min(nbytes, GROUP_BYTES))]
+
+
 def tile_to_device(period, nbytes, torch, dev):
     """a device haystack of nbytes made of copies of `period` (host numpy bytes): a 1 GiB host array would cost
     more time than the measurement.  The period is 4093 tiles of 4 KiB -- NOT the 16 MiB it was at first: a K1b
@@ -605,11 +658,16 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
     Each: {gbps, frac (of 8 TB/s), ms_per_step, matches}.  Device-resident, 10 timed steps."""
     import numpy as np
     out = {}
+
+    def roof(kms, n):  # the scan stage's roofline, as the headline's: algorithmic bytes / its event-pair time
+        ach = (nbytes + 24 * n) / (kms * 1e-3) / 1e9 if kms > 0 else 0.0
+        return {"bound": "hbm", "achieved": round(ach, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                "kernel_ms": kms, "algorithmic_bytes": int(nbytes + 24 * n)}
     try:
         k1a = capi.Automaton(w["patterns"], w["mk"], capi.IMPL_DFA, kernel=capi.KERNEL_DFA_WALK)
         ms, n, kms = timed_steps(k1a, w["hay"].data_ptr(), nbytes, torch)
         out["k1a"] = {"kernel": "k1a_scan+k1a_walk", "gbps": round(nbytes / ms / 1e6, 2), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
-                      "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
+                      "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n, "roofline": roof(kms, n)}
         k1a.close()
     except Exception as e:
         out["k1a"] = {"skipped": repr(e)}
@@ -619,7 +677,8 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
         ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch)
         out["T_words"] = {"what": "cfg2's set over a-z words of 1-10 letters, single spaces, one pattern planted per KiB "
                                   "(period: 4093 tiles of 4 KiB)", "gbps": round(nbytes / ms / 1e6, 2),
-                          "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
+                          "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n,
+                          "roofline": roof(kms, n)}
         del hay
     except Exception as e:
         out["T_words"] = {"skipped": repr(e)}
@@ -640,11 +699,37 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
                                 "third line (tests/gen.py names_haystack, period: 4093 tiles of 4 KiB): the reference benchmark's long shape",
                         "kernel": capi.KERNEL_NAMES[ac.info.kernel], "gbps": round(nbytes / ms / 1e6, 2),
                         "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n,
-                        "level1_survivor_pct": surv}
+                        "level1_survivor_pct": surv, "roofline": roof(kms, n)}
         ac.close()
         del hay
     except Exception as e:
         out["prose"] = {"skipped": repr(e)}
+    # where the matches are must not decide what a byte costs (the reference's loop: src/lib.rs:59): the headline's text
+    # with dense stretches (the hot pipeline takes the groups they lie in), and the whole curve from sparse to dense
+    try:
+        hay = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        hot, dens = {}, {}
+        for name in ("H1", "H100"):
+            w["ac"].generate(hay.data_ptr(), nbytes, 1, 11)
+            torch.cuda.synchronize()
+            overlay_planted(hay, w["patterns"], 32, hot_regions(name, nbytes), torch, dev)
+            ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch, steps=8, warmup=3)
+            hot[name] = {"gbps": round(nbytes / ms / 1e6, 2), "frac": round(nbytes / ms / 1e6 / HBM_PEAK_GBPS, 4),
+                         "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n, "roofline": roof(kms, n)}
+        hot["what"] = ("the headline's text T with a pattern planted every 32 bytes in ONE 64 KiB region (H1) / in every 100th 256 KiB "
+                       "group, whole: 1 % of the groups (H100)")
+        out["hot"] = hot
+        for every in DENSITIES:
+            w["ac"].generate(hay.data_ptr(), nbytes, 1, 11)
+            torch.cuda.synchronize()
+            overlay_planted(hay, w["patterns"], every, None, torch, dev)
+            ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch, steps=6, warmup=3)
+            dens[str(every)] = {"gbps": round(nbytes / ms / 1e6, 2), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
+        dens["what"] = "the headline's text T + a pattern planted every N bytes everywhere: N -> GB/s (whole step, 1 GiB)"
+        out["density"] = dens
+        del hay
+    except Exception as e:
+        out["density"] = {"skipped": repr(e)}
     return out
 
 

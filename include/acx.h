@@ -28,7 +28,7 @@ extern "C" {
  * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 5
+#define ACX_VERSION 6
 
 /* status codes */
 #define ACX_OK 0
@@ -303,6 +303,13 @@ void acx_free_result(acx_result_t *r);
  * alone).  The totals of acx_profile_read cover the measured calls only. */
 int acx_profile_enable(acx_automaton_t *a, int on);
 int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
+/* Which way the handle's calls went (always counted, no events involved): out[0] calls finished by the sparse kernels
+ * alone, [1] calls that also ran the hot pipeline (a dense stretch of the input costs the groups it lies in, not the
+ * call: reference behaviour /root/reference/src/lib.rs:59), [2] hot groups in all, [3] prefix hits beyond their tiles'
+ * slots in all, [4] calls on the tile-ordered dense path, [5] calls on its radix-sort form, [6] calls that were redone
+ * with a larger overflow list, [7] calls K0 answered.  reset != 0 clears the counters. */
+#define ACX_PATH_STATS 8
+int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset);
 
 /* ---- device memory helpers so that a host without torch can stage data ---- */
 int acx_device_alloc(void **d_ptr, uint64_t bytes);
