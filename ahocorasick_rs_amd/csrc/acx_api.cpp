@@ -336,8 +336,9 @@ struct Workspace {
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
     bool flags_dirty = true;          // the control blocks' counters are not known to be zero
     uint32_t *ctl = nullptr;          // device: the sparse path's two control blocks (device_types.hpp), used by the calls in turn
-    uint4 *ovf_recs = nullptr;        // K1b's hits beyond a tile's slots (ovf_cap records of 32 B)
-    uint64_t ovf_cap = 0;
+    uint4 *ovf_recs = nullptr;        // K1b's hits beyond a tile's slots: OVF_LISTS lists of ovf_cap records of 32 B
+    uint64_t ovf_cap = 0;             //   records per list
+    uint32_t *ovf_counts = nullptr;   //   the lists' fill counters, two sets (one per control block), a cache line each
     uint32_t *hot_list = nullptr;     // groups left to the hot pipeline (group_cap ids)
     acx_match_t *final = nullptr;     // sparse path: output buffer the next call writes into
     uint64_t final_cap = 0;
@@ -475,7 +476,7 @@ void free_ws(Workspace &w, int device) {
     for (int i = 0; i < 2; i++) { (void)hipFree(w.keys[i]); (void)hipFree(w.pids[i]); }
     (void)hipFree(w.S); (void)hipFree(w.E); (void)hipFree(w.M);
     (void)hipFree(w.flags); (void)hipFree(w.idx); (void)hipFree(w.temp);
-    (void)hipFree(w.summary); (void)hipFree(w.ctl); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
+    (void)hipFree(w.summary); (void)hipFree(w.ctl); (void)hipFree(w.ovf_counts); (void)hipFree(w.block_counts); (void)hipFree(w.region_off);
     (void)hipFree(w.recs); (void)hipFree(w.hrecs); (void)hipFree(w.hit_counts);
     free_tiles(w);
     g_bufs.put(w.final, device);
@@ -552,6 +553,8 @@ int ensure_common(Ctx *c) {
         HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline
         HIPCHK(hipMalloc((void **)&w.ctl, 2 * CTL_WORDS * 4));
         HIPCHK(hipMemset(w.ctl, 0, 2 * CTL_WORDS * 4));
+        HIPCHK(hipMalloc((void **)&w.ovf_counts, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
+        HIPCHK(hipMemset(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 16400)); // counts of <= 8192 regions + their exact bases
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
@@ -613,13 +616,13 @@ int ensure_occ_capacity(Ctx *c, uint64_t want) {
 // sparse path: the list of K1b's hits beyond their tiles' slots (dense stretches of the input; device_types.hpp: control
 // block) -- room for `want` records; both control blocks learn where it is (and where the hot list is).  The stream is idle.
 constexpr uint64_t OVF_PER_TILE = 16; // records per tile to start with (a quarter of the slots; grown when an input needs more)
-int set_overflow_room(Ctx *c, uint64_t want) {
+int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
     Workspace &w = c->ws;
-    want = std::min<uint64_t>(want, 0xFFFFFFF0ull);
+    want = std::min<uint64_t>(std::max<uint64_t>(want, 64), 0xFFFFFFF0ull / OVF_LISTS);
     if (want > w.ovf_cap) {
         HIPCHK(hipStreamSynchronize(c->stream));
         (void)hipFree(w.ovf_recs); w.ovf_recs = nullptr; w.ovf_cap = 0;
-        HIPCHK(hipMalloc((void **)&w.ovf_recs, want * 32));
+        HIPCHK(hipMalloc((void **)&w.ovf_recs, want * OVF_LISTS * 32));
         w.ovf_cap = want;
     }
     uint32_t h[2 * CTL_WORDS] = {};
@@ -627,11 +630,14 @@ int set_overflow_room(Ctx *c, uint64_t want) {
         uint32_t *blk = h + b * CTL_WORDS;
         blk[CTL_OVF_CAP] = (uint32_t)w.ovf_cap;
         const uint64_t recs = (uint64_t)(uintptr_t)w.ovf_recs, list = (uint64_t)(uintptr_t)w.hot_list;
+        const uint64_t counts = (uint64_t)(uintptr_t)(w.ovf_counts + (size_t)b * OVF_LISTS * OVF_COUNT_STRIDE);
         std::memcpy(blk + CTL_OVF_RECS, &recs, 8);
         std::memcpy(blk + CTL_HOT_LIST, &list, 8);
+        std::memcpy(blk + CTL_OVF_COUNTS, &counts, 8);
     }
     HIPCHK(hipStreamSynchronize(c->stream));
     HIPCHK(hipMemcpy(w.ctl, h, sizeof h, hipMemcpyHostToDevice)); // (the counters with them: clear)
+    HIPCHK(hipMemset(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
     w.flags_dirty = false;
     return ACX_OK;
 }
@@ -658,7 +664,7 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
         w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
         HIPCHK(hipMalloc((void **)&w.hot_list, cap_groups * 4));
-        int rc = set_overflow_room(c, std::max<uint64_t>(4096, cap_tiles * OVF_PER_TILE));
+        int rc = set_overflow_room(c, (cap_tiles * OVF_PER_TILE + OVF_LISTS - 1) / OVF_LISTS);
         if (rc) return rc;
     }
     T.n_tiles = (uint32_t)tiles;
@@ -903,7 +909,7 @@ enum class Attempt { Done, GoDense, Again };
 // send the whole call to the dense path and keep the handle there for eight more calls).  *lost: the hot pipeline gave
 // up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
 constexpr uint64_t HOT_INLINE = 64; // hot groups whose capacity the output buffer has room for anyway
-int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t n_ovf, uint64_t *seg_counts,
+int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t ovf_max, uint64_t *seg_counts,
             const uint64_t *cp_pre, bool *lost) {
     acx_automaton *a = c.a;
     Ctx *x = c.c;
@@ -921,7 +927,7 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     uint32_t *hot_abort = (uint32_t *)(w.summary + 10);
     HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
     HIPCHK_RC(hipMemsetAsync(w.summary + 10, 0, 16, st));
-    HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, n_hot, w.ovf_recs, n_ovf,
+    HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, n_hot, abort_flag, ovf_max,
                               w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, st));
     // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
     // instead (one more round trip, next to that much hot work)
@@ -933,12 +939,17 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
         if (rc) return rc;
         const uint64_t n = std::min<uint64_t>(w.h_pinned[14], bound); // (meaningless when the pipeline gave up: bounded all the same)
         if (n >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
-        HIPCHK_RC(hipStreamSynchronize(st));
-        g_bufs.put(w.final, a->device);
-        w.final = nullptr; w.final_cap = 0;
-        HIPCHK_RC(g_bufs.get((void **)&w.final, std::max<uint64_t>(n, 1) * sizeof(acx_match_t), a->device));
-        w.final_cap = std::max<uint64_t>(n, 1);
+        if (n > w.final_cap) {
+            HIPCHK_RC(hipStreamSynchronize(st));
+            g_bufs.put(w.final, a->device);
+            w.final = nullptr; w.final_cap = 0;
+            HIPCHK_RC(g_bufs.get((void **)&w.final, n * sizeof(acx_match_t), a->device));
+            w.final_cap = n;
+        }
     }
+    // an input that is dense (nearly) everywhere: the dense path proper takes the handle's next calls -- its scan writes
+    // the hits where its verification reads them, no sparse attempt in front
+    if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) x->dense_hold = 8;
     const uint64_t pub = seq | (1ull << 63);
     HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, w.final, w.summary,
                         abort_flag, hot_abort, w.h_pinned, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
@@ -981,6 +992,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     if (w.flags_dirty) {
         HIPCHK_RC(hipMemsetAsync(w.ctl, 0, 12, st));
         HIPCHK_RC(hipMemsetAsync(w.ctl + CTL_WORDS, 0, 12, st));
+        HIPCHK_RC(hipMemsetAsync(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4, st));
     }
     w.flags_dirty = true;
     // two control blocks used in turn: this attempt's write kernel clears the other one
@@ -1059,13 +1071,13 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     w.flags_dirty = false; // the write kernel left the next control block clean
     add_scan_profile(a, x, c.len, c.timed);
     uint64_t gave_up = w.h_pinned[5];
-    const uint64_t n_hot = w.h_pinned[12], n_ovf = w.h_pinned[13];
-    if (gave_up == 2 && !c.ovf_grown && n_ovf <= 3 * c.tiles * HIT_SLOTS) {
-        // K1b found more hits beyond their tiles' slots than the overflow list holds (nothing else is wrong): with a
-        // list of the size this input needs the sparse kernels + the hot pipeline take it -- again, once
+    const uint64_t n_hot = w.h_pinned[12], n_ovf = w.h_pinned[13], ovf_max = w.h_pinned[11];
+    if (gave_up == 2 && !c.ovf_grown && ovf_max * OVF_LISTS <= 3 * c.tiles * HIT_SLOTS + (OVF_LISTS << 12)) {
+        // K1b found more hits beyond their tiles' slots than an overflow list holds (nothing else is wrong): with lists
+        // of the size this input needs the sparse kernels + the hot pipeline take it -- again, once
         HIPCHK_RC(hipStreamSynchronize(st));
         HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
-        if ((rc = set_overflow_room(x, n_ovf + n_ovf / 4 + 4096)) == ACX_OK) {
+        if ((rc = set_overflow_room(x, ovf_max + ovf_max / 4 + 64)) == ACX_OK) {
             c.ovf_grown = true;
             c.leads_counted = false;
             c.event_at_post = false;
@@ -1077,7 +1089,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     if (c.ovf_grown && gave_up != 2) a->path[6]++;
     if (!gave_up && n_hot) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
         bool lost = false;
-        if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)n_ovf, seg_counts, cp_pre, &lost)) != ACX_OK) return rc;
+        if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, &lost)) != ACX_OK) return rc;
         if (lost) gave_up = 1;
         else { a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf; }
     } else if (!gave_up) {

@@ -127,14 +127,21 @@ __host__ __device__ inline uint64_t hcnt_index(uint64_t tile, uint32_t nw, uint3
 // leaves the other one clear for the next call).  Sink::abort_flag / the kernels' abort_flag parameter point at the
 // block's first word; the others are reached from there (u32 indexes):
 //   [CTL_ABORT]     the call cannot be finished on the sparse path at all (K1a's slots overflowed, ...)
-//   [CTL_OVF_COUNT] K1b: prefix hits beyond a tile's HIT_SLOTS -- appended to the overflow list, nothing is lost
+//   [CTL_OVF_LOST]  an overflow list was too small: hits were lost (the host grows the lists and repeats the call)
 //   [CTL_HOT_COUNT] groups k_tile_main left to the HOT pipeline (a staged tile with overflow hits, a full bucket,
 //                   more than GROUP_MAX matches, an uncertifiable chain): their ids are in the hot list
-//   [CTL_OVF_CAP]   records the overflow list holds;  [CTL_OVF_RECS] (u64) the list;  [CTL_HOT_LIST] (u64) n_groups ids
+//   [CTL_OVF_CAP]   records ONE overflow list holds;  [CTL_OVF_RECS] (u64) the lists, back to back;  [CTL_HOT_LIST]
+//                   (u64) n_groups ids;  [CTL_OVF_COUNTS] (u64) the lists' fill counters
+// K1b files prefix hits beyond a tile's HIT_SLOTS in OVF_LISTS overflow lists, by tile index (nothing is lost).  Not ONE
+// list: a counter takes ~16 returning atomics per microsecond whoever asks (measured, round 5: a haystack that is dense
+// everywhere -- 400 000 pushes -- kept the scan busy for 24 ms on one counter, and 1 % of hot groups doubled its time),
+// so the counters are OVF_LISTS words on cache lines of their own; the tiles of a dense stretch are consecutive and
+// spread over all of them.
 // One dense region no longer costs the whole call the dense path: the sparse kernels finish every other group, the
 // hot groups (+ their context tiles) go through the tile-ordered dense machinery, k_tile_write splices both by the
 // groups' counts (reference behaviour: the cost per byte does not depend on where the matches are, src/lib.rs:59).
-constexpr uint32_t CTL_ABORT = 0, CTL_OVF_COUNT = 1, CTL_HOT_COUNT = 2, CTL_OVF_CAP = 4, CTL_OVF_RECS = 6, CTL_HOT_LIST = 8;
+constexpr uint32_t CTL_ABORT = 0, CTL_OVF_LOST = 1, CTL_HOT_COUNT = 2, CTL_OVF_CAP = 4, CTL_OVF_RECS = 6, CTL_HOT_LIST = 8, CTL_OVF_COUNTS = 10;
+constexpr uint32_t OVF_LISTS = 256, OVF_COUNT_STRIDE = 16; // lists; u32 words from one list's counter to the next (64 bytes)
 constexpr uint32_t CTL_WORDS = 16;         // u32 words per block
 constexpr uint32_t HOT_BIT = 0x80000000u;  // TileSpace::btot[g]: the group is the hot pipeline's (low bits: its matches)
 struct Sink {

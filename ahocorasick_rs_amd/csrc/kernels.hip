@@ -584,6 +584,11 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //       the count is a plain store; dense mode: appended to the wave's region.  The kernel
 //       never walks the DFA and never compares pattern tails (k_tile_main / k_walk_hits do).
 // All LDS is ONE static object with the L1 table at offset 0.
+// measurements only (tools/build_variant.sh -DACX_K1B_ABLATE=n; the results of such a build are WRONG): 1 = level 1 and
+// the streaming alone (no compaction, no level 2); 2 = + the compaction (no level 2)
+#ifndef ACX_K1B_ABLATE
+#define ACX_K1B_ABLATE 0
+#endif
 constexpr int K1B_ROWS = 4;
 static_assert(K1B_ROWS * 1024 == (1 << TILE_BITS), "a K1b tile is a tile of the hit slots");
 static_assert((DT_GROUP << TILE_BITS) <= (1u << 16), "group-relative key positions of the dense path's words");
@@ -918,15 +923,29 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // (sparse mode: a hit beyond the slots still takes its place in the buffer; its slot word says "nowhere")
         const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, keep ? dst : 0xFFFFFFFFu);
         const uint4 r1 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
-        if (SLOTS && found && !keep) {
-            // more hits than the tile holds (a dense stretch of the input): the hit goes to the call's overflow list --
-            // the tile's count says "overfull", k_tile_main leaves its group to the hot pipeline (device_types.hpp: control block)
-            uint32_t *ctl = GK.abort_flag;
-            const uint32_t i = atomicAdd(ctl + CTL_OVF_COUNT, 1u);
-            if (i < ctl[CTL_OVF_CAP]) {
-                uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * (uint64_t)i;
-                o[0] = make_uint4(r0.x, r0.y, r0.z, 0);
-                o[1] = r1;
+        if (SLOTS) {
+            // more hits than the tile holds (a dense stretch of the input): those go to the call's overflow list -- the
+            // tile's count says "overfull", k_tile_main leaves its group to the hot pipeline (device_types.hpp: control
+            // block).  ONE atomic per wave and push, on the counter of the tile's list
+            const unsigned long long om = __ballot(found && !keep);
+            if (om) {
+                uint32_t *ctl = GK.abort_flag;
+                const uint32_t list = (uint32_t)tile & (OVF_LISTS - 1); // (wave-uniform: the hits of a push are one tile's)
+                uint32_t *cnt = *(uint32_t *const *)(ctl + CTL_OVF_COUNTS) + list * OVF_COUNT_STRIDE;
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(om)) base = atomicAdd(cnt, (uint32_t)__popcll(om));
+                base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(om));
+                const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
+                const uint32_t cap = ctl[CTL_OVF_CAP];
+                if (found && !keep) {
+                    if (i < cap) {
+                        uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * ((uint64_t)list * cap + i);
+                        o[0] = make_uint4(r0.x, r0.y, r0.z, 0);
+                        o[1] = r1;
+                    } else {
+                        ctl[CTL_OVF_LOST] = 1;
+                    }
+                }
             }
         }
         if (np > HB) { // more hits at once than the buffer holds: straight to HBM
@@ -1008,10 +1027,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     uint32_t stM = 0, tileM = 0, nM = 0, offM = 0, bitM = 0;
     uint64_t winM = 0;
     bool liveC = true; // BIG: the lane's survivor of the batch in C passed the bitmap
-    // (advance = advance_front + advance_ab; ACX_K1B_EARLY: the windows of a tile's last batch are requested at the END of
-    // the tile's own iteration -- one iteration of the XCD's other waves less between a tile's load and the re-read of its
-    // survivors' windows, which then still hit the L2 -- and the front stages run at the top of the next one)
-    auto advance_front = [&]() __attribute__((always_inline)) {
+    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
         // ---- stage C: compare the slots with their windows
         if (stC) {
             if (nC) {
@@ -1100,9 +1116,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             }
             nC = nB; stC = stB; tileC = tileB;
         }
-        nB = 0; stB = 0;
-    };
-    auto advance_ab = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
         if (BIG) {
             // ---- stage A -> B: fetch the first 8 bytes of the queued survivors' windows
             if (q1c) {
@@ -1134,15 +1147,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         q1c = 0;
         __builtin_amdgcn_wave_barrier();
     };
-    auto advance = [&](uint32_t tileQ, uint32_t stQ) __attribute__((always_inline)) {
-        advance_front();
-        advance_ab(tileQ, stQ);
-    };
-#ifndef ACX_K1B_EARLY
-#define ACX_K1B_EARLY 0
-#endif
-    constexpr bool EARLY = ACX_K1B_EARLY != 0;
-    constexpr uint64_t DRAIN = (BIG ? 4 : 3) - (EARLY ? 1 : 0); // extra iterations that empty the pipeline
+    // (measured in round 5, same-box pairs: requesting the windows of a tile's last batch at the END of the tile's own
+    // iteration -- half the distance between a tile's load and the re-read of its survivors' windows -- changes neither
+    // the L2 misses (TCC_MISS 13.40 M -> 12.93 M per GiB on cfg2: the XCD's 4 MiB do not hold a tile for one iteration of
+    // its 512 waves either) nor the kernel's time: the kernel is bound by its VALU instructions, 91 % busy)
+    constexpr uint64_t DRAIN = BIG ? 4 : 3; // extra iterations that empty the pipeline
 
     for (uint64_t tile = gw; tile < ntiles + DRAIN * nw; tile += nw) {
         // Everything loaded during the previous iteration (the tile prefetch and the level-2
@@ -1150,8 +1159,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // the compiler wait for those loads HERE, not with a vmcnt(0) somewhere in the middle of level 1.
         asm volatile("" : "+v"(nxt0), "+v"(nxt1), "+v"(nxt2), "+v"(nxt3), "+v"(nxtL.x), "+v"(nxtL.y));
         // the previous tile's remaining survivors: its last batch (possibly empty)
-        if constexpr (EARLY) advance_front();
-        else advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
+#if ACX_K1B_ABLATE != 1 && ACX_K1B_ABLATE != 2
+        advance((uint32_t)(tile - nw), tile >= gw + nw && tile - nw < ntiles ? 2u : 0u);
+#else
+        q1c = 0;
+#endif
         if (tile >= ntiles) continue;
 
         // ---- level 1 on this tile
@@ -1323,6 +1335,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // without a survivor compute along and do not store)
         if constexpr (!SH) {
             uint64_t m64 = (uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32);
+#if ACX_K1B_ABLATE == 1
+            if (m64 == 0x123456789ull) q1[lane] = 1; // (keeps the masks alive)
+            m64 = 0;
+#endif
             while (true) {
                 const bool has = m64 != 0;
                 const unsigned long long act = __ballot(has);
@@ -1358,12 +1374,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         }
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
-        if constexpr (EARLY) { // ... and their windows are requested at once
-            if (stB) advance_front(); // (a batch that moved on in the middle of the compaction still sits in B)
-            advance_ab((uint32_t)tile, 2u);
-        }
     }
     hit_flush();
+#if ACX_K1B_ABLATE != 0
+    if (SLOTS) for (uint32_t k = lane; k < GK.cnt_iters; k += 64) GK.hcnt[gw * GK.cnt_iters + k] = 0; // (no hits: no garbage for the post stage)
+#endif
     if (SLOTS && (kC & 15)) { // the counts of the wave's last tiles
         __builtin_amdgcn_wave_barrier();
         if (lane < (kC & 15)) GK.hcnt[gw * GK.cnt_iters + (kC & ~15u) + lane] = L.cb[wave][lane];
@@ -2536,10 +2551,9 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         stop = *O.hot_abort != 0;
         why = stop ? 1 : 0;
     } else {
-        // sparse path: more overflow hits than their list holds = hits were lost (the host grows the list or takes the dense path)
+        // sparse path: an overflow list was too small = hits were lost (the host grows the lists or takes the dense path)
         n_hot = DENSE ? 0u : abort_flag[CTL_HOT_COUNT];
-        n_ovf = DENSE ? 0u : abort_flag[CTL_OVF_COUNT];
-        why = abort_flag[CTL_ABORT] != 0 ? 1u : (!DENSE && n_ovf > abort_flag[CTL_OVF_CAP]) ? 2u : 0u;
+        why = abort_flag[CTL_ABORT] != 0 ? 1u : (!DENSE && abort_flag[CTL_OVF_LOST] != 0) ? 2u : 0u;
         stop = why != 0;
     }
     const uint64_t *sgw = T.sgw + (O.seq & 1) * 2 * (uint64_t)T.sg_cap;
@@ -2563,11 +2577,25 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         }
         uint64_t *other = T.sgw + ((O.seq & 1) ^ 1) * 2 * (uint64_t)T.sg_cap;
         for (uint32_t k = t; k < 2 * T.sg_cap; k += WRITE_THREADS) other[k] = 0;
+        // the overflow lists' fill (pass 0 of the sparse path): total and fullest list, for the host; the next call's counters: clear
+        uint32_t ovf_max = 0;
+        if (!DENSE && O.pass == 0) {
+            static_assert(WRITE_THREADS == OVF_LISTS, "one thread per overflow list");
+            const uint32_t mine = (*(const uint32_t *const *)(abort_flag + CTL_OVF_COUNTS))[t * OVF_COUNT_STRIDE];
+            uint32_t sum = mine, mx = mine;
+            for (int o = 32; o > 0; o >>= 1) { sum += __shfl_xor(sum, o); mx = max(mx, (uint32_t)__shfl_xor(mx, o)); }
+            __syncthreads();
+            if ((t & 63) == 0) red[t >> 6] = ((uint64_t)mx << 32) | sum;
+            __syncthreads();
+            for (int k = 0; k < 4; k++) { n_ovf += (uint32_t)red[k]; ovf_max = max(ovf_max, (uint32_t)(red[k] >> 32)); }
+            if (O.next_flag) (*(uint32_t *const *)(O.next_flag + CTL_OVF_COUNTS))[t * OVF_COUNT_STRIDE] = 0;
+        }
         if (t == 0) {
             O.summary[0] = tot[1]; O.summary[2] = tot[2]; O.summary[4] = tot[0];
-            if (O.next_flag) { O.next_flag[CTL_ABORT] = 0; O.next_flag[CTL_OVF_COUNT] = 0; O.next_flag[CTL_HOT_COUNT] = 0; }
+            if (O.next_flag) { O.next_flag[CTL_ABORT] = 0; O.next_flag[CTL_OVF_LOST] = 0; O.next_flag[CTL_HOT_COUNT] = 0; }
             O.host_out[0] = tot[1]; O.host_out[2] = tot[2]; O.host_out[4] = tot[0];
             O.host_out[5] = why;
+            O.host_out[11] = ovf_max;
             O.host_out[12] = n_hot; O.host_out[13] = n_ovf;
             __threadfence_system();
             O.host_out[7] = O.pub;
@@ -2798,17 +2826,21 @@ constexpr uint32_t HV_TILES = GROUP_TILES + MAX_LOOKBACK + 1;        // tiles a 
 constexpr uint32_t HV_BLOCKS = (HV_TILES + 3) / 4;                   // workgroups (of four waves) per hot group
 template <bool ANCH>
 __global__ __launch_bounds__(256) void k_hot_verify(DevAutomaton A, Segments G, TileSpace T, const uint32_t *hot_list, uint32_t n_hot,
-                                                    const uint4 *ovf, uint32_t n_ovf, uint32_t lookback, DenseTiles D, int key_mode,
+                                                    const uint32_t *ctl, uint32_t ovf_blocks, uint32_t lookback, DenseTiles D, int key_mode,
                                                     uint32_t lead, const uint8_t *__restrict__ stream, uint64_t len,
                                                     uint32_t *abort_flag) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x >= n_hot * HV_BLOCKS) { // the overflow list
-        const uint32_t b0 = blockIdx.x - n_hot * HV_BLOCKS, nb = gridDim.x - n_hot * HV_BLOCKS;
-        for (uint64_t i0 = (uint64_t)b0 * 256; i0 < n_ovf; i0 += (uint64_t)nb * 256) { // (block-uniform bounds: whole waves loop together)
-            const uint64_t i = i0 + threadIdx.x;
-            const bool live = i < n_ovf;
+    if (blockIdx.x >= n_hot * HV_BLOCKS) { // the overflow lists: ovf_blocks workgroups each
+        const uint32_t q = blockIdx.x - n_hot * HV_BLOCKS, list = q / ovf_blocks, b0 = q % ovf_blocks;
+        const uint32_t cap = ctl[CTL_OVF_CAP];
+        uint32_t n = (*(const uint32_t *const *)(ctl + CTL_OVF_COUNTS))[list * OVF_COUNT_STRIDE];
+        n = n < cap ? n : cap;
+        const uint4 *ovf = *(const uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * (uint64_t)list * cap;
+        for (uint32_t i0 = b0 * 256; i0 < n; i0 += ovf_blocks * 256) { // (block-uniform bounds: whole waves loop together)
+            const uint32_t i = i0 + threadIdx.x;
+            const bool live = i < n;
             uint4 h = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
-            if (live) { h = ovf[2 * i]; w = ovf[2 * i + 1]; }
+            if (live) { h = ovf[2 * (uint64_t)i]; w = ovf[2 * (uint64_t)i + 1]; }
             dense_file_hits<ANCH>(A, G, D, key_mode, lead, stream, len, abort_flag, live, h, w);
         }
         return;
@@ -3092,18 +3124,19 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
 
 // ---- the HOT pipeline's launches (kernels.hpp)
 hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
-                           const uint32_t *hot_list, uint32_t n_hot, const uint4 *ovf, uint32_t n_ovf, const DenseTiles &D,
+                           const uint32_t *hot_list, uint32_t n_hot, const uint32_t *ctl, uint32_t ovf_max, const DenseTiles &D,
                            const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
                            uint64_t seq, hipStream_t st) {
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK || n_hot == 0) return hipErrorInvalidValue;
-    const uint32_t ovb = n_ovf ? std::min<uint32_t>((n_ovf + 255) / 256, 2048u) : 0u;
-    const uint32_t grid = n_hot * HV_BLOCKS + ovb;
+    // workgroups per overflow list: by the fullest one (256 hits per step and workgroup, at most 8 steps)
+    const uint32_t ovb = ovf_max ? std::min<uint32_t>((ovf_max + 2047) / 2048, 16u) : 0u;
+    const uint32_t grid = n_hot * HV_BLOCKS + OVF_LISTS * ovb;
     if (A.max_shift)
-        hipLaunchKernelGGL(k_hot_verify<true>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ovf, n_ovf, lookback, D, key_mode,
+        hipLaunchKernelGGL(k_hot_verify<true>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
                            lead, d_hay, len, hot_abort);
     else
-        hipLaunchKernelGGL(k_hot_verify<false>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ovf, n_ovf, lookback, D, key_mode,
+        hipLaunchKernelGGL(k_hot_verify<false>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
                            lead, d_hay, len, hot_abort);
     hipLaunchKernelGGL(k_dense_main, dim3(n_hot * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
                        key_mode, overlapping ? 1 : 0, D, TD, lookback, lead, hot_abort, HotMain{hot_list, S, seq});

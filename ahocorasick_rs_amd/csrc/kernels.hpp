@@ -105,7 +105,7 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // chunks + what k_tile_main carried over of the start's own chunk: no haystack access).
 // abort_flag / next_flag: the control blocks of this call and of the next one (device_types.hpp).  hot_ok (K1b's prefix
 // hits): groups the sparse kernels cannot finish are listed for the HOT pipeline instead of aborting the call; the write
-// kernel then publishes host_out[12] = hot groups, [13] = overflow hits and -- when there are hot groups -- writes nothing:
+// kernel then publishes host_out[12] = hot groups, [13] = overflow hits, [11] = the fullest overflow list and -- when there are hot groups -- writes nothing:
 // the caller runs hot_verify_main + hot_write (below) and waits for the second publication.
 uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
@@ -115,7 +115,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, hipStream_t st);
 // HOT pipeline: a dense stretch of the input costs the groups it lies in, not the call (reference behaviour: the cost
 // per byte does not depend on where the matches are, /root/reference/src/lib.rs:59).
-//   hot_verify_main  k_hot_verify: the hits of the hot groups' staged tiles (their slots + the overflow list) -> occurrence
+//   hot_verify_main  k_hot_verify: the hits of the hot groups' staged tiles (their slots + the overflow lists of the call's
+//                    control block ctl; ovf_max = the fullest list's fill) -> occurrence
 //                    words in the buckets of their key tiles (D.counts must be zero); k_dense_main over the hot groups'
 //                    dense groups (HOT_SUB each): records in TD.trecs, counts in TD.btot AND credited to the hot group in
 //                    S.btot / the supergroup words of the call's set.  *hot_abort != 0: a bucket overflowed or a chain left
@@ -124,7 +125,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 //   hot_write        the hot groups' records, then the sparse path's write kernel again: every group placed with all
 //                    counts in; host_out {[0], [2], [4] totals, [5] = *hot_abort, [7] = pub}
 hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
-                           const uint32_t *hot_list, uint32_t n_hot, const uint4 *ovf, uint32_t n_ovf, const DenseTiles &D,
+                           const uint32_t *hot_list, uint32_t n_hot, const uint32_t *ctl, uint32_t ovf_max, const DenseTiles &D,
                            const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
                            uint64_t seq, hipStream_t st);
 hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint64_t pub, hipStream_t st);

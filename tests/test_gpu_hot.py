@@ -113,7 +113,7 @@ def test_bucket_and_group_overflow_stay_local():
 
 def test_dense_everywhere_grows_the_overflow_list_and_stays_off_the_dense_path():
     # a pattern every 32 bytes EVERYWHERE (bench.py --dist D's shape): 128 hits per tile, twice the slots -- the overflow
-    # list is grown once for the call, every group is hot, and the hot pipeline is the whole post stage
+    # lists are grown once for the call, every group is hot, and the hot pipeline is the whole post stage
     pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
     hay = gen.gen_uniform(8 << 20, gen.AZ, 12).copy()
     plant(hay, pats, 0, len(hay), 32, 77)
@@ -126,9 +126,10 @@ def test_dense_everywhere_grows_the_overflow_list_and_stays_off_the_dense_path()
         assert np.array_equal(cols(a.find(hay)), want), mk
         st = a.path_stats(reset=True)
         assert st["hot_calls"] == 1 and st["overflow_regrown"] == 1 and st["dense_tiles"] == st["dense_radix"] == 0, st
-        assert np.array_equal(cols(a.find(hay)), want), mk  # (the list keeps its size: no second attempt now)
+        # (an input that is dense everywhere: the handle's next calls go to the dense path proper, no sparse attempt in front)
+        assert np.array_equal(cols(a.find(hay)), want), mk
         st = a.path_stats()
-        assert st["hot_calls"] == 1 and st["overflow_regrown"] == 0, st
+        assert st["dense_tiles"] == 1 and st["hot_calls"] == 0 and st["overflow_regrown"] == 0, st
         a.close()
 
 
