@@ -908,7 +908,7 @@ enum class Attempt { Done, GoDense, Again };
 // path's groups, then the write kernel again.  One dense region costs the groups it lies in, not the call (it used to
 // send the whole call to the dense path and keep the handle there for eight more calls).  *lost: the hot pipeline gave
 // up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
-constexpr uint64_t HOT_INLINE = 64; // hot groups whose capacity the output buffer has room for anyway
+constexpr uint64_t HOT_INLINE = 128; // hot groups whose capacity the output buffer has room for anyway (1 GiB: 3 % of the groups)
 int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t ovf_max, uint64_t *seg_counts,
             const uint64_t *cp_pre, bool *lost) {
     acx_automaton *a = c.a;

@@ -1151,6 +1151,13 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // iteration -- half the distance between a tile's load and the re-read of its survivors' windows -- changes neither
     // the L2 misses (TCC_MISS 13.40 M -> 12.93 M per GiB on cfg2: the XCD's 4 MiB do not hold a tile for one iteration of
     // its 512 waves either) nor the kernel's time: the kernel is bound by its VALU instructions, 91 % busy)
+    // (measured in round 5, same-box triples -- the kernel before / with / the same text without: batches of the survivors of
+    // TWO consecutive tiles of a wave, the pipeline moving every second iteration -- the ablation builds put a quarter of
+    // the kernel, 72 us on T, on level 2, whose instructions are per batch -- brought 1 % on T (285 against 289 us), -1 %
+    // on U, +5 % on the mixed-length set, and cost cfg5 5 % and cfg4 9 % (their tiles fill a batch by themselves); a
+    // first, more general version ran 9 % SLOWER than the kernel it replaced: three more wave-uniform words across
+    // level 1 were v_readlanes in the loop, and the compiler parked the freshly requested windows in other registers
+    // behind an s_waitcnt vmcnt(0) at the end of every advance().  Out of the tree; profiles/r05/exp_pair_*.)
     constexpr uint64_t DRAIN = BIG ? 4 : 3; // extra iterations that empty the pipeline
 
     for (uint64_t tile = gw; tile < ntiles + DRAIN * nw; tile += nw) {
@@ -3129,8 +3136,8 @@ hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping
                            uint64_t seq, hipStream_t st) {
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK || n_hot == 0) return hipErrorInvalidValue;
-    // workgroups per overflow list: by the fullest one (256 hits per step and workgroup, at most 8 steps)
-    const uint32_t ovb = ovf_max ? std::min<uint32_t>((ovf_max + 2047) / 2048, 16u) : 0u;
+    // workgroups per overflow list: by the fullest one (256 hits per step and workgroup: one step each up to 32 workgroups)
+    const uint32_t ovb = ovf_max ? std::min<uint32_t>((ovf_max + 255) / 256, 32u) : 0u;
     const uint32_t grid = n_hot * HV_BLOCKS + OVF_LISTS * ovb;
     if (A.max_shift)
         hipLaunchKernelGGL(k_hot_verify<true>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
