@@ -1195,6 +1195,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             _Pragma("unroll") for (int j = 1; j < 20; j += 2)                                    \
                 w_[j] = __builtin_amdgcn_alignbyte(d_[(j >> 2) + 1], d_[j >> 2], j & 3);         \
             uint32_t m_ = 0, mg_ = 0;                                                            \
+            /* (round 5: the mask that aligns the address to the 8-byte entries is one instruction */\
+            /* per pair, 7 % of the kernel's VALU, and the LDS does read 8 bytes at any address --  */\
+            /* tools/ubench_lds_align.hip; a table addressed by byte, rows overlapping, filters as   */\
+            /* well (simulated: 0.55 % against 0.53 % survivors on T) -- but an unaligned ds_read_b64 */\
+            /* is SLOW: K1b 0.278 -> 0.92 ms, same box, profiles/r05/exp_byte_table_*: the mask stays) */\
             /* all eight table reads of the row are issued before the first test (the scheduler    */\
             /* otherwise keeps ONE read in flight: ds_read, s_waitcnt lgkmcnt(0), test, next read; */\
             /* measured: -2.6 us of 282 -- the other waves covered most of that latency already)    */\
