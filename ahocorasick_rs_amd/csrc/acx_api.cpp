@@ -1639,7 +1639,10 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     D.max_shift = H.max_shift;
     {
         static const char *big_env = std::getenv("ACX_FILTER_BIG"); // measurements: 0 / 1 force the choice
-        D.filter_big = big_env ? (uint32_t)std::atoi(big_env) : (H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
+        // 1: the level-1 table is saturated (10^5 patterns): every position put to both tests; 2: it passes nearly every
+        // position (10^6 patterns): ... and the survivors' windows captured from the row staged in LDS (kernels.hip: K1bLds)
+        D.filter_big = big_env ? (uint32_t)std::atoi(big_env)
+                               : (H.filter_q == 5 && H.filter_density > 0.6 ? 2u : H.filter_q == 5 && H.filter_density > 0.2 ? 1u : 0u);
     }
     D.rank_bits = (uint32_t)std::max(1, bits_for(H.n_patterns ? H.n_patterns - 1 : 0));
     // compact u16 copy of the hot (lowest-id) rows for K1a's LDS tile

@@ -585,7 +585,8 @@ hipError_t launch_dfa_walk(const DevAutomaton &A, const DevAutomaton *Ad, const 
 //       never walks the DFA and never compares pattern tails (k_tile_main / k_walk_hits do).
 // All LDS is ONE static object with the L1 table at offset 0.
 // measurements only (tools/build_variant.sh -DACX_K1B_ABLATE=n; the results of such a build are WRONG): 1 = level 1 and
-// the streaming alone (no compaction, no level 2); 2 = + the compaction (no level 2)
+// the streaming alone (no compaction, no level 2); 2 = + the compaction (no level 2); 3 = BIG: the survivors' windows from one
+// hot line instead of their own
 #ifndef ACX_K1B_ABLATE
 #define ACX_K1B_ABLATE 0
 #endif
@@ -594,12 +595,32 @@ static_assert(K1B_ROWS * 1024 == (1 << TILE_BITS), "a K1b tile is a tile of the 
 static_assert((DT_GROUP << TILE_BITS) <= (1u << 16), "group-relative key positions of the dense path's words");
 constexpr uint32_t K1B_Q1CAP = 64;  // level-1 survivors settled per round (1 per lane)
 constexpr uint32_t K1B_HB = 40;     // prefix hits a wave collects in LDS before one burst store
+// STAGED (round 5; BIG sets whose level-1 table passes nearly every position): the survivors' windows never come from HBM.  Every survivor used to re-read the 8 bytes at its
+// position one iteration later -- 13.5 M gathers per GiB on 10^5 patterns, lines that had left the XCD's L2 by then: 1.7 GB
+// of the kernel's 4.2 GB of traffic, 180 of its 700 us (measured: the same kernel with those loads pointed at one hot
+// line, profiles/r05/exp_cfg4_windows_*).  The bytes are in the wave's registers when level 1 flags them, but at a
+// per-lane position: the row (1 KiB + the 8 bytes behind it) is staged in LDS, the compaction runs row by row, and a
+// survivor's lane reads its window from the stage -- three ALIGNED dwords and two v_alignbyte (an unaligned
+// ds_read_b64 works but is slow: tools/ubench_lds_align.hip, profiles/r05/exp_byte_table_*) -- into a second queue
+// beside the offsets.  Room: the hit buffer shrinks to K1B_HB_BIG records, the redirect keys' Bloom filter is read from
+// global memory (it is touched by the rare redirect entries only).
+constexpr uint32_t K1B_HB_BIG = 4;
+constexpr uint32_t K1B_STAGE_BYTES = 1024 + 16; // a row + the 8 bytes behind it (+ padding to 16)
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
     uint16_t q1[16][K1B_Q1CAP];
-    uint4 hb[16][K1B_HB][2];
+    union {
+        struct {
+            uint4 hb[16][K1B_HB][2];
+            uint32_t rbloom[REDIRECT_BLOOM_WORDS]; // Bloom filter of the keys behind redirect entries
+        } n;
+        struct {
+            uint4 hb[16][K1B_HB_BIG][2];
+            uint8_t stage[16][K1B_STAGE_BYTES] __attribute__((aligned(16))); // the row under compaction
+            uint64_t q1w[16][K1B_Q1CAP];                                      // the queued survivors' windows
+        } b;
+    } u;
     uint32_t cb[16][16]; // sparse mode: hit counts of the wave's last tiles, stored 16 at a time
-    uint32_t rbloom[REDIRECT_BLOOM_WORDS]; // Bloom filter of the keys behind redirect entries
     uint32_t sxy[SHORT_XY_WORDS];          // SH: the short patterns' {X, Y} pair table by middle byte
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
@@ -835,15 +856,18 @@ struct K1bTables {
 // survivors travel through the same queue and pipeline with a flag (bit 15 of the offset) and are settled
 // against the exact codes (two 4-byte gathers: the 1-byte and the 2-byte pattern that may start there)
 // instead of the prefix table.
-template <int Q, bool SLOTS, bool CP, bool BIG, bool SH>
+template <int Q, bool SLOTS, bool CP, int BIGV, bool SH>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
     // `hay` is 16-byte aligned; the first `lead` bytes (< 16) precede the real stream and are
     // never candidates.  Stream position = index - lead.
     __shared__ __attribute__((aligned(16))) K1bLds L;
+    // BIGV: 0 -- the pair test; 1 (BIG) -- every position put to both tests, the survivors' windows gathered; 2 (BIG, STAGED) --
+    // ... their windows captured from the row staged in LDS (K1bLds): sets whose table passes (nearly) every position
+    constexpr bool BIG = BIGV != 0, STAGED = BIGV == 2;
     constexpr uint32_t FLOG = FILTER_ENTRIES_LOG2;
-    constexpr uint32_t HB = K1B_HB;
+    constexpr uint32_t HB = STAGED ? K1B_HB_BIG : K1B_HB;
     // the wave index is wave-uniform: say so, and the tile index, its byte offset, the
     // interior test and most of the prefetch address arithmetic move from VALU to SALU
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -858,7 +882,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
-        for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) L.rbloom[i] = A.rbloom[i];
+        if (!STAGED) for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) L.u.n.rbloom[i] = A.rbloom[i];
     }
     if (SH && threadIdx.x < SHORT_XY_WORDS) L.sxy[threadIdx.x] = A.short_xy[threadIdx.x];
     __syncthreads();
@@ -887,7 +911,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // iteration makes the `s_waitcnt vmcnt(0)` in front of the next tile wait for HBM write latency
     // every iteration; a burst every few iterations does not (measured: 1-2 % of the kernel).
     // Word 3 of a record's first quad carries its destination slot (sparse mode).
-    uint4 (*const hb)[2] = L.hb[wave];
+    uint4 (*const hb)[2] = STAGED ? L.u.b.hb[wave] : L.u.n.hb[wave];
     uint32_t hbn = 0; // wave-uniform fill of the buffer
     auto hit_flush = [&]() __attribute__((always_inline)) {
         if (lane < hbn) {
@@ -1041,7 +1065,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
                 if (next) { // (most such positions end here: the LDS Bloom filter of those keys says no)
                     const uint32_t bit = redirect_bloom_bit(prefix_home_hash(low_bytes(winC, next), next));
-                    if (!((L.rbloom[bit >> 5] >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
+                    const uint32_t bw = STAGED ? A.rbloom[bit >> 5] : L.u.n.rbloom[bit >> 5]; // (STAGED: no room in LDS; these entries are rare)
+                    if (!((bw >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
                 }
                 if (next) code = prefix_walk(A.ptab, ptab_log2, next, winC, nullptr);
                 // a home slot holding another key proves absence unless the slot's filter of
@@ -1093,13 +1118,27 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 offC = offM; winC = winM;
             }
             nC = nM; stC = stM; tileC = tileM;
-            // ---- stage B -> M: hash the windows, fetch their bitmap words
-            if (nB) {
-                if (lane < nB && !(SH && (offB & SHFLAG)))
-                    bitM = A.pbits[prefix_bitmap_bit(gram_hash2(winB & q2mask) + q2salt, ptab_log2) >> 5];
-                offM = offB; winM = winB;
+            if constexpr (STAGED) {
+                // ---- stage A -> M: the queued survivors' windows (captured from the staged row at their compaction) are
+                // hashed and their bitmap words requested -- nothing of the haystack is read again
+                if (q1c) {
+                    if (lane < q1c) {
+                        offM = q1[lane];
+                        winM = L.u.b.q1w[wave][lane];
+                        if (!(SH && (offM & SHFLAG)))
+                            bitM = A.pbits[prefix_bitmap_bit(gram_hash2(winM & q2mask) + q2salt, ptab_log2) >> 5];
+                    }
+                }
+                nM = q1c; stM = stQ; tileM = tileQ;
+            } else {
+                // ---- stage B -> M: hash the windows, fetch their bitmap words
+                if (nB) {
+                    if (lane < nB && !(SH && (offB & SHFLAG)))
+                        bitM = A.pbits[prefix_bitmap_bit(gram_hash2(winB & q2mask) + q2salt, ptab_log2) >> 5];
+                    offM = offB; winM = winB;
+                }
+                nM = nB; stM = stB; tileM = tileB;
             }
-            nM = nB; stM = stB; tileM = tileB;
         } else {
             // ---- stage B -> C: hash the windows, fetch their home slots
             if (nB) {
@@ -1118,10 +1157,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         }
         if (BIG) {
             // ---- stage A -> B: fetch the first 8 bytes of the queued survivors' windows
-            if (q1c) {
+            if (!STAGED && q1c) {
                 if (lane < q1c) {
                     offB = q1[lane];
+#if ACX_K1B_ABLATE == 3 /* measurements: the windows from ONE hot line (results WRONG) */
+                    winB = load_window(stream, len, (uint64_t)(lane & 7) * 8);
+#else
                     winB = load_window(stream, len, (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead);
+#endif
                 }
             }
         } else {
@@ -1143,7 +1186,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 }
             }
         }
-        nB = q1c; stB = stQ; tileB = tileQ;
+        if (!STAGED) { nB = q1c; stB = stQ; tileB = tileQ; }
         q1c = 0;
         __builtin_amdgcn_wave_barrier();
     };
@@ -1158,7 +1201,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // first, more general version ran 9 % SLOWER than the kernel it replaced: three more wave-uniform words across
     // level 1 were v_readlanes in the loop, and the compiler parked the freshly requested windows in other registers
     // behind an s_waitcnt vmcnt(0) at the end of every advance().  Out of the tree; profiles/r05/exp_pair_*.)
-    constexpr uint64_t DRAIN = BIG ? 4 : 3; // extra iterations that empty the pipeline
+    constexpr uint64_t DRAIN = BIG && !STAGED ? 4 : 3; // extra iterations that empty the pipeline (A -> B -> C; BIG: A -> B -> M -> C; STAGED: A -> M -> C)
 
     for (uint64_t tile = gw; tile < ntiles + DRAIN * nw; tile += nw) {
         // Everything loaded during the previous iteration (the tile prefetch and the level-2
@@ -1337,6 +1380,86 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             K1B_LEADS(0, nxt0) K1B_LEADS(1, nxt1) K1B_LEADS(2, nxt2) K1B_LEADS(3, nxt3)
 #undef K1B_LEADS
         }
+        if constexpr (STAGED && Q == 5) {
+            // ---- STAGED: row by row -- the row is staged in LDS (1 KiB + the 8 bytes behind it), the wave's NEXT tile's row is
+            // requested into the registers the row has just left, and the row's survivors are ballot-compacted into Q1
+            // with their windows, which their own lanes read from the stage (three aligned dwords, two v_alignbyte: the
+            // K1bLds comment).  Nothing of the haystack is read a second time.
+            uint8_t *const stg = L.u.b.stage[wave];
+            uint64_t *const q1w = L.u.b.q1w[wave];
+            const uint64_t ntb_ = (tile + nw) * tile_bytes;
+            const bool nfast_ = ntb_ + tile_bytes <= last_block; // (wave-uniform: the next tile lies wholly inside the stream)
+            const uint8_t *const ntp_ = hay + ntb_ + lane * 16;
+            // (two loops: the first one -- the one that runs -- never moves the pipeline: with advance() inside it the whole
+            // pipeline state is loop-carried, and the compiler copied it from register to register in EVERY round, behind
+            // an s_waitcnt vmcnt(0) that waited for the row requested a moment before: K1b 0.70 -> 0.92 ms.  A row whose
+            // survivors do not fit Q1 leaves the first loop and finishes in the second, which may move the pipeline.)
+            auto take = [&](uint32_t &m, uint32_t r, uint32_t flag, const bool has, const unsigned long long act,
+                            const uint32_t np) __attribute__((always_inline)) {
+                const uint32_t j = (uint32_t)__builtin_ctz(m | 0x10000u);
+                m &= m - 1;
+                const uint32_t slot = q1c + __builtin_amdgcn_mbcnt_hi((uint32_t)(act >> 32),
+                                                                      __builtin_amdgcn_mbcnt_lo((uint32_t)act, 0));
+                // (only the lanes with a survivor touch the stage: the lanes' 16-byte stride puts every eighth lane on
+                // the same LDS banks)
+                if (has) {
+                    const uint32_t a = lane * 16 + j; // the survivor's byte in the staged row
+                    const uint32_t *sp = (const uint32_t *)(stg + (a & ~3u));
+                    const uint32_t d0 = sp[0], d1 = sp[1], d2 = sp[2];
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, a & 3u), hi = __builtin_amdgcn_alignbyte(d2, d1, a & 3u);
+                    q1[slot] = (uint16_t)(((r << 10) + a) | flag); // offset in the tile
+                    q1w[slot] = ((uint64_t)hi << 32) | lo;
+                }
+                q1c += np;
+            };
+            auto compact_row = [&](uint32_t m, uint32_t r, uint32_t flag) __attribute__((always_inline)) {
+                bool full = false;
+                while (true) {
+                    const bool has = m != 0;
+                    const unsigned long long act = __ballot(has);
+                    if (!act) break;
+                    const uint32_t np = __popcll(act);
+                    if (q1c + np > K1B_Q1CAP) { full = true; break; }
+                    take(m, r, flag, has, act, np);
+                }
+                if (full) { // (dense survivors: full batches move on in the middle of the row)
+                    while (true) {
+                        const bool has = m != 0;
+                        const unsigned long long act = __ballot(has);
+                        if (!act) break;
+                        const uint32_t np = __popcll(act);
+                        if (q1c + np > K1B_Q1CAP) advance((uint32_t)tile, 1u);
+                        take(m, r, flag, has, act, np);
+                    }
+                }
+            };
+#define K1B_STAGE_ROW(R, VR, RX, RY, MROW, SROW)                                                  \
+            {                                                                                        \
+                const uint32_t rx_ = (RX), ry_ = (RY); /* the 8 bytes behind the row (wave-uniform) */ \
+                __builtin_amdgcn_wave_barrier();                                                     \
+                *(u32x4 *)(stg + lane * 16) = VR;                                                    \
+                if (lane == 0) *(uint2 *)(stg + 1024) = make_uint2(rx_, ry_);                        \
+                __builtin_amdgcn_wave_barrier();                                                     \
+                if (nfast_) VR = K1B_LOAD16(ntp_ + (R) * 1024);                                      \
+                else K1B_ISSUE_ROW(VR, tile + nw, R)                                                 \
+                compact_row(MROW, R, 0u);                                                            \
+                if (SH) compact_row(SROW, R, SHFLAG); /* the side test's survivors, flagged */       \
+            }
+            {
+                // (the look-ahead of row r = the first 8 bytes of row r + 1 of THIS tile: read before that row's
+                // registers are given to the next tile -- row r + 1 is staged after row r)
+                K1B_STAGE_ROW(0, nxt0, __builtin_amdgcn_readfirstlane(nxt1.x), __builtin_amdgcn_readfirstlane(nxt1.y), mrow0, srow0)
+                K1B_STAGE_ROW(1, nxt1, __builtin_amdgcn_readfirstlane(nxt2.x), __builtin_amdgcn_readfirstlane(nxt2.y), mrow1, srow1)
+                K1B_STAGE_ROW(2, nxt2, __builtin_amdgcn_readfirstlane(nxt3.x), __builtin_amdgcn_readfirstlane(nxt3.y), mrow2, srow2)
+                const uint32_t lx_ = nxtL.x, ly_ = nxtL.y;
+                {
+                    const uint64_t off_ = ntb_ + tile_bytes;
+                    nxtL = *(const uint2 *)(hay + (nfast_ || off_ < last_block ? off_ : last_block));
+                }
+                K1B_STAGE_ROW(3, nxt3, lx_, ly_, mrow3, srow3)
+            }
+#undef K1B_STAGE_ROW
+        } else {
         // Prefetch of the wave's next tile, issued LATE: the compaction below, level 2 at the top
         // of the next iteration and the three other waves of the SIMD cover its latency.  Measured
         // (round 1, T): issued before row 0: 310 us; after row 1: 299; after row 2: 293; here: 291;
@@ -1383,6 +1506,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             compact((uint64_t)(mrow0 | (mrow1 << 16)) | ((uint64_t)(mrow2 | (mrow3 << 16)) << 32), 0u);
             // SH: the side test's survivors, flagged (a position may be queued twice: once for each kind of table)
             compact((uint64_t)(srow0 | (srow1 << 16)) | ((uint64_t)(srow2 | (srow3 << 16)) << 32), SHFLAG);
+        }
         }
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
@@ -1453,13 +1577,16 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     if (sh) { ACX_K1B(Q, B, true); } else { ACX_K1B(Q, B, false); }
     switch (A.filter_q) {
     // (Q = 1, 2: only with ACX_NO_SHORT_SPLIT -- the split keeps such patterns out of these tables)
-    case 1: ACX_K1B(1, false, false); break;
-    case 2: ACX_K1B(2, false, false); break;
-    case 3: ACX_K1B_SH(3, false) break;
-    case 4: ACX_K1B_SH(4, false) break;
+    case 1: ACX_K1B(1, 0, false); break;
+    case 2: ACX_K1B(2, 0, false); break;
+    case 3: ACX_K1B_SH(3, 0) break;
+    case 4: ACX_K1B_SH(4, 0) break;
     default:
-        if (A.filter_big) { ACX_K1B_SH(5, true) } // saturated level-1 table: both tests for every position
-        else { ACX_K1B_SH(5, false) }
+        // (saturated level-1 table: both tests for every position; a table that passes nearly every position -- 10^6 patterns --:
+        // ... and the survivors' windows from the staged row, not from HBM)
+        if (A.filter_big >= 2) { ACX_K1B_SH(5, 2) }
+        else if (A.filter_big) { ACX_K1B_SH(5, 1) }
+        else { ACX_K1B_SH(5, 0) }
         break;
     }
 #undef ACX_K1B_SH
