@@ -723,7 +723,8 @@ int bits_for(uint64_t x) { // number of bits needed to represent x
 // K0 takes the call when the haystack is small and nobody asked for a particular scan kernel
 bool small_ok(const acx_automaton *a, uint64_t len) {
     static const bool off = std::getenv("ACX_NO_SMALL") != nullptr;
-    return !off && !a->kernel_forced && len > 0 && len <= SMALL_MAX_LEN && a->host.n_patterns > 0;
+    return !off && !a->kernel_forced && len > 0 && a->host.n_patterns > 0 &&
+           (len <= SMALL_MAX_LEN || (len <= SMALL_PF_MAX_LEN && small_prefilter_ok(a->dev)));
 }
 
 // One K0 launch + one sync.  hay / out: anything the device can address (HBM or pinned host);
@@ -1999,7 +2000,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
         // memory in place), one sync -- no H2D / D2H copies at all
         Workspace &w = c->ws;
         if (!w.pin_hay) {
-            HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_MAX_LEN + 16, hipHostMallocDefault));
+            HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_PF_MAX_LEN + 32, hipHostMallocDefault));
             // (read by the host as soon as the kernel's sequence number shows up: system-coherent)
             HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocCoherent));
         }
@@ -2018,7 +2019,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                 if (!small_polls()) std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
                 else for (uint64_t i = 0; i < n; i++) {
                     const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
-                    m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = v >> 48;
+                    m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = (v >> 48) + 1;
                 }
                 *out = m;
             }

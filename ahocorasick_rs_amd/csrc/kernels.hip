@@ -3366,7 +3366,7 @@ constexpr uint32_t K0_LT_ENTRIES = 8192, K0_LT_IDS = 2048;
 // sequence number in front and a checksum of its middle keyed with that number at the end needs none: the host takes it
 // when the first word shows the call's number and the last one agrees with the middle as the host read it (no assumption
 // about the order in which the line's four 16-byte pieces become visible).  A packed match:
-// pattern : 32 | start : 16 | end : 16 (a K0 haystack has at most 16 384 bytes).  More matches than the line holds go,
+// pattern : 32 | start : 16 | end - 1 : 16 (a K0 haystack has at most 65 536 bytes; a match is not empty).  More matches than the line holds go,
 // packed, to out[] first, behind a system-scope fence.
 constexpr uint32_t K0_LINE_MATCHES = ACX_K0_LINE_MATCHES;
 static_assert(K0_LINE_MATCHES + 3 == K0_LINE_WORDS, "seq, totals, matches, seq");
@@ -3394,12 +3394,20 @@ __device__ __forceinline__ void k0_publish_line(uint64_t *line, uint32_t t, uint
 // costs ~0.3 us there (measured: the kernel took 6.8 us without matches, 8.8 with one 4-byte match, 12.9 with four).
 // MODE 0: the automaton's tables in global memory; MODE 1 (LT above): staged in LDS.
 constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
+// MODE 3 (round 5), the prefilter: haystacks of up to SMALL_PF_MAX_LEN bytes (64 KiB: a packed match carries 16-bit
+// offsets) over any set K1b's tables exist for and that has no 1- or 2-byte patterns.  The occurrences are found
+// the way K1b finds them -- level 1 on every pair of positions (one 8-byte read of the {X, Y} table per pair: from global
+// memory here, 128 KiB, L2-resident; the haystack is in LDS), the exact prefix table for the survivors, ONE 16-byte
+// pattern-info load per candidate -- instead of an anchored walk from every position, which is a chain of dependent table
+// gathers per position and what a call on a large automaton cost: 16 KiB took 38 us, and beyond 16 KiB the call went to
+// the three-kernel pipeline (64 KiB: 63 us).  A position costs one independent gather, whatever the automaton's size.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
                                                  uint32_t len, int key_mode, int overlapping,
                                                  int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq) {
-    __shared__ __attribute__((aligned(16))) uint8_t sh[SMALL_MAX_LEN + 16];
-    constexpr bool LT = MODE == 1, DC = MODE == 2;
+    constexpr bool LT = MODE == 1, DC = MODE == 2, PF = MODE == 3;
+    constexpr uint32_t MAXLEN = PF ? SMALL_PF_MAX_LEN : SMALL_MAX_LEN; // bytes the haystack's LDS image holds
+    __shared__ __attribute__((aligned(16))) uint8_t sh[MAXLEN + 32];
     __shared__ uint32_t ltab[LT ? K0_LT_ENTRIES : 1], lown1[LT ? K0_LT_IDS : 1], lrank[LT ? K0_LT_IDS : 1], llevel[LT ? 258 : 1];
     __shared__ uint64_t plo[DC ? K0_DC_PATTERNS : 1], phi[DC ? K0_DC_PATTERNS : 1]; // DC: the patterns' bytes, masked to their length
     __shared__ uint32_t pl[DC ? K0_DC_PATTERNS : 1], prk[DC ? K0_DC_PATTERNS : 1];  // their lengths and ranks
@@ -3407,7 +3415,7 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     __shared__ uint4 occ[SMALL_MAX_OCC]; // {key lo, key hi, pid, pattern length}
     __shared__ uint16_t order[SMALL_MAX_OCC];
     __shared__ uint8_t syn[SMALL_MAX_OCC], acc[SMALL_MAX_OCC];
-    __shared__ uint32_t cpre[1025]; // code points before every 16-byte slice
+    __shared__ uint32_t cpre[MAXLEN / 16 + 1]; // code points before every 16-byte slice
     __shared__ uint32_t nocc, s_total;
     // the records, assembled here and written as a flat run of dwords: `out` may be pinned HOST memory, where every
     // store instruction's every lane is a transaction of its own -- 4 matches written field by field were 12 partial
@@ -3421,7 +3429,13 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     const bool tiny = len <= 1024;
     if (t == 0) nocc = 0;
     if (t < 256) cls[t] = A.classes[t];
-    for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
+    if (PF && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all readable)
+        for (uint32_t i = 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
+        __syncthreads();
+    } else {
+        for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
+    }
+    if (PF && t < 32) sh[len + t] = 0; // (the bytes behind the haystack are read as part of the last windows)
     if constexpr (LT) {
         const uint32_t ne = A.n_states << A.stride2;
         for (uint32_t i = t; i < ne; i += 1024) ltab[i] = A.table[i];
@@ -3463,8 +3477,70 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
             if (slot < SMALL_MAX_OCC) occ[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
         }
     }
+    if constexpr (PF) {
+        // 8 haystack bytes at any position of the LDS image (two aligned reads)
+        const uint64_t *sh64 = (const uint64_t *)sh;
+        auto ld64 = [&](uint32_t p_) -> uint64_t {
+            const uint32_t q_ = p_ >> 3, r_ = (p_ & 7) * 8;
+            const uint64_t a_ = sh64[q_], b_ = sh64[q_ + 1];
+            return r_ ? (a_ >> r_) | (b_ << (64 - r_)) : a_;
+        };
+        const uint32_t Qf = A.filter_q, GB = Qf - 1;
+        const uint32_t gmask = GB >= 4 ? 0xFFFFFFFFu : (1u << (8 * GB)) - 1u;
+        const bool any = len >= A.k1b_min_len;
+        const uint32_t last = any ? len - A.k1b_min_len : 0; // the last position a pattern can start at
+        // an occurrence of candidate `cand` with its anchor at p?  (the verification of k_tile_main; the haystack: the LDS image)
+        auto candidate = [&](uint32_t p_, uint32_t cand, uint64_t w0, uint64_t w1) {
+            uint32_t rk;
+            uint64_t ps;
+            const uint32_t L = A.max_shift ? verify_candidate<true>(A, (const uint8_t *)sh, len, p_, cand, w0, w1, len - p_, p_, &rk, &ps)
+                                           : verify_candidate<false>(A, (const uint8_t *)sh, len, p_, cand, w0, w1, len - p_, p_, &rk, &ps);
+            if (!L) return;
+            const uint32_t pid = cand & CODE_PID_MASK;
+            const uint64_t key = key_mode == 0   ? ((ps + L) << A.rank_bits) | rk
+                                 : key_mode == 1 ? (ps << A.rank_bits) | pid
+                                                 : (ps << A.rank_bits) | rk;
+            const uint32_t slot = atomicAdd(&nocc, 1u);
+            if (slot < SMALL_MAX_OCC) occ[slot] = make_uint4((uint32_t)key, (uint32_t)(key >> 32), pid, L);
+        };
+        auto survivor = [&](uint32_t p_) { // a level-1 survivor: the exact prefix table, then its candidates
+            const uint64_t w0 = ld64(p_), w1 = ld64(p_ + 8);
+            uint32_t code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            if (code == HIT_NONE) return;
+            if (code & HIT_LIST) {
+                const uint32_t li = code & ~HIT_LIST, nc = A.blist[li];
+                for (uint32_t k = 0; k < nc; k++) candidate(p_, A.blist[li + 1 + k], w0, w1);
+            } else {
+                candidate(p_, code, w0, w1);
+            }
+        };
+        // level 1 (automaton.hpp): positions j (even) and j + 1 share the row of the gram at j + 1 -- eight pairs per
+        // thread and step, their rows requested together (64 KiB: four steps)
+        const uint2 *xy = (const uint2 *)A.filterA;
+        constexpr uint32_t PPS = 8; // pairs per step
+        for (uint32_t j0 = 2 * PPS * t; any && j0 <= last; j0 += 2 * PPS * 1024) {
+            uint64_t w[PPS];
+            uint2 e[PPS];
+#pragma unroll
+            for (uint32_t k = 0; k < PPS; k++) {
+                w[k] = ld64(j0 + 2 * k); // bytes j .. j + 7 of the pair at j = j0 + 2 k
+                const uint32_t W = (uint32_t)(w[k] >> 8) & gmask;
+                e[k] = xy[filter_entry(filter_hash(W))];
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < PPS; k++) {
+                const uint32_t j = j0 + 2 * k;
+                const uint32_t W = (uint32_t)(w[k] >> 8) & gmask;
+                const uint32_t gate = (e[k].x >> (W & 31)) & 1u;
+                const bool s0 = gate && ((e[k].x >> ((uint32_t)w[k] & 31)) & 1u) && j <= last;
+                const bool s1 = gate && ((e[k].y >> ((uint32_t)(w[k] >> (8 * Qf)) & 31)) & 1u) && j + 1 <= last;
+                if (s0) survivor(j);
+                if (s1) survivor(j + 1);
+            }
+        }
+    }
     // ---- all occurrences: anchored walk from every position
-    for (uint32_t pos = t; !DC && pos < len; pos += 1024) {
+    for (uint32_t pos = t; !DC && !PF && pos < len; pos += 1024) {
         uint32_t s = 0;
         uint64_t c0 = 0, c1 = 0; // LT, tiny: the classes of the 16 bytes at pos (independent LDS reads, all in flight)
         if (LT && tiny) {
@@ -3570,7 +3646,23 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     }
     // ---- byte offset -> code point index (src/lib.rs:73-88): lead bytes before the offset
     // (a slice is one aligned 16-byte LDS read and two popcounts -- rounds 1-4 read it byte by byte)
-    if (codepoints) {
+    if (codepoints && PF && len > 16384) {
+        // (more than 1024 slices: SPT consecutive slices per thread, a block scan of the threads' sums)
+        constexpr uint32_t SPT = MAXLEN / 16 / 1024 > 0 ? MAXLEN / 16 / 1024 : 1;
+        uint32_t ls[SPT], sum = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < SPT; k++) {
+            const uint32_t o = (t * SPT + k) * 16;
+            ls[k] = o < len ? leads_in_first(*(const uint4 *)(sh + o), len - o < 16 ? len - o : 16) : 0;
+            sum += ls[k];
+        }
+        uint32_t before = 0;
+        scan_t().exclusive_scan(sum, before, 0u, scan_tmp);
+#pragma unroll
+        for (uint32_t k = 0; k < SPT; k++) { cpre[t * SPT + k] = before; before += ls[k]; }
+        if (t == 1023) cpre[1024 * SPT] = before;
+        __syncthreads();
+    } else if (codepoints) {
         uint32_t leads = 0;
         if (t * 16 < len) leads = leads_in_first(*(const uint4 *)(sh + t * 16), len - t * 16 < 16 ? len - t * 16 : 16);
         if (tiny) {
@@ -3616,7 +3708,7 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
             s = cs; e = ce;
         }
         if (seq) {
-            ((uint64_t *)img)[dst] = (uint64_t)v.z | (s << 32) | (e << 48);
+            ((uint64_t *)img)[dst] = (uint64_t)v.z | (s << 32) | ((e - 1) << 48); // (a match is not empty: end - 1 fits 16 bits up to 64 KiB)
         } else {
             uint32_t *d = img + dst * 6;
             d[0] = v.z; d[1] = 0;
@@ -3650,12 +3742,21 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
                     A.n_patterns <= K0_LT_IDS && A.max_len < 256 && !no_lt;
     const bool dc = A.n_patterns <= K0_DC_PATTERNS && A.min_len >= 1 && A.max_len <= 16 && A.pat_blob && A.pat_off &&
                     (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc;
+    // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS,
+    // from 1 KiB on (shorter: the walk's handful of gathers is as good)
+    const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > 1024));
+    if (len > SMALL_MAX_LEN && !pf) return hipErrorInvalidValue;
 #define ACX_K0(M)                                                                                                      \
     hipLaunchKernelGGL(k0_small<M>, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,            \
                        codepoints ? 1 : 0, out, res, seq)
-    if (dc) ACX_K0(2); else if (lt) ACX_K0(1); else ACX_K0(0);
+    if (pf) ACX_K0(3); else if (dc) ACX_K0(2); else if (lt) ACX_K0(1); else ACX_K0(0);
 #undef ACX_K0
     return hipGetLastError();
+}
+
+bool small_prefilter_ok(const DevAutomaton &A) {
+    static const bool off = std::getenv("ACX_K0_NO_PREFILTER") != nullptr; // (measurements)
+    return !off && A.filter_q >= 3 && A.short_min_len == 0 && A.filterA && A.ptab && A.pinfo && A.max_len < (1u << 15);
 }
 
 // ---------------------------------------------------------------------------

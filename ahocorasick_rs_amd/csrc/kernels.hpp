@@ -71,9 +71,13 @@ hipError_t sort_occurrences(void *temp, size_t temp_bytes, const uint64_t *keys_
 // SMALL_MAX_OCC occurrences, one haystack).  hay / out / res may be pinned host memory.
 // out: SMALL_MAX_OCC records; res[0] = matches written, res[1] != 0: too dense, nothing written.
 constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
+// ... up to SMALL_PF_MAX_LEN bytes for automata K0's prefilter mode takes (small_prefilter_ok: K1b's tables exist, no pattern
+// of 1 or 2 bytes): one workgroup, one launch, whatever the automaton's size
+constexpr uint32_t SMALL_PF_MAX_LEN = 65536;
+bool small_prefilter_ok(const DevAutomaton &A);
 // seq != 0 (the host polls): res is the call's RESULT LINE -- 64 aligned bytes of coherent pinned host memory, written by one
 // store instruction: [0] seq, [1] matches | too dense << 32, [2 .. 6] the first K0_LINE_MATCHES matches packed as
-// pattern | start << 32 | end << 48, [7] seq ^ k0_line_check(words 1 .. 6) -- and out[] takes the matches beyond those, packed the same way, first.
+// pattern | start << 32 | (end - 1) << 48, [7] seq ^ k0_line_check(words 1 .. 6) -- and out[] takes the matches beyond those, packed the same way, first.
 // seq == 0: out[] = acx_match_t records, res[0] / res[1] as above (device memory, read behind a stream synchronisation)
 #define ACX_K0_LINE_MATCHES 5
 constexpr uint32_t K0_LINE_WORDS = 8;
