@@ -776,8 +776,8 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
             }
         }
         for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i]; // (what the caller unpacks the matches from)
-        const uint64_t w1 = line[1];
-        if ((w1 >> 32) == 0) {
+        const uint64_t w1 = line[1]; // matches | too dense << 32 | hash of pin_out << 33
+        if (((w1 >> 32) & 1u) == 0) {
             *n_out = w1 & 0xFFFFFFFFull;
             *done = true;
             std::lock_guard<std::mutex> lk(a->prof_mu);
@@ -911,7 +911,7 @@ enum class Attempt { Done, GoDense, Again };
 // up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
 constexpr uint64_t HOT_INLINE = 128; // hot groups whose capacity the output buffer has room for anyway (1 GiB: 3 % of the groups)
 int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t ovf_max, uint64_t *seg_counts,
-            const uint64_t *cp_pre, bool *lost) {
+            const uint64_t *cp_pre, bool counts_clear, bool *lost) {
     acx_automaton *a = c.a;
     Ctx *x = c.c;
     Workspace &w = x->ws;
@@ -926,8 +926,9 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
         return ACX_OK;
     }
     uint32_t *hot_abort = (uint32_t *)(w.summary + 10);
-    HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
-    HIPCHK_RC(hipMemsetAsync(w.summary + 10, 0, 16, st));
+    // (the bucket counters and the pipeline's abort flag, summary[10]: cleared by the write kernel that announced the hot
+    // groups -- unless the buckets are allocated by this very call)
+    if (!counts_clear) HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
     HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, n_hot, abort_flag, ovf_max,
                               w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, st));
     // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
@@ -1057,8 +1058,12 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         cp_pre = w.blockpre;
     }
     const uint64_t seq = ++x->seq;
+    // (the hot pipeline's bucket counters, when a call of this context has allocated them: the write kernel clears them
+    // when it announces hot groups)
+    uint32_t *hot_counts = c.pre && w.dt.counts && c.tiles + 1 <= w.dt_cap ? w.dt.counts : nullptr;
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, st));
+                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
+                        (uint32_t)(c.tiles + 2), st));
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
     // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
@@ -1090,7 +1095,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     if (c.ovf_grown && gave_up != 2) a->path[6]++;
     if (!gave_up && n_hot) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
         bool lost = false;
-        if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, &lost)) != ACX_OK) return rc;
+        if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, hot_counts != nullptr, &lost)) != ACX_OK) return rc;
         if (lost) gave_up = 1;
         else { a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf; }
     } else if (!gave_up) {
@@ -2015,11 +2020,29 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                 if (!m) return fail(ACX_ENOMEM, "out of memory");
                 // (polled K0: the first matches ride in the result line, the others are in pin_out; all packed)
                 // (the line: the copy run_small checked, not the pinned words themselves)
-                const uint64_t *line = w.h_line + 2, *rest = (const uint64_t *)w.pin_out;
+                const uint64_t *line = w.h_line + 2;
+                volatile const uint64_t *rest = (volatile const uint64_t *)w.pin_out;
                 if (!small_polls()) std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
-                else for (uint64_t i = 0; i < n; i++) {
-                    const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
-                    m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = (v >> 48) + 1;
+                else {
+                    // pin_out and the line are separate writes of the device to host memory: the line carries a hash of what
+                    // pin_out must hold (k0_rest_mix); what is read here is taken when it agrees, read again when not
+                    const uint32_t want = (uint32_t)(w.h_line[1] >> K0_REST_HASH_SHIFT);
+                    const uint64_t sq = c->small_seq;
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (uint32_t spins = 0;; spins++) {
+                        uint32_t hx = 0;
+                        for (uint64_t i = 0; i < n; i++) {
+                            const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
+                            if (i >= ACX_K0_LINE_MATCHES) hx ^= k0_rest_mix(v, (uint32_t)(i - ACX_K0_LINE_MATCHES), sq);
+                            m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = (v >> 48) + 1;
+                        }
+                        if (n <= ACX_K0_LINE_MATCHES || hx == want) break;
+                        cpu_relax();
+                        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+                            hipError_t e = hipStreamSynchronize(c->stream); // (the kernel is over: its writes have arrived)
+                            if (e != hipSuccess || spins > (1u << 20)) { std::free(m); return fail(ACX_EDEVICE, "K0's matches did not arrive"); }
+                        }
+                    }
                 }
                 *out = m;
             }

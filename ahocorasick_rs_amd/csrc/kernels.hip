@@ -2653,6 +2653,11 @@ struct PostOut {
     // the HOT instantiation; hot_abort (pass 1 / HOT): the hot pipeline's own abort flag
     int pass;
     const uint32_t *hot_abort;
+    // pass 0, when hot groups are announced: the hot pipeline's bucket counters (DenseTiles::counts, hot_tiles of them) are
+    // cleared here, 64 per workgroup -- the workgroups are launched anyway and write nothing in that case; two host-side
+    // memsets in the pipeline's way were 16 us of every call with a hot group (null: the host clears them)
+    uint32_t *hot_counts;
+    uint32_t hot_tiles;
 };
 // HOT instantiation: one workgroup per dense group (DT_GROUP tiles) of a hot group of the sparse path
 struct HotWrite {
@@ -2732,6 +2737,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         if (t == 0) {
             O.summary[0] = tot[1]; O.summary[2] = tot[2]; O.summary[4] = tot[0];
             if (O.next_flag) { O.next_flag[CTL_ABORT] = 0; O.next_flag[CTL_OVF_LOST] = 0; O.next_flag[CTL_HOT_COUNT] = 0; }
+            if (!DENSE && O.pass == 0 && n_hot) { O.summary[10] = 0; O.summary[11] = 0; } // (the hot pipeline's flags: no memset in its way)
             O.host_out[0] = tot[1]; O.host_out[2] = tot[2]; O.host_out[4] = tot[0];
             O.host_out[5] = why;
             O.host_out[11] = ovf_max;
@@ -2741,7 +2747,15 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
         }
     }
     if (stop) return;
-    if (!HOT && !DENSE && O.pass == 0 && n_hot) return; // (the hot pipeline first: this kernel runs again behind it)
+    if (!HOT && !DENSE && O.pass == 0 && n_hot) { // (the hot pipeline first: this kernel runs again behind it)
+        if (O.hot_counts && t < GROUP_TILES) {
+            const uint32_t k = g * GROUP_TILES + t;
+            if (k < O.hot_tiles) O.hot_counts[k] = 0;
+            if (g == T.n_groups - 1 && t == 0) // (the counters beyond the last group's tiles)
+                for (uint32_t q = T.n_groups * GROUP_TILES; q < O.hot_tiles; q++) O.hot_counts[q] = 0;
+        }
+        return;
+    }
     uint32_t n;
     if constexpr (HOT) {
         if (gi >= W.n_dense) return;
@@ -2829,7 +2843,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, hipStream_t st) {
+                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, uint32_t *hot_counts, uint32_t hot_tiles,
+                     hipStream_t st) {
     const int ov = overlapping ? 1 : 0;
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
@@ -2844,7 +2859,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;
     }
-    const PostOut O{summary, (volatile uint64_t *)host_out, next_flag, seq, 0, seq, 0, nullptr};
+    const PostOut O{summary, (volatile uint64_t *)host_out, next_flag, seq, 0, seq, 0, nullptr, hot_counts, hot_tiles};
     const HotWrite W0{nullptr, nullptr, nullptr, 0};
     if (cpw)
         hipLaunchKernelGGL((k_tile_write<true, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
@@ -3250,7 +3265,7 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
                              uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
                              uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
     const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
-    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead, 0, 0, nullptr};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead, 0, 0, nullptr, nullptr, 0};
     const HotWrite W{nullptr, nullptr, nullptr, 0};
     if (cp_blockpre)
         hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
@@ -3311,7 +3326,7 @@ hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, co
                      const uint32_t *abort_flag, const uint32_t *hot_abort, uint64_t *host_out, uint64_t seq, uint64_t pub,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
     const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
-    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, seq, lead, pub, 1, hot_abort};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, seq, lead, pub, 1, hot_abort, nullptr, 0};
     const HotWrite W{hot_list, (const uint64_t *)TD.trecs, TD.btot, TD.n_groups};
     const HotWrite W0{nullptr, nullptr, nullptr, 0};
     if (cp_blockpre) {
@@ -3416,7 +3431,7 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     __shared__ uint16_t order[SMALL_MAX_OCC];
     __shared__ uint8_t syn[SMALL_MAX_OCC], acc[SMALL_MAX_OCC];
     __shared__ uint32_t cpre[MAXLEN / 16 + 1]; // code points before every 16-byte slice
-    __shared__ uint32_t nocc, s_total;
+    __shared__ uint32_t nocc, s_total, rest_hash;
     // the records, assembled here and written as a flat run of dwords: `out` may be pinned HOST memory, where every
     // store instruction's every lane is a transaction of its own -- 4 matches written field by field were 12 partial
     // writes over PCIe (measured: the kernel took 12 us on 75-byte haystacks with 4 matches, ~6 without matches)
@@ -3427,7 +3442,7 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     // (haystacks of at most 1 KiB -- one position per thread, at most 64 slices of 16 bytes: the prefix sums below are
     // one wave's shuffles instead of block scans, and an LT walk has its 16 class bytes in registers before it starts)
     const bool tiny = len <= 1024;
-    if (t == 0) nocc = 0;
+    if (t == 0) { nocc = 0; rest_hash = 0; }
     if (t < 256) cls[t] = A.classes[t];
     if (PF && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all readable)
         for (uint32_t i = 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
@@ -3720,12 +3735,22 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     const uint32_t tot = s_total;
     if (seq) {
         const uint64_t *pk = (const uint64_t *)img;
+        uint64_t word1 = tot;
         if (tot > K0_LINE_MATCHES) { // (uniform)
-            for (uint32_t k = t; k < tot - K0_LINE_MATCHES; k += 1024) ((uint64_t *)out)[k] = pk[K0_LINE_MATCHES + k];
+            // out[] and the line are separate writes to host memory: the line says what out[] must hold (k0_rest_mix)
+            uint32_t hx = 0;
+            for (uint32_t k = t; k < tot - K0_LINE_MATCHES; k += 1024) {
+                const uint64_t v = pk[K0_LINE_MATCHES + k];
+                ((uint64_t *)out)[k] = v;
+                hx ^= k0_rest_mix(v, k, seq);
+            }
+            for (int o = 32; o > 0; o >>= 1) hx ^= __shfl_xor(hx, o);
+            if ((t & 63) == 0 && hx) atomicXor(&rest_hash, hx);
             __threadfence_system();
             __syncthreads();
+            word1 |= (uint64_t)rest_hash << K0_REST_HASH_SHIFT;
         }
-        k0_publish_line(res, t, seq, tot, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+        k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
     } else {
         for (uint32_t k = t; k < tot * 6; k += 1024) ((uint32_t *)out)[k] = img[k];
         if (t == 0) *(ulonglong2 *)res = make_ulonglong2(tot, 0); // res[0] = matches, res[1] = 0: one store

@@ -76,7 +76,7 @@ constexpr uint32_t SMALL_MAX_LEN = 16384, SMALL_MAX_OCC = 1024;
 constexpr uint32_t SMALL_PF_MAX_LEN = 65536;
 bool small_prefilter_ok(const DevAutomaton &A);
 // seq != 0 (the host polls): res is the call's RESULT LINE -- 64 aligned bytes of coherent pinned host memory, written by one
-// store instruction: [0] seq, [1] matches | too dense << 32, [2 .. 6] the first K0_LINE_MATCHES matches packed as
+// store instruction: [0] seq, [1] matches | too dense << 32 | hash of out[] << 33, [2 .. 6] the first K0_LINE_MATCHES matches packed as
 // pattern | start << 32 | (end - 1) << 48, [7] seq ^ k0_line_check(words 1 .. 6) -- and out[] takes the matches beyond those, packed the same way, first.
 // seq == 0: out[] = acx_match_t records, res[0] / res[1] as above (device memory, read behind a stream synchronisation)
 #define ACX_K0_LINE_MATCHES 5
@@ -84,6 +84,17 @@ constexpr uint32_t K0_LINE_WORDS = 8;
 // the line's last word = seq ^ k0_line_check(words 1 .. 6): the host takes the line when word 0 carries the call's number AND
 // the last word agrees with the six in the middle as it read them -- whatever order the line's four 16-byte pieces arrive in,
 // a line with a stale or half-written middle is not accepted (it is polled again)
+// The matches beyond the line's (packed, in out[]) are covered too: word 1 of the line carries, above the count, a hash of
+// them (k0_rest_mix per entry, XORed): the host reads out[] behind the line and takes it when the hash agrees -- the line and
+// out[] are separate writes to host memory, and nothing orders their arrival (found in round 5 by a stress run of eight threads
+// on one handle: 1 call in ~30 000 read the PREVIOUS call's entries in out[]; until then consecutive calls with more than five
+// matches happened to carry the same ones in every test).
+__host__ __device__ inline uint32_t k0_rest_mix(uint64_t entry, uint32_t k, uint64_t seq) {
+    uint64_t x = entry ^ ((uint64_t)(k + 1) * 0x9E3779B97F4A7C15ull) ^ (seq * 0xD6E8FEB86659FD93ull);
+    x ^= x >> 29; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 32;
+    return (uint32_t)x & 0x7FFFFFFFu;
+}
+constexpr uint32_t K0_REST_HASH_SHIFT = 33; // word 1: matches (32 bits) | too dense (bit 32) | hash of out[] (31 bits)
 __host__ __device__ inline uint64_t k0_line_check(const uint64_t *mid /* words 1 .. 6 */) {
     uint64_t h = 0x9E3779B97F4A7C15ull;
     for (int i = 0; i < 6; i++) {
@@ -110,13 +121,15 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // abort_flag / next_flag: the control blocks of this call and of the next one (device_types.hpp).  hot_ok (K1b's prefix
 // hits): groups the sparse kernels cannot finish are listed for the HOT pipeline instead of aborting the call; the write
 // kernel then publishes host_out[12] = hot groups, [13] = overflow hits, [11] = the fullest overflow list and -- when there are hot groups -- writes nothing:
-// the caller runs hot_verify_main + hot_write (below) and waits for the second publication.
+// the caller runs hot_verify_main + hot_write (below) and waits for the second publication.  hot_counts (may be null): the
+// hot pipeline's bucket counters (DenseTiles::counts, hot_tiles of them), cleared by the write kernel when it announces hot groups.
 uint32_t tile_lookback(uint32_t max_len);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,
                      const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre,
-                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, hipStream_t st);
+                     const uint8_t *cp_sub, hipEvent_t before_write, bool hot_ok, uint32_t *hot_counts, uint32_t hot_tiles,
+                     hipStream_t st);
 // HOT pipeline: a dense stretch of the input costs the groups it lies in, not the call (reference behaviour: the cost
 // per byte does not depend on where the matches are, /root/reference/src/lib.rs:59).
 //   hot_verify_main  k_hot_verify: the hits of the hot groups' staged tiles (their slots + the overflow lists of the call's

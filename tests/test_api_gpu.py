@@ -171,10 +171,12 @@ def test_concurrent_searches_from_threads():
             for rep in range(6):
                 for k in range(len(hays)):
                     i = (k + t + rep) % len(hays)
-                    if automaton.find_matches_as_indexes(hays[i]) != want[i]:
-                        errors.append(("non-overlapping", t, i))
-                    if automaton.find_matches_as_indexes(hays[i], overlapping=True) != want_ov[i]:
-                        errors.append(("overlapping", t, i))
+                    for ov, expect in ((False, want[i]), (True, want_ov[i])):
+                        got = automaton.find_matches_as_indexes(hays[i], overlapping=ov)
+                        if got != expect:  # (what differs, for the record: a mismatch here has been seen once in ~30 runs)
+                            d = next((k for k, (x, y) in enumerate(zip(got, expect)) if x != y), min(len(got), len(expect)))
+                            errors.append(("overlapping" if ov else "non-overlapping", t, i, len(hays[i]), len(got), len(expect), d,
+                                           got[max(0, d - 1):d + 2], expect[max(0, d - 1):d + 2]))
         except Exception as e:  # noqa: BLE001
             errors.append(repr(e))
 

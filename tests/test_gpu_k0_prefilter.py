@@ -108,3 +108,31 @@ def test_k0_prefilter_code_points():
             assert np.array_equal(got[:, 0], want[:, 0]), (n, mk)
             assert np.array_equal(got[:, 1], b2c[want[:, 1]]) and np.array_equal(got[:, 2], b2c[want[:, 2]]), (n, mk)
             a.close()
+
+
+def test_k0_matches_beyond_the_result_line_are_this_calls():
+    """The matches beyond the fifth travel in a pinned buffer beside the result line: two separate writes to host memory that
+    nothing orders.  Eight threads on one handle, two haystacks with different matches in turn: 1 call in ~30 000 used to
+    return the PREVIOUS call's entries from the sixth on (tools/stress_threads.py found it); the line now carries a hash of
+    what the buffer must hold and the host reads again until it agrees."""
+    import threading
+    import time
+    import ahocorasick_rs_amd as ac
+    pats = gen.gen_patterns(3000, 4, 10, gen.AZ, 71)
+    hays = [gen.gen_textlike(n, 72 + i, pats, plant_every=256).tobytes() for i, n in enumerate([5000, 40_000, 9000])]
+    want = [Oracle(pats, 0, KIND_DFA).find(h) for h in hays]
+    a = ac.BytesAhoCorasick(pats)
+    errors, t_end = [], time.time() + 4.0
+
+    def worker(t):
+        k = t
+        while time.time() < t_end and not errors:
+            i = k % len(hays)
+            if a.find_matches_as_indexes(hays[i]) != want[i]:
+                errors.append((t, i))
+            k += 1
+
+    ts = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert not errors, errors[:3]

@@ -11,7 +11,7 @@ usage: summarize_profiles.py [round]"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r04"
+R = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 
@@ -22,7 +22,7 @@ def short(n):
 
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
                                                                   ("smoke.log", "bench_comparison.txt", "bench_comparison_stream_sync.txt", "ubench_stream.txt", "k0_probe.txt",
-                                                                   "exp_k0_walk_lds_bench_comparison.txt", "exp_k0_walk_global_bench_comparison.txt")]:
+                                                                   "exp_k0_no_prefilter_bench_comparison.txt", "pytest_gpu.log")]:
     if os.path.exists(f) and os.path.getsize(f):
         if f.endswith(".json"):  # (only the JSON line: RCCL prints its banner to stdout)
             lines = [l for l in open(f) if l.startswith("{")]
@@ -36,7 +36,10 @@ for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline 
                  ("cfg4", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg4"),
                  ("cfg5", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg5"),
                  ("dfa_walk", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-target-size --no-cold --kernel dfa_walk"),
-                 ("dense_D", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist D")):
+                 ("dense_D", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist D"),
+                 ("H1", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist H1"),
+                 ("H100", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist H100"),
+                 ("large", "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cold --config large")):
     src = os.path.join(SRC, f"trace_{tag}")
     if not os.path.exists(os.path.join(src, "bench_kernel_stats.csv")):
         continue
@@ -63,11 +66,11 @@ for d in sorted(os.listdir(SRC)):
     for r in csv.DictReader(open(os.path.join(SRC, d, "r_kernel_trace.csv"))):
         dur.setdefault(short(r["Kernel_Name"]), []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     keep = ("k1b_prefilter", "k1a_scan", "k1a_walk", "k1a_walk16", "k1a_dfa_walk", "k_tile_main", "k_tile_write", "k_walk_hits",
-            "k_dense_verify", "k_dense_main")
+            "k_dense_verify", "k_dense_main", "k_hot_verify")
     pmc[d] = {k: {"dispatches": len(dur.get(k, [])), "mean_duration_us": round(sum(dur[k]) / len(dur[k]), 1) if k in dur else None,
                   "mean_counters": {c: round(sum(v) / len(v)) for c, v in cs.items()}}
               for k, cs in acc.items() if k in keep}
-json.dump({"command": P + " [--dist Z | --kernel dfa_walk | --config cfg4 | --config cfg5]", "passes": pmc},
+json.dump({"command": P + " [--dist Z | --kernel dfa_walk | --config cfg4 | cfg5 | mixed | large]", "passes": pmc},
           open(os.path.join(DST, "rocprofv3_pmc.json"), "w"), indent=1)
 
 
