@@ -304,6 +304,8 @@ private:
 };
 
 // ---------------------------------------------------------------------------
+// pinned host scratch of a context, in 64-bit words (Workspace::h_pinned)
+constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PINNED_WORDS = 64;
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -320,8 +322,12 @@ struct Workspace {
                                       // hits, [4] matches written, [5..6] abort flags of the sparse path
     uint64_t *block_counts = nullptr; // device: one per scan workgroup
     uint64_t *region_off = nullptr;   // device: exclusive prefix of the kept counts
-    uint64_t *h_pinned = nullptr;     // pinned host scratch (32 x u64; [8], [9] = result of K0; [7] = seq; [16 .. 23] = K0's
-                                      // polled result line, 64-byte aligned)
+    uint64_t *h_pinned = nullptr;     // pinned host scratch (PINNED_WORDS x u64, 64-byte lines): [0 .. 15] the dense paths' totals
+                                      // (copied behind a stream synchronisation; [8], [9] = result of an unpolled K0), then the
+                                      // POLLED lines, each written by one store and accepted on its check word (kernels.hpp):
+                                      // [16 .. 23] K0's result, [24 .. 31] the sparse path's totals, [32 .. 39] the hot pipeline's
+                                      // early total (hot_totals)
+    uint64_t t_line[8] = {};          // the sparse path's totals: the verified copy of the line (PIN_TOTALS / PIN_HOT_TOTALS)
     uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
@@ -371,8 +377,8 @@ struct Ctx {
     bool post_pending = false; // profiling: ev[2] of the last call has not been read yet
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
-    uint64_t seq = 0;          // sequence number the scan kernel publishes to h_pinned[7]
-    uint64_t small_seq = 0;    // K0 (host entry point): the number it puts at both ends of its result line (h_pinned[16 .. 23])
+    uint64_t seq = 0;          // sequence number the write kernel publishes in the totals' line (h_pinned + PIN_TOTALS)
+    uint64_t small_seq = 0;    // K0 (host entry point): the number its result line carries (h_pinned + PIN_K0)
 };
 
 } // namespace
@@ -559,8 +565,8 @@ int ensure_common(Ctx *c) {
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
         // polled by the host while kernels still run: system-coherent
-        HIPCHK(hipHostMalloc((void **)&w.h_pinned, 256, hipHostMallocCoherent));
-        std::memset(w.h_pinned, 0, 256);
+        HIPCHK(hipHostMalloc((void **)&w.h_pinned, PINNED_WORDS * 8, hipHostMallocCoherent));
+        std::memset(w.h_pinned, 0, PINNED_WORDS * 8);
         w.flags_dirty = true;
     }
     return ACX_OK;
@@ -745,6 +751,8 @@ bool small_polls() {
     return !no_poll;
 }
 
+int wait_line(Ctx *c, uint32_t at, uint64_t seq, uint64_t line[8], const char *what); // (below)
+
 int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
               acx_match_t *out, uint64_t *n_out, bool *done, bool poll = false) {
     *done = false;
@@ -754,27 +762,13 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     const uint64_t seq = poll && small_polls() ? ++c->small_seq : 0;
     HIPCHK(launch_small(view(a, overlapping != 0), hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        seq ? w.h_pinned + 16 : w.h_pinned + 8, seq, c->stream));
+                        seq ? w.h_pinned + PIN_K0 : w.h_pinned + 8, seq, c->stream));
     if (seq) {
         // the result line (kernels.hpp): complete when its first word carries this call's number and its last word
-        // agrees with the six in between AS READ HERE (a copy is checked and used: nothing is read twice)
-        volatile uint64_t *p = w.h_pinned + 16;
+        // agrees with the six in between as read (wait_line: a copy is checked and used)
         uint64_t line[K0_LINE_WORDS];
-        auto complete = [&]() -> bool {
-            if (p[0] != seq) return false;
-            std::atomic_thread_fence(std::memory_order_acquire);
-            for (uint32_t i = 1; i < K0_LINE_WORDS; i++) line[i] = p[i];
-            return line[K0_LINE_WORDS - 1] == (seq ^ k0_line_check(line + 1));
-        };
-        const auto t0 = std::chrono::steady_clock::now();
-        for (uint32_t spins = 0; !complete(); spins++) {
-            cpu_relax();
-            if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
-                HIPCHK(hipStreamSynchronize(c->stream));
-                if (!complete()) return fail(ACX_EDEVICE, "K0 did not publish its result");
-                break;
-            }
-        }
+        int rc = wait_line(c, PIN_K0, seq, line, "K0 did not publish its result");
+        if (rc) return rc;
         for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i]; // (what the caller unpacks the matches from)
         const uint64_t w1 = line[1]; // matches | too dense << 32 | hash of pin_out << 33
         if (((w1 >> 32) & 1u) == 0) {
@@ -836,22 +830,30 @@ void add_scan_profile(acx_automaton *a, Ctx *c, uint64_t len, bool timed) {
     c->ev_pair ^= 1;
 }
 
-// Wait until the scan kernel has published sequence number `seq` to pinned host memory.  The
-// wake-up of a blocking stream synchronisation costs 10-20 us; polling the word the kernel
-// writes costs one PCIe round trip.  Falls back to the stream after a few milliseconds.
-int wait_published(Ctx *c, uint64_t seq, int word = 7) {
-    volatile uint64_t *p = c->ws.h_pinned;
+// Wait until a kernel has published the line that carries `seq` at pinned word `at` (kernels.hpp, k0_line_check: one
+// 64-byte line, one store instruction, [0] seq, [1 .. 6] payload, [7] seq ^ check(payload)) and take a COPY of it: the line
+// is complete when its first word carries the number and its last word agrees with the six in between AS READ HERE --
+// nothing is read twice, and nothing beside the line is read at all (separate device writes to host memory arrive in no
+// particular order).  The wake-up of a blocking stream synchronisation costs 10-20 us; polling costs one PCIe round trip.
+// Falls back to the stream after a few milliseconds.
+int wait_line(Ctx *c, uint32_t at, uint64_t seq, uint64_t line[8], const char *what) {
+    volatile uint64_t *p = c->ws.h_pinned + at;
+    auto complete = [&]() -> bool {
+        if (p[0] != seq) return false;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (uint32_t i = 1; i < 8; i++) line[i] = p[i];
+        return line[7] == (seq ^ k0_line_check(line + 1));
+    };
     const auto t0 = std::chrono::steady_clock::now();
-    for (uint32_t spins = 0; p[word] != seq; spins++) {
+    for (uint32_t spins = 0; !complete(); spins++) {
         cpu_relax();
-        if ((spins & 1023) == 1023 &&
-            std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
             HIPCHK(hipStreamSynchronize(c->stream));
-            if (p[word] != seq) return fail(ACX_EDEVICE, "the scan kernel did not publish its totals");
+            if (!complete()) return fail(ACX_EDEVICE, what);
             break;
         }
     }
-    std::atomic_thread_fence(std::memory_order_acquire);
+    line[0] = seq;
     return ACX_OK;
 }
 
@@ -936,10 +938,11 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * GROUP_MAX + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
     if (bound > w.final_cap) {
         const uint64_t pub_t = seq | (1ull << 62);
-        HIPCHK_RC(hot_totals(T, seq, w.h_pinned, pub_t, st));
-        int rc = wait_published(x, pub_t, 15);
+        HIPCHK_RC(hot_totals(T, seq, w.h_pinned + PIN_HOT_TOTALS, pub_t, st));
+        uint64_t early[8];
+        int rc = wait_line(x, PIN_HOT_TOTALS, pub_t, early, "the hot pipeline did not publish its total");
         if (rc) return rc;
-        const uint64_t n = std::min<uint64_t>(w.h_pinned[14], bound); // (meaningless when the pipeline gave up: bounded all the same)
+        const uint64_t n = std::min<uint64_t>(early[1], bound); // (meaningless when the pipeline gave up: bounded all the same)
         if (n >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
         if (n > w.final_cap) {
             HIPCHK_RC(hipStreamSynchronize(st));
@@ -954,11 +957,11 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) x->dense_hold = 8;
     const uint64_t pub = seq | (1ull << 63);
     HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, w.final, w.summary,
-                        abort_flag, hot_abort, w.h_pinned, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
+                        abort_flag, hot_abort, w.h_pinned + PIN_TOTALS, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
     if (c.early_event && c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st)); // (again: behind the kernels queued since)
-    int rc = wait_published(x, pub);
+    int rc = wait_line(x, PIN_TOTALS, pub, w.t_line, "the write kernel did not publish its totals");
     if (rc) return rc;
-    if (w.h_pinned[5] != 0) {
+    if ((w.t_line[4] & 0xFF) != 0) {
         c.no_dense_tiles = true;
         *lost = true;
     }
@@ -1062,7 +1065,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // when it announces hot groups)
     uint32_t *hot_counts = c.pre && w.dt.counts && c.tiles + 1 <= w.dt_cap ? w.dt.counts : nullptr;
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
-                        next_flag, w.h_pinned, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
+                        next_flag, w.h_pinned + PIN_TOTALS, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
                         (uint32_t)(c.tiles + 2), st));
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
@@ -1073,11 +1076,13 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         if (c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st));
         c.event_at_post = c.r->done != nullptr;
     }
-    if ((rc = wait_published(x, seq)) != ACX_OK) return rc;
+    if ((rc = wait_line(x, PIN_TOTALS, seq, w.t_line, "the write kernel did not publish its totals")) != ACX_OK) return rc;
     w.flags_dirty = false; // the write kernel left the next control block clean
     add_scan_profile(a, x, c.len, c.timed);
-    uint64_t gave_up = w.h_pinned[5];
-    const uint64_t n_hot = w.h_pinned[12], n_ovf = w.h_pinned[13], ovf_max = w.h_pinned[11];
+    // the line (k_tile_write): [1] matches, [2] occurrences, [3] prefix hits, [4] why | hot groups << 8, [5] overflow hits |
+    // the fullest overflow list << 32
+    uint64_t gave_up = w.t_line[4] & 0xFF;
+    const uint64_t n_hot = w.t_line[4] >> 8, n_ovf = w.t_line[5] & 0xFFFFFFFFull, ovf_max = w.t_line[5] >> 32;
     if (gave_up == 2 && !c.ovf_grown && ovf_max * OVF_LISTS <= 3 * c.tiles * HIT_SLOTS + (OVF_LISTS << 12)) {
         // K1b found more hits beyond their tiles' slots than an overflow list holds (nothing else is wrong): with lists
         // of the size this input needs the sparse kernels + the hot pipeline take it -- again, once
@@ -1113,9 +1118,9 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         *what = Attempt::GoDense;
         return ACX_OK;
     }
-    c.n_raw = w.h_pinned[0];
-    c.n_hits = w.h_pinned[2];
-    c.n_final = w.h_pinned[4];
+    c.n_raw = w.t_line[2]; // (the hot pipeline's second publication when it ran)
+    c.n_hits = w.t_line[3];
+    c.n_final = w.t_line[1];
     c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
     w.final = nullptr;
     c.localized = seg_counts != nullptr;
@@ -1184,7 +1189,7 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     if (seg_counts && (rc = zero_counts(c)) != ACX_OK) return rc;
-    HIPCHK_RC(dense_tiles_write(a->dev, c.key_mode, w.TD, c.d_hay, c.r->d_matches, w.summary, zero_flag, w.h_pinned, c.lead,
+    HIPCHK_RC(dense_tiles_write(a->dev, c.key_mode, w.TD, c.d_hay, c.r->d_matches, w.summary, zero_flag, w.h_pinned + PIN_TOTALS, c.lead,
                                 c.G, seg_counts, nullptr, nullptr, st));
     c.localized = seg_counts != nullptr;
     c.queued = true;

@@ -2625,9 +2625,8 @@ __device__ __forceinline__ uint64_t code_point_of(const uint8_t *__restrict__ ha
 // dwords (coalesced).  The stretch starts at the sum of the counts of the groups in front (the
 // full supergroups' words + the counts of the groups in front inside the own supergroup).
 // Group 0 -- the first to run -- adds up ALL supergroup words and publishes the call's totals
-// {[0] occurrences, [2] prefix hits, [4] matches, [5] aborted, [7] seq} to host_out (pinned,
-// system-coherent host memory the host polls: seq is written last, behind a system-scope
-// fence), mirrors them in `summary`, clears the abort flag and the supergroup words the NEXT
+// to host_out (pinned, system-coherent host memory the host polls: ONE self-checking line,
+// publish_line below), mirrors them in `summary`, clears the abort flag and the supergroup words the NEXT
 // call will use: the host returns while the records are still being written (they are consumed
 // in stream order).
 // seg_counts != null (batch of haystacks, byte offsets): the records get offsets local to
@@ -2640,13 +2639,30 @@ constexpr uint32_t WRITE_THREADS = 256;
 constexpr uint32_t WRITE_CHUNK = 256;
 // cp.blockpre != null (str API, one haystack): byte offsets -> code-point indexes on the way out.
 struct CodePointTables { const uint8_t *hay; const uint64_t *blockpre; const uint8_t *sub; const uint32_t *pchars; };
+// ONE aligned 64-byte line of coherent pinned host memory, written by ONE store instruction (four lanes x 16 bytes): [0] seq,
+// [1 .. 6] payload, [7] seq ^ k0_line_check(payload).  The host polls word 0 and takes a COPY of the line when the last
+// word agrees with the payload as read: separate writes to host memory arrive in no particular order (round 5: K0's matches
+// beside its line did not, 1 call in ~30 000), so everything a poller reads is one such line -- the totals of the sparse path
+// too (until round 5: eight words, a system-scope fence, then the number).
+__device__ __forceinline__ void publish_line(volatile uint64_t *line, uint32_t t, uint64_t seq, const uint64_t (&mid)[6]) {
+    if (t >= 4) return;
+    const uint64_t last = seq ^ k0_line_check(mid);
+    uint64_t w[2];
+#pragma unroll
+    for (uint32_t k = 0; k < 2; k++) {
+        const uint32_t i = 2 * t + k;
+        w[k] = i == 0 ? seq : i == 7 ? last : mid[i - 1 > 5 ? 5 : i - 1];
+    }
+    ((ulonglong2 *)line)[t] = make_ulonglong2(w[0], w[1]);
+}
 struct PostOut {
     uint64_t *summary;           // device mirror of the totals
-    volatile uint64_t *host_out; // pinned host memory the host polls
+    volatile uint64_t *host_out; // pinned host memory the host polls: ONE line (publish_line): [1] matches, [2] occurrences, [3] prefix
+                                 // hits, [4] why | hot groups << 8, [5] overflow hits | fullest overflow list << 32
     uint32_t *next_flag;         // the control block of the NEXT call: left clear
     uint64_t seq;                // this call's sequence number (its parity selects the set of supergroup words)
     uint32_t lead;               // DENSE: index = stream position + lead
-    uint64_t pub;                // what group 0 writes to host_out[7] behind the totals (pass 0: seq)
+    uint64_t pub;                // the number group 0's line carries (pass 0: seq)
     // pass 0: the call's first (normally only) write kernel -- when k_tile_main left groups to the hot pipeline it only
     // publishes {[12] hot groups, [13] overflow hits} and writes nothing; pass 1: the write kernel behind the hot
     // pipeline -- the hot groups' counts are in T.btot / the supergroup words by then, their records are written by
@@ -2690,7 +2706,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     }
     // (the flags are stable by now: their writers completed)
     bool stop;
-    uint32_t n_hot = 0, n_ovf = 0, why = 0; // why (host_out[5]): 1 the call gave up, 2 only the overflow list was too small
+    uint32_t n_hot = 0, n_ovf = 0, why = 0; // why (the line's word 4): 1 the call gave up, 2 only the overflow list was too small
     if (HOT || O.pass == 1) {
         stop = *O.hot_abort != 0;
         why = stop ? 1 : 0;
@@ -2738,13 +2754,10 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
             O.summary[0] = tot[1]; O.summary[2] = tot[2]; O.summary[4] = tot[0];
             if (O.next_flag) { O.next_flag[CTL_ABORT] = 0; O.next_flag[CTL_OVF_LOST] = 0; O.next_flag[CTL_HOT_COUNT] = 0; }
             if (!DENSE && O.pass == 0 && n_hot) { O.summary[10] = 0; O.summary[11] = 0; } // (the hot pipeline's flags: no memset in its way)
-            O.host_out[0] = tot[1]; O.host_out[2] = tot[2]; O.host_out[4] = tot[0];
-            O.host_out[5] = why;
-            O.host_out[11] = ovf_max;
-            O.host_out[12] = n_hot; O.host_out[13] = n_ovf;
-            __threadfence_system();
-            O.host_out[7] = O.pub;
         }
+        // (every thread holds the totals: lanes 0 .. 3 write the line)
+        const uint64_t mid[6] = {tot[0], tot[1], tot[2], (uint64_t)why | ((uint64_t)n_hot << 8), (uint64_t)n_ovf | ((uint64_t)ovf_max << 32), 0};
+        publish_line(O.host_out, t, O.pub, mid);
     }
     if (stop) return;
     if (!HOT && !DENSE && O.pass == 0 && n_hot) { // (the hot pipeline first: this kernel runs again behind it)
@@ -2837,7 +2850,7 @@ uint32_t tile_lookback(uint32_t max_len) {
 }
 
 // Verify, order, resolve and compact the hits of the whole call into out[] (capacity
-// n_groups * GROUP_MAX suffices).  host_out[5] != 0 afterwards: the output did not fit the sparse
+// n_groups * GROUP_MAX suffices).  The published line's `why` != 0 afterwards: the output did not fit the sparse
 // path and out[] / the totals are meaningless.
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
@@ -3298,7 +3311,7 @@ hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping
 }
 
 // the call's matches once the hot groups' counts are in (the supergroup words of the call's set), for a caller that sizes
-// the output exactly: host_out[14] = matches, then host_out[15] = pub behind a system-scope fence
+// the output exactly: host_out = ONE line (publish_line), [1] = matches
 __global__ void k_hot_totals(TileSpace S, uint64_t seq, volatile uint64_t *host_out, uint64_t pub) {
     uint64_t m = 0;
     const uint64_t *sgw = S.sgw + (seq & 1) * 2 * (uint64_t)S.sg_cap;
@@ -3308,11 +3321,8 @@ __global__ void k_hot_totals(TileSpace S, uint64_t seq, volatile uint64_t *host_
     __shared__ uint64_t red[4];
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        host_out[14] = red[0] + red[1] + red[2] + red[3];
-        __threadfence_system();
-        host_out[15] = pub;
-    }
+    const uint64_t mid[6] = {red[0] + red[1] + red[2] + red[3], 0, 0, 0, 0, 0};
+    publish_line(host_out, threadIdx.x, pub, mid);
 }
 hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint64_t pub, hipStream_t st) {
     hipLaunchKernelGGL(k_hot_totals, dim3(1), dim3(256), 0, st, S, seq, (volatile uint64_t *)host_out, pub);

@@ -108,9 +108,11 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write
-// kernel publishes {[0] occurrences, [2] prefix hits, [4] matches, [5] aborted, [7] seq} to
-// host_out (pinned host memory; [7] = seq is written last, the host may poll it while the write
-// kernel still runs) and clears *next_flag for the next call.  seq: the context's call counter
+// kernel publishes the call's totals as ONE 64-byte line of pinned host memory, one store instruction -- host_out:
+// {[0] seq, [1] matches, [2] occurrences, [3] prefix hits, [4] why (1 aborted, 2 an overflow list was too small) | hot
+// groups << 8, [5] overflow hits | the fullest overflow list << 32, [6] 0, [7] seq ^ k0_line_check([1 .. 6])}; the host may
+// poll it while the write kernel still runs and takes the line when its check word agrees (round 5; until then eight
+// separate words, a fence, then seq) -- and clears *next_flag for the next call.  seq: the context's call counter
 // (its parity selects the set of supergroup words, TileSpace::sgw).  Aborted: the output did not fit
 // the slots, out[] and the totals are meaningless.  seg_counts != null (batch, byte offsets):
 // offsets are made local to the match's haystack (G) and the per-haystack counts are accumulated
@@ -120,7 +122,7 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // chunks + what k_tile_main carried over of the start's own chunk: no haystack access).
 // abort_flag / next_flag: the control blocks of this call and of the next one (device_types.hpp).  hot_ok (K1b's prefix
 // hits): groups the sparse kernels cannot finish are listed for the HOT pipeline instead of aborting the call; the write
-// kernel then publishes host_out[12] = hot groups, [13] = overflow hits, [11] = the fullest overflow list and -- when there are hot groups -- writes nothing:
+// kernel then -- when its line announces hot groups -- writes nothing:
 // the caller runs hot_verify_main + hot_write (below) and waits for the second publication.  hot_counts (may be null): the
 // hot pipeline's bucket counters (DenseTiles::counts, hot_tiles of them), cleared by the write kernel when it announces hot groups.
 uint32_t tile_lookback(uint32_t max_len);
@@ -138,9 +140,9 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 //                    dense groups (HOT_SUB each): records in TD.trecs, counts in TD.btot AND credited to the hot group in
 //                    S.btot / the supergroup words of the call's set.  *hot_abort != 0: a bucket overflowed or a chain left
 //                    its context (the caller redoes the call on the radix-sort form of the dense path)
-//   hot_totals       host_out[14] = the call's matches, [15] = pub (for a caller that sizes the output exactly)
+//   hot_totals       host_out: one 64-byte line (seq, payload, check): [1] = the call's matches (for a caller that sizes the output exactly)
 //   hot_write        the hot groups' records, then the sparse path's write kernel again: every group placed with all
-//                    counts in; host_out {[0], [2], [4] totals, [5] = *hot_abort, [7] = pub}
+//                    counts in; host_out: the totals' line again ([4] = *hot_abort != 0), seq = pub
 hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
                            const uint32_t *hot_list, uint32_t n_hot, const uint32_t *ctl, uint32_t ovf_max, const DenseTiles &D,
                            const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
