@@ -41,6 +41,18 @@ int fail(int code, const std::string &msg) {
     g_err = msg;
     return code;
 }
+// The device's occurrence indexes are 32 bits wide: a call that would enumerate more is cut into byte ranges (run_chunked).
+// The limit of ONE pass (ACX_MAX_OCC lowers it: tests) and what a pass returns when it hits it -- run_find's business,
+// never the caller's.
+constexpr int TOO_MANY_OCC = -1006;
+uint64_t occ_limit() {
+    const char *e = std::getenv("ACX_MAX_OCC");
+    const uint64_t hard = (1ull << 32) - 2;
+    if (!e) return hard;
+    const uint64_t v = std::strtoull(e, nullptr, 10);
+    return v && v < hard ? v : hard;
+}
+int fail_occ() { return fail(TOO_MANY_OCC, "more than 2^32 occurrences in one pass"); }
 int hipfail(hipError_t e, const char *what) {
     (void)hipGetLastError(); // the runtime's "last error" is sticky: the next launch check must not see this one
     return fail(e == hipErrorOutOfMemory ? ACX_ENOMEM : ACX_EDEVICE, std::string(what) + ": " + hipGetErrorString(e));
@@ -556,7 +568,7 @@ struct Lease {
 int ensure_common(Ctx *c) {
     Workspace &w = c->ws;
     if (!w.summary) {
-        HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline
+        HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline, [12], [13] the cut of a byte range
         HIPCHK(hipMalloc((void **)&w.ctl, 2 * CTL_WORDS * 4));
         HIPCHK(hipMemset(w.ctl, 0, 2 * CTL_WORDS * 4));
         HIPCHK(hipMalloc((void **)&w.ovf_counts, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
@@ -943,7 +955,13 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
         int rc = wait_line(x, PIN_HOT_TOTALS, pub_t, early, "the hot pipeline did not publish its total");
         if (rc) return rc;
         const uint64_t n = std::min<uint64_t>(early[1], bound); // (meaningless when the pipeline gave up: bounded all the same)
-        if (n >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+        if (n >= occ_limit()) {
+            // (the call goes on in byte ranges on this context: the control blocks and both sets of supergroup words clear again)
+            w.flags_dirty = true;
+            HIPCHK_RC(hipStreamSynchronize(st));
+            HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
+            return fail_occ();
+        }
         if (n > w.final_cap) {
             HIPCHK_RC(hipStreamSynchronize(st));
             g_bufs.put(w.final, a->device);
@@ -1177,6 +1195,7 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
         return ACX_OK;
     }
     const uint64_t n_final = w.h_pinned[8], n_raw = w.h_pinned[9];
+    if (std::max(n_raw, w.h_pinned[2]) >= occ_limit()) return fail_occ(); // (the tiles' counts and their prefixes are 32 bits wide)
     if (n_raw > 8 * c.tiles) x->dense_hold = 8;
     else if (x->dense_hold > 0) x->dense_hold--;
     c.n_raw = n_raw;
@@ -1274,7 +1293,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
             HIPCHK_RC(hipMemcpyAsync(w.h_pinned + 10, bases + grid, 8, hipMemcpyDeviceToHost, st));
             HIPCHK_RC(hipStreamSynchronize(st));
             c.exact_total = w.h_pinned[10];
-            if (c.exact_total >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+            if (c.exact_total >= occ_limit()) return fail_occ();
             // (an eighth of headroom: the NEXT call's uniform regions -- capacity / grid each -- then hold an
             // output that is spread as evenly as this one, and it needs no second pass)
             if ((rc = ensure_occ_capacity(x, c.exact_total + c.exact_total / 8 + 64 * (uint64_t)grid)) != ACX_OK) return rc;
@@ -1283,7 +1302,7 @@ int attempt_dense(FindCall &c, Attempt *what) {
         *what = Attempt::Again;
         return ACX_OK;
     }
-    if (n_raw >= (1ull << 32) - 2) return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+    if (n_raw >= occ_limit()) return fail_occ();
     if (n_raw > 8 * c.tiles) x->dense_hold = 8;
     else if (x->dense_hold > 0) x->dense_hold--;
     c.n_raw = n_raw;
@@ -1393,8 +1412,10 @@ int run_pipeline(FindCall &c) {
 }
 
 // d_hay must stay valid until the result's device work is done (acx_result accessors wait for it)
+int run_chunked(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, int overlapping, int codepoints,
+                acx_result **out, bool wait, uint64_t piece, int depth);
 int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G,
-             int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait) {
+             int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait, int depth = 0) {
     *out = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
         static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
@@ -1448,12 +1469,109 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
     };
     c.early_event = !wait;
     c.timed = a->prof && (a->prof_every <= 1 || (x->prof_calls++ % (uint32_t)a->prof_every) == 0);
-    const int rc = body();
+    // (tests: ACX_CHUNK_BYTES cuts every one-haystack call longer than that, whatever it holds)
+    const char *cb = depth == 0 && !segmented ? std::getenv("ACX_CHUNK_BYTES") : nullptr;
+    const uint64_t forced = cb ? std::strtoull(cb, nullptr, 10) : 0;
+    int rc = forced && len > forced ? TOO_MANY_OCC : body();
     if (rc != ACX_OK) {
         (void)hipStreamSynchronize(st);
         acx_free_result(r);
-        return rc;
+        if (rc != TOO_MANY_OCC) return rc;
+        // more occurrences than one pass can index: the haystack in byte ranges, one after the other (a batch is the
+        // caller's to cut -- at a haystack boundary, where nothing has to be carried over)
+        const uint64_t m = a->host.max_len ? a->host.max_len - 1 : 0;
+        const uint64_t piece = forced && len > forced ? forced : len / 2;
+        if (segmented || depth >= 40 || piece <= 2 * m + 16)
+            return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
+        return run_chunked(a, x, d_hay, len, overlapping, codepoints, out, wait, piece, depth + 1);
     }
+    *out = r;
+    return ACX_OK;
+}
+
+// One haystack in byte ranges of `piece` bytes, searched one after the other; the pieces' matches, cut where the ranges
+// meet, are copied into one result with global offsets.  The reference's loop has no limit on what it reports
+// (/root/reference/src/lib.rs:53, 59: an iterator); one pass here has -- 2^32 occurrences, the width of the device's
+// indexes.  What couples the ranges is what couples the ranks of a sharded haystack (distributed.py):
+//   overlapping      a range reports the occurrences that END in (lo, hi]; it is scanned from max_len - 1 bytes before lo;
+//   non-overlapping  a range reports the matches that START in [carry, hi): the iteration resumes at `carry`, the end of
+//                    the last match in front (or lo); a match that starts before hi ends at most max_len - 1 bytes behind
+//                    it, so the scan stops there, and nothing the truncated window hides beats what it shows.
+// Code points (str API): the pieces run on byte offsets, the conversion runs once over the whole result.
+int run_chunked(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, int overlapping, int codepoints,
+                acx_result **out, bool wait, uint64_t piece, int depth) {
+    *out = nullptr;
+    hipStream_t st = x->stream;
+    Workspace &w = x->ws;
+    const uint64_t m = a->host.max_len ? a->host.max_len - 1 : 0;
+    struct Piece { acx_match_t *buf; uint64_t first, n, shift; };
+    std::vector<Piece> pieces;
+    auto drop = [&]() { for (auto &p : pieces) g_bufs.put(p.buf, a->device); pieces.clear(); };
+    uint64_t total = 0, carry = 0;
+    if (int rc = ensure_common(x)) return rc; // (the context's scratch: the first call of a context may be this one)
+    uint64_t *cut = w.summary + 12; // (two device words of the context's scratch)
+    for (uint64_t lo = 0; lo < len;) {
+        const uint64_t hi = std::min(len, lo + piece);
+        const bool last = hi == len;
+        uint64_t a0, a1;
+        if (overlapping) { a0 = lo > m ? lo - m : 0; a1 = hi; }
+        else { carry = std::max(carry, lo); a0 = carry; a1 = last ? len : std::min(len, hi + m); }
+        if (a0 >= hi) { lo = hi; continue; } // (a match from the ranges in front covers this one)
+        acx_result *r = nullptr;
+        a->path[8]++;
+        int rc = run_find(a, x, d_hay + a0, a1 - a0, Segments{nullptr, 1, 0}, overlapping, 0, &r, true, true, depth);
+        if (rc != ACX_OK) { drop(); return rc; }
+        uint64_t first = 0, n = r->n, last_end = 0;
+        if (n && ((overlapping && lo > 0) || (!overlapping && !last))) {
+            // overlapping: the occurrences that end at or before lo belong to the range in front (a prefix: ordered by
+            // end); non-overlapping: the matches that start at or behind hi to the next one (a suffix: ordered by start)
+            hipError_t e = overlapping ? cut_point(r->d_matches, n, true, a0, lo + 1, cut, st)
+                                       : cut_point(r->d_matches, n, false, a0, hi, cut, st);
+            if (e == hipSuccess) e = hipMemcpyAsync(w.h_pinned + 8, cut, 16, hipMemcpyDeviceToHost, st);
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { acx_free_result(r); drop(); return hipfail(e, "cut of a byte range"); }
+            if (overlapping) first = w.h_pinned[8];
+            else { n = w.h_pinned[8]; last_end = w.h_pinned[9]; }
+        } else if (n && !overlapping) {
+            last_end = len; // (the last range: nothing follows)
+        }
+        if (n > first) {
+            pieces.push_back(Piece{r->d_matches, first, n - first, a0});
+            r->d_matches = nullptr; // (ours now)
+            total += n - first;
+        }
+        acx_free_result(r);
+        if (!overlapping) carry = std::max(std::max(carry, hi), last_end);
+        lo = hi;
+    }
+    acx_result *r = new (std::nothrow) acx_result();
+    if (!r) { drop(); return fail(ACX_ENOMEM, "out of memory"); }
+    r->device = a->device;
+    r->n = total;
+    auto body = [&]() -> int {
+        if (!total) return ACX_OK;
+        hipError_t e = g_bufs.get((void **)&r->d_matches, total * sizeof(acx_match_t), a->device);
+        if (e != hipSuccess) return hipfail(e, "result of a call in byte ranges");
+        uint64_t at = 0;
+        for (auto &p : pieces) {
+            if ((e = copy_shifted(r->d_matches + at, p.buf + p.first, p.n, p.shift, st)) != hipSuccess) return hipfail(e, "copy_shifted");
+            at += p.n;
+        }
+        if (codepoints) {
+            const Segments one{nullptr, 1, 0};
+            FindCall c{a, x, d_hay, len, one, overlapping != 0, true, false, r, 0};
+            c.n_final = total;
+            int rc = finish_matches(c);
+            if (rc) return rc;
+        }
+        return ACX_OK;
+    };
+    int rc = body();
+    hipError_t e = hipStreamSynchronize(st); // (the pieces' buffers go back to the pool: nothing may still read them)
+    drop();
+    if (rc == ACX_OK && e != hipSuccess) rc = hipfail(e, "a call in byte ranges");
+    if (rc != ACX_OK) { acx_free_result(r); return rc; }
+    (void)wait; // (synchronised either way)
     *out = r;
     return ACX_OK;
 }

@@ -3877,6 +3877,48 @@ hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *bl
 }
 
 // ---------------------------------------------------------------------------
+// a call cut into byte ranges (acx_api.cpp, run_chunked): where a piece's matches are cut, and the pieces' matches
+// copied into the call's result with their offsets made global
+// ---------------------------------------------------------------------------
+// m[0 .. n) is ordered so that {m[i].field + shift < limit} holds for a PREFIX of it (non-overlapping matches by their
+// start, overlapping occurrences by their end).  out[0] = the length of that prefix, out[1] = the end (+ shift) of its last
+// element (0 when it is empty).  One thread per element: the one that sees the border writes.
+__global__ void k_cut_point(const acx_match_t *__restrict__ m, uint64_t n, int by_end, uint64_t shift, uint64_t limit, uint64_t *out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t v = (by_end ? m[i].end : m[i].start) + shift;
+    if (v >= limit) return;
+    if (i + 1 < n) {
+        const uint64_t nx = (by_end ? m[i + 1].end : m[i + 1].start) + shift;
+        if (nx < limit) return;
+    }
+    out[0] = i + 1;
+    out[1] = m[i].end + shift;
+}
+hipError_t cut_point(const acx_match_t *m, uint64_t n, bool by_end, uint64_t shift, uint64_t limit, uint64_t *out, hipStream_t st) {
+    hipError_t e = hipMemsetAsync(out, 0, 16, st);
+    if (e != hipSuccess || !n) return e;
+    hipLaunchKernelGGL(k_cut_point, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, m, n, by_end ? 1 : 0, shift, limit, out);
+    return hipGetLastError();
+}
+// dst[0 .. n) = src[0 .. n) with start and end moved by `shift`; a thread per 64-bit word (three per match: coalesced)
+__global__ void k_copy_shifted(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, uint64_t words, uint64_t shift) {
+    const uint64_t w = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (w >= words) return;
+    dst[w] = src[w] + (w % 3 ? shift : 0);
+}
+hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, uint64_t shift, hipStream_t st) {
+    static_assert(sizeof(acx_match_t) == 24, "three words per match");
+    for (uint64_t at = 0; at < n;) { // (launches of at most 2^30 matches: the grid's 32 bits)
+        const uint64_t k = std::min<uint64_t>(n - at, 1ull << 30);
+        hipLaunchKernelGGL(k_copy_shifted, dim3((uint32_t)((3 * k + 255) / 256)), dim3(256), 0, st, (uint64_t *)(dst + at),
+                           (const uint64_t *)(src + at), 3 * k, shift);
+        at += k;
+    }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
 // batch: local offsets + per-haystack counts
 // ---------------------------------------------------------------------------
 __global__ void k_localize(Segments G, const uint8_t *__restrict__ hay, uint64_t len,

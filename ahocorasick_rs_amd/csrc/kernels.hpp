@@ -195,6 +195,13 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
 hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre, const uint8_t *sub,
                           acx_match_t *m, uint64_t n, hipStream_t st);
 
+// ---- a call cut into byte ranges (acx_api.cpp, run_chunked)
+// cut_point: m[0 .. n) ordered so that {field + shift < limit} holds for a prefix (field: start, or end when by_end):
+// out[0] = the prefix's length, out[1] = end + shift of its last element (device words; cleared here).
+// copy_shifted: dst = src with start and end moved by shift.
+hipError_t cut_point(const acx_match_t *m, uint64_t n, bool by_end, uint64_t shift, uint64_t limit, uint64_t *out, hipStream_t st);
+hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, uint64_t shift, hipStream_t st);
+
 // ---- batch: make offsets local to each haystack, count matches per haystack.
 // base_cp != nullptr: subtract the code-point index of the haystack start
 // (computed from blockpre) instead of the byte offset.

@@ -28,7 +28,7 @@ extern "C" {
  * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 6
+#define ACX_VERSION 7
 
 /* status codes */
 #define ACX_OK 0
@@ -40,10 +40,12 @@ extern "C" {
 #define ACX_ENOMEM (-4)
 #define ACX_EDEVICE (-5)     /* HIP runtime / no device / kernel failure      */
 #define ACX_ETOOBIG (-6)     /* automaton or haystack exceeds an encoding limit: 2^24 patterns, 2^30
-                                states, a haystack stream of 2^38 bytes, or a call on the dense
-                                output path that enumerates 2^32 occurrences or more before the
-                                match kind is applied (e.g. thousands of identical short patterns
-                                in a Standard set over a long haystack)                          */
+                                states, a haystack stream of 2^38 bytes.  A ONE-haystack call that
+                                would enumerate 2^32 occurrences or more in one pass (the width of the
+                                device's indexes) is cut into byte ranges that are searched one after
+                                the other (round 5; acx_path_stats [8]) -- the error remains for a
+                                BATCH that does (cut it at a haystack boundary) and for a range of
+                                ~2 * max pattern length bytes that still does                     */
 
 /* enum PyMatchKind, src/lib.rs:92-108 */
 #define ACX_MATCH_STANDARD 0
@@ -307,8 +309,9 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
  * alone, [1] calls that also ran the hot pipeline (a dense stretch of the input costs the groups it lies in, not the
  * call: reference behaviour /root/reference/src/lib.rs:59), [2] hot groups in all, [3] prefix hits beyond their tiles'
  * slots in all, [4] calls on the tile-ordered dense path, [5] calls on its radix-sort form, [6] calls that were redone
- * with a larger overflow list, [7] calls K0 answered.  reset != 0 clears the counters. */
-#define ACX_PATH_STATS 8
+ * with a larger overflow list, [7] calls K0 answered, [8] byte ranges searched for calls that were cut (more than 2^32
+ * occurrences in one pass: the pieces count in [0 .. 7] as well).  reset != 0 clears the counters. */
+#define ACX_PATH_STATS 9
 int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset);
 
 /* ---- device memory helpers so that a host without torch can stage data ---- */
