@@ -410,9 +410,16 @@ struct acx_automaton {
     // entry per state in the view) and through its trie records (grec: own1 in their third word).  Taken by the
     // kernels that read those tables (K0, k_tile_main, k_walk_hits, k_dense_verify; k1a_walk, the walks' emit
     // paths through the device-resident copy d_dev_nov) when the call is not overlapping; has_nov = false: no copies.
+    // Round 5: an OVERLAPPING search takes the view too -- one occurrence per string under its lowest id -- and the result
+    // is expanded where it is complete (expand_copies: every occurrence becomes the run of its string's copies, ids
+    // ascending, as the reference reports them): the copies cost their records, not a verification, a sort slot and a
+    // 2^32-limited index each.  x_cnt[pid] = the later copies of a lowest id (0 otherwise), x_off[pid] = where their ids
+    // begin in x_ids (host: K0's pinned result is expanded on the host; d_x*: the same in HBM).
     DevAutomaton dev_nov{};
     const DevAutomaton *d_dev_nov = nullptr;
     bool has_nov = false;
+    std::vector<uint32_t> x_cnt, x_off, x_ids;
+    const uint32_t *d_xcnt = nullptr, *d_xoff = nullptr, *d_xids = nullptr;
     std::vector<void *> allocs;
     int kernel = ACX_KERNEL_DFA_WALK;
     int implementation = ACX_IMPL_AUTO; // the caller's hint (replicas are built with the same one)
@@ -750,11 +757,14 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 // poll: hay and out are host memory the kernel reads / writes in place: wait for the number the kernel publishes
 // behind its last store instead of synchronising the stream (tools/ubench_roundtrip.hip: 6 us against 11)
 // the device tables a call takes: a non-overlapping search never needs the later copies of a string (acx_automaton::dev_nov)
+// (an overlapping search as well since round 5: its result is expanded to the copies afterwards -- expand_copies)
 inline const DevAutomaton &view(const acx_automaton *a, bool overlapping) {
-    return !overlapping && a->has_nov ? a->dev_nov : a->dev;
+    (void)overlapping;
+    return a->has_nov ? a->dev_nov : a->dev;
 }
 inline const DevAutomaton *d_view(const acx_automaton *a, bool overlapping) { // (the same, resident in HBM)
-    return !overlapping && a->has_nov ? a->d_dev_nov : a->d_dev;
+    (void)overlapping;
+    return a->has_nov ? a->d_dev_nov : a->d_dev;
 }
 
 // (ACX_SMALL_SYNC, measurements: always synchronise the stream -- and then the records are plain acx_match_t)
@@ -774,7 +784,7 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     const uint64_t seq = poll && small_polls() ? ++c->small_seq : 0;
     HIPCHK(launch_small(view(a, overlapping != 0), hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        seq ? w.h_pinned + PIN_K0 : w.h_pinned + 8, seq, c->stream));
+                        seq ? w.h_pinned + PIN_K0 : w.h_pinned + 8, seq, c->stream, !(overlapping && a->has_nov)));
     if (seq) {
         // the result line (kernels.hpp): complete when its first word carries this call's number and its last word
         // agrees with the six in between as read (wait_line: a copy is checked and used)
@@ -1411,6 +1421,49 @@ int run_pipeline(FindCall &c) {
     return ACX_OK;
 }
 
+// Overlapping search over a set with copies of a string: the pipeline ran on the view without the later copies (one
+// occurrence per string, lowest id); every occurrence becomes the run of its string's copies, ids ascending -- the order
+// the reference reports them in (one state's match list, in the order the patterns were added).  In place of r->d_matches;
+// batch: the per-haystack counts follow.  One round trip (the number of records).
+int expand_copies(acx_automaton *a, Ctx *x, acx_result *r, bool segmented) {
+    const uint64_t n = r->n;
+    if (!n) return ACX_OK;
+    hipStream_t st = x->stream;
+    Workspace &w = x->ws;
+    int rc = ensure_common(x);
+    if (rc) return rc;
+    const uint64_t n_hay = segmented ? r->n_hay : 0;
+    const size_t tb = scan_temp_bytes(std::max(n, n_hay) + 1) + 256;
+    void *temp = nullptr;
+    uint64_t *k = nullptr, *offs = nullptr, *incl = nullptr;
+    acx_match_t *out = nullptr;
+    auto done = [&](int code) -> int {
+        (void)hipStreamSynchronize(st); // (the scratch goes back to the pool: nothing may still use it)
+        g_bufs.put(temp, a->device); g_bufs.put(k, a->device); g_bufs.put(offs, a->device); g_bufs.put(incl, a->device);
+        g_bufs.put(out, a->device);
+        return code;
+    };
+    HIPCHK_RC(g_bufs.get(&temp, tb, a->device));
+    if (hipError_t e = g_bufs.get((void **)&k, (n + 1) * 8, a->device); e != hipSuccess) return done(hipfail(e, "expand_copies"));
+    if (hipError_t e = g_bufs.get((void **)&offs, (n + 1) * 8, a->device); e != hipSuccess) return done(hipfail(e, "expand_copies"));
+    hipError_t e = copy_runs(r->d_matches, n, a->d_xcnt, temp, tb, k, offs, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(w.h_pinned + 8, offs + n, 8, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return done(hipfail(e, "expand_copies"));
+    const uint64_t total = w.h_pinned[8];
+    if (total == n) return done(ACX_OK); // (no occurrence of a string with copies)
+    if ((e = g_bufs.get((void **)&out, total * sizeof(acx_match_t), a->device)) != hipSuccess) return done(hipfail(e, "expand_copies"));
+    e = expand_copies_write(r->d_matches, n, offs, a->d_xoff, a->d_xids, out, total, st);
+    if (e == hipSuccess && n_hay) {
+        if ((e = g_bufs.get((void **)&incl, n_hay * 8, a->device)) == hipSuccess)
+            e = expand_copies_counts(temp, tb, r->d_counts, n_hay, incl, offs, st);
+    }
+    if (e != hipSuccess) return done(hipfail(e, "expand_copies"));
+    std::swap(out, r->d_matches); // (the unexpanded buffer goes back to the pool with the scratch)
+    r->n = total;
+    return done(ACX_OK);
+}
+
 // d_hay must stay valid until the result's device work is done (acx_result accessors wait for it)
 int run_chunked(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, int overlapping, int codepoints,
                 acx_result **out, bool wait, uint64_t piece, int depth);
@@ -1441,13 +1494,18 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
             HIPCHK_RC(g_bufs.get((void **)&r->d_matches, SMALL_MAX_OCC * sizeof(acx_match_t), a->device));
             bool done = false;
             int rc = run_small(a, x, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
-            if (rc || done) return rc;
+            if (rc) return rc;
+            if (done) return overlapping && a->has_nov ? expand_copies(a, x, r, false) : ACX_OK;
             g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
             r->d_matches = nullptr;
         }
         if (len > 0 && a->host.n_patterns > 0) {
             int rc = run_pipeline(c);
             if (rc) return rc;
+            if (overlapping && a->has_nov) { // (copies of a string: the view reported the lowest ids)
+                if ((rc = expand_copies(a, x, r, segmented)) != ACX_OK) return rc;
+                c.queued = false; // (synchronised)
+            }
         } else {
             // nothing to scan (a batch of empty haystacks, or no patterns): the per-haystack counts come
             // out of the buffer cache uninitialised -- they are this call's to clear
@@ -1917,6 +1975,20 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
                 a->dev_nov.grec = reinterpret_cast<const uint4 *>(p2);
             }
             if ((rc = upload(a, st, &a->dev_nov, (size_t)1, &a->d_dev_nov)) != ACX_OK) return destroy(rc);
+            // the copies of every lowest id, for the expansion of an overlapping search's result
+            a->x_cnt.assign(H.n_patterns, 0);
+            a->x_off.assign(H.n_patterns, 0);
+            a->x_ids.reserve(n_later);
+            for (uint32_t s2 = 0; s2 < H.n_states; s2++) {
+                const uint32_t b = H.own_off[s2], e2 = H.own_off[s2 + 1];
+                if (e2 - b < 2) continue;
+                a->x_off[H.own_pid[b]] = (uint32_t)a->x_ids.size();
+                a->x_cnt[H.own_pid[b]] = e2 - b - 1;
+                for (uint32_t k = b + 1; k < e2; k++) a->x_ids.push_back(H.own_pid[k]);
+            }
+            if ((rc = upload(a, st, a->x_cnt.data(), a->x_cnt.size(), &a->d_xcnt)) != ACX_OK) return destroy(rc);
+            if ((rc = upload(a, st, a->x_off.data(), a->x_off.size(), &a->d_xoff)) != ACX_OK) return destroy(rc);
+            if ((rc = upload(a, st, a->x_ids.data(), a->x_ids.size(), &a->d_xids)) != ACX_OK) return destroy(rc);
             a->has_nov = true;
         }
     }
@@ -2165,6 +2237,23 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                             hipError_t e = hipStreamSynchronize(c->stream); // (the kernel is over: its writes have arrived)
                             if (e != hipSuccess || spins > (1u << 20)) { std::free(m); return fail(ACX_EDEVICE, "K0's matches did not arrive"); }
                         }
+                    }
+                }
+                if (overlapping && a->has_nov) { // (copies of a string: K0 reported the lowest ids -- expand_copies, on the host)
+                    uint64_t total = 0;
+                    for (uint64_t i = 0; i < n; i++) total += 1 + a->x_cnt[m[i].pattern];
+                    if (total != n) {
+                        acx_match_t *m2 = (acx_match_t *)std::malloc(total * sizeof(acx_match_t));
+                        if (!m2) { std::free(m); return fail(ACX_ENOMEM, "out of memory"); }
+                        uint64_t at = 0;
+                        for (uint64_t i = 0; i < n; i++) {
+                            m2[at++] = m[i];
+                            const uint32_t *ids = a->x_ids.data() + a->x_off[m[i].pattern];
+                            for (uint32_t q = 0; q < a->x_cnt[m[i].pattern]; q++) { m2[at] = m[i]; m2[at++].pattern = ids[q]; }
+                        }
+                        std::free(m);
+                        m = m2;
+                        n = total;
                     }
                 }
                 *out = m;

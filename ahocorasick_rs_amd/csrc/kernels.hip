@@ -2105,8 +2105,12 @@ size_t scan_temp_bytes(uint64_t n) {
     (void)rocprim::exclusive_scan(nullptr, c, (const uint64_t *)nullptr, (uint64_t *)nullptr,
                                   (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(),
                                   (hipStream_t)0);
+    size_t d = 0;
+    (void)rocprim::inclusive_scan(nullptr, d, (const uint64_t *)nullptr, (uint64_t *)nullptr,
+                                  (size_t)n + 1, rocprim::plus<uint64_t>(), (hipStream_t)0);
     size_t m = a > b ? a : b;
-    return m > c ? m : c;
+    m = m > c ? m : c;
+    return m > d ? m : d;
 }
 
 hipError_t prefix_max(void *temp, size_t temp_bytes, const uint64_t *E, uint64_t *M,
@@ -3769,14 +3773,14 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
 }
 
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
-                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st) {
+                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st, bool direct_ok) {
     // (ACX_K0_NO_LDS_TABLE: measurements)
     static const bool no_lt = std::getenv("ACX_K0_NO_LDS_TABLE") != nullptr;
     static const bool no_dc = std::getenv("ACX_K0_NO_DIRECT") != nullptr;
     const bool lt = A.table && ((uint64_t)A.n_states << A.stride2) <= K0_LT_ENTRIES && A.n_states <= K0_LT_IDS &&
                     A.n_patterns <= K0_LT_IDS && A.max_len < 256 && !no_lt;
     const bool dc = A.n_patterns <= K0_DC_PATTERNS && A.min_len >= 1 && A.max_len <= 16 && A.pat_blob && A.pat_off &&
-                    (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc;
+                    (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc && direct_ok;
     // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS,
     // from 1 KiB on (shorter: the walk's handful of gathers is as good)
     const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > 1024));
@@ -3915,6 +3919,62 @@ hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, ui
                            (const uint64_t *)(src + at), 3 * k, shift);
         at += k;
     }
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------
+// copies of a pattern, overlapping searches (acx_api.cpp, expand_copies): the search ran on the view without the later
+// copies -- one occurrence per STRING, under the lowest id --; here every occurrence becomes the run of its string's copies
+// (the reference reports them together, ids ascending: they sit in ONE state's match list in the order they were added,
+// aho-corasick 1.1.4 nfa/noncontiguous.rs add_match; pinned by tests/test_gpu_round4.py and the oracle)
+// ---------------------------------------------------------------------------
+__global__ void k_copy_counts(const acx_match_t *__restrict__ m, uint64_t n, const uint32_t *__restrict__ xcnt, uint64_t *k) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > n) return;
+    k[i] = i < n ? 1 + (uint64_t)xcnt[m[i].pattern] : 0; // (one more element: the exclusive prefix's last one is the total)
+}
+hipError_t copy_runs(const acx_match_t *m, uint64_t n, const uint32_t *xcnt, void *temp, size_t temp_bytes, uint64_t *k,
+                     uint64_t *offs, hipStream_t st) {
+    hipLaunchKernelGGL(k_copy_counts, dim3((uint32_t)((n + 256) / 256)), dim3(256), 0, st, m, n, xcnt, k);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    return rocprim::exclusive_scan(temp, temp_bytes, k, offs, (uint64_t)0, (size_t)n + 1, rocprim::plus<uint64_t>(), st);
+}
+// one thread per record of the output: its occurrence by binary search in the runs' offsets (strictly increasing), coalesced writes
+__global__ void k_expand_copies(const acx_match_t *__restrict__ m, uint64_t n, const uint64_t *__restrict__ offs,
+                                const uint32_t *__restrict__ xoff, const uint32_t *__restrict__ xids, acx_match_t *out, uint64_t total) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= total) return;
+    uint64_t lo = 0, hi = n; // offs[lo] <= j < offs[hi]
+    while (hi - lo > 1) {
+        const uint64_t mid = lo + (hi - lo) / 2;
+        if (offs[mid] <= j) lo = mid; else hi = mid;
+    }
+    const acx_match_t v = m[lo];
+    const uint64_t r = j - offs[lo];
+    acx_match_t o = v;
+    if (r) o.pattern = xids[xoff[v.pattern] + (r - 1)];
+    out[j] = o;
+}
+hipError_t expand_copies_write(const acx_match_t *m, uint64_t n, const uint64_t *offs, const uint32_t *xoff, const uint32_t *xids,
+                               acx_match_t *out, uint64_t total, hipStream_t st) {
+    if (total >= (1ull << 39)) return hipErrorInvalidValue; // (the grid's 32 bits x 256; 2^39 records = 13 TB)
+    hipLaunchKernelGGL(k_expand_copies, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, st, m, n, offs, xoff, xids, out, total);
+    return hipGetLastError();
+}
+// batch: the per-haystack counts of the expanded result -- the occurrences of haystack h are [C[h-1], C[h]) of the
+// unexpanded one (C: inclusive prefix of its counts), their records [offs[C[h-1]], offs[C[h]])
+__global__ void k_expand_counts(const uint64_t *__restrict__ incl, const uint64_t *__restrict__ offs, uint64_t *counts, uint64_t n_hay) {
+    const uint64_t h = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (h >= n_hay) return;
+    counts[h] = offs[incl[h]] - offs[h ? incl[h - 1] : 0];
+}
+hipError_t expand_copies_counts(void *temp, size_t temp_bytes, uint64_t *counts, uint64_t n_hay, uint64_t *incl, const uint64_t *offs,
+                                hipStream_t st) {
+    if (!n_hay) return hipSuccess;
+    hipError_t e = rocprim::inclusive_scan(temp, temp_bytes, counts, incl, (size_t)n_hay, rocprim::plus<uint64_t>(), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_expand_counts, dim3((uint32_t)((n_hay + 255) / 256)), dim3(256), 0, st, incl, offs, counts, n_hay);
     return hipGetLastError();
 }
 

@@ -104,7 +104,9 @@ __host__ __device__ inline uint64_t k0_line_check(const uint64_t *mid /* words 1
     return h ^ (h >> 32);
 }
 hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
-                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st);
+                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st, bool direct_ok = true);
+// (direct_ok = false: not MODE 2 -- it compares against the patterns themselves, every copy of a string, whatever view of the
+// tables A is: an overlapping search over a set with copies expects one occurrence per string, acx_api.cpp expand_copies)
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write
@@ -201,6 +203,18 @@ hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *bl
 // copy_shifted: dst = src with start and end moved by shift.
 hipError_t cut_point(const acx_match_t *m, uint64_t n, bool by_end, uint64_t shift, uint64_t limit, uint64_t *out, hipStream_t st);
 hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, uint64_t shift, hipStream_t st);
+
+// ---- copies of a pattern, overlapping searches (acx_api.cpp, expand_copies): the search reports one occurrence per string
+// (lowest id); xcnt[pid] = its later copies, xoff[pid] = where their ids begin in xids[].
+// copy_runs: k[i] = 1 + xcnt[m[i].pattern] (k[n] = 0), offs = exclusive prefix of k over n + 1 elements (offs[n] = records);
+// expand_copies_write: out[offs[i] ..] = the copies of occurrence i, ids ascending; expand_copies_counts (batch): counts[]
+// of the unexpanded result -> of the expanded one (incl: n_hay words of scratch).  temp: scan_temp_bytes(max(n, n_hay) + 1).
+hipError_t copy_runs(const acx_match_t *m, uint64_t n, const uint32_t *xcnt, void *temp, size_t temp_bytes, uint64_t *k,
+                     uint64_t *offs, hipStream_t st);
+hipError_t expand_copies_write(const acx_match_t *m, uint64_t n, const uint64_t *offs, const uint32_t *xoff, const uint32_t *xids,
+                               acx_match_t *out, uint64_t total, hipStream_t st);
+hipError_t expand_copies_counts(void *temp, size_t temp_bytes, uint64_t *counts, uint64_t n_hay, uint64_t *incl, const uint64_t *offs,
+                                hipStream_t st);
 
 // ---- batch: make offsets local to each haystack, count matches per haystack.
 // base_cp != nullptr: subtract the code-point index of the haystack start
