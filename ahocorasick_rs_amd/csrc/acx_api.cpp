@@ -418,6 +418,11 @@ struct acx_automaton {
     DevAutomaton dev_nov{};
     const DevAutomaton *d_dev_nov = nullptr;
     bool has_nov = false;
+    // expand_ov: overlapping searches do that -- when at least a quarter of the ids are later copies (ACX_EXPAND_COPIES=1 / 0:
+    // whenever there is one / never).  The expansion is a pass over the complete result and a round trip for its size
+    // (cfg4's 100 000 random patterns hold half a dozen accidental duplicates: 0.79 -> 0.87 ms when it was taken for them);
+    // a set with a few copies enumerates them on the device as before, at the cost of those few.
+    bool expand_ov = false;
     std::vector<uint32_t> x_cnt, x_off, x_ids;
     const uint32_t *d_xcnt = nullptr, *d_xoff = nullptr, *d_xids = nullptr;
     std::vector<void *> allocs;
@@ -759,12 +764,10 @@ bool small_ok(const acx_automaton *a, uint64_t len) {
 // the device tables a call takes: a non-overlapping search never needs the later copies of a string (acx_automaton::dev_nov)
 // (an overlapping search as well since round 5: its result is expanded to the copies afterwards -- expand_copies)
 inline const DevAutomaton &view(const acx_automaton *a, bool overlapping) {
-    (void)overlapping;
-    return a->has_nov ? a->dev_nov : a->dev;
+    return (overlapping ? a->expand_ov : a->has_nov) ? a->dev_nov : a->dev;
 }
 inline const DevAutomaton *d_view(const acx_automaton *a, bool overlapping) { // (the same, resident in HBM)
-    (void)overlapping;
-    return a->has_nov ? a->d_dev_nov : a->d_dev;
+    return (overlapping ? a->expand_ov : a->has_nov) ? a->d_dev_nov : a->d_dev;
 }
 
 // (ACX_SMALL_SYNC, measurements: always synchronise the stream -- and then the records are plain acx_match_t)
@@ -784,7 +787,7 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     const uint64_t seq = poll && small_polls() ? ++c->small_seq : 0;
     HIPCHK(launch_small(view(a, overlapping != 0), hay, (uint32_t)len, key_mode, overlapping != 0, codepoints != 0, out,
-                        seq ? w.h_pinned + PIN_K0 : w.h_pinned + 8, seq, c->stream, !(overlapping && a->has_nov)));
+                        seq ? w.h_pinned + PIN_K0 : w.h_pinned + 8, seq, c->stream, !(overlapping && a->expand_ov)));
     if (seq) {
         // the result line (kernels.hpp): complete when its first word carries this call's number and its last word
         // agrees with the six in between as read (wait_line: a copy is checked and used)
@@ -1495,14 +1498,14 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
             bool done = false;
             int rc = run_small(a, x, d_hay, len, overlapping, codepoints, r->d_matches, &r->n, &done);
             if (rc) return rc;
-            if (done) return overlapping && a->has_nov ? expand_copies(a, x, r, false) : ACX_OK;
+            if (done) return overlapping && a->expand_ov ? expand_copies(a, x, r, false) : ACX_OK;
             g_bufs.put(r->d_matches, a->device); // dense: the general pipeline takes over
             r->d_matches = nullptr;
         }
         if (len > 0 && a->host.n_patterns > 0) {
             int rc = run_pipeline(c);
             if (rc) return rc;
-            if (overlapping && a->has_nov) { // (copies of a string: the view reported the lowest ids)
+            if (overlapping && a->expand_ov) { // (copies of a string: the view reported the lowest ids)
                 if ((rc = expand_copies(a, x, r, segmented)) != ACX_OK) return rc;
                 c.queued = false; // (synchronised)
             }
@@ -1990,6 +1993,8 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
             if ((rc = upload(a, st, a->x_off.data(), a->x_off.size(), &a->d_xoff)) != ACX_OK) return destroy(rc);
             if ((rc = upload(a, st, a->x_ids.data(), a->x_ids.size(), &a->d_xids)) != ACX_OK) return destroy(rc);
             a->has_nov = true;
+            const char *xe = std::getenv("ACX_EXPAND_COPIES");
+            a->expand_ov = xe ? std::atoi(xe) != 0 : n_later * 4 >= (uint64_t)H.n_patterns;
         }
     }
     HIPCHK_A(hipStreamSynchronize(st));
@@ -2239,7 +2244,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                         }
                     }
                 }
-                if (overlapping && a->has_nov) { // (copies of a string: K0 reported the lowest ids -- expand_copies, on the host)
+                if (overlapping && a->expand_ov) { // (copies of a string: K0 reported the lowest ids -- expand_copies, on the host)
                     uint64_t total = 0;
                     for (uint64_t i = 0; i < n; i++) total += 1 + a->x_cnt[m[i].pattern];
                     if (total != n) {

@@ -57,7 +57,13 @@ def test_hundreds_of_copies_where_every_position_matches(kernel):
     a.close()
 
 
-def test_a_few_copies_in_a_large_set_sparse_path_batch_and_code_points(monkeypatch):
+@pytest.mark.parametrize("force", [None, "1"])
+def test_a_few_copies_in_a_large_set_sparse_path_batch_and_code_points(monkeypatch, force):
+    # force None: a set with a few copies enumerates them on the device, as before (the expansion is a pass over the result and
+    # a round trip: taken when a quarter of the ids are copies); "1" (ACX_EXPAND_COPIES, read when the automaton is built):
+    # the expansion all the same -- both ways are the reference's answer
+    if force:
+        monkeypatch.setenv("ACX_EXPAND_COPIES", force)
     base = gen.gen_patterns(3000, 4, 10, gen.AZ, 5)
     r = random.Random(2)
     pats = list(base)
