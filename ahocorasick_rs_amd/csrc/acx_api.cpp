@@ -388,6 +388,8 @@ struct Ctx {
     Workspace ws;
     bool post_pending = false; // profiling: ev[2] of the last call has not been read yet
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
+    bool hold_dense_input = false; // why: the INPUT was dense (the hold ends with the first call that is not) -- or the sparse
+                                   // kernels gave up on it for another reason (counted down: one failed attempt in nine calls)
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
     uint64_t seq = 0;          // sequence number the write kernel publishes in the totals' line (h_pinned + PIN_TOTALS)
     uint64_t small_seq = 0;    // K0 (host entry point): the number its result line carries (h_pinned + PIN_K0)
@@ -985,7 +987,7 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     }
     // an input that is dense (nearly) everywhere: the dense path proper takes the handle's next calls -- its scan writes
     // the hits where its verification reads them, no sparse attempt in front
-    if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) x->dense_hold = 8;
+    if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) { x->dense_hold = 8; x->hold_dense_input = true; }
     const uint64_t pub = seq | (1ull << 63);
     HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, w.final, w.summary,
                         abort_flag, hot_abort, w.h_pinned + PIN_TOTALS, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
@@ -1144,6 +1146,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
         if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
         x->dense_hold = 8;
+        x->hold_dense_input = false; // (unless the dense path finds the input dense: below)
         c.leads_counted = false;
         c.cp_done = false;
         *what = Attempt::GoDense;
@@ -1209,8 +1212,10 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
     }
     const uint64_t n_final = w.h_pinned[8], n_raw = w.h_pinned[9];
     if (std::max(n_raw, w.h_pinned[2]) >= occ_limit()) return fail_occ(); // (the tiles' counts and their prefixes are 32 bits wide)
-    if (n_raw > 8 * c.tiles) x->dense_hold = 8;
-    else if (x->dense_hold > 0) x->dense_hold--;
+    // (round 5: a hold that a dense INPUT set ends with the first input that is not dense -- the dense path on a sparse input
+    // costs 2-3x, eight calls of it were the price of one dense call in front: bench.py's 8 GiB run behind its density sweep)
+    if (n_raw > 8 * c.tiles) { x->dense_hold = 8; x->hold_dense_input = true; }
+    else if (x->dense_hold > 0) x->dense_hold = x->hold_dense_input ? 0 : x->dense_hold - 1;
     c.n_raw = n_raw;
     c.n_hits = w.h_pinned[2];
     c.n_final = n_final;
@@ -1316,8 +1321,10 @@ int attempt_dense(FindCall &c, Attempt *what) {
         return ACX_OK;
     }
     if (n_raw >= occ_limit()) return fail_occ();
-    if (n_raw > 8 * c.tiles) x->dense_hold = 8;
-    else if (x->dense_hold > 0) x->dense_hold--;
+    // (round 5: a hold that a dense INPUT set ends with the first input that is not dense -- the dense path on a sparse input
+    // costs 2-3x, eight calls of it were the price of one dense call in front: bench.py's 8 GiB run behind its density sweep)
+    if (n_raw > 8 * c.tiles) { x->dense_hold = 8; x->hold_dense_input = true; }
+    else if (x->dense_hold > 0) x->dense_hold = x->hold_dense_input ? 0 : x->dense_hold - 1;
     c.n_raw = n_raw;
     c.n_hits = c.pre ? w.h_pinned[2] : 0;
     *what = Attempt::Done;

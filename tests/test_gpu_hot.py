@@ -130,6 +130,15 @@ def test_dense_everywhere_grows_the_overflow_list_and_stays_off_the_dense_path()
         assert np.array_equal(cols(a.find(hay)), want), mk
         st = a.path_stats()
         assert st["dense_tiles"] == 1 and st["hot_calls"] == 0 and st["overflow_regrown"] == 0, st
+        # ... until an input that is not dense comes along: ONE call of it on the dense path, then the sparse kernels again
+        # (until round 5 eight calls, each 2-3x the sparse path's time)
+        plain = gen.gen_textlike(8 << 20, 12, pats).tobytes()
+        want_plain = o.find_raw(plain)
+        for expect in ("dense_tiles", "sparse", "sparse"):
+            a.path_stats(reset=True)
+            assert np.array_equal(cols(a.find(plain)), want_plain), (mk, expect)
+            st = a.path_stats()
+            assert st[expect] == 1 and sum(st[k] for k in ("sparse", "hot_calls", "dense_tiles", "dense_radix")) == 1, (expect, st)
         a.close()
 
 
