@@ -44,6 +44,31 @@ int fail(int code, const std::string &msg) {
 // The device's occurrence indexes are 32 bits wide: a call that would enumerate more is cut into byte ranges (run_chunked).
 // The limit of ONE pass (ACX_MAX_OCC lowers it: tests) and what a pass returns when it hits it -- run_find's business,
 // never the caller's.
+// ACX_HOST_TRACE=1 (measurements): where the host's microseconds of a device-resident call go -- steady-clock stamps at ten
+// points of acx_find_device .. acx_free_result, the mean of every interval printed when the process ends.
+struct HostTrace {
+    static constexpr int N = 10;
+    bool on = std::getenv("ACX_HOST_TRACE") != nullptr;
+    int64_t t[N] = {}, sum[N] = {};
+    uint64_t rounds = 0;
+    static int64_t now() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+    void mark(int i) {
+        if (!on) return;
+        const int64_t v = now();
+        if (i == 0 && t[N - 1]) sum[0] += v - t[N - 1]; // (from the end of the last round: the caller's own time)
+        if (i > 0 && t[i - 1]) sum[i] += v - t[i - 1];
+        t[i] = v;
+        if (i == N - 1) rounds++;
+    }
+    ~HostTrace() {
+        if (!on || !rounds) return;
+        static const char *what[N] = {"caller (free .. next call)", "lease", "up to the scan's launch", "the scan's launch", "the post kernels' launches",
+                                      "events up to the wait", "wait for the totals' line", "return", "caller (return .. free)", "free"};
+        std::fprintf(stderr, "ACX_HOST_TRACE: %llu rounds, mean microseconds per interval\n", (unsigned long long)rounds);
+        for (int i = 0; i < N; i++) std::fprintf(stderr, "  %-32s %8.2f\n", what[i], sum[i] / 1e3 / rounds);
+    }
+};
+HostTrace g_trace;
 constexpr int TOO_MANY_OCC = -1006;
 uint64_t occ_limit() {
     const char *e = std::getenv("ACX_MAX_OCC");
@@ -1054,8 +1079,10 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         // (str API, one haystack: the code-point prefix runs on the second stream as soon as the scan
         // is done -- the event it waits for rides on the scan's own dispatch, no packet in between)
         side_after = cp_sub && !c.segmented ? (prof ? scan_stop_ev(x) : x->fork_ev) : nullptr;
+        g_trace.mark(2);
         HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
                                    prof ? scan_stop_ev(x) : side_after, cp_sub));
+        g_trace.mark(3);
         c.leads_counted = cp_sub != nullptr;
     } else {
         // the failureless walk: the scan writes the hits it settles itself and every tile's count, the
@@ -1100,6 +1127,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
                         next_flag, w.h_pinned + PIN_TOTALS, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
                         (uint32_t)(c.tiles + 2), st));
+    g_trace.mark(4);
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
     // accessors wait for (nothing more is queued behind the write kernel unless a fix-up follows)
@@ -1109,7 +1137,9 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         if (c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st));
         c.event_at_post = c.r->done != nullptr;
     }
+    g_trace.mark(5);
     if ((rc = wait_line(x, PIN_TOTALS, seq, w.t_line, "the write kernel did not publish its totals")) != ACX_OK) return rc;
+    g_trace.mark(6);
     w.flags_dirty = false; // the write kernel left the next control block clean
     add_scan_profile(a, x, c.len, c.timed);
     // the line (k_tile_write): [1] matches, [2] occurrences, [3] prefix hits, [4] why | hot groups << 8, [5] overflow hits |
@@ -1527,7 +1557,7 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
             // by an event the result's accessors wait for
             if (wait) {
                 HIPCHK_RC(hipStreamSynchronize(st));
-            } else {
+            } else if (std::getenv("ACX_EXP_NO_DONE_EVENT") == nullptr) {
                 if (!r->done) r->done = g_events.get(a->device);
                 if (!r->done) HIPCHK_RC(hipStreamSynchronize(st));
                 else HIPCHK_RC(hipEventRecord(r->done, st)); // (again, if a fix-up was queued behind an early record)
@@ -1536,6 +1566,8 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
         return ACX_OK;
     };
     c.early_event = !wait;
+    static const bool exp_no_done = std::getenv("ACX_EXP_NO_DONE_EVENT") != nullptr; // (EXPERIMENT: results unfenced)
+    if (exp_no_done) c.early_event = false;
     c.timed = a->prof && (a->prof_every <= 1 || (x->prof_calls++ % (uint32_t)a->prof_every) == 0);
     // (tests: ACX_CHUNK_BYTES cuts every one-haystack call longer than that, whatever it holds)
     const char *cb = depth == 0 && !segmented ? std::getenv("ACX_CHUNK_BYTES") : nullptr;
@@ -2152,9 +2184,16 @@ int acx_find_device(acx_automaton_t *a, const void *d_hay, uint64_t len, const u
     }
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD)
         return run_find(a, nullptr, nullptr, 0, G, overlapping, codepoints, out, true, true); // the error, no device state
-    Lease lease(a);
-    // returns when the totals are known; accessors of the result wait for the rest of its device work
-    return run_find(a, lease.c, (const uint8_t *)d_hay, len, G, overlapping, codepoints, out, true, false);
+    g_trace.mark(0);
+    int rc;
+    {
+        Lease lease(a);
+        g_trace.mark(1);
+        // returns when the totals are known; accessors of the result wait for the rest of its device work
+        rc = run_find(a, lease.c, (const uint8_t *)d_hay, len, G, overlapping, codepoints, out, true, false);
+    }
+    g_trace.mark(7);
+    return rc;
 }
 
 uint64_t acx_result_count(const acx_result_t *r) { return r ? r->n : 0; }
@@ -2187,6 +2226,8 @@ int acx_result_copy_counts(const acx_result_t *r, uint64_t *host_counts) {
 
 void acx_free_result(acx_result_t *r) {
     if (!r) return;
+    g_trace.mark(8);
+    struct AtExit { ~AtExit() { g_trace.mark(9); } } at_exit;
     // the buffers may still be written by the call's last kernels: the cache holds them back until
     // the event has fired (one event guards both buffers; nobody waits here -- a batch caller that
     // frees a result and starts the next call used to sit out the write kernel in this function)
