@@ -1557,7 +1557,7 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
             // by an event the result's accessors wait for
             if (wait) {
                 HIPCHK_RC(hipStreamSynchronize(st));
-            } else if (std::getenv("ACX_EXP_NO_DONE_EVENT") == nullptr) {
+            } else {
                 if (!r->done) r->done = g_events.get(a->device);
                 if (!r->done) HIPCHK_RC(hipStreamSynchronize(st));
                 else HIPCHK_RC(hipEventRecord(r->done, st)); // (again, if a fix-up was queued behind an early record)
@@ -1566,8 +1566,6 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
         return ACX_OK;
     };
     c.early_event = !wait;
-    static const bool exp_no_done = std::getenv("ACX_EXP_NO_DONE_EVENT") != nullptr; // (EXPERIMENT: results unfenced)
-    if (exp_no_done) c.early_event = false;
     c.timed = a->prof && (a->prof_every <= 1 || (x->prof_calls++ % (uint32_t)a->prof_every) == 0);
     // (tests: ACX_CHUNK_BYTES cuts every one-haystack call longer than that, whatever it holds)
     const char *cb = depth == 0 && !segmented ? std::getenv("ACX_CHUNK_BYTES") : nullptr;
