@@ -69,6 +69,21 @@ struct HostTrace {
     }
 };
 HostTrace g_trace;
+// (the same for the host-memory entry point acx_find beyond K0's sizes: copy in, pipeline, copy out)
+struct HostTrace3 {
+    bool on = std::getenv("ACX_HOST_TRACE") != nullptr;
+    int64_t t0 = 0, sum[4] = {};
+    uint64_t rounds = 0;
+    void begin() { if (on) t0 = HostTrace::now(); }
+    void lap(int i) { if (!on) return; const int64_t v = HostTrace::now(); sum[i] += v - t0; t0 = v; if (i == 3) rounds++; }
+    ~HostTrace3() {
+        if (!on || !rounds) return;
+        static const char *what[4] = {"stage (host -> device copy queued)", "pipeline until the totals are known", "wait + device -> host copy", "free"};
+        std::fprintf(stderr, "ACX_HOST_TRACE acx_find: %llu rounds, mean microseconds\n", (unsigned long long)rounds);
+        for (int i = 0; i < 4; i++) std::fprintf(stderr, "  %-40s %8.2f\n", what[i], sum[i] / 1e3 / rounds);
+    }
+};
+HostTrace3 g_trace_find;
 constexpr int TOO_MANY_OCC = -1006;
 uint64_t occ_limit() {
     const char *e = std::getenv("ACX_MAX_OCC");
@@ -366,6 +381,8 @@ struct Workspace {
                                       // early total (hot_totals)
     uint64_t t_line[8] = {};          // the sparse path's totals: the verified copy of the line (PIN_TOTALS / PIN_HOT_TOTALS)
     uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
+    acx_match_t *pin_final = nullptr; // host entry point, mid-size calls: pinned host memory the write kernel's records go to
+    uint64_t pin_final_cap = 0;       // (records)
     uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
@@ -484,6 +501,8 @@ struct acx_result {
     uint64_t *d_counts = nullptr;
     uint64_t n_hay = 0;
     hipEvent_t done = nullptr; // non-null: device work that fills the buffers may still be running
+    bool borrowed = false;     // d_matches is the context's pinned host buffer (acx_find: the write kernel's records land where
+                               // the host reads them); never handed to a caller, never given to the buffer cache
 };
 
 namespace {
@@ -540,6 +559,7 @@ void free_ws(Workspace &w, int device) {
     (void)hipFree(w.blockcnt); (void)hipFree(w.blockpre); (void)hipFree(w.blocksub);
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
+    if (w.pin_final) (void)hipHostFree(w.pin_final);
     if (w.pin_hay) (void)hipHostFree(w.pin_hay);
     if (w.pin_out) (void)hipHostFree(w.pin_out);
     for (int i = 0; i < Workspace::RING; i++) {
@@ -945,6 +965,10 @@ struct FindCall {
     bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
     bool no_dense_tiles = false; // dense path: the tile-ordered form gave up on this call (the radix-sort form takes it)
     bool ovf_grown = false;      // sparse path: the overflow list was grown for this call (one more attempt)
+    bool host_result = false;    // the caller reads the matches on the host right away (acx_find): the sparse path writes them
+                                 // to the context's pinned buffer when its capacity fits (PIN_FINAL_MAX), no copy kernel-side
+    acx_match_t *out = nullptr;  // sparse path: where the write kernels put the records (w.final, or w.pin_final)
+    uint64_t out_cap = 0;
     bool counts_zeroed = false; // batch: the per-haystack counts are zero or being accumulated into
     uint64_t exact_total = 0;
     bool timed = false;         // this call carries the profiling events (every prof_every-th call of a context)
@@ -963,6 +987,7 @@ enum class Attempt { Done, GoDense, Again };
 // path's groups, then the write kernel again.  One dense region costs the groups it lies in, not the call (it used to
 // send the whole call to the dense path and keep the handle there for eight more calls).  *lost: the hot pipeline gave
 // up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
+constexpr uint64_t PIN_FINAL_MAX = 32ull << 20; // bytes of pinned result buffer a context keeps for host calls (acx_find up to ~8 MiB)
 constexpr uint64_t HOT_INLINE = 128; // hot groups whose capacity the output buffer has room for anyway (1 GiB: 3 % of the groups)
 int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t ovf_max, uint64_t *seg_counts,
             const uint64_t *cp_pre, bool counts_clear, bool *lost) {
@@ -988,7 +1013,11 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
     // instead (one more round trip, next to that much hot work)
     const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * GROUP_MAX + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
-    if (bound > w.final_cap) {
+    if (bound > c.out_cap && c.out != w.final) { // (the pinned buffer is not regrown: the dense path takes this call)
+        *lost = true;
+        return ACX_OK;
+    }
+    if (bound > w.final_cap && c.out == w.final) {
         const uint64_t pub_t = seq | (1ull << 62);
         HIPCHK_RC(hot_totals(T, seq, w.h_pinned + PIN_HOT_TOTALS, pub_t, st));
         uint64_t early[8];
@@ -1008,13 +1037,14 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
             w.final = nullptr; w.final_cap = 0;
             HIPCHK_RC(g_bufs.get((void **)&w.final, n * sizeof(acx_match_t), a->device));
             w.final_cap = n;
+            c.out = w.final; c.out_cap = n;
         }
     }
     // an input that is dense (nearly) everywhere: the dense path proper takes the handle's next calls -- its scan writes
     // the hits where its verification reads them, no sparse attempt in front
     if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) { x->dense_hold = 8; x->hold_dense_input = true; }
     const uint64_t pub = seq | (1ull << 63);
-    HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, w.final, w.summary,
+    HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, c.out, w.summary,
                         abort_flag, hot_abort, w.h_pinned + PIN_TOTALS, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
     if (c.early_event && c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st)); // (again: behind the kernels queued since)
     int rc = wait_line(x, PIN_TOTALS, pub, w.t_line, "the write kernel did not publish its totals");
@@ -1047,10 +1077,24 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // (room for every group's capacity + what a few hot groups can report beyond it: run_hot)
     const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX +
                              (c.pre ? std::min<uint64_t>(T.n_groups, HOT_INLINE) * HOT_SUB * DT_GMAX : 0);
-    if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
-    if (!w.final) {
-        HIPCHK_RC(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
-        w.final_cap = out_cap;
+    const bool pin = c.host_result && !c.segmented && out_cap * sizeof(acx_match_t) <= PIN_FINAL_MAX &&
+                     !(c.overlapping && a->expand_ov);
+    if (pin && w.pin_final_cap < out_cap) {
+        HIPCHK_RC(hipStreamSynchronize(st));
+        if (w.pin_final) (void)hipHostFree(w.pin_final);
+        w.pin_final = nullptr; w.pin_final_cap = 0;
+        HIPCHK_RC(hipHostMalloc((void **)&w.pin_final, out_cap * sizeof(acx_match_t), hipHostMallocDefault));
+        w.pin_final_cap = out_cap;
+    }
+    if (pin) {
+        c.out = w.pin_final; c.out_cap = w.pin_final_cap;
+    } else {
+        if (w.final && w.final_cap < out_cap) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+        if (!w.final) {
+            HIPCHK_RC(g_bufs.get((void **)&w.final, out_cap * sizeof(acx_match_t), a->device));
+            w.final_cap = out_cap;
+        }
+        c.out = w.final; c.out_cap = w.final_cap;
     }
     if (w.flags_dirty) {
         HIPCHK_RC(hipMemsetAsync(w.ctl, 0, 12, st));
@@ -1124,7 +1168,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // (the hot pipeline's bucket counters, when a call of this context has allocated them: the write kernel clears them
     // when it announces hot groups)
     uint32_t *hot_counts = c.pre && w.dt.counts && c.tiles + 1 <= w.dt_cap ? w.dt.counts : nullptr;
-    HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, w.final, w.summary, abort_flag,
+    HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, c.out, w.summary, abort_flag,
                         next_flag, w.h_pinned + PIN_TOTALS, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
                         (uint32_t)(c.tiles + 2), st));
     g_trace.mark(4);
@@ -1185,8 +1229,13 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     c.n_raw = w.t_line[2]; // (the hot pipeline's second publication when it ran)
     c.n_hits = w.t_line[3];
     c.n_final = w.t_line[1];
-    c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
-    w.final = nullptr;
+    if (c.out == w.final) {
+        c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
+        w.final = nullptr;
+    } else {
+        c.r->d_matches = c.out;   // the context's pinned buffer: the caller (acx_find) copies out of it under its lease
+        c.r->borrowed = true;
+    }
     c.localized = seg_counts != nullptr;
     c.cp_done = cp_pre != nullptr;
     c.queued = !c.event_at_post; // k_tile_write is still running (and the event that fences it is in place)
@@ -1508,7 +1557,8 @@ int expand_copies(acx_automaton *a, Ctx *x, acx_result *r, bool segmented) {
 int run_chunked(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, int overlapping, int codepoints,
                 acx_result **out, bool wait, uint64_t piece, int depth);
 int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G,
-             int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait, int depth = 0) {
+             int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait, int depth = 0,
+             bool host_result = false) {
     *out = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
         static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
@@ -1526,6 +1576,7 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
     r->n_hay = segmented ? G.n_hay : 0;
     FindCall c{a, x, d_hay, len, G, overlapping != 0, codepoints != 0, segmented, r,
                overlapping ? 0 : a->host.match_kind};
+    c.host_result = host_result;
     auto body = [&]() -> int {
         if (segmented) {
             HIPCHK_RC(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
@@ -2229,7 +2280,7 @@ void acx_free_result(acx_result_t *r) {
     // the buffers may still be written by the call's last kernels: the cache holds them back until
     // the event has fired (one event guards both buffers; nobody waits here -- a batch caller that
     // frees a result and starts the next call used to sit out the write kernel in this function)
-    g_bufs.put(r->d_matches, r->device, r->done, r->d_counts);
+    g_bufs.put(r->borrowed ? nullptr : r->d_matches, r->device, r->done, r->d_counts);
     delete r;
 }
 
@@ -2313,12 +2364,43 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             return ACX_OK;
         }
     }
+    g_trace_find.begin();
     rc = stage_host(a, c, hay, len, nullptr, 0);
+    g_trace_find.lap(0);
     if (rc == ACX_OK)
-        rc = run_find(a, c, c->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false);
+        rc = run_find(a, c, c->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false, 0, true);
     if (rc != ACX_OK) return rc;
+    g_trace_find.lap(1);
+    if (r->borrowed) {
+        // the write kernel's records are in the context's pinned buffer: wait for the kernel (a few microseconds behind the
+        // totals: polled, a blocking wait's wake-up costs more than the kernel), copy them out -- no device-to-host copy call
+        if (r->done) {
+            const auto t0 = std::chrono::steady_clock::now();
+            hipError_t e;
+            for (uint32_t spins = 0; (e = hipEventQuery(r->done)) == hipErrorNotReady; spins++) {
+                cpu_relax();
+                if ((spins & 255) == 255 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) {
+                    e = hipEventSynchronize(r->done);
+                    break;
+                }
+            }
+            if (e != hipSuccess) { acx_free_result(r); return hipfail(e, "the write kernel"); }
+        } else {
+            HIPCHK(hipStreamSynchronize(c->stream));
+        }
+        *n_out = r->n;
+        if (r->n) {
+            acx_match_t *m = (acx_match_t *)std::malloc(r->n * sizeof(acx_match_t));
+            if (!m) { acx_free_result(r); return fail(ACX_ENOMEM, "out of memory"); }
+            std::memcpy(m, r->d_matches, r->n * sizeof(acx_match_t));
+            *out = m;
+        }
+        rc = ACX_OK;
+    } else
     rc = download_matches(r, out, n_out); // waits for the call's device work: the staging buffer is free again
+    g_trace_find.lap(2);
     acx_free_result(r);
+    g_trace_find.lap(3);
     return rc;
 }
 
