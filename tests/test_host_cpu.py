@@ -25,6 +25,31 @@ def test_c_abi_exports_every_declared_symbol():
     for n in names:
         assert hasattr(L, n), n
     assert L.acx_version() == capi.ABI_VERSION == int(re.search(r"#define ACX_VERSION (\d+)", hdr).group(1))
+    # (the binding's view of acx_path_stats is as long as the header's array)
+    assert len(capi.Automaton.PATH_STATS) == int(re.search(r"#define ACX_PATH_STATS (\d+)", hdr).group(1))
+
+
+def test_result_line_check_is_the_same_function_on_both_sides():
+    # the host accepts a polled 64-byte line (K0's result, the sparse path's totals) when its last word equals
+    # seq ^ check(words 1 .. 6): ONE inline function in kernels.hpp compiled for the device and for the host.  Its value is
+    # pinned here against a restatement, so that an edit on one side of the boundary cannot pass unnoticed.
+    src = open(os.path.join(ROOT, "ahocorasick_rs_amd", "csrc", "kernels.hpp")).read()
+    body = src[src.index("inline uint64_t k0_line_check"):]
+    body = body[:body.index("\n}\n") + 3]
+    for needle in ("0x9E3779B97F4A7C15ull", "0xFF51AFD7ED558CCDull", "(h << 6) + (h >> 2)", "h ^ (h >> 32)"):
+        assert needle in body, needle
+    M = (1 << 64) - 1
+
+    def check(mid, h0):
+        h = h0
+        for v in mid:
+            h ^= (v + 0x9E3779B97F4A7C15 + ((h << 6) & M) + (h >> 2)) & M
+            h = (h * 0xFF51AFD7ED558CCD) & M
+        return h ^ (h >> 32)
+
+    h0 = int(re.search(r"uint64_t h = (0x[0-9A-Fa-f]+)ull", body).group(1), 16)
+    a, b = check([1, 2, 3, 4, 5, 6], h0), check([1, 2, 3, 4, 5, 7], h0)
+    assert a != b and check([0] * 6, h0) != 0  # (an all-zero line never validates itself against seq = 0)
 
 
 def test_shard_range_twin_of_the_distributed_helper():
