@@ -391,8 +391,13 @@ struct Workspace {
     DenseTiles dt{};                  // dense path, tile-ordered: occurrence buckets by key tile
     TileSpace TD{};                   //   its groups' reported occurrences (64-bit words), counts, supergroup words
     uint64_t dt_cap = 0;              //   tiles both are allocated for
-    TileSpace T{};                    // sparse path (hit slots + tile kernels)
-    uint64_t tile_cap = 0;            // tiles T is allocated for
+    TileSpace T{};                    // sparse path (the tiles' hits + tile kernels)
+    uint64_t tile_cap = 0;            // tiles T's group arrays, the hot list and the overflow lists are allocated for
+    uint4 *hslots = nullptr;          // K1a's hit slots and counts (T.hslots / T.hcnt of a K1a call), slot_cap tiles
+    uint32_t *hcnt = nullptr;
+    uint64_t slot_cap = 0;
+    uint64_t *titems = nullptr;       // K1b's items (T.titems of a K1b call: TILE_ITEMS words per tile), item_cap tiles
+    uint64_t item_cap = 0;
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
     bool flags_dirty = true;          // the control blocks' counters are not known to be zero
     uint32_t *ctl = nullptr;          // device: the sparse path's two control blocks (device_types.hpp), used by the calls in turn
@@ -531,9 +536,12 @@ int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T
 
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
-    (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
+    (void)hipFree(w.hslots); (void)hipFree(w.hcnt); (void)hipFree(w.titems);
+    (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
     (void)hipFree(w.hot_list); (void)hipFree(w.ovf_recs);
     w.hot_list = nullptr; w.ovf_recs = nullptr; w.ovf_cap = 0;
+    w.hslots = nullptr; w.hcnt = nullptr; w.titems = nullptr;
+    w.slot_cap = w.item_cap = 0;
     T = TileSpace{};
     w.tile_cap = 0;
     w.group_cap = 0;
@@ -697,9 +705,12 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
     Workspace &w = c->ws;
     want = std::min<uint64_t>(std::max<uint64_t>(want, 64), 0xFFFFFFF0ull / OVF_LISTS);
     if (want > w.ovf_cap) {
+        // (the new lists first: a failed allocation leaves the old ones -- and the control blocks that point at them -- as they are)
         HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(w.ovf_recs); w.ovf_recs = nullptr; w.ovf_cap = 0;
-        HIPCHK(hipMalloc((void **)&w.ovf_recs, want * OVF_LISTS * 32));
+        uint4 *fresh = nullptr;
+        HIPCHK(hipMalloc((void **)&fresh, want * OVF_LISTS * 32));
+        (void)hipFree(w.ovf_recs);
+        w.ovf_recs = fresh;
         w.ovf_cap = want;
     }
     uint32_t h[2 * CTL_WORDS] = {};
@@ -719,31 +730,49 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
     return ACX_OK;
 }
 
-// sparse path: hit slots for `tiles` tiles of index space, group arrays.  One bucket beyond the
-// last tile exists (an occurrence may END exactly at the end of the last tile).
-int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
+// sparse path: the tiles' hits for `tiles` tiles of index space (K1b -- pre -- : items; K1a: hit slots + counts), group
+// arrays.  One bucket beyond the last tile exists (an occurrence may END exactly at the end of the last tile).
+// Nothing is marked as allocated before every allocation of its kind has succeeded: a failure leaves the workspace
+// without that kind (free_tiles), never with control blocks that point at freed memory.
+int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles, bool pre) {
     Workspace &w = c->ws;
     TileSpace &T = w.T;
     const uint64_t groups = (tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
+    const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
     if (tiles > w.tile_cap) {
         free_tiles(w);
         if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
-        const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
         const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
-        HIPCHK(hipMalloc((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32));
-        HIPCHK(hipMalloc((void **)&T.hcnt, (cap_tiles + 16 * 1024 + 16) * 4)); // + one slot per K1b wave (layout slack)
         const uint64_t cap_super = (cap_groups + 63) / 64;
-        HIPCHK(hipMalloc((void **)&T.trecs, cap_groups * GROUP_MAX * 16));
-        HIPCHK(hipMalloc((void **)&T.btot, cap_groups * 4));
-        HIPCHK(hipMalloc((void **)&T.sgw, 4 * cap_super * 8));
-        HIPCHK(hipMemset(T.sgw, 0, 4 * cap_super * 8)); // both sets start clear
+        int rc = ACX_OK;
+        auto grab = [&](void **p, uint64_t bytes) { if (rc == ACX_OK && hipMalloc(p, bytes) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMalloc (tile workspace)"); };
+        grab((void **)&T.trecs, cap_groups * GROUP_MAX * 16);
+        grab((void **)&T.btot, cap_groups * 4);
+        grab((void **)&T.sgw, 4 * cap_super * 8);
+        grab((void **)&w.hot_list, cap_groups * 4);
+        if (rc == ACX_OK && hipMemset(T.sgw, 0, 4 * cap_super * 8) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMemset"); // both sets start clear
+        if (rc == ACX_OK) rc = set_overflow_room(c, (cap_tiles * OVF_PER_TILE + OVF_LISTS - 1) / OVF_LISTS);
+        if (rc != ACX_OK) { free_tiles(w); return rc; }
         T.sg_cap = (uint32_t)cap_super;
         w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
-        HIPCHK(hipMalloc((void **)&w.hot_list, cap_groups * 4));
-        int rc = set_overflow_room(c, (cap_tiles * OVF_PER_TILE + OVF_LISTS - 1) / OVF_LISTS);
-        if (rc) return rc;
     }
+    if (pre && tiles > w.item_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(w.titems); w.titems = nullptr; w.item_cap = 0;
+        HIPCHK(hipMalloc((void **)&w.titems, cap_tiles * TILE_ITEMS * 8));
+        w.item_cap = cap_tiles;
+    }
+    if (!pre && tiles > w.slot_cap) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        (void)hipFree(w.hslots); (void)hipFree(w.hcnt); w.hslots = nullptr; w.hcnt = nullptr; w.slot_cap = 0;
+        HIPCHK(hipMalloc((void **)&w.hslots, cap_tiles * HIT_SLOTS * 32));
+        HIPCHK(hipMalloc((void **)&w.hcnt, (cap_tiles + 16 * 1024 + 16) * 4)); // + one slot per scan wave (layout slack)
+        w.slot_cap = cap_tiles;
+    }
+    T.hslots = pre ? nullptr : w.hslots;
+    T.hcnt = pre ? nullptr : w.hcnt;
+    T.titems = pre ? w.titems : nullptr;
     T.n_tiles = (uint32_t)tiles;
     T.n_groups = (uint32_t)groups;
     return ACX_OK;
@@ -1062,7 +1091,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     Ctx *x = c.c;
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
-    int rc = ensure_tiles(a, x, c.tiles);
+    int rc = ensure_tiles(a, x, c.tiles, c.pre);
     if (rc) return rc;
     TileSpace &T = w.T;
     // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk) instead of the
@@ -1106,7 +1135,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     uint32_t *abort_flag = w.ctl + CTL_WORDS * x->flag_idx;
     uint32_t *next_flag = w.ctl + CTL_WORDS * (x->flag_idx ^ 1);
     x->flag_idx ^= 1;
-    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters};
+    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters, T.titems};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     const bool prof = c.timed;
@@ -2017,6 +2046,15 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
         D.pinfo = reinterpret_cast<const uint4 *>(pi);
     }
+    { // the prefix table's FAT form: K1b's hit-slot mode settles a key's only candidate with the gather that fetches the key
+        void *fat = nullptr;
+        const size_t fat_bytes = ((size_t)32 << H.ptab_log2);
+        if (hipMalloc(&fat, fat_bytes) != hipSuccess) { (void)hipGetLastError(); return destroy(fail(ACX_ENOMEM, "out of device memory (prefix table)")); }
+        a->allocs.push_back(fat);
+        if (build_fat_table(D.ptab, H.ptab_log2, D.pinfo, H.filter_q2, (uint4 *)fat, st) != hipSuccess)
+            return destroy(fail(ACX_EDEVICE, "could not build the prefix table's fat form"));
+        D.pfat = (const uint4 *)fat;
+    }
     H.blob.resize(H.blob.size() + 16, 0); // the verification compares 8 bytes at a time
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)
@@ -2174,6 +2212,17 @@ uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2) {
 void acx_free_host(acx_host_automaton_t *h) { delete h; }
 
 void acx_free_automaton(acx_automaton_t *a) {
+#ifdef ACX_MAIN_CLOCK
+    {   // measurements: k_tile_main's phases, summed over its groups (100 MHz ticks)
+        unsigned long long c[16] = {};
+        (void)hipDeviceSynchronize();
+        if (acx::main_clock_read(c) == hipSuccess && c[15]) {
+            std::fprintf(stderr, "k_tile_main clock: groups %llu; per group, us: counts+scan %.2f, lines' items %.2f, unverified %.2f, sort %.2f, sync+greedy %.2f, compaction %.2f; unverified items %.1f of %.1f per group\n",
+                         c[15], c[0] / 100.0 / c[15], c[1] / 100.0 / c[15], c[2] / 100.0 / c[15], c[3] / 100.0 / c[15], c[4] / 100.0 / c[15], c[5] / 100.0 / c[15],
+                         (double)c[12] / c[15], (double)c[13] / c[15]);
+        }
+    }
+#endif
     if (!a) return;
     DeviceScope scope(a->device);
     for (Ctx *c : a->ctxs) destroy_ctx(c, a->device);
