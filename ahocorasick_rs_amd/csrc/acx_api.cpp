@@ -2046,19 +2046,19 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
         if ((rc = upload(a, st, H.pinfo.data(), H.pinfo.size(), &pi)) != ACX_OK) return destroy(rc);
         D.pinfo = reinterpret_cast<const uint4 *>(pi);
     }
+    H.blob.resize(H.blob.size() + 16, 0); // the verification compares 8 bytes at a time
+    UP(H.blob, pat_blob)
+    UP(H.offsets, pat_off)
+#undef UP
     { // the prefix table's FAT form: K1b's hit-slot mode settles a key's only candidate with the gather that fetches the key
         void *fat = nullptr;
         const size_t fat_bytes = ((size_t)32 << H.ptab_log2);
         if (hipMalloc(&fat, fat_bytes) != hipSuccess) { (void)hipGetLastError(); return destroy(fail(ACX_ENOMEM, "out of device memory (prefix table)")); }
         a->allocs.push_back(fat);
-        if (build_fat_table(D.ptab, H.ptab_log2, D.pinfo, H.filter_q2, (uint4 *)fat, st) != hipSuccess)
+        if (build_fat_table(D, H.match_kind, (uint4 *)fat, st) != hipSuccess)
             return destroy(fail(ACX_EDEVICE, "could not build the prefix table's fat form"));
         D.pfat = (const uint4 *)fat;
     }
-    H.blob.resize(H.blob.size() + 16, 0); // the verification compares 8 bytes at a time
-    UP(H.blob, pat_blob)
-    UP(H.offsets, pat_off)
-#undef UP
     if ((rc = upload(a, st, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
     if ((rc = upload(a, st, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
     {
@@ -2217,9 +2217,8 @@ void acx_free_automaton(acx_automaton_t *a) {
         unsigned long long c[16] = {};
         (void)hipDeviceSynchronize();
         if (acx::main_clock_read(c) == hipSuccess && c[15]) {
-            std::fprintf(stderr, "k_tile_main clock: groups %llu; per group, us: counts+scan %.2f, lines' items %.2f, unverified %.2f, sort %.2f, sync+greedy %.2f, compaction %.2f; unverified items %.1f of %.1f per group\n",
-                         c[15], c[0] / 100.0 / c[15], c[1] / 100.0 / c[15], c[2] / 100.0 / c[15], c[3] / 100.0 / c[15], c[4] / 100.0 / c[15], c[5] / 100.0 / c[15],
-                         (double)c[12] / c[15], (double)c[13] / c[15]);
+            std::fprintf(stderr, "k_tile_main clock (last launch): groups %llu; per group, ticks of s_memrealtime: counts+scan %.1f, lines' items %.1f, unverified %.1f, sort %.1f, sync+greedy %.1f, compaction %.1f; unverified items %.1f per group\n",
+                         c[15], (double)c[0] / c[15], (double)c[1] / c[15], (double)c[2] / c[15], (double)c[3] / c[15], (double)c[4] / c[15], (double)c[5] / c[15], (double)c[6] / c[15]);
         }
     }
 #endif

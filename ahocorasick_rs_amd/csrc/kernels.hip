@@ -841,22 +841,15 @@ __device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
     return __popcll(valid & HI & ~cont);
 }
 
-// Does the only candidate of a FAT prefix-table entry (info = {rank | length << 24, the 12 bytes behind the key's first q2};
-// its length is at most min(q2 + 12, 16): build_fat_table) occur where the 16 haystack bytes (w0, w1) start?  The key's own
-// bytes are known to agree (entry_matches); what is compared here is the tail, from byte q2 on.
-__device__ __forceinline__ bool fat_tail_matches(const uint4 info, uint32_t q2, uint64_t w0, uint64_t w1) {
-    const uint32_t L = info.x >> 24;
-    if (q2 < 8) { // (uniform)
-        const uint64_t h0 = q2 ? (w0 >> (8 * q2)) | (w1 << (64 - 8 * q2)) : w0;
-        const uint64_t h1 = q2 ? (w1 >> (8 * q2)) : w1;
-        const uint32_t need = L > q2 ? L - q2 : 0u; // <= 12, <= 16 - q2
-        const uint64_t m0 = need >= 8 ? ~0ull : ((1ull << (8 * need)) - 1);
-        const uint64_t m1 = need > 8 ? ((1ull << (8 * (need - 8))) - 1) : 0;
-        return ((((h0 ^ (((uint64_t)info.z << 32) | info.y)) & m0) | ((h1 ^ (uint64_t)info.w) & m1)) == 0);
-    }
-    const uint32_t need = L > 8 ? L - 8 : 0u; // <= 8
-    const uint64_t m0 = need >= 8 ? ~0ull : ((1ull << (8 * need)) - 1);
-    return ((w1 ^ (((uint64_t)info.z << 32) | info.y)) & m0) == 0;
+// The second half of a FAT prefix-table entry (build_fat_table): {the occurrence's item without its offset -- tie << ITEM_TIE_SHIFT
+// | length --, lo and hi; the pattern's bytes 8 .. 15} when the entry's ONLY candidate can be settled from the 16 haystack
+// bytes (w0, w1) at the hit: no anchor shift, at most 16 bytes, and its key is its first min(8, length) bytes -- so the key
+// compare (entry_matches) has settled a pattern of up to 8 bytes, and a longer one needs its bytes 8 .. length - 1 compared
+// with w1: one xor, one shift.  Zeros: not to be settled here.
+__device__ __forceinline__ bool fat_tail_matches(const uint4 info, uint64_t w1) {
+    const uint32_t L = info.x & ITEM_LEN_MASK; // 1 .. 16
+    const uint64_t d = ((((uint64_t)info.w << 32) | info.z) ^ w1) << ((128u - 8u * L) & 63u); // (L > 8: the bytes beyond the pattern shifted out)
+    return L <= 8 || d == 0;
 }
 
 // what K1b needs of the automaton (the full struct would sit in ~50 SGPRs for the whole kernel)
@@ -1123,12 +1116,10 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                     // (entV: {tie-break rank | length << 24, the 12 bytes behind the key's first Q2}; length 0: not to be
                     // settled here -- a list, a redirect, an anchored or a long pattern): its tail is compared with the
                     // window the pipeline carries, and what leaves the wave is an OCCURRENCE, one 64-bit word -- or nothing
-                    const uint32_t Lw = entV.x >> 24;
+                    const uint32_t Lw = entV.x & ITEM_LEN_MASK;
                     const bool can = same && Lw != 0;
-                    const bool okv = fat_tail_matches(entV, q2len, winC, winC1);
-                    const bool ver = can && okv;
-                    found = found && (!can || okv);
-                    const uint32_t tie = GK.key_mode == 1 ? (code & CODE_PID_MASK) : (entV.x & 0xFFFFFFu);
+                    const bool ver = can && fat_tail_matches(entV, winC1);
+                    found = found && (!can || ver);
                     uint32_t cin = 0;
                     if constexpr (CP) { // lead bytes among the first 16 - (p & 15) bytes of the window, not beyond the stream's end
                         uint32_t n_in = 16 - ((uint32_t)posC & 15);
@@ -1137,18 +1128,20 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                         const uint64_t v1 = n_in > 8 ? (n_in >= 16 ? ~0ull : ~0ull >> (8 * (16 - n_in))) : 0;
                         cin = lead_in_word(winC, v0) + lead_in_word(winC1, v1);
                     }
-                    const uint64_t offw = (uint64_t)(offC & 0xFFFu) << ITEM_OFF_SHIFT;
+                    const uint32_t offw = (offC & 0xFFFu) << (ITEM_OFF_SHIFT - 32); // (the item's high word)
                     // (a displaced key's item names the home slot the walk goes on from: k_tile_main needs no hash of the window first)
                     const uint32_t icode = same ? hcode : ITEM_RETRY | prefix_slot(BIG ? gram_hash2(winC & q2mask) + q2salt : hC, ptab_log2);
-                    uint64_t word = ver ? offw | ((uint64_t)tie << ITEM_TIE_SHIFT) | ((uint64_t)cin << ITEM_CIN_SHIFT) | Lw
-                                        : ITEM_UNVERIFIED | offw | icode;
+                    const uint32_t whi = ver ? entV.y | offw : (uint32_t)(ITEM_UNVERIFIED >> 32) | offw;
+                    const uint32_t wlo = ver ? (CP ? entV.x | (cin << ITEM_CIN_SHIFT) : entV.x) : icode;
+                    uint64_t word = ((uint64_t)whi << 32) | wlo;
+                    const uint32_t tie = (uint32_t)((((uint64_t)entV.y << 32) | entV.x) >> ITEM_TIE_SHIFT); // (the overflow lists' records only)
                     if constexpr (!SH) {
                         cntC += item_push(found, word, posC, ver ? HIT_VERIFIED | tie : hcode, Lw, winC, winC1, tileC, cntC);
                     } else {
-                        if (shC) { found = entC.x != SHORT_NONE; word = ITEM_UNVERIFIED | offw | entC.x; hcode = entC.x; }
+                        if (shC) { found = entC.x != SHORT_NONE; word = ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.x; hcode = entC.x; }
                         cntC += item_push(found, word, posC, ver ? HIT_VERIFIED | tie : hcode, Lw, winC, winC1, tileC, cntC);
                         // (a 1-byte AND a 2-byte pattern at one position: the second item)
-                        cntC += item_push(shC && entC.y != SHORT_NONE, ITEM_UNVERIFIED | offw | entC.y, posC, entC.y, 0u, winC, winC1, tileC, cntC);
+                        cntC += item_push(shC && entC.y != SHORT_NONE, ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.y, posC, entC.y, 0u, winC, winC1, tileC, cntC);
                     }
                 } else if constexpr (!SH) {
                     hit_push(found, posC, hcode, winC, winC1);
@@ -1590,27 +1583,33 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
 }
 
 // The prefix table in its FAT form (device_types.hpp: DevAutomaton::pfat), built once per automaton from the table and the
-// pattern infos: slot i = {the 16-byte entry, the info of its ONLY candidate -- or zeros when K1b cannot settle it from the 16
-// haystack bytes its pipeline carries: a list of candidates, a redirect, an anchored pattern, one of more than min(Q2 + 12,
-// 16) bytes}.
-__global__ void k_build_fat(const uint4 *__restrict__ ptab, uint64_t n_slots, const uint4 *__restrict__ pinfo, uint32_t q2,
-                            uint4 *__restrict__ fat) {
+// patterns: slot i = {the 16-byte entry, the second half described at fat_tail_matches -- or zeros when K1b cannot settle the
+// entry from the 16 haystack bytes its pipeline carries: a list of candidates, a redirect, an anchored pattern, one of more
+// than 16 bytes, a key shorter than min(8, the pattern)}.  tie: the pattern's rank, or (key_mode 1, LeftmostFirst) its id.
+__global__ void k_build_fat(const uint4 *__restrict__ ptab, uint64_t n_slots, const uint32_t *__restrict__ plen,
+                            const uint32_t *__restrict__ rank, const uint8_t *__restrict__ pat_blob,
+                            const uint64_t *__restrict__ pat_off, int key_mode, uint4 *__restrict__ fat) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
     const uint4 e = ptab[i];
     uint4 v = make_uint4(0, 0, 0, 0);
     if (e.z != PREFIX_EMPTY && ((e.z >> 4) & 15u) == 0 && !(e.w & HIT_LIST) && ((e.w >> CODE_SHIFT_SHIFT) & CODE_SHIFT_MASK) == 0) {
-        const uint4 pi = pinfo[e.w & CODE_PID_MASK];
-        const uint32_t L = pi.x >> 24, cap = q2 + 12 < 16 ? q2 + 12 : 16;
-        if (L != 0 && L != 255 && L <= cap) v = pi;
+        const uint32_t pid = e.w & CODE_PID_MASK, L = plen[pid], K = e.z & 15u;
+        if (L >= 1 && L <= 16 && K == (L < 8 ? L : 8)) {
+            const uint64_t item = ((uint64_t)(key_mode == 1 ? pid : rank[pid]) << ITEM_TIE_SHIFT) | L;
+            uint64_t hi = 0;
+            for (uint32_t k = 8; k < L; k++) hi |= (uint64_t)pat_blob[pat_off[pid] + k] << (8 * (k - 8));
+            v = make_uint4((uint32_t)item, (uint32_t)(item >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
     }
     fat[2 * i] = e;
     fat[2 * i + 1] = v;
 }
 
-hipError_t build_fat_table(const uint32_t *ptab, uint32_t ptab_log2, const uint4 *pinfo, uint32_t q2, uint4 *fat, hipStream_t st) {
-    const uint64_t n = 1ull << ptab_log2;
-    hipLaunchKernelGGL(k_build_fat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)ptab, n, pinfo, q2, fat);
+hipError_t build_fat_table(const DevAutomaton &A, int key_mode, uint4 *fat, hipStream_t st) {
+    const uint64_t n = 1ull << A.ptab_log2;
+    hipLaunchKernelGGL(k_build_fat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)A.ptab, n, A.plen, A.rank,
+                       A.pat_blob, A.pat_off, key_mode, fat);
     return hipGetLastError();
 }
 
@@ -2367,10 +2366,22 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
     else { *s = rel; *e = rel + L; }
 }
 
+#ifndef ACX_MAIN_PERSISTENT
+#define ACX_MAIN_PERSISTENT 0
+#endif
 #ifdef ACX_MAIN_CLOCK
-__device__ unsigned long long g_main_clock[16];
-hipError_t main_clock_read(unsigned long long *out) { return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_main_clock), sizeof(g_main_clock)); }
-#define MCLK(i) { __syncthreads(); if (threadIdx.x == 0) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); atomicAdd(&g_main_clock[i], n_ - clk_); clk_ = n_; } }
+// (per group, no atomics: 2 048 groups hammering six counters measured the counters -- ~16 returning atomics per us and address)
+constexpr uint32_t MCLK_GROUPS = 8192;
+__device__ unsigned long long g_main_clock[MCLK_GROUPS][8];
+hipError_t main_clock_read(unsigned long long *out) { // out[16]: sums over the groups of the LAST launch
+    static unsigned long long h[MCLK_GROUPS][8];
+    hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_main_clock), sizeof(h));
+    for (int k = 0; k < 16; k++) out[k] = 0;
+    for (uint32_t g = 0; g < MCLK_GROUPS; g++)
+        if (h[g][7]) { for (int k = 0; k < 7; k++) out[k] += h[g][k]; out[15]++; }
+    return e;
+}
+#define MCLK(i) { __syncthreads(); if (threadIdx.x == 0 && g < MCLK_GROUPS) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); g_main_clock[g][i] = n_ - clk_; clk_ = n_; } }
 #else
 #define MCLK(i)
 #endif
@@ -2393,8 +2404,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         for (uint64_t i = (uint64_t)blockIdx.x * MAIN_THREADS + threadIdx.x; i < n_seg; i += (uint64_t)gridDim.x * MAIN_THREADS)
             seg_counts[i] = 0;
 #ifdef ACX_MAIN_CLOCK
-    unsigned long long clk_ = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0) atomicAdd(&g_main_clock[15], 1ull);
+    unsigned long long clk_ = 0;
 #endif
     // (rows padded to an odd number of words: lane t works on row t, and a power-of-two row stride would
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
@@ -2407,31 +2417,47 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     constexpr uint32_t UL_CAP = V2 ? 512 : 1;
     __shared__ uint64_t ul[UL_CAP];                // V2: the unverified items of a round (bits 38:32: the tile's index in the group)
     __shared__ uint32_t fail, stop, tail_base, own_items, all_items, ul_n;
-    const uint32_t t = threadIdx.x, g = blockIdx.x;
-    const uint32_t tile0 = g * GROUP_TILES;
-    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
-    const uint32_t lb = tile0 - first;                               // context tiles in front
+    const uint32_t t = threadIdx.x;
     // anchors (automaton.hpp): a hit lies up to SHIFT_MAX bytes BEHIND the start of its occurrence, so an
     // occurrence that starts in the group's last bytes has its hit in the first tile of the next group: that
     // tile's hits are read too (the occurrences that start beyond the group are dropped like the context's)
     const uint32_t la = ANCH ? 1u : 0u;
-    const uint32_t nb = GROUP_TILES + lb + la;                       // tiles whose hits are read
     // V2: the first line of every staged tile, as 16-byte pieces: piece i = words 2 (i % 8), + 1 of tile i / 8
     constexpr uint32_t PIECES = ITEM_LINE / 2;
     constexpr uint32_t NLD = V2 ? ((GROUP_TILES + MAX_LOOKBACK + 1) * PIECES + MAIN_THREADS - 1) / MAIN_THREADS : 1;
-    uint64_t lx[NLD], ly[NLD];
-    if constexpr (V2) {
+    u32x4 lv[NLD];
+    // V2: the workgroups are PERSISTENT (round 6): a workgroup takes the groups g = blockIdx.x, + gridDim.x, ... and requests
+    // the lines of its NEXT group as soon as the registers of the current group's are free (its first round done) -- a group's
+    // life used to begin with a round trip to HBM for its lines, a third of it, with nothing else to do.
+    auto load_lines = [&](uint32_t gg) __attribute__((always_inline)) {
+        if constexpr (V2) {
+            if (ACX_MAIN_PERSISTENT == 0 && gg != blockIdx.x) return;
+            if (gg >= T.n_groups) return; // (uniform)
+            const uint32_t tile0_ = gg * GROUP_TILES, first_ = tile0_ >= lookback ? tile0_ - lookback : 0;
+            const uint32_t nb_ = GROUP_TILES + (tile0_ - first_) + la;
 #pragma unroll
-        for (uint32_t k = 0; k < NLD; k++) {
-            const uint32_t i = t + k * MAIN_THREADS, j = i / PIECES;
-            lx[k] = ly[k] = 0;
-            if (j < nb && first + j < T.n_tiles) {
-                const u32x4 v = *(const u32x4 *)(T.titems + (uint64_t)(first + j) * TILE_ITEMS + (i % PIECES) * 2);
-                lx[k] = ((uint64_t)v.y << 32) | v.x;
-                ly[k] = ((uint64_t)v.w << 32) | v.z;
+            for (uint32_t k = 0; k < NLD; k++) {
+                const uint32_t i = t + k * MAIN_THREADS, j = i / PIECES;
+                if (j < nb_ && first_ + j < T.n_tiles)
+                    lv[k] = *(const u32x4 *)(T.titems + (uint64_t)(first_ + j) * TILE_ITEMS + (i % PIECES) * 2);
+                else
+                    lv[k] = u32x4{0, 0, 0, 0};
             }
         }
-    }
+    };
+    load_lines(blockIdx.x);
+    // (!V2: one workgroup per group -- the loop body runs once, and the compiler knows)
+    constexpr bool PERSISTENT = V2 && ACX_MAIN_PERSISTENT != 0;
+    for (uint32_t g = blockIdx.x, again = 0; g < T.n_groups && (PERSISTENT || !again); g += gridDim.x, again = 1) {
+    __syncthreads(); // (the previous group's stage is read no more)
+#ifdef ACX_MAIN_CLOCK
+    clk_ = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0 && g < MCLK_GROUPS) { for (int k_ = 0; k_ < 7; k_++) g_main_clock[g][k_] = 0; g_main_clock[g][7] = 1; }
+#endif
+    const uint32_t tile0 = g * GROUP_TILES;
+    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
+    const uint32_t lb = tile0 - first;                               // context tiles in front
+    const uint32_t nb = GROUP_TILES + lb + la;                       // tiles whose hits are read
     // ---- hits of the staged tiles: exclusive prefix of the counts (wave 0: 64 tiles, wave 1: the
     // few beyond -- nb <= 69)
     uint32_t c = 0;
@@ -2461,7 +2487,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
 #pragma unroll
         for (uint32_t k = 0; k < NLD; k++) {
             const uint32_t i = t + k * MAIN_THREADS;
-            if (i % PIECES == 0 && i / PIECES < nb) tcnt[i / PIECES] = (uint32_t)lx[k] & 0xFFFFu;
+            if (i % PIECES == 0 && i / PIECES < nb) tcnt[i / PIECES] = lv[k].x & 0xFFFFu;
         }
         __syncthreads();
         if (t < nb) {
@@ -2491,10 +2517,11 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     const uint32_t H = hoff[nb];
     MCLK(0)
     if (stop) return;
-    if (fail) { give_up(); return; }
+    if (fail) { give_up(); load_lines(g + gridDim.x); continue; }
     if (V2 ? all_items == 0 : H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
         if (t == 0) T.btot[g] = 0;
-        return;
+        load_lines(g + gridDim.x);
+        continue;
     }
     // index space: index = stream position + lead; a tile / bucket is 4 KiB of it
     const uint64_t idx_lo = (uint64_t)tile0 << TILE_BITS, idx_hi = idx_lo + ((uint64_t)GROUP_TILES << TILE_BITS);
@@ -2591,13 +2618,15 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         for (uint32_t k = 0; k < NLD; k++) {
             const uint32_t i = t + k * MAIN_THREADS, j = i / PIECES, w = (i % PIECES) * 2;
             const uint32_t cj = j < nb ? tcnt[j] : 0u; // (not ITEM_OVERFULL here: the group would have given up)
-            if (w >= 1 && w <= cj) { if (!(lx[k] & ITEM_UNVERIFIED)) take_verified(lx[k], j); else put(lx[k], j); }
-            if (w + 1 <= cj) { if (!(ly[k] & ITEM_UNVERIFIED)) take_verified(ly[k], j); else put(ly[k], j); }
+            const uint64_t ix = ((uint64_t)lv[k].y << 32) | lv[k].x, iy = ((uint64_t)lv[k].w << 32) | lv[k].z;
+            if (w >= 1 && w <= cj) { if (!(ix & ITEM_UNVERIFIED)) take_verified(ix, j); else put(ix, j); }
+            if (w + 1 <= cj) { if (!(iy & ITEM_UNVERIFIED)) take_verified(iy, j); else put(iy, j); }
         }
+        load_lines(g + gridDim.x); // (in flight while this group is finished)
         __syncthreads();
         MCLK(1)
 #ifdef ACX_MAIN_CLOCK
-        if (t == 0) { atomicAdd(&g_main_clock[12], (unsigned long long)ul_n); atomicAdd(&g_main_clock[13], (unsigned long long)all_items); }
+        if (t == 0 && g < MCLK_GROUPS) g_main_clock[g][6] = ul_n;
 #endif
         uint32_t Hx = H, wi0 = ITEM_LINE; // the rounds behind round 0: items to walk, the word the first of a tile is in
         if (ul_n > UL_CAP) { // (block-uniform) the list overflowed: all items again, by the prefix of the FULL counts
@@ -2630,23 +2659,34 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
                 if ((code & ITEM_RETRY) == ITEM_RETRY) {
                     // a displaced key: the probe sequence from the slot behind its home slot, in the FAT table -- the first of
                     // those entries is requested together with the window, and a final entry brings its candidate's info along
+                    // (the two slots behind the home slot are requested at once, with the window: a displaced key sits in one
+                    // of them nearly always -- one round trip instead of a chain of them)
                     const uint32_t mask = (1u << A.ptab_log2) - 1;
                     uint32_t idx = code & ~ITEM_RETRY;
                     code = HIT_NONE;
-                    for (;;) {
-                        idx = (idx + 1) & mask;
-                        const uint4 e = A.pfat[2 * (size_t)idx], v = A.pfat[2 * (size_t)idx + 1];
-                        if (e.z == PREFIX_EMPTY) break;
-                        if (!entry_matches(e, w0)) continue;
-                        if ((e.z >> 4) & 15u) { code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0); break; } // (a redirect: the general walk)
+                    // 0: not this entry, go on; 1: the walk is over (code: what is left to settle, or HIT_NONE)
+                    auto examine = [&](const uint4 e, const uint4 v) -> bool {
+                        if (e.z == PREFIX_EMPTY) return true;
+                        if (!entry_matches(e, w0)) return false;
+                        if ((e.z >> 4) & 15u) { code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0); return true; } // (a redirect: the general walk)
                         code = e.w;
-                        if ((v.x >> 24) != 0) { // settled here, like K1b's own
+                        if ((v.x & ITEM_LEN_MASK) != 0) { // settled here, like K1b's own
                             code = HIT_NONE;
-                            const uint32_t L = v.x >> 24;
-                            if (fat_tail_matches(v, A.filter_q2, w0, w1) && L <= segment_end(G, len, p) - p)
-                                stage(p, e.w & CODE_PID_MASK, L, v.x & 0xFFFFFFu, CP ? leads_in_chunk(p, w0, w1) : 0u);
+                            const uint32_t L = v.x & ITEM_LEN_MASK, tie = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> ITEM_TIE_SHIFT);
+                            if (fat_tail_matches(v, w1) && L <= segment_end(G, len, p) - p)
+                                stage(p, tie, L, tie, CP ? leads_in_chunk(p, w0, w1) : 0u);
                         }
-                        break;
+                        return true;
+                    };
+                    const uint32_t i1 = (idx + 1) & mask, i2 = (idx + 2) & mask;
+                    const uint4 e1 = A.pfat[2 * (size_t)i1], v1 = A.pfat[2 * (size_t)i1 + 1];
+                    const uint4 e2 = A.pfat[2 * (size_t)i2], v2 = A.pfat[2 * (size_t)i2 + 1];
+                    if (!examine(e1, v1) && !examine(e2, v2)) {
+                        idx = i2;
+                        for (;;) {
+                            idx = (idx + 1) & mask;
+                            if (examine(A.pfat[2 * (size_t)idx], A.pfat[2 * (size_t)idx + 1])) break;
+                        }
                     }
                     if (code == HIT_NONE) continue;
                 }
@@ -2693,7 +2733,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     }
     __syncthreads();
     MCLK(2)
-    if (fail) { give_up(); return; }
+    if (fail) { give_up(); continue; }
     // ---- order every bucket (words are unique), largest end per bucket
     // (buckets, not tiles read: the look-ahead tile of an anchored set has no bucket -- with four context tiles,
     // patterns longer than 10 KiB, `t < nb` reached one row beyond the stage)
@@ -2715,6 +2755,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     __syncthreads();
     MCLK(3)
     uint32_t cnt = 0, accepted = 0; // reported occurrences of output bucket t (wave 0)
+    bool fail_late = false;
     if (overlapping) {
         if (t < GROUP_TILES) { cnt = bn[lb + t]; accepted = cnt >= 32 ? 0xFFFFFFFFu : (1u << cnt) - 1; }
     } else {
@@ -2766,9 +2807,10 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             }
         }
         __syncthreads();
-        if (fail) { give_up(); return; }
+        if (fail) { give_up(); fail_late = true; }
     }
     MCLK(4)
+    if (fail_late) continue;
     // ---- compact the reported occurrences of the 64 output buckets into the group's stretch
     if (t < 64) {
         uint32_t incl = cnt, occ = t < GROUP_TILES ? bn[lb + t] : 0u;
@@ -2812,6 +2854,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         }
     }
     MCLK(5)
+    } // (the workgroup's next group)
 }
 
 // non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
@@ -3098,6 +3141,24 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     }
 }
 
+// workgroups of the persistent k_tile_main<.., V2>: as many as the device holds at once (asked once per device and instantiation)
+static uint32_t main_grid(const void *kernel, int inst, uint32_t n_groups) {
+    static uint32_t resident[16][4] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    uint32_t &r = resident[dev & 15][inst & 3];
+    if (r == 0) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)MAIN_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
+        (void)hipGetLastError();
+        static const char *env = std::getenv("ACX_MAIN_PER_CU"); // measurements
+        if (env && std::atoi(env) > 0) per_cu = std::atoi(env);
+        r = (uint32_t)per_cu * (uint32_t)cus;
+    }
+    return n_groups < r ? n_groups : r;
+}
+
 uint32_t tile_lookback(uint32_t max_len) {
     // context tiles in front of a group: longer than the longest pattern by at least 2 KiB
     const uint64_t need = (uint64_t)(max_len ? max_len - 1 : 0) + 2048;
@@ -3118,7 +3179,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     const bool cpw = cp_blockpre != nullptr; // the write kernel converts to code points: the occurrences carry their chunk counts
 #define ACX_TILE_MAIN_V(AN, CPW, V)                                                                                    \
-    hipLaunchKernelGGL((k_tile_main<AN, CPW, V>), dim3(T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback, \
+    hipLaunchKernelGGL((k_tile_main<AN, CPW, V>), dim3(V && ACX_MAIN_PERSISTENT != 0 ? main_grid((const void *)k_tile_main<AN, CPW, V>, (AN ? 2 : 0) + (CPW ? 1 : 0), T.n_groups) : T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback, \
                        lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0, hot_ok ? 1 : 0)
 #define ACX_TILE_MAIN(AN, CPW) { if (T.titems) ACX_TILE_MAIN_V(AN, CPW, true); else ACX_TILE_MAIN_V(AN, CPW, false); }
     if (A.max_shift) { if (cpw) ACX_TILE_MAIN(true, true) else ACX_TILE_MAIN(true, false) }

@@ -61,8 +61,8 @@ hipError_t launch_walk_hits(const DevAutomaton &A, const Segments &G, const Sink
 #ifdef ACX_MAIN_CLOCK
 hipError_t main_clock_read(unsigned long long *out); // measurements (tools/build_variant.sh -DACX_MAIN_CLOCK=1): k_tile_main's phases
 #endif
-// the prefix table's FAT form (DevAutomaton::pfat: 2 x 16 bytes per slot), from the table and the pattern infos
-hipError_t build_fat_table(const uint32_t *ptab, uint32_t ptab_log2, const uint4 *pinfo, uint32_t q2, uint4 *fat, hipStream_t st);
+// the prefix table's FAT form (DevAutomaton::pfat: 2 x 16 bytes per slot), from the uploaded table and patterns
+hipError_t build_fat_table(const DevAutomaton &A, int key_mode, uint4 *fat, hipStream_t st);
 size_t prefilter_lds_bytes(); // static LDS of K1b
 // rows of the hot16 table K1a can stage for this automaton and LDS size
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds);
