@@ -856,7 +856,6 @@ __device__ __forceinline__ bool fat_tail_matches(const uint4 info, uint64_t w1) 
 struct K1bTables {
     const uint32_t *filterA;
     const uint32_t *ptab;
-    const uint4 *pfat;     // hit-slot mode: the prefix table in its FAT form (entry + the only candidate's pattern info, 32 bytes)
     const uint32_t *rbloom;
     const uint32_t *pbits; // BIG: the bitmap in front of the prefix table
     uint32_t ptab_log2, filter_q2, min_len; // min_len: the shortest pattern IN THESE TABLES (DevAutomaton::k1b_min_len)
@@ -977,9 +976,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         obn = 0;
     };
     // the lanes with found == true push `word` into the words 1 + cnt, 2 + cnt, ... of `tile` (cnt is wave-uniform).  An
-    // item beyond the tile's words goes to the call's overflow lists as a 32-byte record {p, ocode, olen}{w0, w1}
-    // (ocode: the candidate code, or HIT_VERIFIED | tie with the length in olen).  Returns the number of items pushed.
-    auto item_push = [&](bool found, uint64_t word, uint64_t p, uint32_t ocode, uint32_t olen, uint64_t w0, uint64_t w1,
+    // item beyond the tile's words goes to the call's overflow lists as a 32-byte prefix-hit record {p, ocode}{the 16
+    // haystack bytes at p}.  Returns the number of items pushed.
+    auto item_push = [&](bool found, uint64_t word, uint64_t p, uint32_t ocode, uint64_t w0,
                          uint64_t tile, uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
         const unsigned long long fm = __ballot(found);
         if (!fm) return 0;
@@ -1004,7 +1003,8 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             if (found && !keep) {
                 if (i < cap) {
                     uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * ((uint64_t)list * cap + i);
-                    o[0] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), ocode, olen);
+                    const uint64_t w1 = load_window(stream, len, p + 8); // (the pipeline carries the first 8 bytes only)
+                    o[0] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), ocode, 0u);
                     o[1] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
                 } else {
                     ctl[CTL_OVF_LOST] = 1;
@@ -1076,7 +1076,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
     uint32_t offB = 0, offC = 0, hC = 0; // (hC: the hash of the window in C -- its home slot, its bit in the slot's filter of displaced keys)
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
-    uint4 entV = make_uint4(0, 0, 0, 0); // hit-slot mode: the second half of the FAT entry (the only candidate's pattern info)
     // BIG: one more stage between B and C.  The prefix table of such a set has outgrown the L2
     // (measured on 10^5 patterns: 54 M L2 misses per GiB, the kernel bound by them); the windows are
     // first put to the bitmap of the groups' first Q2 bytes (L2-resident), and only the ones it
@@ -1112,36 +1111,21 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 bool found = (same && code != HIT_NONE) || retry;
                 uint32_t hcode = same ? code : HIT_RETRY;
                 if constexpr (SLOTS) {
-                    // ---- in-scan verification (round 6): the FAT entry brought the pattern info of the key's ONLY candidate
-                    // (entV: {tie-break rank | length << 24, the 12 bytes behind the key's first Q2}; length 0: not to be
-                    // settled here -- a list, a redirect, an anchored or a long pattern): its tail is compared with the
-                    // window the pipeline carries, and what leaves the wave is an OCCURRENCE, one 64-bit word -- or nothing
-                    const uint32_t Lw = entV.x & ITEM_LEN_MASK;
-                    const bool can = same && Lw != 0;
-                    const bool ver = can && fat_tail_matches(entV, winC1);
-                    found = found && (!can || ver);
-                    uint32_t cin = 0;
-                    if constexpr (CP) { // lead bytes among the first 16 - (p & 15) bytes of the window, not beyond the stream's end
-                        uint32_t n_in = 16 - ((uint32_t)posC & 15);
-                        if (len - posC < n_in) n_in = (uint32_t)(len - posC);
-                        const uint64_t v0 = n_in >= 8 ? ~0ull : (n_in ? ~0ull >> (8 * (8 - n_in)) : 0);
-                        const uint64_t v1 = n_in > 8 ? (n_in >= 16 ? ~0ull : ~0ull >> (8 * (16 - n_in))) : 0;
-                        cin = lead_in_word(winC, v0) + lead_in_word(winC1, v1);
-                    }
+                    // an ITEM (device_types.hpp): the hit's offset in its tile and its candidate code -- one 64-bit word.  (Round 6
+                    // measured the step further: the candidate's bytes brought along by 32-byte "fat" table entries and
+                    // compared HERE, so that an item is a finished occurrence -- +12 .. 19 us on this kernel, which is bound by
+                    // its VALU instructions, for nothing k_tile_main got faster by: DESIGN section 4, profiles/r06/exp_in_scan_*.)
+                    // A displaced key's item names the home slot the walk goes on from: k_tile_main needs no hash of the window first.
                     const uint32_t offw = (offC & 0xFFFu) << (ITEM_OFF_SHIFT - 32); // (the item's high word)
-                    // (a displaced key's item names the home slot the walk goes on from: k_tile_main needs no hash of the window first)
                     const uint32_t icode = same ? hcode : ITEM_RETRY | prefix_slot(BIG ? gram_hash2(winC & q2mask) + q2salt : hC, ptab_log2);
-                    const uint32_t whi = ver ? entV.y | offw : (uint32_t)(ITEM_UNVERIFIED >> 32) | offw;
-                    const uint32_t wlo = ver ? (CP ? entV.x | (cin << ITEM_CIN_SHIFT) : entV.x) : icode;
-                    uint64_t word = ((uint64_t)whi << 32) | wlo;
-                    const uint32_t tie = (uint32_t)((((uint64_t)entV.y << 32) | entV.x) >> ITEM_TIE_SHIFT); // (the overflow lists' records only)
+                    uint64_t word = ((uint64_t)((uint32_t)(ITEM_UNVERIFIED >> 32) | offw) << 32) | icode;
                     if constexpr (!SH) {
-                        cntC += item_push(found, word, posC, ver ? HIT_VERIFIED | tie : hcode, Lw, winC, winC1, tileC, cntC);
+                        cntC += item_push(found, word, posC, hcode, winC, tileC, cntC);
                     } else {
                         if (shC) { found = entC.x != SHORT_NONE; word = ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.x; hcode = entC.x; }
-                        cntC += item_push(found, word, posC, ver ? HIT_VERIFIED | tie : hcode, Lw, winC, winC1, tileC, cntC);
+                        cntC += item_push(found, word, posC, hcode, winC, tileC, cntC);
                         // (a 1-byte AND a 2-byte pattern at one position: the second item)
-                        cntC += item_push(shC && entC.y != SHORT_NONE, ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.y, posC, entC.y, 0u, winC, winC1, tileC, cntC);
+                        cntC += item_push(shC && entC.y != SHORT_NONE, ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.y, posC, entC.y, winC, tileC, cntC);
                     }
                 } else if constexpr (!SH) {
                     hit_push(found, posC, hcode, winC, winC1);
@@ -1171,14 +1155,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                         entC.x = A.short_codes[(uint32_t)winM & 0xFFu];
                         entC.y = A.short_codes[256u + ((uint32_t)winM & 0xFFFFu)];
                     } else {
-                        if constexpr (SLOTS) {
-                            const uint4 *fe = A.pfat + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 2;
-                            entC = fe[0]; entV = fe[1];
-                        } else {
-                            entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 4);
-                        }
+                        entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 4);
                     }
-                    winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + (offM & OFFMASK) - lead + 8);
+                    if (!SLOTS) winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + (offM & OFFMASK) - lead + 8); // (region mode: the records carry 16 bytes)
                 }
                 offC = offM; winC = winM;
             }
@@ -1213,15 +1192,11 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                         entC.x = A.short_codes[(uint32_t)winB & 0xFFu];
                         entC.y = A.short_codes[256u + ((uint32_t)winB & 0xFFFFu)];
                     } else {
-                        if constexpr (SLOTS) {
-                            const uint4 *fe = A.pfat + (size_t)prefix_slot(hB, ptab_log2) * 2;
-                            entC = fe[0]; entV = fe[1];
-                        } else {
-                            entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
-                        }
+                        entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
                     }
                 }
-                offC = offB; hC = hB; winC = winB; winC1 = winB1;
+                offC = offB; hC = hB; winC = winB;
+                if (!SLOTS) winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
         }
@@ -1234,14 +1209,18 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 }
             }
         } else {
-            // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
+            // ---- stage A -> B: fetch the windows of the queued survivors: 16 bytes for the records of region mode, the 8 the
+            // key compare needs in hit-slot mode (an item carries no haystack bytes)
             if (q1c) {
                 // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
                 const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
                 if (lane < q1c) {
                     offB = q1[lane];
                     const uint64_t p_ = (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead;
-                    if (inside) {
+                    if constexpr (SLOTS) {
+                        if (inside) __builtin_memcpy(&winB, stream + p_, 8);
+                        else winB = load_window(stream, len, p_);
+                    } else if (inside) {
                         u32x4 w_;
                         __builtin_memcpy(&w_, stream + p_, 16);
                         winB = ((uint64_t)w_.y << 32) | w_.x;
@@ -1647,11 +1626,10 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
     dim3 g(grid), b(1024);
-    const K1bTables T{A.filterA, A.ptab, A.pfat, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.k1b_min_len, cp_sub,
+    const K1bTables T{A.filterA, A.ptab, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.k1b_min_len, cp_sub,
                       A.short_xy, A.short_codes, A.short_min_len};
     const bool sh = A.short_min_len != 0; // the set has patterns of 1 or 2 bytes: the side test runs too
     if (cp_sub && (lead != 0 || !K.titems)) return hipErrorInvalidValue;
-    if (K.titems && !A.pfat) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
 #define ACX_K1B_LAUNCH(Q, S, C, B, H)                                                                      \
     hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B, H>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
