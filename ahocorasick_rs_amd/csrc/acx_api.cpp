@@ -391,13 +391,8 @@ struct Workspace {
     DenseTiles dt{};                  // dense path, tile-ordered: occurrence buckets by key tile
     TileSpace TD{};                   //   its groups' reported occurrences (64-bit words), counts, supergroup words
     uint64_t dt_cap = 0;              //   tiles both are allocated for
-    TileSpace T{};                    // sparse path (the tiles' hits + tile kernels)
-    uint64_t tile_cap = 0;            // tiles T's group arrays, the hot list and the overflow lists are allocated for
-    uint4 *hslots = nullptr;          // K1a's hit slots and counts (T.hslots / T.hcnt of a K1a call), slot_cap tiles
-    uint32_t *hcnt = nullptr;
-    uint64_t slot_cap = 0;
-    uint64_t *titems = nullptr;       // K1b's items (T.titems of a K1b call: TILE_ITEMS words per tile), item_cap tiles
-    uint64_t item_cap = 0;
+    TileSpace T{};                    // sparse path (hit slots + tile kernels)
+    uint64_t tile_cap = 0;            // tiles T is allocated for
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
     bool flags_dirty = true;          // the control blocks' counters are not known to be zero
     uint32_t *ctl = nullptr;          // device: the sparse path's two control blocks (device_types.hpp), used by the calls in turn
@@ -536,12 +531,9 @@ int upload(acx_automaton *a, hipStream_t st, const T *src, size_t count, const T
 
 void free_tiles(Workspace &w) {
     TileSpace &T = w.T;
-    (void)hipFree(w.hslots); (void)hipFree(w.hcnt); (void)hipFree(w.titems);
-    (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
+    (void)hipFree(T.hslots); (void)hipFree(T.hcnt); (void)hipFree(T.trecs); (void)hipFree(T.btot); (void)hipFree(T.sgw);
     (void)hipFree(w.hot_list); (void)hipFree(w.ovf_recs);
     w.hot_list = nullptr; w.ovf_recs = nullptr; w.ovf_cap = 0;
-    w.hslots = nullptr; w.hcnt = nullptr; w.titems = nullptr;
-    w.slot_cap = w.item_cap = 0;
     T = TileSpace{};
     w.tile_cap = 0;
     w.group_cap = 0;
@@ -730,22 +722,24 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
     return ACX_OK;
 }
 
-// sparse path: the tiles' hits for `tiles` tiles of index space (K1b -- pre -- : items; K1a: hit slots + counts), group
-// arrays.  One bucket beyond the last tile exists (an occurrence may END exactly at the end of the last tile).
-// Nothing is marked as allocated before every allocation of its kind has succeeded: a failure leaves the workspace
-// without that kind (free_tiles), never with control blocks that point at freed memory.
-int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles, bool pre) {
+// sparse path: hit slots for `tiles` tiles of index space, group arrays.  One bucket beyond the
+// last tile exists (an occurrence may END exactly at the end of the last tile).
+// Nothing is marked as allocated before every allocation has succeeded: a failure leaves the workspace without its tile
+// arrays (free_tiles), never with control blocks that point at freed memory.
+int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
     Workspace &w = c->ws;
     TileSpace &T = w.T;
     const uint64_t groups = (tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
-    const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
     if (tiles > w.tile_cap) {
         free_tiles(w);
         if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
+        const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
         const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
         const uint64_t cap_super = (cap_groups + 63) / 64;
         int rc = ACX_OK;
         auto grab = [&](void **p, uint64_t bytes) { if (rc == ACX_OK && hipMalloc(p, bytes) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMalloc (tile workspace)"); };
+        grab((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32);
+        grab((void **)&T.hcnt, (cap_tiles + 16 * 1024 + 16) * 4); // + one slot per K1b wave (layout slack)
         grab((void **)&T.trecs, cap_groups * GROUP_MAX * 16);
         grab((void **)&T.btot, cap_groups * 4);
         grab((void **)&T.sgw, 4 * cap_super * 8);
@@ -757,22 +751,6 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles, bool pre) {
         w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
     }
-    if (pre && tiles > w.item_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(w.titems); w.titems = nullptr; w.item_cap = 0;
-        HIPCHK(hipMalloc((void **)&w.titems, cap_tiles * TILE_ITEMS * 8));
-        w.item_cap = cap_tiles;
-    }
-    if (!pre && tiles > w.slot_cap) {
-        HIPCHK(hipStreamSynchronize(c->stream));
-        (void)hipFree(w.hslots); (void)hipFree(w.hcnt); w.hslots = nullptr; w.hcnt = nullptr; w.slot_cap = 0;
-        HIPCHK(hipMalloc((void **)&w.hslots, cap_tiles * HIT_SLOTS * 32));
-        HIPCHK(hipMalloc((void **)&w.hcnt, (cap_tiles + 16 * 1024 + 16) * 4)); // + one slot per scan wave (layout slack)
-        w.slot_cap = cap_tiles;
-    }
-    T.hslots = pre ? nullptr : w.hslots;
-    T.hcnt = pre ? nullptr : w.hcnt;
-    T.titems = pre ? w.titems : nullptr;
     T.n_tiles = (uint32_t)tiles;
     T.n_groups = (uint32_t)groups;
     return ACX_OK;
@@ -1091,7 +1069,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     Ctx *x = c.c;
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
-    int rc = ensure_tiles(a, x, c.tiles, c.pre);
+    int rc = ensure_tiles(a, x, c.tiles);
     if (rc) return rc;
     TileSpace &T = w.T;
     // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk) instead of the
@@ -1135,7 +1113,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     uint32_t *abort_flag = w.ctl + CTL_WORDS * x->flag_idx;
     uint32_t *next_flag = w.ctl + CTL_WORDS * (x->flag_idx ^ 1);
     x->flag_idx ^= 1;
-    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters, T.titems};
+    const Sink K{nullptr, nullptr, 0, c.key_mode, T.hslots, T.hcnt, abort_flag, c.lead, T.cnt_nw, T.cnt_iters};
     // batch with byte offsets: the write kernel localises and counts per haystack itself
     uint64_t *seg_counts = c.segmented && !c.codepoints ? c.r->d_counts : nullptr;
     const bool prof = c.timed;
@@ -2050,15 +2028,6 @@ int acx_build(const uint8_t *blob, const uint64_t *offsets, uint64_t n_patterns,
     UP(H.blob, pat_blob)
     UP(H.offsets, pat_off)
 #undef UP
-    { // the prefix table's FAT form: K1b's hit-slot mode settles a key's only candidate with the gather that fetches the key
-        void *fat = nullptr;
-        const size_t fat_bytes = ((size_t)32 << H.ptab_log2);
-        if (hipMalloc(&fat, fat_bytes) != hipSuccess) { (void)hipGetLastError(); return destroy(fail(ACX_ENOMEM, "out of device memory (prefix table)")); }
-        a->allocs.push_back(fat);
-        if (build_fat_table(D, H.match_kind, (uint4 *)fat, st) != hipSuccess)
-            return destroy(fail(ACX_EDEVICE, "could not build the prefix table's fat form"));
-        D.pfat = (const uint4 *)fat;
-    }
     if ((rc = upload(a, st, H.classes, (size_t)256, &D.classes)) != ACX_OK) return destroy(rc);
     if ((rc = upload(a, st, &a->dev, (size_t)1, &a->d_dev)) != ACX_OK) return destroy(rc);
     {
@@ -2212,16 +2181,6 @@ uint32_t acx_prefix_slot(uint64_t gram, uint32_t q2, uint32_t log2) {
 void acx_free_host(acx_host_automaton_t *h) { delete h; }
 
 void acx_free_automaton(acx_automaton_t *a) {
-#ifdef ACX_MAIN_CLOCK
-    {   // measurements: k_tile_main's phases, summed over its groups (100 MHz ticks)
-        unsigned long long c[16] = {};
-        (void)hipDeviceSynchronize();
-        if (acx::main_clock_read(c) == hipSuccess && c[15]) {
-            std::fprintf(stderr, "k_tile_main clock (last launch): groups %llu; per group, ticks of s_memrealtime: counts+scan %.1f, lines' items %.1f, unverified %.1f, sort %.1f, sync+greedy %.1f, compaction %.1f; unverified items %.1f per group\n",
-                         c[15], (double)c[0] / c[15], (double)c[1] / c[15], (double)c[2] / c[15], (double)c[3] / c[15], (double)c[4] / c[15], (double)c[5] / c[15], (double)c[6] / c[15]);
-        }
-    }
-#endif
     if (!a) return;
     DeviceScope scope(a->device);
     for (Ctx *c : a->ctxs) destroy_ctx(c, a->device);

@@ -28,11 +28,6 @@ struct DevAutomaton {
     const uint32_t *by_rank;     // n_patterns: the pattern of a rank (inverse of rank)
     const uint32_t *filterA;     // FILTER_WORDS: level-1 {X, Y} table of the K1b prefilter
     const uint32_t *ptab;        // prefix table: 4 u32 per entry (gram lo, hi, state|flags, pid or list)
-    const uint4 *pfat;           // the same table in its FAT form (round 6, built on the device from ptab + pinfo): 2 x 16 bytes per
-                                 // slot -- the entry, then {tie-break rank | length << 24, the 12 bytes behind the key's first Q2}
-                                 // of the entry's ONLY candidate when K1b can settle it from the 16 bytes it carries (no
-                                 // anchor shift, at most min(Q2 + 12, 16) bytes), else zeros: K1b's hit-slot mode verifies in
-                                 // its compare stage, with no further gather
     const uint32_t *blist;       // candidate lists of prefixes shared by several patterns
     const uint32_t *rbloom;      // REDIRECT_BLOOM_WORDS: Bloom filter of the keys behind redirect entries
     const uint32_t *pbits;       // 2^(ptab_log2 + 3) bits: the groups' first Q2 bytes (prefix_bitmap_bit)
@@ -149,29 +144,6 @@ constexpr uint32_t CTL_ABORT = 0, CTL_OVF_LOST = 1, CTL_HOT_COUNT = 2, CTL_OVF_C
 constexpr uint32_t OVF_LISTS = 256, OVF_COUNT_STRIDE = 16; // lists; u32 words from one list's counter to the next (64 bytes)
 constexpr uint32_t CTL_WORDS = 16;         // u32 words per block
 constexpr uint32_t HOT_BIT = 0x80000000u;  // TileSpace::btot[g]: the group is the hot pipeline's (low bits: its matches)
-// Round 6 -- what K1b leaves per tile in hit-slot mode: ITEMS of ONE 64-bit word instead of 32-byte prefix-hit records.
-// A tile owns TILE_ITEMS words: word 0 = the header (the number of items that follow; ITEM_OVERFULL: more than fit -- the
-// rest is in the overflow lists, as 32-byte records), words 1 .. = the items
-//   verified   [63] 0 | [62:51] offset of the occurrence's start in its tile | [50:27] tie (rank; LeftmostFirst: pattern id)
-//              | [26:22] str API: lead bytes of the start's 16-byte chunk at or behind the start | [21:0] pattern length
-//              -- K1b compared the pattern's tail itself: the prefix table's entries (the FAT form, 32 bytes: the
-//              16-byte entry + the only candidate's pattern info) bring the candidate's bytes with the key, in ONE gather
-//   unverified [63] 1 | [62:51] offset of the hit in its tile | [31:0] candidate code (a pattern id | anchor shift << 24,
-//              HIT_LIST | index, or ITEM_RETRY | home slot: a displaced key -- the probe sequence goes on behind that slot)
-//              -- a key shared by several patterns, a pattern filed under an anchor, one longer than the 16 bytes that
-//              travel through the pipeline, a displaced key: k_tile_main settles those, the 16 haystack bytes at the hit
-//              re-read from the stream (k_tile_main keeps bits [38:32] for the tile's index in its group)
-// k_tile_main reads header + the first 15 items of every staged tile as ONE 128-byte line per tile, all lines of a group in
-// flight together: no count array in front of the records (one dependent round trip less), and for verified items no pattern
-// info behind them (two less) -- the kernel is bound by exactly those round trips.
-constexpr uint32_t TILE_ITEMS = 64;            // words per tile, header included
-constexpr uint32_t ITEM_LINE = 16;             // words k_tile_main requests up front (one 128-byte line)
-constexpr uint32_t ITEM_OVERFULL = 0xFFFFu;    // header: the tile's items did not fit
-constexpr uint64_t ITEM_UNVERIFIED = 1ull << 63;
-constexpr uint32_t ITEM_RETRY = 0xC0000000u;   // unverified item's code: bits 31 and 30 set, the home slot below (HIT_LIST codes: bit 31 only)
-constexpr uint32_t ITEM_OFF_SHIFT = 51, ITEM_TIE_SHIFT = 27, ITEM_CIN_SHIFT = 22;
-constexpr uint32_t ITEM_LEN_MASK = (1u << ITEM_CIN_SHIFT) - 1;
-
 struct Sink {
     uint4 *recs;            // region mode: region_cap * quads uint4 per region
     uint64_t *block_counts; // region mode: one per region
@@ -182,7 +154,6 @@ struct Sink {
     uint32_t *abort_flag;   // hit-slot mode: the call's control block (above); [0] set when the slots cannot hold the output
     uint32_t lead;          // index = stream position + lead
     uint32_t cnt_nw, cnt_iters;
-    uint64_t *titems;       // hit-slot mode, K1b: n_tiles * TILE_ITEMS words (header + items, above); K1a keeps hslots / hcnt
 };
 
 // Dense outputs, tile-ordered (round 4; kernels.hip: k_dense_verify / k_dense_main): occurrences are filed by
@@ -204,9 +175,8 @@ struct DenseTiles {
 
 // Storage of the sparse path, sized by the number of tiles / groups of the stream.
 struct TileSpace {
-    uint4 *hslots;      // K1a: n_tiles * HIT_SLOTS * 2
-    uint32_t *hcnt;     // K1a: n_tiles (+ slack), indexed by hcnt_index(tile, cnt_nw, cnt_iters)
-    uint64_t *titems;   // K1b: n_tiles * TILE_ITEMS words (header + items); null: the call's hits are in hslots / hcnt
+    uint4 *hslots;      // n_tiles * HIT_SLOTS * 2
+    uint32_t *hcnt;     // n_tiles (+ slack), indexed by hcnt_index(tile, cnt_nw, cnt_iters)
     uint32_t cnt_nw, cnt_iters;
     uint4 *trecs;       // groups * GROUP_MAX: the REPORTED occurrences of a group, in order
     uint32_t *btot;     // reported occurrences of each group

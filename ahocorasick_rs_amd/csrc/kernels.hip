@@ -600,29 +600,21 @@ constexpr uint32_t K1B_HB = 40;     // prefix hits a wave collects in LDS before
 // global memory (it is touched by the rare redirect entries only).
 constexpr uint32_t K1B_HB_BIG = 4;
 constexpr uint32_t K1B_STAGE_BYTES = 1024 + 16; // a row + the 8 bytes behind it (+ padding to 16)
-constexpr uint32_t K1B_OB = 40;     // hit-slot mode: items (one 64-bit word + its destination) a wave collects before one burst store
-constexpr uint32_t K1B_OB_BIG = 8;
 struct K1bLds {
     uint32_t xy[FILTER_WORDS];
     uint16_t q1[16][K1B_Q1CAP];
     union {
-        struct { // region mode (dense output): 32-byte prefix-hit records
+        struct {
             uint4 hb[16][K1B_HB][2];
             uint32_t rbloom[REDIRECT_BLOOM_WORDS]; // Bloom filter of the keys behind redirect entries
         } n;
-        struct { // hit-slot mode: items (device_types.hpp)
-            uint64_t obw[16][K1B_OB];
-            uint32_t obd[16][K1B_OB];
-            uint32_t rbloom[REDIRECT_BLOOM_WORDS];
-        } s;
-        struct { // STAGED, either mode
+        struct {
             uint4 hb[16][K1B_HB_BIG][2];
-            uint64_t obw[16][K1B_OB_BIG];
-            uint32_t obd[16][K1B_OB_BIG];
             uint8_t stage[16][K1B_STAGE_BYTES] __attribute__((aligned(16))); // the row under compaction
             uint64_t q1w[16][K1B_Q1CAP];                                      // the queued survivors' windows
         } b;
     } u;
+    uint32_t cb[16][16]; // sparse mode: hit counts of the wave's last tiles, stored 16 at a time
     uint32_t sxy[SHORT_XY_WORDS];          // SH: the short patterns' {X, Y} pair table by middle byte
 };
 static_assert(sizeof(K1bLds) <= 160 * 1024, "K1b LDS image exceeds 160 KiB");
@@ -834,24 +826,6 @@ __device__ __forceinline__ uint32_t lead_bytes_in_word(uint32_t w) {
     return 4 - __popc(cont);
 }
 
-// lead (non-continuation) bytes among the bytes of w selected by `valid` (0x80 per byte kept)
-__device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
-    const uint64_t HI = 0x8080808080808080ull;
-    const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
-    return __popcll(valid & HI & ~cont);
-}
-
-// The second half of a FAT prefix-table entry (build_fat_table): {the occurrence's item without its offset -- tie << ITEM_TIE_SHIFT
-// | length --, lo and hi; the pattern's bytes 8 .. 15} when the entry's ONLY candidate can be settled from the 16 haystack
-// bytes (w0, w1) at the hit: no anchor shift, at most 16 bytes, and its key is its first min(8, length) bytes -- so the key
-// compare (entry_matches) has settled a pattern of up to 8 bytes, and a longer one needs its bytes 8 .. length - 1 compared
-// with w1: one xor, one shift.  Zeros: not to be settled here.
-__device__ __forceinline__ bool fat_tail_matches(const uint4 info, uint64_t w1) {
-    const uint32_t L = info.x & ITEM_LEN_MASK; // 1 .. 16
-    const uint64_t d = ((((uint64_t)info.w << 32) | info.z) ^ w1) << ((128u - 8u * L) & 63u); // (L > 8: the bytes beyond the pattern shifted out)
-    return L <= 8 || d == 0;
-}
-
 // what K1b needs of the automaton (the full struct would sit in ~50 SGPRs for the whole kernel)
 struct K1bTables {
     const uint32_t *filterA;
@@ -895,14 +869,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     // region mode: every WAVE owns a region of the hit sink and keeps its cursor in an SGPR --
     // no atomic, no cross-lane traffic on the push path
     const uint32_t region = blockIdx.x * 16 + wave;
-    uint4 *const hrec = SLOTS ? nullptr : GK.recs + (uint64_t)region * GK.region_cap * 2;
+    uint4 *const hrec = SLOTS ? GK.hslots : GK.recs + (uint64_t)region * GK.region_cap * 2;
     const uint32_t hcap = SLOTS ? 0u : (uint32_t)(GK.region_cap < 0xFFFFFFFFull ? GK.region_cap : 0xFFFFFFFFull);
     uint32_t hcur = 0;
     {
         const uint4 *src = (const uint4 *)A.filterA;
         uint4 *dst = (uint4 *)L.xy;
         for (uint32_t i = threadIdx.x; i < sizeof(L.xy) / 16; i += blockDim.x) dst[i] = src[i];
-        if (!STAGED) for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) (SLOTS ? L.u.s.rbloom : L.u.n.rbloom)[i] = A.rbloom[i];
+        if (!STAGED) for (uint32_t i = threadIdx.x; i < REDIRECT_BLOOM_WORDS; i += blockDim.x) L.u.n.rbloom[i] = A.rbloom[i];
     }
     if (SH && threadIdx.x < SHORT_XY_WORDS) L.sxy[threadIdx.x] = A.short_xy[threadIdx.x];
     __syncthreads();
@@ -926,98 +900,85 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     constexpr uint32_t OFFMASK = SH ? 0x0FFFu : 0xFFFFu; // a queued offset (12 bits); SH: bit 15 = a survivor of the side test
     constexpr uint32_t SHFLAG = 0x8000u;
 
-    // What the wave found leaves it THROUGH an LDS buffer that is stored in bursts: on this architecture
-    // stores count in vmcnt like loads, so a store issued every iteration makes the `s_waitcnt vmcnt(0)` in
-    // front of the next tile wait for HBM write latency every iteration; a burst every few iterations does
-    // not (measured: 1-2 % of the kernel).
-    // Region mode (dense output): prefix hits, 32-byte records (position, code, the 16 haystack bytes).
+    // Prefix hits leave the wave THROUGH an LDS buffer that is stored in bursts of up to K1B_HB
+    // records: on this architecture stores count in vmcnt like loads, so a store issued every
+    // iteration makes the `s_waitcnt vmcnt(0)` in front of the next tile wait for HBM write latency
+    // every iteration; a burst every few iterations does not (measured: 1-2 % of the kernel).
+    // Word 3 of a record's first quad carries its destination slot (sparse mode).
     uint4 (*const hb)[2] = STAGED ? L.u.b.hb[wave] : L.u.n.hb[wave];
     uint32_t hbn = 0; // wave-uniform fill of the buffer
     auto hit_flush = [&]() __attribute__((always_inline)) {
         if (lane < hbn) {
-            const uint4 r0 = hb[lane][0];
+            uint4 r0 = hb[lane][0];
             const uint4 r1 = hb[lane][1];
-            const uint32_t s = hcur + lane;
-            if (s < hcap) { hrec[2 * (uint64_t)s] = r0; hrec[2 * (uint64_t)s + 1] = r1; }
+            if (SLOTS) {
+                const uint32_t dst = r0.w;
+                r0.w = 0;
+                if (dst != 0xFFFFFFFFu) { hrec[2 * (uint64_t)dst] = r0; hrec[2 * (uint64_t)dst + 1] = r1; }
+            } else {
+                const uint32_t s = hcur + lane;
+                if (s < hcap) { hrec[2 * (uint64_t)s] = r0; hrec[2 * (uint64_t)s + 1] = r1; }
+            }
         }
-        hcur += hbn; // keeps counting past the capacity
+        if (!SLOTS) hcur += hbn; // keeps counting past the capacity
         hbn = 0;
     };
-    // the lanes with found == true push (p, code, 16 window bytes).  Returns the number of hits pushed.
-    auto hit_push = [&](bool found, uint64_t p, uint32_t code, uint64_t w0, uint64_t w1) __attribute__((always_inline)) -> uint32_t {
+    // the lanes with found == true push (p, code, 16 window bytes); sparse mode: into the slots
+    // cnt, cnt + 1, ... of `tile` (cnt is wave-uniform).  Returns the number of hits pushed.
+    auto hit_push = [&](bool found, uint64_t p, uint32_t code, uint64_t w0, uint64_t w1, uint64_t tile,
+                        uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
         const unsigned long long fm = __ballot(found);
         if (!fm) return 0;
         const uint32_t np = (uint32_t)__popcll(fm);
         const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
-        const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, 0u);
+        uint32_t dst = 0;
+        bool keep = found;
+        if (SLOTS) {
+            const uint32_t slot = cnt + rk;
+            keep = found && slot < HIT_SLOTS;
+            dst = (uint32_t)tile * HIT_SLOTS + slot;
+        }
+        // (sparse mode: a hit beyond the slots still takes its place in the buffer; its slot word says "nowhere")
+        const uint4 r0 = make_uint4((uint32_t)p, (uint32_t)(p >> 32), code, keep ? dst : 0xFFFFFFFFu);
         const uint4 r1 = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
+        if (SLOTS) {
+            // more hits than the tile holds (a dense stretch of the input): those go to the call's overflow list -- the
+            // tile's count says "overfull", k_tile_main leaves its group to the hot pipeline (device_types.hpp: control
+            // block).  ONE atomic per wave and push, on the counter of the tile's list
+            const unsigned long long om = __ballot(found && !keep);
+            if (om) {
+                uint32_t *ctl = GK.abort_flag;
+                const uint32_t list = (uint32_t)tile & (OVF_LISTS - 1); // (wave-uniform: the hits of a push are one tile's)
+                uint32_t *cnt = *(uint32_t *const *)(ctl + CTL_OVF_COUNTS) + list * OVF_COUNT_STRIDE;
+                uint32_t base = 0;
+                if (lane == (uint32_t)__builtin_ctzll(om)) base = atomicAdd(cnt, (uint32_t)__popcll(om));
+                base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(om));
+                const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
+                const uint32_t cap = ctl[CTL_OVF_CAP];
+                if (found && !keep) {
+                    if (i < cap) {
+                        uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * ((uint64_t)list * cap + i);
+                        o[0] = make_uint4(r0.x, r0.y, r0.z, 0);
+                        o[1] = r1;
+                    } else {
+                        ctl[CTL_OVF_LOST] = 1;
+                    }
+                }
+            }
+        }
         if (np > HB) { // more hits at once than the buffer holds: straight to HBM
-            hit_flush();
-            if (found && hcur + rk < hcap) { hrec[2 * (uint64_t)(hcur + rk)] = r0; hrec[2 * (uint64_t)(hcur + rk) + 1] = r1; }
-            hcur += np;
+            if (SLOTS) {
+                if (keep) { hrec[2 * (uint64_t)dst] = make_uint4(r0.x, r0.y, r0.z, 0); hrec[2 * (uint64_t)dst + 1] = r1; }
+            } else {
+                hit_flush();
+                if (found && hcur + rk < hcap) { hrec[2 * (uint64_t)(hcur + rk)] = r0; hrec[2 * (uint64_t)(hcur + rk) + 1] = r1; }
+                hcur += np;
+            }
             return np;
         }
         if (hbn + np > HB) hit_flush();
         if (found) { hb[hbn + rk][0] = r0; hb[hbn + rk][1] = r1; }
         hbn += np;
-        return np;
-    };
-    // Hit-slot mode (sparse output): ITEMS of one 64-bit word (device_types.hpp) into the words of the hit's tile -- the
-    // wave is their only producer, a tile's header (its count) is a plain store that travels through the same buffer.
-    constexpr uint32_t OB = STAGED ? K1B_OB_BIG : K1B_OB;
-    uint64_t *const obw = STAGED ? L.u.b.obw[wave] : L.u.s.obw[wave];
-    uint32_t *const obd = STAGED ? L.u.b.obd[wave] : L.u.s.obd[wave];
-    uint32_t obn = 0; // wave-uniform fill of the buffer
-    auto item_flush = [&]() __attribute__((always_inline)) {
-        if (lane < obn) {
-            const uint32_t dst = obd[lane];
-            if (dst != 0xFFFFFFFFu) GK.titems[dst] = obw[lane];
-        }
-        obn = 0;
-    };
-    // the lanes with found == true push `word` into the words 1 + cnt, 2 + cnt, ... of `tile` (cnt is wave-uniform).  An
-    // item beyond the tile's words goes to the call's overflow lists as a 32-byte prefix-hit record {p, ocode}{the 16
-    // haystack bytes at p}.  Returns the number of items pushed.
-    auto item_push = [&](bool found, uint64_t word, uint64_t p, uint32_t ocode, uint64_t w0,
-                         uint64_t tile, uint32_t cnt) __attribute__((always_inline)) -> uint32_t {
-        const unsigned long long fm = __ballot(found);
-        if (!fm) return 0;
-        const uint32_t np = (uint32_t)__popcll(fm);
-        const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(fm >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)fm, 0));
-        const uint32_t slot = 1 + cnt + rk;
-        const bool keep = found && slot < TILE_ITEMS;
-        const uint32_t dst = (uint32_t)tile * TILE_ITEMS + slot;
-        // more items than the tile holds (a dense stretch of the input): those go to the call's overflow list -- the
-        // tile's header says "overfull", k_tile_main leaves its group to the hot pipeline (device_types.hpp: control
-        // block).  ONE atomic per wave and push, on the counter of the tile's list
-        const unsigned long long om = __ballot(found && !keep);
-        if (om) {
-            uint32_t *ctl = GK.abort_flag;
-            const uint32_t list = (uint32_t)tile & (OVF_LISTS - 1); // (wave-uniform: the items of a push are one tile's)
-            uint32_t *ocnt = *(uint32_t *const *)(ctl + CTL_OVF_COUNTS) + list * OVF_COUNT_STRIDE;
-            uint32_t base = 0;
-            if (lane == (uint32_t)__builtin_ctzll(om)) base = atomicAdd(ocnt, (uint32_t)__popcll(om));
-            base = __builtin_amdgcn_readlane(base, (int)__builtin_ctzll(om));
-            const uint32_t i = base + __builtin_amdgcn_mbcnt_hi((uint32_t)(om >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)om, 0));
-            const uint32_t cap = ctl[CTL_OVF_CAP];
-            if (found && !keep) {
-                if (i < cap) {
-                    uint4 *o = *(uint4 *const *)(ctl + CTL_OVF_RECS) + 2 * ((uint64_t)list * cap + i);
-                    const uint64_t w1 = load_window(stream, len, p + 8); // (the pipeline carries the first 8 bytes only)
-                    o[0] = make_uint4((uint32_t)p, (uint32_t)(p >> 32), ocode, 0u);
-                    o[1] = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
-                } else {
-                    ctl[CTL_OVF_LOST] = 1;
-                }
-            }
-        }
-        if (np > OB) { // more items at once than the buffer holds: straight to HBM
-            if (keep) GK.titems[dst] = word;
-            return np;
-        }
-        if (obn + np > OB) item_flush();
-        if (found) { obw[obn + rk] = word; obd[obn + rk] = keep ? dst : 0xFFFFFFFFu; }
-        obn += np;
         return np;
     };
     // Tile loads are UNCONDITIONAL (addresses clamped to the last 16-byte block of
@@ -1073,8 +1034,9 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
     uint32_t tileB = 0, tileC = 0; // the tile of the batch (tiles < 2^32: 16 TiB of haystack)
     uint32_t nB = 0, nC = 0;       // survivors in the batch
     uint32_t cntC = 0;             // sparse mode: hits of tileC pushed so far
+    uint32_t kC = 0;               // tiles of this wave that have left stage C
     uint64_t winB = 0, winB1 = 0, winC = 0, winC1 = 0;
-    uint32_t offB = 0, offC = 0, hC = 0; // (hC: the hash of the window in C -- its home slot, its bit in the slot's filter of displaced keys)
+    uint32_t offB = 0, offC = 0;
     uint4 entC = make_uint4(0, 0, PREFIX_EMPTY, 0);
     // BIG: one more stage between B and C.  The prefix table of such a set has outgrown the L2
     // (measured on 10^5 patterns: 54 M L2 misses per GiB, the kernel bound by them); the windows are
@@ -1097,7 +1059,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 uint32_t next = same ? (entC.z >> 4) & 15u : 0u;
                 if (next) { // (most such positions end here: the LDS Bloom filter of those keys says no)
                     const uint32_t bit = redirect_bloom_bit(prefix_home_hash(low_bytes(winC, next), next));
-                    const uint32_t bw = STAGED ? A.rbloom[bit >> 5] : (SLOTS ? L.u.s.rbloom : L.u.n.rbloom)[bit >> 5]; // (STAGED: no room in LDS; these entries are rare)
+                    const uint32_t bw = STAGED ? A.rbloom[bit >> 5] : L.u.n.rbloom[bit >> 5]; // (STAGED: no room in LDS; these entries are rare)
                     if (!((bw >> (bit & 31)) & 1u)) { next = 0; code = HIT_NONE; }
                 }
                 if (next) code = prefix_walk(A.ptab, ptab_log2, next, winC, nullptr);
@@ -1106,41 +1068,29 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 // k_tile_main / k_walk_hits look the window up (no dependent gathers here: walking
                 // the probe sequence in place was measured at +15 % of the kernel on the headline set)
                 // (the four bits of the window's hash that select the filter bit travel in the offset's spare bits)
-                const bool retry = act && !same && ((entC.z >> (8 + prefix_more_index(BIG ? gram_hash2(winC & q2mask) + q2salt : hC))) & 1u);
-                const uint64_t posC = (uint64_t)tileC * tile_bytes + (offC & OFFMASK) - lead;
-                bool found = (same && code != HIT_NONE) || retry;
-                uint32_t hcode = same ? code : HIT_RETRY;
-                if constexpr (SLOTS) {
-                    // an ITEM (device_types.hpp): the hit's offset in its tile and its candidate code -- one 64-bit word.  (Round 6
-                    // measured the step further: the candidate's bytes brought along by 32-byte "fat" table entries and
-                    // compared HERE, so that an item is a finished occurrence -- +12 .. 19 us on this kernel, which is bound by
-                    // its VALU instructions, for nothing k_tile_main got faster by: DESIGN section 4, profiles/r06/exp_in_scan_*.)
-                    // A displaced key's item names the home slot the walk goes on from: k_tile_main needs no hash of the window first.
-                    const uint32_t offw = (offC & 0xFFFu) << (ITEM_OFF_SHIFT - 32); // (the item's high word)
-                    const uint32_t icode = same ? hcode : ITEM_RETRY | prefix_slot(BIG ? gram_hash2(winC & q2mask) + q2salt : hC, ptab_log2);
-                    uint64_t word = ((uint64_t)((uint32_t)(ITEM_UNVERIFIED >> 32) | offw) << 32) | icode;
-                    if constexpr (!SH) {
-                        cntC += item_push(found, word, posC, hcode, winC, tileC, cntC);
-                    } else {
-                        if (shC) { found = entC.x != SHORT_NONE; word = ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.x; hcode = entC.x; }
-                        cntC += item_push(found, word, posC, hcode, winC, tileC, cntC);
-                        // (a 1-byte AND a 2-byte pattern at one position: the second item)
-                        cntC += item_push(shC && entC.y != SHORT_NONE, ITEM_UNVERIFIED | ((uint64_t)offw << 32) | entC.y, posC, entC.y, winC, tileC, cntC);
-                    }
-                } else if constexpr (!SH) {
-                    hit_push(found, posC, hcode, winC, winC1);
+                const bool retry = act && !same && ((entC.z >> (8 + (BIG ? prefix_more_index(gram_hash2(winC & q2mask) + q2salt) : offC >> 16))) & 1u);
+                if constexpr (!SH) {
+                    cntC += hit_push((same && code != HIT_NONE) || retry, (uint64_t)tileC * tile_bytes + (offC & 0xFFFFu) - lead,
+                                     same ? code : HIT_RETRY, winC, winC1, tileC, cntC);
                 } else {
+                    const uint64_t posC = (uint64_t)tileC * tile_bytes + (offC & OFFMASK) - lead;
+                    bool found = (same && code != HIT_NONE) || retry;
+                    uint32_t hcode = same ? code : HIT_RETRY;
                     if (shC) { found = entC.x != SHORT_NONE; hcode = entC.x; }
-                    hit_push(found, posC, hcode, winC, winC1);
+                    cntC += hit_push(found, posC, hcode, winC, winC1, tileC, cntC);
                     // (a 1-byte AND a 2-byte pattern at one position: the second hit)
-                    hit_push(shC && entC.y != SHORT_NONE, posC, entC.y, winC, winC1);
+                    cntC += hit_push(shC && entC.y != SHORT_NONE, posC, entC.y, winC, winC1, tileC, cntC);
                 }
             }
             if (stC == 2) { // the tile is complete
-                if (SLOTS) { // its header: the count (through the items' buffer)
-                    if (obn + 1 > OB) item_flush();
-                    if (lane == 0) { obw[obn] = cntC < TILE_ITEMS ? cntC : ITEM_OVERFULL; obd[obn] = tileC * TILE_ITEMS; }
-                    obn++;
+                if (SLOTS) { // its count: through LDS, 16 tiles of the wave per store
+                    if (lane == 0) L.cb[wave][kC & 15] = cntC <= HIT_SLOTS ? cntC : HIT_SLOTS + 1; // (HIT_SLOTS + 1: overfull)
+                    if ((kC & 15) == 15) {
+                        __builtin_amdgcn_wave_barrier();
+                        if (lane < 16) GK.hcnt[gw * GK.cnt_iters + (kC - 15) + lane] = L.cb[wave][lane];
+                        __builtin_amdgcn_wave_barrier();
+                    }
+                    kC++;
                 }
                 cntC = 0;
             }
@@ -1157,7 +1107,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                     } else {
                         entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(gram_hash2(winM & q2mask) + q2salt, ptab_log2) * 4);
                     }
-                    if (!SLOTS) winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + (offM & OFFMASK) - lead + 8); // (region mode: the records carry 16 bytes)
+                    winC1 = load_window(stream, len, (uint64_t)tileM * tile_bytes + (offM & OFFMASK) - lead + 8);
                 }
                 offC = offM; winC = winM;
             }
@@ -1195,8 +1145,7 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                         entC = *(const uint4 *)(A.ptab + (size_t)prefix_slot(hB, ptab_log2) * 4);
                     }
                 }
-                offC = offB; hC = hB; winC = winB;
-                if (!SLOTS) winC1 = winB1;
+                offC = offB | (prefix_more_index(hB) << 16); winC = winB; winC1 = winB1;
             }
             nC = nB; stC = stB; tileC = tileB;
         }
@@ -1209,18 +1158,14 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                 }
             }
         } else {
-            // ---- stage A -> B: fetch the windows of the queued survivors: 16 bytes for the records of region mode, the 8 the
-            // key compare needs in hit-slot mode (an item carries no haystack bytes)
+            // ---- stage A -> B: fetch the 16-byte windows of the queued survivors
             if (q1c) {
                 // (wave-uniform: every window of a tile that ends 16 bytes inside the stream is one unaligned load)
                 const bool inside = ((uint64_t)tileQ + 1) * tile_bytes + 16 <= total;
                 if (lane < q1c) {
                     offB = q1[lane];
                     const uint64_t p_ = (uint64_t)tileQ * tile_bytes + (offB & OFFMASK) - lead;
-                    if constexpr (SLOTS) {
-                        if (inside) __builtin_memcpy(&winB, stream + p_, 8);
-                        else winB = load_window(stream, len, p_);
-                    } else if (inside) {
+                    if (inside) {
                         u32x4 w_;
                         __builtin_memcpy(&w_, stream + p_, 16);
                         winB = ((uint64_t)w_.y << 32) | w_.x;
@@ -1548,48 +1493,18 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         __builtin_amdgcn_wave_barrier();
         // Q1 now holds this tile's (remaining) survivors: stage A
     }
-    if (SLOTS) item_flush();
-    else {
-        hit_flush();
-        if (lane == 0) GK.block_counts[region] = hcur;
+    hit_flush();
+    if (SLOTS && (kC & 15)) { // the counts of the wave's last tiles
+        __builtin_amdgcn_wave_barrier();
+        if (lane < (kC & 15)) GK.hcnt[gw * GK.cnt_iters + (kC & ~15u) + lane] = L.cb[wave][lane];
     }
+    if (!SLOTS && lane == 0) GK.block_counts[region] = hcur;
 #undef K1B_LOAD16
 #undef K1B_ISSUE_ROW
 #undef K1B_ISSUE_TILE
 #undef K1B_ROW
 #undef K1B_ROW_BIG
 #undef K1B_BYTE_REG
-}
-
-// The prefix table in its FAT form (device_types.hpp: DevAutomaton::pfat), built once per automaton from the table and the
-// patterns: slot i = {the 16-byte entry, the second half described at fat_tail_matches -- or zeros when K1b cannot settle the
-// entry from the 16 haystack bytes its pipeline carries: a list of candidates, a redirect, an anchored pattern, one of more
-// than 16 bytes, a key shorter than min(8, the pattern)}.  tie: the pattern's rank, or (key_mode 1, LeftmostFirst) its id.
-__global__ void k_build_fat(const uint4 *__restrict__ ptab, uint64_t n_slots, const uint32_t *__restrict__ plen,
-                            const uint32_t *__restrict__ rank, const uint8_t *__restrict__ pat_blob,
-                            const uint64_t *__restrict__ pat_off, int key_mode, uint4 *__restrict__ fat) {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_slots) return;
-    const uint4 e = ptab[i];
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (e.z != PREFIX_EMPTY && ((e.z >> 4) & 15u) == 0 && !(e.w & HIT_LIST) && ((e.w >> CODE_SHIFT_SHIFT) & CODE_SHIFT_MASK) == 0) {
-        const uint32_t pid = e.w & CODE_PID_MASK, L = plen[pid], K = e.z & 15u;
-        if (L >= 1 && L <= 16 && K == (L < 8 ? L : 8)) {
-            const uint64_t item = ((uint64_t)(key_mode == 1 ? pid : rank[pid]) << ITEM_TIE_SHIFT) | L;
-            uint64_t hi = 0;
-            for (uint32_t k = 8; k < L; k++) hi |= (uint64_t)pat_blob[pat_off[pid] + k] << (8 * (k - 8));
-            v = make_uint4((uint32_t)item, (uint32_t)(item >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
-        }
-    }
-    fat[2 * i] = e;
-    fat[2 * i + 1] = v;
-}
-
-hipError_t build_fat_table(const DevAutomaton &A, int key_mode, uint4 *fat, hipStream_t st) {
-    const uint64_t n = 1ull << A.ptab_log2;
-    hipLaunchKernelGGL(k_build_fat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const uint4 *)A.ptab, n, A.plen, A.rank,
-                       A.pat_blob, A.pat_off, key_mode, fat);
-    return hipGetLastError();
 }
 
 size_t prefilter_lds_bytes() { return sizeof(K1bLds); }
@@ -1618,7 +1533,7 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
     return (total + (uint64_t)K1B_ROWS * 1024 - 1) / ((uint64_t)K1B_ROWS * 1024);
 }
 
-// K.titems != null: sparse mode (the tiles' items); else region mode (per-wave regions)
+// K.hslots != null: sparse mode (hit slots + counts); else region mode (per-wave regions)
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
                             uint32_t grid, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
                             uint8_t *cp_sub) {
@@ -1629,13 +1544,13 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     const K1bTables T{A.filterA, A.ptab, A.rbloom, A.pbits, A.ptab_log2, A.filter_q2, A.k1b_min_len, cp_sub,
                       A.short_xy, A.short_codes, A.short_min_len};
     const bool sh = A.short_min_len != 0; // the set has patterns of 1 or 2 bytes: the side test runs too
-    if (cp_sub && (lead != 0 || !K.titems)) return hipErrorInvalidValue;
+    if (cp_sub && (lead != 0 || !K.hslots)) return hipErrorInvalidValue;
     // the events (measurement only) ride on the dispatch itself: no barrier packets, no gaps
 #define ACX_K1B_LAUNCH(Q, S, C, B, H)                                                                      \
     hipExtLaunchKernelGGL((k1b_prefilter<Q, S, C, B, H>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
 #define ACX_K1B(Q, B, H)                                                                                   \
     if (cp_sub) ACX_K1B_LAUNCH(Q, true, true, B, H);                                                       \
-    else if (K.titems) ACX_K1B_LAUNCH(Q, true, false, B, H);                                               \
+    else if (K.hslots) ACX_K1B_LAUNCH(Q, true, false, B, H);                                               \
     else ACX_K1B_LAUNCH(Q, false, false, B, H)
 #define ACX_K1B_SH(Q, B)                                                                                   \
     if (sh) { ACX_K1B(Q, B, true); } else { ACX_K1B(Q, B, false); }
@@ -2272,6 +2187,12 @@ hipError_t write_matches(const uint32_t *pids, const uint64_t *S, const uint64_t
 // up.  If there is none (a chain of overlapping occurrences longer than the context: periodic
 // patterns on periodic text), or a bucket overflows, the group raises the abort flag and the
 // host redoes the call on the dense path, whose resolve is global.
+// lead (non-continuation) bytes among the bytes of w selected by `valid` (0x80 per byte kept)
+__device__ __forceinline__ uint32_t lead_in_word(uint64_t w, uint64_t valid) {
+    const uint64_t HI = 0x8080808080808080ull;
+    const uint64_t cont = w & ((~w) << 1) & HI; // continuation: bit7 = 1, bit6 = 0
+    return __popcll(valid & HI & ~cont);
+}
 
 // str API: how many of the lead bytes of the 16-byte chunk that holds a match's start lie AT OR BEHIND the start
 // (0 .. 16) -- k_tile_main has the 16 haystack bytes at the start in registers (the hit's window, or the head it
@@ -2283,6 +2204,9 @@ constexpr uint32_t CP_UNKNOWN = 31, CP_BITS = 5;
 #define ACX_MAIN_THREADS 256
 #endif
 constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
+#ifndef ACX_MAIN_THREADS_W32
+#define ACX_MAIN_THREADS_W32 128 // threads of the instantiation with narrow staged words (sixteen groups per CU)
+#endif
 // How many groups a CU works on at once is what this latency-bound kernel lives on.  LDS (14.7 KiB) and VGPRs
 // (63) allow 8 workgroups of four waves per CU, but 256-thread workgroups are admitted up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) per CU (MI355X guide): the 106 SGPRs the compiler takes by itself
@@ -2336,39 +2260,30 @@ __device__ __forceinline__ void span_of(uint32_t rank_bits, int key_mode, uint4 
 }
 
 // span of a staged occurrence, relative to the first staged tile (a start may lie in front of it)
-template <bool CP>
-__device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, uint64_t r, int32_t *s, int32_t *e) {
-    const uint32_t lb = 64 - REL_BITS - rank_bits - (CP ? CP_BITS : 0); // (CP: the carried count sits above the length)
-    const int32_t rel = (int32_t)(r >> (64 - REL_BITS)), L = (int32_t)(r & ((1ull << lb) - 1));
+// (W32 -- the narrow form of a staged word, round 6: [ key position & 4095 : 12 | tie : rank_bits | length : 20 - rank_bits ] in 32
+// bits; the bucket b the word lies in supplies the rest of the position)
+constexpr uint32_t W32_FIELD = 20; // bits of tie + length in a narrow staged word
+template <bool CP, bool W32>
+__device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, uint64_t r, uint32_t b, int32_t *s, int32_t *e) {
+    int32_t rel, L;
+    if constexpr (W32) {
+        rel = (int32_t)((b << TILE_BITS) | ((uint32_t)r >> W32_FIELD));
+        L = (int32_t)((uint32_t)r & ((1u << (W32_FIELD - rank_bits)) - 1));
+    } else {
+        const uint32_t lb = 64 - REL_BITS - rank_bits - (CP ? CP_BITS : 0); // (CP: the carried count sits above the length)
+        rel = (int32_t)(r >> (64 - REL_BITS));
+        L = (int32_t)(r & ((1ull << lb) - 1));
+    }
     if (key_mode == 0) { *e = rel; *s = rel - L; }
     else { *s = rel; *e = rel + L; }
 }
 
-#ifndef ACX_MAIN_PERSISTENT
-#define ACX_MAIN_PERSISTENT 0
-#endif
-#ifdef ACX_MAIN_CLOCK
-// (per group, no atomics: 2 048 groups hammering six counters measured the counters -- ~16 returning atomics per us and address)
-constexpr uint32_t MCLK_GROUPS = 8192;
-__device__ unsigned long long g_main_clock[MCLK_GROUPS][8];
-hipError_t main_clock_read(unsigned long long *out) { // out[16]: sums over the groups of the LAST launch
-    static unsigned long long h[MCLK_GROUPS][8];
-    hipError_t e = hipMemcpyFromSymbol(h, HIP_SYMBOL(g_main_clock), sizeof(h));
-    for (int k = 0; k < 16; k++) out[k] = 0;
-    for (uint32_t g = 0; g < MCLK_GROUPS; g++)
-        if (h[g][7]) { for (int k = 0; k < 7; k++) out[k] += h[g][k]; out[15]++; }
-    return e;
-}
-#define MCLK(i) { __syncthreads(); if (threadIdx.x == 0 && g < MCLK_GROUPS) { const unsigned long long n_ = __builtin_amdgcn_s_memrealtime(); g_main_clock[g][i] = n_ - clk_; clk_ = n_; } }
-#else
-#define MCLK(i)
-#endif
-// V2 (round 6, K1b's hits): the staged tiles hold ITEMS (device_types.hpp: one 64-bit word each, the tile's count in the
-// word in front of them) instead of 32-byte hit records behind a count array -- header + the first 15 items of every
-// staged tile are requested as ONE 128-byte line per tile, all lines of the group in flight together; a verified item (K1b
-// compared the pattern's tail itself) is staged as it is.  !V2: K1a's hit slots (records + counts), as before.
-template <bool ANCH, bool CP, bool V2>
-__global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+// W32 (round 6): staged words of 32 bits -- pattern sets whose tie-break field and lengths fit W32_FIELD bits together (10^4
+// patterns of up to 63 bytes), byte offsets.  The stage is what decides how many groups a CU works on at once, and this
+// kernel lives on groups in flight: with narrow words a group takes 8 KiB of LDS, and with NT = 128 threads (two waves)
+// sixteen groups fit a CU instead of eight -- all 4 096 groups of a 1 GiB haystack are resident at once.
+template <bool ANCH, bool CP, bool W32, uint32_t NT>
+__global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
@@ -2379,76 +2294,38 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     // the CALL nothing; without it such a group raises the abort flag and the call is redone on the dense path.
     // (batch: the per-haystack counts k_tile_write adds to -- cleared here, no memset in front of the scan)
     if (seg_counts)
-        for (uint64_t i = (uint64_t)blockIdx.x * MAIN_THREADS + threadIdx.x; i < n_seg; i += (uint64_t)gridDim.x * MAIN_THREADS)
+        for (uint64_t i = (uint64_t)blockIdx.x * NT + threadIdx.x; i < n_seg; i += (uint64_t)gridDim.x * NT)
             seg_counts[i] = 0;
-#ifdef ACX_MAIN_CLOCK
-    unsigned long long clk_ = 0;
-#endif
     // (rows padded to an odd number of words: lane t works on row t, and a power-of-two row stride would
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
-    __shared__ uint64_t st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
+    static_assert(!(W32 && CP), "a narrow staged word has no room for the carried lead-byte count");
+    using SW = typename std::conditional<W32, uint32_t, uint64_t>::type;
+    __shared__ SW st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
     __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
     __shared__ int32_t bmax[STAGE_BUCKETS];        // largest end per bucket
-    __shared__ uint32_t hoff[STAGE_BUCKETS + 2];   // exclusive prefix of the tiles' hit counts (V2: of the items beyond the first line)
-    __shared__ uint32_t tcnt[STAGE_BUCKETS + 2];   // V2: items of every staged tile
+    __shared__ uint32_t hoff[STAGE_BUCKETS + 2];   // exclusive prefix of the tiles' hit counts
     __shared__ uint32_t synm[STAGE_BUCKETS], accm[STAGE_BUCKETS]; // per bucket: sync points / accepted
-    constexpr uint32_t UL_CAP = V2 ? 512 : 1;
-    __shared__ uint64_t ul[UL_CAP];                // V2: the unverified items of a round (bits 38:32: the tile's index in the group)
-    __shared__ uint32_t fail, stop, tail_base, own_items, all_items, ul_n;
-    const uint32_t t = threadIdx.x;
+    __shared__ uint32_t fail, stop, tail_base;
+    const uint32_t t = threadIdx.x, g = blockIdx.x;
+    const uint32_t tile0 = g * GROUP_TILES;
+    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
+    const uint32_t lb = tile0 - first;                               // context tiles in front
     // anchors (automaton.hpp): a hit lies up to SHIFT_MAX bytes BEHIND the start of its occurrence, so an
     // occurrence that starts in the group's last bytes has its hit in the first tile of the next group: that
     // tile's hits are read too (the occurrences that start beyond the group are dropped like the context's)
     const uint32_t la = ANCH ? 1u : 0u;
-    // V2: the first line of every staged tile, as 16-byte pieces: piece i = words 2 (i % 8), + 1 of tile i / 8
-    constexpr uint32_t PIECES = ITEM_LINE / 2;
-    constexpr uint32_t NLD = V2 ? ((GROUP_TILES + MAX_LOOKBACK + 1) * PIECES + MAIN_THREADS - 1) / MAIN_THREADS : 1;
-    u32x4 lv[NLD];
-    // V2: the workgroups are PERSISTENT (round 6): a workgroup takes the groups g = blockIdx.x, + gridDim.x, ... and requests
-    // the lines of its NEXT group as soon as the registers of the current group's are free (its first round done) -- a group's
-    // life used to begin with a round trip to HBM for its lines, a third of it, with nothing else to do.
-    auto load_lines = [&](uint32_t gg) __attribute__((always_inline)) {
-        if constexpr (V2) {
-            if (ACX_MAIN_PERSISTENT == 0 && gg != blockIdx.x) return;
-            if (gg >= T.n_groups) return; // (uniform)
-            const uint32_t tile0_ = gg * GROUP_TILES, first_ = tile0_ >= lookback ? tile0_ - lookback : 0;
-            const uint32_t nb_ = GROUP_TILES + (tile0_ - first_) + la;
-#pragma unroll
-            for (uint32_t k = 0; k < NLD; k++) {
-                const uint32_t i = t + k * MAIN_THREADS, j = i / PIECES;
-                if (j < nb_ && first_ + j < T.n_tiles)
-                    lv[k] = *(const u32x4 *)(T.titems + (uint64_t)(first_ + j) * TILE_ITEMS + (i % PIECES) * 2);
-                else
-                    lv[k] = u32x4{0, 0, 0, 0};
-            }
-        }
-    };
-    load_lines(blockIdx.x);
-    // (!V2: one workgroup per group -- the loop body runs once, and the compiler knows)
-    constexpr bool PERSISTENT = V2 && ACX_MAIN_PERSISTENT != 0;
-    for (uint32_t g = blockIdx.x, again = 0; g < T.n_groups && (PERSISTENT || !again); g += gridDim.x, again = 1) {
-    __syncthreads(); // (the previous group's stage is read no more)
-#ifdef ACX_MAIN_CLOCK
-    clk_ = __builtin_amdgcn_s_memrealtime();
-    if (threadIdx.x == 0 && g < MCLK_GROUPS) { for (int k_ = 0; k_ < 7; k_++) g_main_clock[g][k_] = 0; g_main_clock[g][7] = 1; }
-#endif
-    const uint32_t tile0 = g * GROUP_TILES;
-    const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
-    const uint32_t lb = tile0 - first;                               // context tiles in front
     const uint32_t nb = GROUP_TILES + lb + la;                       // tiles whose hits are read
     // ---- hits of the staged tiles: exclusive prefix of the counts (wave 0: 64 tiles, wave 1: the
-    // few beyond -- nb <= 69)
+    // few beyond -- nb <= 68)
     uint32_t c = 0;
     bool overfull = false; // the tile's hits did not fit its slots (K1b: the rest is in the overflow list)
-    if constexpr (!V2) {
-        if (t < nb && first + t < T.n_tiles) {
-            c = T.hcnt[hcnt_index(first + t, T.cnt_nw, T.cnt_iters)];
-            overfull = c > HIT_SLOTS;
-            c = c < HIT_SLOTS ? c : HIT_SLOTS;
-        }
+    if (t < nb && first + t < T.n_tiles) {
+        c = T.hcnt[hcnt_index(first + t, T.cnt_nw, T.cnt_iters)];
+        overfull = c > HIT_SLOTS;
+        c = c < HIT_SLOTS ? c : HIT_SLOTS;
     }
     if (t < STAGE_BUCKETS) { bn[t] = 0; bmax[t] = 0; }
-    if (t == 0) { fail = 0; stop = *abort_flag; own_items = 0; all_items = 0; }
+    if (t == 0) { fail = 0; stop = *abort_flag; }
     // the group gives up: all threads get here together
     auto give_up = [&]() {
         if (t == 0) {
@@ -2461,24 +2338,6 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             }
         }
     };
-    if constexpr (V2) { // the headers: word 0 of every tile's line
-#pragma unroll
-        for (uint32_t k = 0; k < NLD; k++) {
-            const uint32_t i = t + k * MAIN_THREADS;
-            if (i % PIECES == 0 && i / PIECES < nb) tcnt[i / PIECES] = lv[k].x & 0xFFFFu;
-        }
-        __syncthreads();
-        if (t < nb) {
-            c = tcnt[t];
-            overfull = c == ITEM_OVERFULL;
-            const uint32_t all = overfull ? TILE_ITEMS - 1 : c;
-            if (all) {
-                atomicAdd(&all_items, all);
-                if (t >= lb && t < lb + GROUP_TILES) atomicAdd(&own_items, all);
-            }
-            c = all > ITEM_LINE - 1 ? all - (ITEM_LINE - 1) : 0u; // the items beyond the first line
-        }
-    }
     uint32_t incl = c;
     if (t < 128) { // (lanes beyond nb carry zeros)
         for (int o = 1; o < 64; o <<= 1) {
@@ -2493,13 +2352,11 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     if (overfull) fail = 1;
     __syncthreads();
     const uint32_t H = hoff[nb];
-    MCLK(0)
     if (stop) return;
-    if (fail) { give_up(); load_lines(g + gridDim.x); continue; }
-    if (V2 ? all_items == 0 : H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
+    if (fail) { give_up(); return; }
+    if (H == 0) { // nothing staged at all (sparse inputs): the group reports nothing
         if (t == 0) T.btot[g] = 0;
-        load_lines(g + gridDim.x);
-        continue;
+        return;
     }
     // index space: index = stream position + lead; a tile / bucket is 4 KiB of it
     const uint64_t idx_lo = (uint64_t)tile0 << TILE_BITS, idx_hi = idx_lo + ((uint64_t)GROUP_TILES << TILE_BITS);
@@ -2510,43 +2367,63 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
     const uint64_t complete = first == 0 ? 0 : first_idx + (key_mode == 0 ? margin : 0);
     const int32_t wlow = first == 0 ? 0 : (int32_t)margin; // relative to first_idx
     const uint32_t rank_bits = A.rank_bits, len_bits = 64 - REL_BITS - rank_bits;
-    // (cin -- CP only: lead bytes of the start's 16-byte chunk at or behind the start, or CP_UNKNOWN)
-    auto stage = [&](uint64_t ps, uint32_t pid, uint32_t L, uint32_t rk, uint32_t cin) { // ps: where the occurrence starts
-        const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
-        if (kidx < complete || kidx >= idx_hi) return; // another group's (or nobody's) business
-        const uint32_t rel = (uint32_t)(kidx - first_idx);
-        const uint32_t b = rel >> TILE_BITS;
-        const uint32_t r = atomicAdd(&bn[b], 1u);
-        if (r < STAGE_SLOTS) {
-            uint64_t word = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
-            if constexpr (CP) word |= (uint64_t)cin << (len_bits - CP_BITS);
-            st[b][r] = word;
-        } else fail = 1;
-    };
-    // lead bytes among the first (16 - (ps & 15)) bytes of the window (x0, x1) at ps, not beyond the stream's end
-    auto leads_in_chunk = [&](uint64_t ps, uint64_t x0, uint64_t x1) -> uint32_t {
-        uint32_t n_in = 16 - (uint32_t)(ps & 15);
-        if (len - ps < n_in) n_in = (uint32_t)(len - ps);
-        const uint64_t v0 = n_in >= 8 ? ~0ull : (n_in ? ~0ull >> (8 * (8 - n_in)) : 0);
-        const uint64_t v1 = n_in > 8 ? (n_in >= 16 ? ~0ull : ~0ull >> (8 * (16 - n_in))) : 0;
-        return lead_in_word(x0, v0) + lead_in_word(x1, v1);
-    };
-    // one prefix hit {position, candidate code, the 16 haystack bytes at the position}: every candidate verified, its occurrences staged
-    auto settle = [&](uint64_t p, uint32_t code, uint64_t w0, uint64_t w1) {
-        uint64_t room = 0, back = 0;
-        uint32_t nc = 1, li = 0;
-        bool list = false;
-        if (ANCH) { // the haystack's start matters only to patterns filed behind their beginning
-            uint64_t seg_lo, seg_hi;
-            segment_bounds(G, len, p, &seg_lo, &seg_hi);
-            room = seg_hi - p; back = p - seg_lo;
-        } else {
-            room = segment_end(G, len, p) - p;
+    // ---- verify: one thread per hit
+    for (uint32_t h = t; h < H; h += NT) {
+        uint32_t lo = 0, hi = nb; // tile j = the last one with hoff[j] <= h
+        while (hi - lo > 1) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (hoff[mid] <= h) lo = mid; else hi = mid;
         }
-        if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
-        if (code == HIT_NONE) nc = 0;
-        else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
-        if (!list) {
+        const uint4 *rec = T.hslots + ((uint64_t)(first + lo) * HIT_SLOTS + (h - hoff[lo])) * 2;
+        const uint4 r0 = rec[0];
+        const uint4 w = rec[1]; // (unconditional: in flight together with the first half)
+        const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
+        uint64_t w0 = 0, w1 = 0, room = 0, back = 0;
+        uint32_t nc = 1, li = 0, code = r0.z;
+        const bool verified = code != HIT_RETRY && (code & HIT_VERIFIED) != 0;
+        bool list = false;
+        if (!verified) {
+            w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
+            if (ANCH) { // the haystack's start matters only to patterns filed behind their beginning
+                uint64_t seg_lo, seg_hi;
+                segment_bounds(G, len, p, &seg_lo, &seg_hi);
+                room = seg_hi - p; back = p - seg_lo;
+            } else {
+                room = segment_end(G, len, p) - p;
+            }
+            if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
+            if (code == HIT_NONE) nc = 0;
+            else if (code & HIT_LIST) { list = true; li = code & ~HIT_LIST; nc = A.blist[li]; }
+        }
+        // (cin -- CP only: lead bytes of the start's 16-byte chunk at or behind the start, or CP_UNKNOWN)
+        auto stage = [&](uint64_t ps, uint32_t pid, uint32_t L, uint32_t rk, uint32_t cin) { // ps: where the occurrence starts
+            const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
+            if (kidx < complete || kidx >= idx_hi) return; // another group's (or nobody's) business
+            const uint32_t rel = (uint32_t)(kidx - first_idx);
+            const uint32_t b = rel >> TILE_BITS;
+            const uint32_t r = atomicAdd(&bn[b], 1u);
+            if (r < STAGE_SLOTS) {
+                if constexpr (W32) {
+                    st[b][r] = ((rel & ((1u << TILE_BITS) - 1)) << W32_FIELD) | ((key_mode == 1 ? pid : rk) << (W32_FIELD - rank_bits)) | L;
+                } else {
+                    uint64_t word = ((((uint64_t)rel << rank_bits) | (key_mode == 1 ? pid : rk)) << len_bits) | L;
+                    if constexpr (CP) word |= (uint64_t)cin << (len_bits - CP_BITS);
+                    st[b][r] = word;
+                }
+            } else fail = 1;
+        };
+        // lead bytes among the first (16 - (ps & 15)) bytes of the window (x0, x1) at ps, not beyond the stream's end
+        auto leads_in_chunk = [&](uint64_t ps, uint64_t x0, uint64_t x1) -> uint32_t {
+            uint32_t n_in = 16 - (uint32_t)(ps & 15);
+            if (len - ps < n_in) n_in = (uint32_t)(len - ps);
+            const uint64_t v0 = n_in >= 8 ? ~0ull : (n_in ? ~0ull >> (8 * (8 - n_in)) : 0);
+            const uint64_t v1 = n_in > 8 ? (n_in >= 16 ? ~0ull : ~0ull >> (8 * (16 - n_in))) : 0;
+            return lead_in_word(x0, v0) + lead_in_word(x1, v1);
+        };
+        if (verified) {
+            const uint32_t pid = code & ~HIT_VERIFIED;
+            stage(p, pid, r0.w, key_mode == 1 ? 0u : A.rank[pid], CP_UNKNOWN);
+        } else if (!list) {
             uint32_t rk;
             uint64_t ps = p, x0 = w0, x1 = w1;
             const uint32_t L = nc ? verify_candidate<ANCH>(A, stream, len, p, code, w0, w1, room, back, &rk, &ps,
@@ -2568,150 +2445,9 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
                 if (two && L1) stage(ps1, pid1 & CODE_PID_MASK, L1, rk1, CP ? leads_in_chunk(ps1, b0, b1) : 0u);
             }
         }
-    };
-    if constexpr (V2) {
-        // ---- the items (device_types.hpp).  A verified one is an occurrence and is staged as it is.  The others -- a displaced
-        // key, a list of candidates, an anchored or a long pattern -- are collected in `ul` and settled by ONE loop, one
-        // thread each (the group lasts as long as its slowest thread: an item must not wait behind another of its thread).
-        // Rounds: the first lines' items (again while the list is full), then the items beyond the first lines, a list at a time.
-        auto offset_of = [&](uint64_t item, uint32_t j) -> uint64_t {
-            return ((uint64_t)(first + j) << TILE_BITS) + ((uint32_t)(item >> ITEM_OFF_SHIFT) & 0xFFFu) - lead;
-        };
-        auto take_verified = [&](uint64_t item, uint32_t j) {
-            const uint64_t p = offset_of(item, j);
-            const uint32_t L = (uint32_t)item & ITEM_LEN_MASK, tie = (uint32_t)(item >> ITEM_TIE_SHIFT) & 0xFFFFFFu;
-            if (L <= segment_end(G, len, p) - p) stage(p, tie, L, tie, CP ? (uint32_t)(item >> ITEM_CIN_SHIFT) & 31u : 0u);
-        };
-        // Rounds: round 0 = the first lines' items, from the registers; then the items beyond the first lines, a list at a
-        // time.  Should round 0's unverified items not fit the list (more than UL_CAP of them among the first 15 of 69 tiles:
-        // dense stretches of keys with several candidates), its list is dropped and the later rounds walk ALL items of the
-        // staged tiles instead, skipping the verified ones of the first lines -- those are staged already.
-        auto put = [&](uint64_t item, uint32_t j) { // an unverified item into the list
-            const uint32_t i = atomicAdd(&ul_n, 1u);
-            if (i < UL_CAP) ul[i] = item | ((uint64_t)j << 32);
-        };
-        if (t == 0) ul_n = 0;
-        __syncthreads();
-#pragma unroll
-        for (uint32_t k = 0; k < NLD; k++) {
-            const uint32_t i = t + k * MAIN_THREADS, j = i / PIECES, w = (i % PIECES) * 2;
-            const uint32_t cj = j < nb ? tcnt[j] : 0u; // (not ITEM_OVERFULL here: the group would have given up)
-            const uint64_t ix = ((uint64_t)lv[k].y << 32) | lv[k].x, iy = ((uint64_t)lv[k].w << 32) | lv[k].z;
-            if (w >= 1 && w <= cj) { if (!(ix & ITEM_UNVERIFIED)) take_verified(ix, j); else put(ix, j); }
-            if (w + 1 <= cj) { if (!(iy & ITEM_UNVERIFIED)) take_verified(iy, j); else put(iy, j); }
-        }
-        load_lines(g + gridDim.x); // (in flight while this group is finished)
-        __syncthreads();
-        MCLK(1)
-#ifdef ACX_MAIN_CLOCK
-        if (t == 0 && g < MCLK_GROUPS) g_main_clock[g][6] = ul_n;
-#endif
-        uint32_t Hx = H, wi0 = ITEM_LINE; // the rounds behind round 0: items to walk, the word the first of a tile is in
-        if (ul_n > UL_CAP) { // (block-uniform) the list overflowed: all items again, by the prefix of the FULL counts
-            __syncthreads();
-            uint32_t cc = t < nb ? tcnt[t] : 0u, in2 = cc;
-            if (t == 0) ul_n = 0;
-            if (t < 128) {
-                for (int o = 1; o < 64; o <<= 1) {
-                    const uint32_t v = __shfl_up(in2, o);
-                    if ((int)(t & 63) >= o) in2 += v;
-                }
-                if (t == 63) tail_base = in2;
-            }
-            __syncthreads();
-            if (t >= 64 && t < 128) in2 += tail_base;
-            if (t <= nb) hoff[t] = in2 - cc;
-            __syncthreads();
-            Hx = hoff[nb];
-            wi0 = 1;
-        }
-        for (uint32_t xbase = 0;; xbase += UL_CAP) {
-            const uint32_t nu = ul_n < UL_CAP ? ul_n : UL_CAP;
-            for (uint32_t h = t; h < nu; h += MAIN_THREADS) {
-                const uint64_t item = ul[h];
-                const uint32_t j = (uint32_t)(item >> 32) & 0x7Fu;
-                const uint64_t p = offset_of(item, j);
-                uint32_t code = (uint32_t)item;
-                uint64_t w0, w1;
-                load_window16(stream, len, p, &w0, &w1);
-                if ((code & ITEM_RETRY) == ITEM_RETRY) {
-                    // a displaced key: the probe sequence from the slot behind its home slot, in the FAT table -- the first of
-                    // those entries is requested together with the window, and a final entry brings its candidate's info along
-                    // (the two slots behind the home slot are requested at once, with the window: a displaced key sits in one
-                    // of them nearly always -- one round trip instead of a chain of them)
-                    const uint32_t mask = (1u << A.ptab_log2) - 1;
-                    uint32_t idx = code & ~ITEM_RETRY;
-                    code = HIT_NONE;
-                    // 0: not this entry, go on; 1: the walk is over (code: what is left to settle, or HIT_NONE)
-                    auto examine = [&](const uint4 e, const uint4 v) -> bool {
-                        if (e.z == PREFIX_EMPTY) return true;
-                        if (!entry_matches(e, w0)) return false;
-                        if ((e.z >> 4) & 15u) { code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0); return true; } // (a redirect: the general walk)
-                        code = e.w;
-                        if ((v.x & ITEM_LEN_MASK) != 0) { // settled here, like K1b's own
-                            code = HIT_NONE;
-                            const uint32_t L = v.x & ITEM_LEN_MASK, tie = (uint32_t)((((uint64_t)v.y << 32) | v.x) >> ITEM_TIE_SHIFT);
-                            if (fat_tail_matches(v, w1) && L <= segment_end(G, len, p) - p)
-                                stage(p, tie, L, tie, CP ? leads_in_chunk(p, w0, w1) : 0u);
-                        }
-                        return true;
-                    };
-                    const uint32_t i1 = (idx + 1) & mask, i2 = (idx + 2) & mask;
-                    const uint4 e1 = A.pfat[2 * (size_t)i1], v1 = A.pfat[2 * (size_t)i1 + 1];
-                    const uint4 e2 = A.pfat[2 * (size_t)i2], v2 = A.pfat[2 * (size_t)i2 + 1];
-                    if (!examine(e1, v1) && !examine(e2, v2)) {
-                        idx = i2;
-                        for (;;) {
-                            idx = (idx + 1) & mask;
-                            if (examine(A.pfat[2 * (size_t)idx], A.pfat[2 * (size_t)idx + 1])) break;
-                        }
-                    }
-                    if (code == HIT_NONE) continue;
-                }
-                settle(p, code, w0, w1);
-            }
-            if (xbase >= Hx) break; // (block-uniform)
-            __syncthreads();
-            if (t == 0) ul_n = 0;
-            __syncthreads();
-            const uint32_t hend = Hx - xbase < UL_CAP ? Hx : xbase + UL_CAP;
-            for (uint32_t h = xbase + t; h < hend; h += MAIN_THREADS) {
-                uint32_t lo = 0, hi = nb; // tile j = the last one with hoff[j] <= h
-                while (hi - lo > 1) {
-                    const uint32_t mid = (lo + hi) >> 1;
-                    if (hoff[mid] <= h) lo = mid; else hi = mid;
-                }
-                const uint32_t wi = wi0 + (h - hoff[lo]);
-                const uint64_t item = T.titems[(uint64_t)(first + lo) * TILE_ITEMS + wi];
-                if (item & ITEM_UNVERIFIED) put(item, lo); // (a chunk is no longer than the list)
-                else if (wi >= ITEM_LINE) take_verified(item, lo);
-            }
-            __syncthreads();
-        }
-    } else {
-        // ---- verify: one thread per hit
-        for (uint32_t h = t; h < H; h += MAIN_THREADS) {
-            uint32_t lo = 0, hi = nb; // tile j = the last one with hoff[j] <= h
-            while (hi - lo > 1) {
-                const uint32_t mid = (lo + hi) >> 1;
-                if (hoff[mid] <= h) lo = mid; else hi = mid;
-            }
-            const uint4 *rec = T.hslots + ((uint64_t)(first + lo) * HIT_SLOTS + (h - hoff[lo])) * 2;
-            const uint4 r0 = rec[0];
-            const uint4 w = rec[1]; // (unconditional: in flight together with the first half)
-            const uint64_t p = ((uint64_t)r0.y << 32) | r0.x;
-            const uint32_t code = r0.z;
-            if (code != HIT_RETRY && (code & HIT_VERIFIED) != 0) {
-                const uint32_t pid = code & ~HIT_VERIFIED;
-                stage(p, pid, r0.w, key_mode == 1 ? 0u : A.rank[pid], CP_UNKNOWN);
-            } else {
-                settle(p, code, ((uint64_t)w.y << 32) | w.x, ((uint64_t)w.w << 32) | w.z);
-            }
-        }
     }
     __syncthreads();
-    MCLK(2)
-    if (fail) { give_up(); continue; }
+    if (fail) { give_up(); return; }
     // ---- order every bucket (words are unique), largest end per bucket
     // (buckets, not tiles read: the look-ahead tile of an anchored set has no bucket -- with four context tiles,
     // patterns longer than 10 KiB, `t < nb` reached one row beyond the stage)
@@ -2720,20 +2456,18 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
         const uint32_t n = bn[t];
         int32_t mx = 0;
         for (uint32_t i = 0; i < n; i++) {
-            const uint64_t v = st[t][i];
+            const SW v = st[t][i];
             uint32_t j = i;
             while (j > 0 && st[t][j - 1] > v) { st[t][j] = st[t][j - 1]; j--; }
             st[t][j] = v;
             int32_t s, e;
-            staged_span<CP>(rank_bits, key_mode, v, &s, &e);
+            staged_span<CP, W32>(rank_bits, key_mode, v, t, &s, &e);
             mx = max(mx, e);
         }
         bmax[t] = mx;
     }
     __syncthreads();
-    MCLK(3)
     uint32_t cnt = 0, accepted = 0; // reported occurrences of output bucket t (wave 0)
-    bool fail_late = false;
     if (overlapping) {
         if (t < GROUP_TILES) { cnt = bn[lb + t]; accepted = cnt >= 32 ? 0xFFFFFFFFu : (1u << cnt) - 1; }
     } else {
@@ -2747,7 +2481,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             uint32_t sm = 0;
             for (uint32_t i = 0; i < n; i++) {
                 int32_t s, e;
-                staged_span<CP>(rank_bits, key_mode, st[t][i], &s, &e);
+                staged_span<CP, W32>(rank_bits, key_mode, st[t][i], t, &s, &e);
                 if (s >= wlow && m <= s) sm |= 1u << i;
                 m = max(m, e);
             }
@@ -2772,7 +2506,7 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
                 int32_t pos = INT32_MIN;
                 for (;;) { // forward again, to the end of bucket ob
                     int32_t s, e;
-                    staged_span<CP>(rank_bits, key_mode, st[b][i], &s, &e);
+                    staged_span<CP, W32>(rank_bits, key_mode, st[b][i], (uint32_t)b, &s, &e);
                     const bool take = s >= pos;
                     if (take) pos = e;
                     if ((uint32_t)b == ob && take) { accepted |= 1u << i; cnt++; }
@@ -2785,10 +2519,8 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             }
         }
         __syncthreads();
-        if (fail) { give_up(); fail_late = true; }
+        if (fail) { give_up(); return; }
     }
-    MCLK(4)
-    if (fail_late) continue;
     // ---- compact the reported occurrences of the 64 output buckets into the group's stretch
     if (t < 64) {
         uint32_t incl = cnt, occ = t < GROUP_TILES ? bn[lb + t] : 0u;
@@ -2807,7 +2539,11 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             for (uint32_t k = 0; accepted; k++) {
                 const uint32_t i = __builtin_ctz(accepted);
                 accepted &= accepted - 1;
-                const uint64_t r = st[lb + t][i];
+                uint64_t r = st[lb + t][i];
+                if constexpr (W32) // (the wide form of the word: what follows is one code for both)
+                    r = ((((uint64_t)(((lb + t) << TILE_BITS) | ((uint32_t)r >> W32_FIELD)) << rank_bits) |
+                          (((uint32_t)r >> (W32_FIELD - rank_bits)) & ((1u << rank_bits) - 1))) << len_bits) |
+                        ((uint32_t)r & ((1u << (W32_FIELD - rank_bits)) - 1));
                 const uint64_t x = r >> len_bits; // rel << rank_bits | tie
                 const uint64_t key = x + (base << rank_bits);
                 if constexpr (CP) { // length | carried count << 24 (k_tile_write takes it apart)
@@ -2827,12 +2563,10 @@ __global__ ACX_MAIN_BOUNDS ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segmen
             T.btot[g] = n;
             uint64_t *sgw = T.sgw + (seq & 1) * 2 * (uint64_t)T.sg_cap;
             __hip_atomic_fetch_add(sgw + g / SUPER, (uint64_t)n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, ((uint64_t)occ << 32) | (V2 ? own_items : hoff[lb + GROUP_TILES] - hoff[lb]),
+            __hip_atomic_fetch_add(sgw + T.sg_cap + g / SUPER, ((uint64_t)occ << 32) | (hoff[lb + GROUP_TILES] - hoff[lb]),
                                    __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
     }
-    MCLK(5)
-    } // (the workgroup's next group)
 }
 
 // non-continuation (lead) bytes in [p, end): whole aligned 8-byte words, the bytes outside the
@@ -3119,24 +2853,6 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     }
 }
 
-// workgroups of the persistent k_tile_main<.., V2>: as many as the device holds at once (asked once per device and instantiation)
-static uint32_t main_grid(const void *kernel, int inst, uint32_t n_groups) {
-    static uint32_t resident[16][4] = {};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    uint32_t &r = resident[dev & 15][inst & 3];
-    if (r == 0) {
-        int per_cu = 0, cus = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)MAIN_THREADS, 0) != hipSuccess || per_cu < 1) per_cu = 4;
-        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 1) cus = 256;
-        (void)hipGetLastError();
-        static const char *env = std::getenv("ACX_MAIN_PER_CU"); // measurements
-        if (env && std::atoi(env) > 0) per_cu = std::atoi(env);
-        r = (uint32_t)per_cu * (uint32_t)cus;
-    }
-    return n_groups < r ? n_groups : r;
-}
-
 uint32_t tile_lookback(uint32_t max_len) {
     // context tiles in front of a group: longer than the longest pattern by at least 2 KiB
     const uint64_t need = (uint64_t)(max_len ? max_len - 1 : 0) + 2048;
@@ -3156,14 +2872,19 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue; // (the caller keeps such automata off this path)
     const bool cpw = cp_blockpre != nullptr; // the write kernel converts to code points: the occurrences carry their chunk counts
-#define ACX_TILE_MAIN_V(AN, CPW, V)                                                                                    \
-    hipLaunchKernelGGL((k_tile_main<AN, CPW, V>), dim3(V && ACX_MAIN_PERSISTENT != 0 ? main_grid((const void *)k_tile_main<AN, CPW, V>, (AN ? 2 : 0) + (CPW ? 1 : 0), T.n_groups) : T.n_groups), dim3(MAIN_THREADS), 0, st, A, G, key_mode, ov, T, lookback, \
+    // narrow staged words (k_tile_main<.., W32, ..>): the tie-break field and the longest pattern's length fit W32_FIELD bits
+    // together, byte offsets (ACX_MAIN_WIDE=1: always the wide form -- measurements)
+    static const bool wide_env = std::getenv("ACX_MAIN_WIDE") != nullptr;
+    uint32_t lbits = 0;
+    while ((1u << lbits) <= A.max_len) lbits++;
+    const bool w32 = !cpw && !wide_env && A.rank_bits + lbits <= W32_FIELD;
+#define ACX_TILE_MAIN_W(AN, CPW, W, N)                                                                                \
+    hipLaunchKernelGGL((k_tile_main<AN, CPW, W, N>), dim3(T.n_groups), dim3(N), 0, st, A, G, key_mode, ov, T, lookback, \
                        lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0, hot_ok ? 1 : 0)
-#define ACX_TILE_MAIN(AN, CPW) { if (T.titems) ACX_TILE_MAIN_V(AN, CPW, true); else ACX_TILE_MAIN_V(AN, CPW, false); }
-    if (A.max_shift) { if (cpw) ACX_TILE_MAIN(true, true) else ACX_TILE_MAIN(true, false) }
-    else { if (cpw) ACX_TILE_MAIN(false, true) else ACX_TILE_MAIN(false, false) }
+#define ACX_TILE_MAIN(AN) { if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS); else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32); else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS); }
+    if (A.max_shift) ACX_TILE_MAIN(true) else ACX_TILE_MAIN(false)
 #undef ACX_TILE_MAIN
-#undef ACX_TILE_MAIN_V
+#undef ACX_TILE_MAIN_W
     if (before_write) { // (what the write kernel needs from another stream: the code-point prefix)
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;
@@ -3215,7 +2936,6 @@ __device__ __forceinline__ void dense_file_hits(const DevAutomaton &A, const Seg
     const unsigned long long below_me = (1ull << lane) - 1;
     uint64_t p = 0, w0 = 0, w1 = 0, room = 0, back = 0;
     uint32_t code = HIT_NONE;
-    bool ver = false; // K1b settled the hit itself (round 6): {p, HIT_VERIFIED | tie, length} -- only the haystack's end is checked
     if (live) {
         p = ((uint64_t)h.y << 32) | h.x;
         w0 = ((uint64_t)w.y << 32) | w.x; w1 = ((uint64_t)w.w << 32) | w.z;
@@ -3223,7 +2943,6 @@ __device__ __forceinline__ void dense_file_hits(const DevAutomaton &A, const Seg
         segment_bounds(G, len, p, &seg_lo, &seg_hi);
         room = seg_hi - p; back = p - seg_lo;
         code = h.z;
-        ver = !(code & HIT_LIST) && (code & HIT_VERIFIED) != 0;
         if (code == HIT_RETRY) code = prefix_code(A.ptab, A.ptab_log2, A.filter_q2, w0);
     }
     const bool list = code != HIT_NONE && (code & HIT_LIST) != 0;
@@ -3233,12 +2952,8 @@ __device__ __forceinline__ void dense_file_hits(const DevAutomaton &A, const Seg
         uint32_t L = 0, rk = 0, cand = 0;
         uint64_t ps = 0;
         if (k < nc) {
-            if (ver) { // (tie = what the occurrence word carries: the rank, or the pattern id of LeftmostFirst)
-                cand = rk = code & CODE_PID_MASK; ps = p; L = h.w <= room ? h.w : 0u;
-            } else {
-                cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
-                L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
-            }
+            cand = list ? A.blist[li + 1 + k] : code; // pattern id | anchor shift << 24
+            L = verify_candidate<ANCH>(A, stream, len, p, cand, w0, w1, room, back, &rk, &ps);
         }
         const bool have = L != 0;
         const uint64_t kidx = (key_mode == 0 ? ps + L : ps) + lead;
@@ -3290,7 +3005,7 @@ __global__ __launch_bounds__(256) void k_dense_verify(DevAutomaton A, Segments G
 // when that is hot, else by the (one) hot neighbour that stages it as context (the last tiles of a group) or looks
 // ahead into it (its first tile).  Workgroups beyond the hot groups' take the overflow list (its hits belong to
 // overfull tiles, whose groups are always hot).
-static_assert(TILE_ITEMS <= 65, "one wave reads a tile's items in one step");
+static_assert(HIT_SLOTS <= 64, "one wave reads a tile's hit slots in one step");
 constexpr uint32_t HV_TILES = GROUP_TILES + MAX_LOOKBACK + 1;        // tiles a hot group stages at most
 constexpr uint32_t HV_BLOCKS = (HV_TILES + 3) / 4;                   // workgroups (of four waves) per hot group
 template <bool ANCH>
@@ -3324,27 +3039,14 @@ __global__ __launch_bounds__(256) void k_hot_verify(DevAutomaton A, Segments G, 
     if (tile >= T.n_tiles) return;
     const uint32_t owner = tile / GROUP_TILES;
     if (owner != g && (T.btot[owner] & HOT_BIT)) return; // a hot group files its own tiles
-    // (K1b's items, device_types.hpp: a verified one becomes the record {p, HIT_VERIFIED | tie, length}, an unverified one
-    // {p, code} with its 16 haystack bytes read again)
-    const uint64_t *items = T.titems + (uint64_t)tile * TILE_ITEMS;
-    uint32_t c = (uint32_t)items[0] & 0xFFFFu;
-    c = c < TILE_ITEMS - 1 ? c : TILE_ITEMS - 1;
+    uint32_t c = T.hcnt[hcnt_index(tile, T.cnt_nw, T.cnt_iters)];
+    c = c < HIT_SLOTS ? c : HIT_SLOTS;
     if (c == 0) return;
     const bool live = lane < c;
     uint4 h = make_uint4(0, 0, 0, 0), w = make_uint4(0, 0, 0, 0);
     if (live) {
-        const uint64_t item = items[1 + lane];
-        const uint64_t p = ((uint64_t)tile << TILE_BITS) + ((uint32_t)(item >> ITEM_OFF_SHIFT) & 0xFFFu) - lead;
-        if (item & ITEM_UNVERIFIED) {
-            uint64_t w0, w1;
-            load_window16(stream, len, p, &w0, &w1);
-            const uint32_t icode = (uint32_t)item; // (a displaced key's item names its home slot: here the window is looked up again)
-            h = make_uint4((uint32_t)p, (uint32_t)(p >> 32), (icode & ITEM_RETRY) == ITEM_RETRY ? HIT_RETRY : icode, 0u);
-            w = make_uint4((uint32_t)w0, (uint32_t)(w0 >> 32), (uint32_t)w1, (uint32_t)(w1 >> 32));
-        } else {
-            h = make_uint4((uint32_t)p, (uint32_t)(p >> 32), HIT_VERIFIED | ((uint32_t)(item >> ITEM_TIE_SHIFT) & 0xFFFFFFu),
-                           (uint32_t)item & ITEM_LEN_MASK);
-        }
+        const uint4 *rec = T.hslots + ((uint64_t)tile * HIT_SLOTS + lane) * 2;
+        h = rec[0]; w = rec[1];
     }
     dense_file_hits<ANCH>(A, G, D, key_mode, lead, stream, len, abort_flag, live, h, w);
 }

@@ -58,11 +58,6 @@ uint32_t walk_hits_grid(uint32_t hit_regions);
 hipError_t launch_walk_hits(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
                             const Sink &occ, uint32_t occ_grid, const uint8_t *d_hay, uint64_t len,
                             hipStream_t st);
-#ifdef ACX_MAIN_CLOCK
-hipError_t main_clock_read(unsigned long long *out); // measurements (tools/build_variant.sh -DACX_MAIN_CLOCK=1): k_tile_main's phases
-#endif
-// the prefix table's FAT form (DevAutomaton::pfat: 2 x 16 bytes per slot), from the uploaded table and patterns
-hipError_t build_fat_table(const DevAutomaton &A, int key_mode, uint4 *fat, hipStream_t st);
 size_t prefilter_lds_bytes(); // static LDS of K1b
 // rows of the hot16 table K1a can stage for this automaton and LDS size
 uint32_t dfa_walk_hot_rows(uint32_t n_states, uint32_t stride2, size_t max_lds);
