@@ -394,6 +394,7 @@ struct Workspace {
     TileSpace T{};                    // sparse path (hit slots + tile kernels)
     uint64_t tile_cap = 0;            // tiles T is allocated for
     uint64_t group_cap = 0;           // groups T.gstate is allocated for
+    uint32_t trecs_gmax = 0;          // records per group T.trecs is allocated for (GROUP_MAX; GROUP_MAX_WIDE once a call needed it)
     bool flags_dirty = true;          // the control blocks' counters are not known to be zero
     uint32_t *ctl = nullptr;          // device: the sparse path's two control blocks (device_types.hpp), used by the calls in turn
     uint4 *ovf_recs = nullptr;        // K1b's hits beyond a tile's slots: OVF_LISTS lists of ovf_cap records of 32 B
@@ -432,6 +433,8 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     bool hold_dense_input = false; // why: the INPUT was dense (the hold ends with the first call that is not) -- or the sparse
                                    // kernels gave up on it for another reason (counted down: one failed attempt in nine calls)
+    bool wide = false;         // the sparse path's post stage runs in its WIDE form (device_types.hpp: GROUP_MAX_WIDE): the last
+                               // call's groups mostly gave up on the narrow one (a match every 100 - 500 bytes)
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
     uint64_t seq = 0;          // sequence number the write kernel publishes in the totals' line (h_pinned + PIN_TOTALS)
     uint64_t small_seq = 0;    // K0 (host entry point): the number its result line carries (h_pinned + PIN_K0)
@@ -537,6 +540,7 @@ void free_tiles(Workspace &w) {
     T = TileSpace{};
     w.tile_cap = 0;
     w.group_cap = 0;
+    w.trecs_gmax = 0;
 }
 
 void free_dense_tiles(Workspace &w) {
@@ -726,21 +730,24 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
 // last tile exists (an occurrence may END exactly at the end of the last tile).
 // Nothing is marked as allocated before every allocation has succeeded: a failure leaves the workspace without its tile
 // arrays (free_tiles), never with control blocks that point at freed memory.
-int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
+int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles, uint32_t gmax) {
     Workspace &w = c->ws;
     TileSpace &T = w.T;
     const uint64_t groups = (tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
-    if (tiles > w.tile_cap) {
+    if (tiles > w.tile_cap || gmax > w.trecs_gmax) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        // (grown, never shrunk: what the larger of the two demands -- tiles, records per group -- had is kept)
+        const uint64_t cap_tiles = tiles > w.tile_cap ? tiles + tiles / 8 + GROUP_TILES : w.tile_cap;
+        const uint32_t cap_gmax = std::max(gmax, w.trecs_gmax);
         free_tiles(w);
         if (w.final) { g_bufs.put(w.final, a->device); w.final = nullptr; }
-        const uint64_t cap_tiles = tiles + tiles / 8 + GROUP_TILES;
         const uint64_t cap_groups = (cap_tiles + 1 + GROUP_TILES - 1) / GROUP_TILES;
         const uint64_t cap_super = (cap_groups + 63) / 64;
         int rc = ACX_OK;
         auto grab = [&](void **p, uint64_t bytes) { if (rc == ACX_OK && hipMalloc(p, bytes) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMalloc (tile workspace)"); };
         grab((void **)&T.hslots, cap_tiles * HIT_SLOTS * 32);
         grab((void **)&T.hcnt, (cap_tiles + 16 * 1024 + 16) * 4); // + one slot per K1b wave (layout slack)
-        grab((void **)&T.trecs, cap_groups * GROUP_MAX * 16);
+        grab((void **)&T.trecs, cap_groups * cap_gmax * 16);
         grab((void **)&T.btot, cap_groups * 4);
         grab((void **)&T.sgw, 4 * cap_super * 8);
         grab((void **)&w.hot_list, cap_groups * 4);
@@ -750,9 +757,11 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles) {
         T.sg_cap = (uint32_t)cap_super;
         w.group_cap = cap_groups;
         w.tile_cap = cap_tiles;
+        w.trecs_gmax = cap_gmax;
     }
     T.n_tiles = (uint32_t)tiles;
     T.n_groups = (uint32_t)groups;
+    T.gmax = gmax;
     return ACX_OK;
 }
 
@@ -972,6 +981,7 @@ struct FindCall {
     bool chunked_walk = false;  // dense path, K1a: the failureless walk ran out of item room, walk in chunks
     bool no_dense_tiles = false; // dense path: the tile-ordered form gave up on this call (the radix-sort form takes it)
     bool ovf_grown = false;      // sparse path: the overflow list was grown for this call (one more attempt)
+    bool wide_tried = false;     // sparse path: the call was repeated with the wide form of the post stage
     bool host_result = false;    // the caller reads the matches on the host right away (acx_find): the sparse path writes them
                                  // to the context's pinned buffer when its capacity fits (PIN_FINAL_MAX), no copy kernel-side
     acx_match_t *out = nullptr;  // sparse path: where the write kernels put the records (w.final, or w.pin_final)
@@ -1019,7 +1029,7 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
                               w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, st));
     // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
     // instead (one more round trip, next to that much hot work)
-    const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * GROUP_MAX + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
+    const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * T.gmax + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
     if (bound > c.out_cap && c.out != w.final) { // (the pinned buffer is not regrown: the dense path takes this call)
         *lost = true;
         return ACX_OK;
@@ -1069,7 +1079,10 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     Ctx *x = c.c;
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
-    int rc = ensure_tiles(a, x, c.tiles);
+    // (the wide form of the post stage: K1b's hits only -- the hot pipeline behind it is theirs)
+    const bool wide = x->wide && c.pre;
+    const uint32_t gmax = wide ? GROUP_MAX_WIDE : GROUP_MAX;
+    int rc = ensure_tiles(a, x, c.tiles, gmax);
     if (rc) return rc;
     TileSpace &T = w.T;
     // automata of at most 32 byte classes: the failureless walk (k1a_scan + k1a_walk) instead of the
@@ -1082,7 +1095,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     T.cnt_nw = c.pre ? c.scan_grid * 16 : pfac ? pgrid * 16 : 1;
     T.cnt_iters = T.cnt_nw > 1 ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
     // (room for every group's capacity + what a few hot groups can report beyond it: run_hot)
-    const uint64_t out_cap = (uint64_t)T.n_groups * GROUP_MAX +
+    const uint64_t out_cap = (uint64_t)T.n_groups * gmax +
                              (c.pre ? std::min<uint64_t>(T.n_groups, HOT_INLINE) * HOT_SUB * DT_GMAX : 0);
     const bool pin = c.host_result && !c.segmented && out_cap * sizeof(acx_match_t) <= PIN_FINAL_MAX &&
                      !(c.overlapping && a->expand_ov);
@@ -1212,6 +1225,24 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         (void)hipGetLastError(); // (no room for it: the dense path)
     }
     if (c.ovf_grown && gave_up != 2) a->path[6]++;
+    // many groups gave up on the narrow stage although their tiles' slots held the hits (a match every 100 - 500 bytes: more
+    // than 24 occurrences in a 4 KiB bucket, more than GROUP_MAX in a group): the context takes the WIDE form of the post stage
+    // -- this call again, its next calls from the start -- instead of handing every group to the hot pipeline and the handle
+    // to the dense path (until round 5: 2 437 -> 1 057 GB/s between a match every 512 and every 256 bytes)
+    static const bool no_wide = std::getenv("ACX_NO_WIDE") != nullptr; // measurements
+    if (!gave_up && c.pre && !wide && !c.wide_tried && !no_wide && T.n_groups >= 32 && n_hot * 32 > T.n_groups &&
+        n_ovf * 8 <= w.t_line[3]) {
+        HIPCHK_RC(hipStreamSynchronize(st));
+        HIPCHK_RC(hipMemsetAsync(T.sgw, 0, 4 * (uint64_t)T.sg_cap * 8, st));
+        if (seg_counts) HIPCHK_RC(hipMemsetAsync(c.r->d_counts, 0, std::max<uint64_t>(c.G.n_hay, 1) * 8, st));
+        x->wide = true;
+        c.wide_tried = true;
+        c.leads_counted = false;
+        c.event_at_post = false;
+        a->path[9]++;
+        *what = Attempt::Again;
+        return ACX_OK;
+    }
     if (!gave_up && n_hot) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
         bool lost = false;
         if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, hot_counts != nullptr, &lost)) != ACX_OK) return rc;
@@ -1236,6 +1267,8 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     c.n_raw = w.t_line[2]; // (the hot pipeline's second publication when it ran)
     c.n_hits = w.t_line[3];
     c.n_final = w.t_line[1];
+    // (back to the narrow form -- twice the groups in flight -- when the input no longer needs the wide one)
+    if (wide && n_hot == 0 && c.n_raw * 5 < (uint64_t)T.n_groups * GROUP_MAX * 2) x->wide = false;
     if (c.out == w.final) {
         c.r->d_matches = w.final; // hand the buffer over; the next call takes a fresh one
         w.final = nullptr;

@@ -115,6 +115,11 @@ constexpr uint32_t GROUP_TILES = ACX_GROUP_TILES;  // tiles per workgroup of k_t
 #define ACX_GROUP_MAX 1024
 #endif
 constexpr uint32_t GROUP_MAX = ACX_GROUP_MAX;  // reported matches per group
+// The WIDE form of the sparse path's post stage (round 6): stages of STAGE_SLOTS_WIDE occurrences per 4 KiB bucket and stretches
+// of GROUP_MAX_WIDE matches per group -- inputs with a match every 100 - 500 bytes stay on the sparse kernels (until round 5 a
+// group of more than GROUP_MAX matches, or a bucket of more than 24 occurrences, left it: from one match per 256 bytes on the
+// whole call went to the dense path, 2.3x slower).  A context takes the wide form after a call whose groups mostly gave up.
+constexpr uint32_t GROUP_MAX_WIDE = 4 * GROUP_MAX;
 constexpr uint32_t MAX_LOOKBACK = 4;  // context tiles k_tile_main can stage in front of a group
 // Where a tile's hit count lives: the counts of the tiles ONE K1b wave scans (tile, tile + nw,
 // tile + 2 nw, ...) are contiguous, so that the wave writes them 16 at a time with one store
@@ -178,7 +183,8 @@ struct TileSpace {
     uint4 *hslots;      // n_tiles * HIT_SLOTS * 2
     uint32_t *hcnt;     // n_tiles (+ slack), indexed by hcnt_index(tile, cnt_nw, cnt_iters)
     uint32_t cnt_nw, cnt_iters;
-    uint4 *trecs;       // groups * GROUP_MAX: the REPORTED occurrences of a group, in order
+    uint4 *trecs;       // groups * gmax: the REPORTED occurrences of a group, in order
+    uint32_t gmax;      // records a group's stretch of trecs holds: GROUP_MAX, or GROUP_MAX_WIDE (the wide form of k_tile_main)
     uint32_t *btot;     // reported occurrences of each group
     uint64_t *sgw;      // 2 sets (used by the calls in turn) of 2 * sg_cap words: per supergroup of 64
                         // groups, the sum of their counts / of their statistics (kernels.hip)

@@ -2233,6 +2233,7 @@ constexpr uint32_t STAGE_BUCKETS = GROUP_TILES + MAX_LOOKBACK;
 constexpr uint32_t STAGE_SLOTS = ACX_STAGE_SLOTS;
 static_assert(GROUP_TILES <= 64, "one wave owns the output buckets of a group");
 static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit mask");
+constexpr uint32_t STAGE_SLOTS_WIDE = 64; // the wide form (device_types.hpp: GROUP_MAX_WIDE): the flags are 64-bit masks
 // A staged occurrence is ONE 64-bit word (the group's LDS footprint decides how many groups a CU
 // works on at once, and the kernel is bound by the latency of its gathers, not by anything it
 // computes): [ rel : 19 | tie : rank_bits | length : 45 - rank_bits ], rel = index of the key
@@ -2282,8 +2283,9 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 // patterns of up to 63 bytes), byte offsets.  The stage is what decides how many groups a CU works on at once, and this
 // kernel lives on groups in flight: with narrow words a group takes 8 KiB of LDS, and with NT = 128 threads (two waves)
 // sixteen groups fit a CU instead of eight -- all 4 096 groups of a 1 GiB haystack are resident at once.
-template <bool ANCH, bool CP, bool W32, uint32_t NT>
-__global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+// SLOTS: occurrences a bucket stages -- SLOTS, or SLOTS_WIDE (the wide form: inputs with a match every 100 - 500 bytes).
+template <bool ANCH, bool CP, bool W32, uint32_t NT, uint32_t SLOTS>
+__global__ __launch_bounds__(NT, NT == 128 ? 8 : SLOTS > 32 ? 4 : 6) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
@@ -2300,11 +2302,12 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
     // put all 64 lanes on the same LDS banks -- measured: 67 % of this kernel's LDS cycles were conflicts)
     static_assert(!(W32 && CP), "a narrow staged word has no room for the carried lead-byte count");
     using SW = typename std::conditional<W32, uint32_t, uint64_t>::type;
-    __shared__ SW st[STAGE_BUCKETS][STAGE_SLOTS + 1]; // staged occurrences by bucket of key position
+    __shared__ SW st[STAGE_BUCKETS][SLOTS + 1]; // staged occurrences by bucket of key position
     __shared__ uint32_t bn[STAGE_BUCKETS];         // occurrences per bucket
     __shared__ int32_t bmax[STAGE_BUCKETS];        // largest end per bucket
     __shared__ uint32_t hoff[STAGE_BUCKETS + 2];   // exclusive prefix of the tiles' hit counts
-    __shared__ uint32_t synm[STAGE_BUCKETS], accm[STAGE_BUCKETS]; // per bucket: sync points / accepted
+    using MK = typename std::conditional<(SLOTS > 32), uint64_t, uint32_t>::type; // one flag per slot of a bucket
+    __shared__ MK synm[STAGE_BUCKETS];             // per bucket: sync points
     __shared__ uint32_t fail, stop, tail_base;
     const uint32_t t = threadIdx.x, g = blockIdx.x;
     const uint32_t tile0 = g * GROUP_TILES;
@@ -2402,7 +2405,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
             const uint32_t rel = (uint32_t)(kidx - first_idx);
             const uint32_t b = rel >> TILE_BITS;
             const uint32_t r = atomicAdd(&bn[b], 1u);
-            if (r < STAGE_SLOTS) {
+            if (r < SLOTS) {
                 if constexpr (W32) {
                     st[b][r] = ((rel & ((1u << TILE_BITS) - 1)) << W32_FIELD) | ((key_mode == 1 ? pid : rk) << (W32_FIELD - rank_bits)) | L;
                 } else {
@@ -2467,9 +2470,10 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
         bmax[t] = mx;
     }
     __syncthreads();
-    uint32_t cnt = 0, accepted = 0; // reported occurrences of output bucket t (wave 0)
+    uint32_t cnt = 0; // reported occurrences of output bucket t (wave 0)
+    MK accepted = 0;
     if (overlapping) {
-        if (t < GROUP_TILES) { cnt = bn[lb + t]; accepted = cnt >= 32 ? 0xFFFFFFFFu : (1u << cnt) - 1; }
+        if (t < GROUP_TILES) { cnt = bn[lb + t]; accepted = cnt >= 8 * sizeof(MK) ? ~(MK)0 : ((MK)1 << cnt) - 1; }
     } else {
         // ---- certified sync points.  Only occurrences of the last (lookback + 1) buckets can end
         // beyond the start of one in bucket t (an occurrence spans at most max_len - 1 bytes
@@ -2478,11 +2482,11 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
             int32_t m = 0;
             for (uint32_t b = t > lookback + 1 ? t - lookback - 1 : 0; b < t; b++) m = max(m, bmax[b]);
             const uint32_t n = bn[t];
-            uint32_t sm = 0;
+            MK sm = 0;
             for (uint32_t i = 0; i < n; i++) {
                 int32_t s, e;
                 staged_span<CP, W32>(rank_bits, key_mode, st[t][i], t, &s, &e);
-                if (s >= wlow && m <= s) sm |= 1u << i;
+                if (s >= wlow && m <= s) sm |= (MK)1 << i;
                 m = max(m, e);
             }
             synm[t] = sm;
@@ -2493,7 +2497,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
             const uint32_t ob = lb + t;
             int b = (int)ob, i = 0;
             bool ok = true;
-            while (!((synm[b] >> i) & 1u)) { // walk back to a sync point
+            while (!((synm[b] >> i) & 1)) { // walk back to a sync point
                 if (--i < 0) {
                     do { b--; } while (b >= 0 && bn[b] == 0);
                     if (b < 0) { ok = false; break; }
@@ -2509,7 +2513,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
                     staged_span<CP, W32>(rank_bits, key_mode, st[b][i], (uint32_t)b, &s, &e);
                     const bool take = s >= pos;
                     if (take) pos = e;
-                    if ((uint32_t)b == ob && take) { accepted |= 1u << i; cnt++; }
+                    if ((uint32_t)b == ob && take) { accepted |= (MK)1 << i; cnt++; }
                     if (++i >= (int)bn[b]) {
                         if ((uint32_t)b == ob) break;
                         do { b++; } while (bn[b] == 0); // ob is not empty: terminates there at the latest
@@ -2530,14 +2534,14 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
         }
         const uint32_t total = __shfl(incl, 63);
         for (int o = 32; o > 0; o >>= 1) occ += __shfl_down(occ, o);
-        if (total > GROUP_MAX) {
+        if (total > T.gmax) {
             give_up(); // (wave 0 is here as a whole)
         } else {
             // records {key lo, key hi, tie, length} in stream coordinates (k_tile_write maps a rank to its pattern)
-            uint4 *dst = T.trecs + (uint64_t)g * GROUP_MAX + (incl - cnt);
+            uint4 *dst = T.trecs + (uint64_t)g * T.gmax + (incl - cnt);
             const uint64_t base = first_idx - lead;
             for (uint32_t k = 0; accepted; k++) {
-                const uint32_t i = __builtin_ctz(accepted);
+                const uint32_t i = sizeof(MK) == 8 ? (uint32_t)__builtin_ctzll((unsigned long long)accepted) : (uint32_t)__builtin_ctz((uint32_t)accepted);
                 accepted &= accepted - 1;
                 uint64_t r = st[lb + t][i];
                 if constexpr (W32) // (the wide form of the word: what follows is one code for both)
@@ -2556,7 +2560,7 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : 6) ACX_MAIN_SGPR void k_tile_ma
                 }
             }
         }
-        if (t == 0 && total <= GROUP_MAX) {
+        if (t == 0 && total <= T.gmax) {
             // the group's count, and count and statistics added into the words of its supergroup
             // (k_tile_write, which starts when every group is done, places the output with them)
             const uint32_t n = total;
@@ -2813,7 +2817,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
                 const uint64_t key_ = (pos_ << rank_bits) | tie_;
                 v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), (uint32_t)tie_, (uint32_t)(w_ & ((1ull << lenb) - 1)));
             } else {
-                v = T.trecs[(uint64_t)g * GMAX + c0 + i];
+                v = T.trecs[(uint64_t)g * T.gmax + c0 + i]; // (the sparse path's stretches: GROUP_MAX or GROUP_MAX_WIDE records)
             }
             uint32_t carried = CP_UNKNOWN;
             // (str API: k_tile_main<.., CP> packed the count above the length; the dense path's words carry none)
@@ -2878,10 +2882,15 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     uint32_t lbits = 0;
     while ((1u << lbits) <= A.max_len) lbits++;
     const bool w32 = !cpw && !wide_env && A.rank_bits + lbits <= W32_FIELD;
-#define ACX_TILE_MAIN_W(AN, CPW, W, N)                                                                                \
-    hipLaunchKernelGGL((k_tile_main<AN, CPW, W, N>), dim3(T.n_groups), dim3(N), 0, st, A, G, key_mode, ov, T, lookback, \
+    const bool wide = T.gmax > GROUP_MAX; // (the context's choice: acx_api.cpp)
+#define ACX_TILE_MAIN_W(AN, CPW, W, N, SL)                                                                            \
+    hipLaunchKernelGGL((k_tile_main<AN, CPW, W, N, SL>), dim3(T.n_groups), dim3(N), 0, st, A, G, key_mode, ov, T, lookback, \
                        lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0, hot_ok ? 1 : 0)
-#define ACX_TILE_MAIN(AN) { if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS); else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32); else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS); }
+#define ACX_TILE_MAIN(AN) {                                                                                           \
+        if (wide) { if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS_WIDE); else if (w32) ACX_TILE_MAIN_W(AN, false, true, MAIN_THREADS, STAGE_SLOTS_WIDE); else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS_WIDE); } \
+        else if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS);                                        \
+        else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32, STAGE_SLOTS);                                \
+        else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS); }
     if (A.max_shift) ACX_TILE_MAIN(true) else ACX_TILE_MAIN(false)
 #undef ACX_TILE_MAIN
 #undef ACX_TILE_MAIN_W

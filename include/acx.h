@@ -23,12 +23,16 @@
 extern "C" {
 #endif
 
-/* 5: acx_host_tables_t grew (short-pattern tables), acx_device_synchronize_on, acx_comm_* added (round 4);
+/* 8: acx_path_stats gained [9] (round 6: calls repeated with the wide form of the sparse path's post stage);
+ * 7: acx_path_stats gained [8] (byte ranges of calls that were cut); K0's result line carries end - 1 and a hash of the
+ *    matches beside it (round 5);
+ * 6: acx_path_stats added (round 5);
+ * 5: acx_host_tables_t grew (short-pattern tables), acx_device_synchronize_on, acx_comm_* added (round 4);
  * 4: acx_host_tables_t grew (walk_t3b / walk_t3r / walk_grec, round 3);
  * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 7
+#define ACX_VERSION 8
 
 /* status codes */
 #define ACX_OK 0
@@ -310,8 +314,10 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
  * call: reference behaviour /root/reference/src/lib.rs:59), [2] hot groups in all, [3] prefix hits beyond their tiles'
  * slots in all, [4] calls on the tile-ordered dense path, [5] calls on its radix-sort form, [6] calls that were redone
  * with a larger overflow list, [7] calls K0 answered, [8] byte ranges searched for calls that were cut (more than 2^32
- * occurrences in one pass: the pieces count in [0 .. 7] as well).  reset != 0 clears the counters. */
-#define ACX_PATH_STATS 9
+ * occurrences in one pass: the pieces count in [0 .. 7] as well), [9] calls that were repeated with the WIDE form of the
+ * sparse path's post stage (a match every 100 - 500 bytes: the context keeps that form while its inputs are like that).
+ * reset != 0 clears the counters. */
+#define ACX_PATH_STATS 10
 int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset);
 
 /* ---- device memory helpers so that a host without torch can stage data ---- */
