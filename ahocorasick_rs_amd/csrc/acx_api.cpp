@@ -433,6 +433,8 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     bool hold_dense_input = false; // why: the INPUT was dense (the hold ends with the first call that is not) -- or the sparse
                                    // kernels gave up on it for another reason (counted down: one failed attempt in nine calls)
+    int dense_full = 0;        // > 0: calls left for which the tile-ordered dense path runs k_dense_main in its full form (a group
+                               // did not fit the compact stage)
     bool wide = false;         // the sparse path's post stage runs in its WIDE form (device_types.hpp: GROUP_MAX_WIDE): the last
                                // call's groups mostly gave up on the narrow one (a match every 100 - 500 bytes)
     int flag_idx = 0;          // which of the two abort flags the next sparse attempt uses
@@ -1311,7 +1313,11 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
     HIPCHK_RC(dense_tiles_verify(view(a, c.overlapping), c.G, H, hit_grid, w.dt, c.key_mode, c.lead, c.d_hay, c.len, abort_flag, st));
     // (the hit regions' fill: summary[2] = hits kept, [3] = the fullest region)
     HIPCHK_RC(sink_summary(w.hit_counts, hit_grid, hit_cap, w.hit_counts, hit_grid, hit_cap, w.summary, w.region_off, st));
-    HIPCHK_RC(dense_tiles_main(a->dev, c.key_mode, c.overlapping, w.dt, w.TD, c.lead, abort_flag, w.summary, st));
+    // (k_dense_main in its compact form -- sixteen groups per CU -- unless a call of this context did not fit it lately)
+    static const bool no_compact = std::getenv("ACX_NO_DENSE_COMPACT") != nullptr; // measurements
+    bool compact = x->dense_full == 0 && !no_compact;
+    if (x->dense_full > 0) x->dense_full--;
+    HIPCHK_RC(dense_tiles_main(a->dev, c.key_mode, c.overlapping, w.dt, w.TD, c.lead, abort_flag, w.summary, compact, st));
     // ([0..3]: the hit regions' fill; [8] matches, [9] occurrences, [10] the abort flag -- not [7], [11]: the words the
     // sparse path and K0 publish their sequence numbers in)
     HIPCHK_RC(hipMemcpyAsync(w.h_pinned, w.summary, 32, hipMemcpyDeviceToHost, st));
@@ -1323,6 +1329,14 @@ int attempt_dense_tiles(FindCall &c, Attempt *what) {
         if ((rc = ensure_hits(x, (uint64_t)hit_grid * (hit_max + hit_max / 8 + 64))) != ACX_OK) return rc;
         *what = Attempt::Again;
         return ACX_OK;
+    }
+    if (compact && (uint32_t)w.h_pinned[10] == 2) { // a group's occurrences did not fit the compact stage: the kernel again, full
+        x->dense_full = 8;
+        HIPCHK_RC(hipMemsetAsync(w.TD.sgw, 0, 2 * (uint64_t)w.TD.sg_cap * 8, st));
+        HIPCHK_RC(hipMemsetAsync(w.summary + 10, 0, 16, st));
+        HIPCHK_RC(dense_tiles_main(a->dev, c.key_mode, c.overlapping, w.dt, w.TD, c.lead, abort_flag, w.summary, false, st));
+        HIPCHK_RC(hipMemcpyAsync(w.h_pinned + 8, w.summary + 8, 24, hipMemcpyDeviceToHost, st));
+        HIPCHK_RC(hipStreamSynchronize(st));
     }
     if ((uint32_t)w.h_pinned[10] != 0) { // a bucket overflowed / a chain left its context: the radix-sort form
         c.no_dense_tiles = true;

@@ -3103,20 +3103,28 @@ __device__ __forceinline__ void sort_bucket(uint64_t *bucket, const uint64_t *sr
     for (int e = 0; e < EPL; e++) { const uint32_t i = lane * EPL + e; v[e] = i < n ? src[i] : ~0ull; }
     wave_bitonic_sort<EPL>(v, lane);
 #pragma unroll
-    for (int e = 0; e < EPL; e++) bucket[lane * EPL + e] = v[e];
+    for (int e = 0; e < EPL; e++) if (lane * EPL + e < n) bucket[lane * EPL + e] = v[e]; // (the padding sorts behind the words: not stored)
 }
 
 // LDS: static part below + dynamic: arr[nb_max][DT_SLOTS] (the staged buckets), syn[], acc[] (one byte per staged
 // occurrence, by virtual index = position in the staged array without its gaps), nb_max = DT_GROUP + lookback --
 // sized by the automaton's lookback so that sets with short patterns get 5 workgroups per CU, not 3
-using dt_scan_max = rocprim::block_scan<int32_t, DT_THREADS>;
-using dt_scan_sum = rocprim::block_scan<uint32_t, DT_THREADS>;
+template <uint32_t NT>
 struct DtLds {
+    using scan_max = rocprim::block_scan<int32_t, NT>;
+    using scan_sum = rocprim::block_scan<uint32_t, NT>;
     uint32_t cnt[DT_STAGE], voff[DT_STAGE + 1];
-    union { typename dt_scan_max::storage_type mx; typename dt_scan_sum::storage_type sum; } scan;
+    union { typename scan_max::storage_type mx; typename scan_sum::storage_type sum; } scan;
     uint32_t first_sync, total, stop;
 };
 static size_t dense_main_lds(uint32_t lookback) { return (size_t)(DT_GROUP + lookback) * DT_SLOTS * (8 + 2); }
+// COMPACT (round 6): the staged buckets lie back to back (a group's stage is as long as its occurrences, not DT_SLOTS words per
+// bucket): DT_COMPACT_WORDS words -- 10 KiB of LDS instead of 26 -- and NT = 128 threads, so that sixteen groups fit a CU
+// instead of six: the kernel is a chain of latencies per group (buckets -> sort -> scans -> chains), it lives on groups in
+// flight.  A group with more staged occurrences sets the abort flag to DT_ABORT_COMPACT: the host repeats the kernel in its
+// full form (inputs denser than ~200 occurrences per tile: the context then keeps to the full form).
+constexpr uint32_t DT_COMPACT_WORDS = 1024, DT_ABORT_COMPACT = 2;
+static size_t dense_main_lds_compact() { return (size_t)DT_COMPACT_WORDS * (8 + 2); }
 
 // HOT pipeline (hot.list != null): the workgroups take the dense groups of the hot groups of the sparse path (HOT_SUB each),
 // and a group's count is credited to ITS hot group in the sparse path's TileSpace (hot.S: btot keeps its HOT_BIT, the
@@ -3126,18 +3134,23 @@ struct HotMain {
     TileSpace S;          // the sparse path's groups
     uint64_t seq;         // the call's sequence number (its set of supergroup words)
 };
-__global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, uint32_t max_len, int key_mode, int overlapping,
-                                                           DenseTiles D, TileSpace T, uint32_t lookback, uint32_t lead,
-                                                           uint32_t *abort_flag, HotMain hot) {
-    __shared__ DtLds L;
+template <uint32_t NT, bool COMPACT>
+__global__ __launch_bounds__(NT) void k_dense_main(uint32_t rank_bits, uint32_t max_len, int key_mode, int overlapping,
+                                                   DenseTiles D, TileSpace T, uint32_t lookback, uint32_t lead,
+                                                   uint32_t *abort_flag, HotMain hot) {
+    __shared__ DtLds<NT> L;
+    using dt_scan_max = typename DtLds<NT>::scan_max;
+    using dt_scan_sum = typename DtLds<NT>::scan_sum;
     extern __shared__ __attribute__((aligned(16))) uint8_t dt_dyn[];
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
     const uint32_t gs = hot.list ? hot.list[blockIdx.x / HOT_SUB] : 0u;
     const uint32_t g = hot.list ? gs * HOT_SUB + blockIdx.x % HOT_SUB : blockIdx.x;
     if (g >= T.n_groups) return; // (hot: the last group of the sparse path may reach beyond the stream's tiles)
     const uint32_t nb_max = DT_GROUP + lookback;
-    uint64_t (*const arr)[DT_SLOTS] = (uint64_t (*)[DT_SLOTS])dt_dyn;
-    uint8_t *const syn = dt_dyn + (size_t)nb_max * DT_SLOTS * 8, *const acc = syn + (size_t)nb_max * DT_SLOTS;
+    // (the stage: bucket b's words from word row(b) on -- DT_SLOTS apart, or, COMPACT, back to back: then a virtual index IS a word's place)
+    uint64_t *const arr = (uint64_t *)dt_dyn;
+    const uint32_t cap_words = COMPACT ? DT_COMPACT_WORDS : nb_max * DT_SLOTS;
+    uint8_t *const syn = dt_dyn + (size_t)cap_words * 8, *const acc = syn + cap_words;
     const uint32_t tile0 = g * DT_GROUP;
     const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0; // first staged tile
     const uint32_t lb = tile0 - first, nb = DT_GROUP + lb;
@@ -3163,16 +3176,21 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         if (t == 0) T.btot[g] = 0;
         return;
     }
+    if (COMPACT && N > DT_COMPACT_WORDS) { // (uniform) the full form takes the call
+        if (t == 0) atomicCAS(abort_flag, 0u, DT_ABORT_COMPACT);
+        return;
+    }
+    auto row = [&](uint32_t b) -> uint64_t * { return arr + (COMPACT ? L.voff[b] : b * DT_SLOTS); };
     // ---- load + sort: a wave takes the buckets wave, wave + 4 (words are unique and compare like their keys); the
     // sort runs in registers (wave_bitonic_sort), sized by the bucket's fill
-    for (uint32_t b = wave; b < nb; b += DT_THREADS / 64) {
+    for (uint32_t b = wave; b < nb; b += NT / 64) {
         const uint32_t n = L.cnt[b];
         const uint64_t *src = D.words + (uint64_t)(first + b) * DT_SLOTS;
         if (n == 0) continue;
-        if (n <= 64) sort_bucket<1>(arr[b], src, n, lane);
-        else if (n <= 128) sort_bucket<2>(arr[b], src, n, lane);
-        else if (n <= 256) sort_bucket<4>(arr[b], src, n, lane);
-        else sort_bucket<8>(arr[b], src, n, lane);
+        if (n <= 64) sort_bucket<1>(row(b), src, n, lane);
+        else if (n <= 128) sort_bucket<2>(row(b), src, n, lane);
+        else if (n <= 256) sort_bucket<4>(row(b), src, n, lane);
+        else sort_bucket<8>(row(b), src, n, lane);
     }
     __syncthreads();
     // virtual index v -> its bucket and word; spans relative to the first staged tile (position = bucket << 12 | rel)
@@ -3184,14 +3202,14 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
 #pragma unroll
         for (uint32_t q = 1; q < DT_STAGE; q++) { const bool in = v >= vo[q]; b += in ? 1u : 0u; off = in ? vo[q] : off; }
         *b_ = b;
-        return arr[b][v - off];
+        return COMPACT ? arr[v] : arr[b * DT_SLOTS + (v - off)];
     };
     auto span = [&](uint32_t b, uint64_t w, int32_t *s_, int32_t *e_) {
         const int32_t rel = (int32_t)((b << TILE_BITS) | (uint32_t)(w >> 52)), Ln = (int32_t)(w & ((1ull << len_bits) - 1));
         if (key_mode == 0) { *e_ = rel; *s_ = rel - Ln; } else { *s_ = rel; *e_ = rel + Ln; }
     };
     auto span_at = [&](uint32_t v, int32_t *s_, int32_t *e_) { uint32_t b; const uint64_t w = locate(v, &b); span(b, w, s_, e_); };
-    const uint32_t C = (N + DT_THREADS - 1) / DT_THREADS; // elements per thread (<= 16)
+    const uint32_t C = (N + NT - 1) / NT; // elements per thread (<= 16)
     const uint32_t v0 = t * C, v1 = v0 + C < N ? v0 + C : N;
     if (overlapping) {
         for (uint32_t v = v0; v < v1; v++) acc[v] = 1;
@@ -3218,7 +3236,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
         // beyond the context (periodic patterns on periodic text): the radix-sort path resolves globally
         if (L.first_sync > out0) { if (t == 0) *abort_flag = 1; return; }
         // ---- greedy chains: every sync point walks to the next one
-        for (uint32_t v = t; v < N; v += DT_THREADS) {
+        for (uint32_t v = t; v < N; v += NT) {
             if (!syn[v]) continue;
             int32_t s_, pos;
             span_at(v, &s_, &pos);
@@ -3238,7 +3256,7 @@ __global__ __launch_bounds__(DT_THREADS) void k_dense_main(uint32_t rank_bits, u
     for (uint32_t v = v0 > out0 ? v0 : out0; v < v1; v++) cntm += acc[v];
     uint32_t at = 0;
     dt_scan_sum().exclusive_scan(cntm, at, 0u, L.scan.sum);
-    if (t == DT_THREADS - 1) L.total = at + cntm;
+    if (t == NT - 1) L.total = at + cntm;
     __syncthreads();
     const uint32_t total = L.total;
     // (ONE 64-bit word per reported occurrence: [key position relative to the group's first tile : 16 | tie | length];
@@ -3291,11 +3309,15 @@ hipError_t dense_tiles_verify(const DevAutomaton &A, const Segments &G, const Si
 }
 
 hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlapping, const DenseTiles &D, const TileSpace &T,
-                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, hipStream_t st) {
+                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, bool compact, hipStream_t st) {
     const uint32_t lookback = tile_lookback(A.max_len);
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(k_dense_main, dim3(T.n_groups), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len, key_mode,
-                       overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
+    if (compact)
+        hipLaunchKernelGGL((k_dense_main<128, true>), dim3(T.n_groups), dim3(128), dense_main_lds_compact(), st, A.rank_bits, A.max_len, key_mode,
+                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
+    else
+        hipLaunchKernelGGL((k_dense_main<DT_THREADS, false>), dim3(T.n_groups), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len, key_mode,
+                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
     hipLaunchKernelGGL(k_dense_totals, dim3(1), dim3(256), 0, st, T, summary);
     return hipGetLastError();
 }
@@ -3331,7 +3353,7 @@ hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping
     else
         hipLaunchKernelGGL(k_hot_verify<false>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
                            lead, d_hay, len, hot_abort);
-    hipLaunchKernelGGL(k_dense_main, dim3(n_hot * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
+    hipLaunchKernelGGL((k_dense_main<DT_THREADS, false>), dim3(n_hot * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
                        key_mode, overlapping ? 1 : 0, D, TD, lookback, lead, hot_abort, HotMain{hot_list, S, seq});
     return hipGetLastError();
 }

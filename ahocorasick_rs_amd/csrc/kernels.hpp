@@ -162,8 +162,9 @@ hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, co
 hipError_t dense_tiles_verify(const DevAutomaton &A, const Segments &G, const Sink &hits, uint32_t hit_grid,
                               const DenseTiles &D, int key_mode, uint32_t lead, const uint8_t *d_hay, uint64_t len,
                               uint32_t *abort_flag, hipStream_t st);
+// (compact: the kernel's narrow-stage form, sixteen groups per CU; the abort flag reads 2 when a group did not fit: again, full)
 hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlapping, const DenseTiles &D, const TileSpace &T,
-                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, hipStream_t st);
+                            uint32_t lead, uint32_t *abort_flag, uint64_t *summary, bool compact, hipStream_t st);
 hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpace &T, const uint8_t *d_hay, acx_match_t *out,
                              uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
                              uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st);
