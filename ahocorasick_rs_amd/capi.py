@@ -98,7 +98,8 @@ def lib() -> ctypes.CDLL:
     L = ctypes.CDLL(os.environ.get("ACX_LIB", _SO), mode=ctypes.RTLD_GLOBAL)  # ACX_LIB: experiments with variant builds
     vp, u64, i32 = ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int
     L.acx_version.restype = i32
-    if L.acx_version() != ABI_VERSION:
+    # (ACX_LIB_ANY_ABI=1 with ACX_LIB: same-box measurements against an older build of the library)
+    if L.acx_version() != ABI_VERSION and not (os.environ.get("ACX_LIB") and os.environ.get("ACX_LIB_ANY_ABI")):
         raise ImportError(f"libacx_hip.so speaks C ABI version {L.acx_version()}, this binding version {ABI_VERSION}: "
                           "rebuild (python -c 'import __graft_entry__ as g; g.build()')")
     L.acx_last_error.restype = ctypes.c_char_p

@@ -1610,6 +1610,8 @@ int expand_copies(acx_automaton *a, Ctx *x, acx_result *r, bool segmented) {
 // d_hay must stay valid until the result's device work is done (acx_result accessors wait for it)
 int run_chunked(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, int overlapping, int codepoints,
                 acx_result **out, bool wait, uint64_t piece, int depth);
+int run_batch_split(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G, int overlapping,
+                    int codepoints, acx_result **out, int depth);
 int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G,
              int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait, int depth = 0,
              bool host_result = false) {
@@ -1680,14 +1682,82 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
         (void)hipStreamSynchronize(st);
         acx_free_result(r);
         if (rc != TOO_MANY_OCC) return rc;
-        // more occurrences than one pass can index: the haystack in byte ranges, one after the other (a batch is the
-        // caller's to cut -- at a haystack boundary, where nothing has to be carried over)
+        // more occurrences than one pass can index: the haystack in byte ranges, one after the other -- a batch in two parts,
+        // cut at a haystack boundary, where nothing has to be carried over (round 6; until then the error was the caller's)
         const uint64_t m = a->host.max_len ? a->host.max_len - 1 : 0;
         const uint64_t piece = forced && len > forced ? forced : len / 2;
+        if (segmented && depth < 40) return run_batch_split(a, x, d_hay, len, G, overlapping, codepoints, out, depth + 1);
         if (segmented || depth >= 40 || piece <= 2 * m + 16)
             return fail(ACX_ETOOBIG, "more than 2^32 occurrences");
         return run_chunked(a, x, d_hay, len, overlapping, codepoints, out, wait, piece, depth + 1);
     }
+    *out = r;
+    return ACX_OK;
+}
+
+// A batch whose occurrences one pass cannot index (2^32, the width of the device's indexes): its haystacks in two parts,
+// searched one after the other on the same context -- each part again a batch (or, a part of ONE haystack, a call of its
+// own, which may go on in byte ranges) -- and the parts' matches (offsets are local to their haystack: nothing to shift)
+// and per-haystack counts put behind one another.  The reference's loop has no limit (/root/reference/src/lib.rs:53, 59).
+int run_batch_split(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G, int overlapping,
+                    int codepoints, acx_result **out, int depth) {
+    *out = nullptr;
+    hipStream_t st = x->stream;
+    Workspace &w = x->ws;
+    const uint64_t n = G.n_hay;
+    a->path[8]++;
+    auto one_haystack = [&](const uint8_t *h, uint64_t hl, acx_result **r) -> int { // a part of one haystack: its count is its matches
+        int rc = run_find(a, x, h, hl, Segments{nullptr, 1, 0}, overlapping, codepoints, r, true, true, depth);
+        if (rc != ACX_OK) return rc;
+        hipError_t e = g_bufs.get((void **)&(*r)->d_counts, 8, a->device);
+        if (e == hipSuccess) e = hipMemcpyAsync((*r)->d_counts, &(*r)->n, 8, hipMemcpyHostToDevice, st);
+        if (e == hipSuccess) e = hipStreamSynchronize(st);
+        if (e != hipSuccess) { acx_free_result(*r); *r = nullptr; return hipfail(e, "count of a one-haystack part"); }
+        (*r)->n_hay = 1;
+        return ACX_OK;
+    };
+    if (n <= 1) return one_haystack(d_hay, len, out);
+    const uint64_t half = n / 2;
+    uint64_t cut = 0; // the first byte of haystack `half`
+    uint64_t *reb = nullptr; // the second part's offsets, from its first byte
+    if (G.uniform_len) {
+        cut = half * G.uniform_len;
+    } else {
+        HIPCHK(hipMemcpyAsync(w.h_pinned + 8, G.offsets + half, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        cut = w.h_pinned[8];
+        HIPCHK(g_bufs.get((void **)&reb, (n - half + 1) * 8, a->device));
+        hipError_t e = rebase_offsets(reb, G.offsets + half, n - half + 1, cut, st);
+        if (e != hipSuccess) { g_bufs.put(reb, a->device); return hipfail(e, "rebase_offsets"); }
+    }
+    acx_result *ra = nullptr, *rb = nullptr;
+    auto part = [&](const uint8_t *h, uint64_t hl, const uint64_t *offs, uint64_t k, acx_result **r) -> int {
+        if (k == 1) return one_haystack(h, hl, r);
+        const Segments S{G.uniform_len ? nullptr : offs, k, G.uniform_len};
+        return run_find(a, x, h, hl, S, overlapping, codepoints, r, true, true, depth);
+    };
+    int rc = part(d_hay, cut, G.offsets, half, &ra);
+    if (rc == ACX_OK) rc = part(d_hay + cut, len - cut, reb, n - half, &rb);
+    acx_result *r = rc == ACX_OK ? new (std::nothrow) acx_result() : nullptr;
+    if (rc == ACX_OK && !r) rc = fail(ACX_ENOMEM, "out of memory");
+    if (rc == ACX_OK) {
+        r->device = a->device;
+        r->n_hay = n;
+        r->n = ra->n + rb->n;
+        hipError_t e = g_bufs.get((void **)&r->d_counts, n * 8, a->device);
+        if (e == hipSuccess && r->n) e = g_bufs.get((void **)&r->d_matches, r->n * sizeof(acx_match_t), a->device);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->d_counts, ra->d_counts, half * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess) e = hipMemcpyAsync(r->d_counts + half, rb->d_counts, (n - half) * 8, hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && ra->n) e = hipMemcpyAsync(r->d_matches, ra->d_matches, ra->n * sizeof(acx_match_t), hipMemcpyDeviceToDevice, st);
+        if (e == hipSuccess && rb->n) e = hipMemcpyAsync(r->d_matches + ra->n, rb->d_matches, rb->n * sizeof(acx_match_t), hipMemcpyDeviceToDevice, st);
+        if (e != hipSuccess) rc = hipfail(e, "result of a batch in two parts");
+    }
+    hipError_t e2 = hipStreamSynchronize(st); // (the parts' buffers go back to the pool: nothing may still read them)
+    if (rc == ACX_OK && e2 != hipSuccess) rc = hipfail(e2, "a batch in two parts");
+    if (ra) acx_free_result(ra);
+    if (rb) acx_free_result(rb);
+    if (reb) g_bufs.put(reb, a->device);
+    if (rc != ACX_OK) { if (r) acx_free_result(r); return rc; }
     *out = r;
     return ACX_OK;
 }

@@ -3955,6 +3955,16 @@ __global__ void k_copy_shifted(uint64_t *__restrict__ dst, const uint64_t *__res
     if (w >= words) return;
     dst[w] = src[w] + (w % 3 ? shift : 0);
 }
+// dst[i] = src[i] - base: the offsets of the haystacks of a batch's second part, from that part's first byte (acx_api.cpp: a
+// batch beyond 2^32 occurrences in one pass is cut at a haystack boundary)
+__global__ void k_rebase_offsets(uint64_t *__restrict__ dst, const uint64_t *__restrict__ src, uint64_t n, uint64_t base) {
+    const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i] - base;
+}
+hipError_t rebase_offsets(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st) {
+    if (n) hipLaunchKernelGGL(k_rebase_offsets, dim3((uint32_t)((n + 255) / 256)), dim3(256), 0, st, dst, src, n, base);
+    return hipGetLastError();
+}
 hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, uint64_t shift, hipStream_t st) {
     static_assert(sizeof(acx_match_t) == 24, "three words per match");
     for (uint64_t at = 0; at < n;) { // (launches of at most 2^30 matches: the grid's 32 bits)

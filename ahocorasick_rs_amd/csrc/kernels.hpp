@@ -204,6 +204,8 @@ hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *bl
 // copy_shifted: dst = src with start and end moved by shift.
 hipError_t cut_point(const acx_match_t *m, uint64_t n, bool by_end, uint64_t shift, uint64_t limit, uint64_t *out, hipStream_t st);
 hipError_t copy_shifted(acx_match_t *dst, const acx_match_t *src, uint64_t n, uint64_t shift, hipStream_t st);
+// rebase_offsets: dst[i] = src[i] - base (the second part of a batch that is cut at a haystack boundary)
+hipError_t rebase_offsets(uint64_t *dst, const uint64_t *src, uint64_t n, uint64_t base, hipStream_t st);
 
 // ---- copies of a pattern, overlapping searches (acx_api.cpp, expand_copies): the search reports one occurrence per string
 // (lowest id); xcnt[pid] = its later copies, xoff[pid] = where their ids begin in xids[].

@@ -127,17 +127,52 @@ def test_a_pass_over_its_limit_is_cut_until_the_pieces_fit(monkeypatch):
         a.close()
 
 
-def test_a_batch_over_the_limit_still_says_so(monkeypatch):
-    # a batch is the caller's to cut (at a haystack boundary nothing is carried over): the error stays, with its message
-    pats = [b"ab", b"b"]
-    a = capi.Automaton(pats, 0)
-    hays = [b"ab" * 200_000] * 3
-    monkeypatch.setenv("ACX_MAX_OCC", "1000")
+def test_a_batch_over_the_limit_is_cut_at_haystack_boundaries(monkeypatch):
+    # round 6: a batch whose occurrences one pass cannot index is searched in two parts, cut at a haystack boundary (each
+    # part again a batch, a part of one haystack a call of its own that may go on in byte ranges); until then: ACX_ETOOBIG
+    pats = [b"ab", b"b", b"bab"]
+    import random
+    r = random.Random(5)
+    hays = [b"ab" * r.randint(1, 60_000) + bytes(r.choice(b"abc") for _ in range(r.randint(0, 300))) for _ in range(7)] + [b"", b"abab"]
+    for mk, ov in ((0, False), (0, True), (1, False), (2, False)):
+        o = Oracle(pats, mk, KIND_DFA)
+        a = capi.Automaton(pats, mk)
+        want = [o.find_raw(h, overlapping=ov) for h in hays]
+        monkeypatch.setenv("ACX_MAX_OCC", "50000")
+        monkeypatch.setenv("ACX_NO_BUCKET", "1")
+        a.path_stats(reset=True)
+        m, counts = a.find_batch(hays, overlapping=ov)
+        st = a.path_stats()
+        monkeypatch.delenv("ACX_MAX_OCC")
+        monkeypatch.delenv("ACX_NO_BUCKET")
+        assert st["byte_ranges"] >= 2, st
+        assert list(counts) == [len(x) for x in want], (mk, ov)
+        got = cols(m)
+        assert np.array_equal(got, np.concatenate([x.reshape(-1, 3) for x in want]).astype(np.uint64)), (mk, ov)
+        a.close()
+
+
+def test_a_uniform_batch_and_code_points_over_the_limit(monkeypatch):
+    import torch
+    pats = ["é☃", "☃", "a☃é", "ab"]
+    a = capi.Automaton([p.encode() for p in pats], 2)
+    o = Oracle([p.encode() for p in pats], 2, KIND_DFA)
+    text = ("aé☃☃ab" * 4000)
+    hays = [text.encode()] * 9
+    monkeypatch.setenv("ACX_MAX_OCC", "20000")
     monkeypatch.setenv("ACX_NO_BUCKET", "1")
-    with pytest.raises(ValueError, match="2\\^32 occurrences"):
-        a.find_batch(hays)
+    m, counts = a.find_batch(hays, codepoints=True)
+    one = o.find_raw(hays[0])
+    b2c = byte_to_code_point(hays[0])
+    want_one = np.stack([one[:, 0], b2c[one[:, 1]], b2c[one[:, 2]]], 1).astype(np.uint64)
+    assert list(counts) == [len(one)] * 9
+    assert np.array_equal(cols(m), np.concatenate([want_one] * 9))
+    # ... and haystacks of one length, resident on the device (byte offsets)
+    blob = torch.frombuffer(bytearray(b"".join(hays)), dtype=torch.uint8).cuda()
+    res = a.find_device(blob.data_ptr(), blob.numel(), n_hay=9, uniform_len=len(hays[0]))
     monkeypatch.delenv("ACX_MAX_OCC")
     monkeypatch.delenv("ACX_NO_BUCKET")
-    m, counts = a.find_batch(hays)
-    assert list(counts) == [200_000] * 3
+    got = cols(res.matches())
+    assert np.array_equal(got, np.concatenate([one.astype(np.uint64)] * 9))
+    assert list(res.counts()) == [len(one)] * 9
     a.close()

@@ -10,7 +10,7 @@ ARGS=${1:-}
 shift
 for rep in 1 2; do
   for v in "$@"; do
-    if [ "$v" = tree ]; then unset ACX_LIB; else export ACX_LIB=/root/repo/variants/libacx_$v.so; fi
+    if [ "$v" = tree ]; then unset ACX_LIB; else export ACX_LIB=/root/repo/variants/libacx_$v.so; export ACX_LIB_ANY_ABI=1; fi
     timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-target-size --no-cold $ARGS > $OUT/${v}_$rep.json 2> $OUT/${v}_$rep.err
     python - <<PY
 import json
