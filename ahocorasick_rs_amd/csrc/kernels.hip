@@ -2234,6 +2234,9 @@ constexpr uint32_t STAGE_SLOTS = ACX_STAGE_SLOTS;
 static_assert(GROUP_TILES <= 64, "one wave owns the output buckets of a group");
 static_assert(STAGE_SLOTS <= 32, "sync / accept flags of a bucket are one 32-bit mask");
 constexpr uint32_t STAGE_SLOTS_WIDE = 64; // the wide form (device_types.hpp: GROUP_MAX_WIDE): the flags are 64-bit masks
+// (narrow words leave room: 28 slots keep sixteen 128-thread groups on a CU -- 9.3 KiB each -- and a bucket of a haystack with a
+// match every 512 bytes, 12 occurrences on average, overflows 200 times less often than with 24)
+constexpr uint32_t STAGE_SLOTS_W32 = 28;
 // A staged occurrence is ONE 64-bit word (the group's LDS footprint decides how many groups a CU
 // works on at once, and the kernel is bound by the latency of its gathers, not by anything it
 // computes): [ rel : 19 | tie : rank_bits | length : 45 - rank_bits ], rel = index of the key
@@ -2889,7 +2892,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 #define ACX_TILE_MAIN(AN) {                                                                                           \
         if (wide) { if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS_WIDE); else if (w32) ACX_TILE_MAIN_W(AN, false, true, MAIN_THREADS, STAGE_SLOTS_WIDE); else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS_WIDE); } \
         else if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS);                                        \
-        else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32, STAGE_SLOTS);                                \
+        else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32, STAGE_SLOTS_W32);                            \
         else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS); }
     if (A.max_shift) ACX_TILE_MAIN(true) else ACX_TILE_MAIN(false)
 #undef ACX_TILE_MAIN

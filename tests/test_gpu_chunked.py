@@ -153,7 +153,6 @@ def test_a_batch_over_the_limit_is_cut_at_haystack_boundaries(monkeypatch):
 
 
 def test_a_uniform_batch_and_code_points_over_the_limit(monkeypatch):
-    import torch
     pats = ["é☃", "☃", "a☃é", "ab"]
     a = capi.Automaton([p.encode() for p in pats], 2)
     o = Oracle([p.encode() for p in pats], 2, KIND_DFA)
@@ -168,11 +167,14 @@ def test_a_uniform_batch_and_code_points_over_the_limit(monkeypatch):
     assert list(counts) == [len(one)] * 9
     assert np.array_equal(cols(m), np.concatenate([want_one] * 9))
     # ... and haystacks of one length, resident on the device (byte offsets)
-    blob = torch.frombuffer(bytearray(b"".join(hays)), dtype=torch.uint8).cuda()
-    res = a.find_device(blob.data_ptr(), blob.numel(), n_hay=9, uniform_len=len(hays[0]))
+    blob = np.frombuffer(b"".join(hays), dtype=np.uint8)
+    buf = capi.DeviceBuffer(blob.size).upload(blob)
+    res = a.find_device(buf.ptr, blob.size, n_hay=9, uniform_len=len(hays[0]))
     monkeypatch.delenv("ACX_MAX_OCC")
     monkeypatch.delenv("ACX_NO_BUCKET")
     got = cols(res.matches())
     assert np.array_equal(got, np.concatenate([one.astype(np.uint64)] * 9))
     assert list(res.counts()) == [len(one)] * 9
+    res.free()
+    buf.free()
     a.close()
