@@ -1190,6 +1190,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // (the hot pipeline's bucket counters, when a call of this context has allocated them: the write kernel clears them
     // when it announces hot groups)
     uint32_t *hot_counts = c.pre && w.dt.counts && c.tiles + 1 <= w.dt_cap ? w.dt.counts : nullptr;
+    T.w8 = tile_words_narrow(view(a, c.overlapping), cp_pre != nullptr) ? 1u : 0u; // (what the groups' stretches hold: kernels.hpp)
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, c.out, w.summary, abort_flag,
                         next_flag, w.h_pinned + PIN_TOTALS, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
                         (uint32_t)(c.tiles + 2), st));

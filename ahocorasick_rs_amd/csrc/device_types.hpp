@@ -185,6 +185,8 @@ struct TileSpace {
     uint32_t cnt_nw, cnt_iters;
     uint4 *trecs;       // groups * gmax: the REPORTED occurrences of a group, in order
     uint32_t gmax;      // records a group's stretch of trecs holds: GROUP_MAX, or GROUP_MAX_WIDE (the wide form of k_tile_main)
+    uint32_t w8;        // trecs holds ONE 64-bit word per reported occurrence -- [key position : 44 | tie : rank_bits | length : 20 -
+                        // rank_bits] -- not a 16-byte record: the narrow-word form of k_tile_main (tile_words_narrow, kernels.hpp)
     uint32_t *btot;     // reported occurrences of each group
     uint64_t *sgw;      // 2 sets (used by the calls in turn) of 2 * sg_cap words: per supergroup of 64
                         // groups, the sum of their counts / of their statistics (kernels.hip)

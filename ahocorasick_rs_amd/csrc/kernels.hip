@@ -2542,15 +2542,16 @@ __global__ __launch_bounds__(NT, NT == 128 ? 8 : SLOTS > 32 ? 4 : 6) ACX_MAIN_SG
         } else {
             // records {key lo, key hi, tie, length} in stream coordinates (k_tile_write maps a rank to its pattern)
             uint4 *dst = T.trecs + (uint64_t)g * T.gmax + (incl - cnt);
+            uint64_t *dst8 = (uint64_t *)T.trecs + (uint64_t)g * T.gmax + (incl - cnt); // (W32: ONE word per reported occurrence)
             const uint64_t base = first_idx - lead;
             for (uint32_t k = 0; accepted; k++) {
                 const uint32_t i = sizeof(MK) == 8 ? (uint32_t)__builtin_ctzll((unsigned long long)accepted) : (uint32_t)__builtin_ctz((uint32_t)accepted);
                 accepted &= accepted - 1;
                 uint64_t r = st[lb + t][i];
-                if constexpr (W32) // (the wide form of the word: what follows is one code for both)
-                    r = ((((uint64_t)(((lb + t) << TILE_BITS) | ((uint32_t)r >> W32_FIELD)) << rank_bits) |
-                          (((uint32_t)r >> (W32_FIELD - rank_bits)) & ((1u << rank_bits) - 1))) << len_bits) |
-                        ((uint32_t)r & ((1u << (W32_FIELD - rank_bits)) - 1));
+                if constexpr (W32) { // [ key position in the stream : 44 | tie | length ] (k_tile_write, T.w8)
+                    dst8[k] = ((base + (((lb + t) << TILE_BITS) | ((uint32_t)r >> W32_FIELD))) << W32_FIELD) | ((uint32_t)r & ((1u << W32_FIELD) - 1));
+                    continue;
+                }
                 const uint64_t x = r >> len_bits; // rel << rank_bits | tie
                 const uint64_t key = x + (base << rank_bits);
                 if constexpr (CP) { // length | carried count << 24 (k_tile_write takes it apart)
@@ -2820,7 +2821,14 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
                 const uint64_t key_ = (pos_ << rank_bits) | tie_;
                 v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), (uint32_t)tie_, (uint32_t)(w_ & ((1ull << lenb) - 1)));
             } else {
-                v = T.trecs[(uint64_t)g * T.gmax + c0 + i]; // (the sparse path's stretches: GROUP_MAX or GROUP_MAX_WIDE records)
+                if (T.w8) { // (uniform) the narrow-word form's reported occurrences: [key position : 44 | tie | length]
+                    const uint64_t w_ = ((const uint64_t *)T.trecs)[(uint64_t)g * T.gmax + c0 + i];
+                    const uint32_t lb_ = W32_FIELD - rank_bits, f_ = (uint32_t)w_ & ((1u << W32_FIELD) - 1), tie_ = f_ >> lb_;
+                    const uint64_t key_ = ((w_ >> W32_FIELD) << rank_bits) | tie_;
+                    v = make_uint4((uint32_t)key_, (uint32_t)(key_ >> 32), tie_, f_ & ((1u << lb_) - 1));
+                } else {
+                    v = T.trecs[(uint64_t)g * T.gmax + c0 + i]; // (the sparse path's stretches: GROUP_MAX or GROUP_MAX_WIDE records)
+                }
             }
             uint32_t carried = CP_UNKNOWN;
             // (str API: k_tile_main<.., CP> packed the count above the length; the dense path's words carry none)
@@ -2860,6 +2868,16 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     }
 }
 
+// narrow staged words (k_tile_main<.., W32, ..>): the tie-break field and the longest pattern's length fit W32_FIELD bits
+// together, byte offsets (ACX_MAIN_WIDE=1: always the wide form -- measurements).  The groups' stretches then hold ONE 64-bit
+// word per reported occurrence (TileSpace::w8): the caller sets that flag by this function.
+bool tile_words_narrow(const DevAutomaton &A, bool codepoints) {
+    static const bool wide_env = std::getenv("ACX_MAIN_WIDE") != nullptr;
+    uint32_t lbits = 0;
+    while ((1u << lbits) <= A.max_len) lbits++;
+    return !codepoints && !wide_env && A.rank_bits + lbits <= W32_FIELD;
+}
+
 uint32_t tile_lookback(uint32_t max_len) {
     // context tiles in front of a group: longer than the longest pattern by at least 2 KiB
     const uint64_t need = (uint64_t)(max_len ? max_len - 1 : 0) + 2048;
@@ -2881,10 +2899,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
     const bool cpw = cp_blockpre != nullptr; // the write kernel converts to code points: the occurrences carry their chunk counts
     // narrow staged words (k_tile_main<.., W32, ..>): the tie-break field and the longest pattern's length fit W32_FIELD bits
     // together, byte offsets (ACX_MAIN_WIDE=1: always the wide form -- measurements)
-    static const bool wide_env = std::getenv("ACX_MAIN_WIDE") != nullptr;
-    uint32_t lbits = 0;
-    while ((1u << lbits) <= A.max_len) lbits++;
-    const bool w32 = !cpw && !wide_env && A.rank_bits + lbits <= W32_FIELD;
+    const bool w32 = tile_words_narrow(A, cpw);
+    if ((T.w8 != 0) != w32) return hipErrorInvalidValue; // (the caller's TileSpace says what the stretches will hold)
     const bool wide = T.gmax > GROUP_MAX; // (the context's choice: acx_api.cpp)
 #define ACX_TILE_MAIN_W(AN, CPW, W, N, SL)                                                                            \
     hipLaunchKernelGGL((k_tile_main<AN, CPW, W, N, SL>), dim3(T.n_groups), dim3(N), 0, st, A, G, key_mode, ov, T, lookback, \

@@ -128,6 +128,9 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // the caller runs hot_verify_main + hot_write (below) and waits for the second publication.  hot_counts (may be null): the
 // hot pipeline's bucket counters (DenseTiles::counts, hot_tiles of them), cleared by the write kernel when it announces hot groups.
 uint32_t tile_lookback(uint32_t max_len);
+// the sparse path's post stage runs with narrow staged words and 8-byte reported occurrences for this automaton / index kind
+// (the caller sets TileSpace::w8 accordingly before tile_post)
+bool tile_words_narrow(const DevAutomaton &A, bool codepoints);
 hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, const TileSpace &T, uint32_t lead,
                      const uint8_t *d_hay, uint64_t len, acx_match_t *out, uint64_t *summary,
                      uint32_t *abort_flag, uint32_t *next_flag, uint64_t *host_out, uint64_t seq,

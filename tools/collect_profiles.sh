@@ -13,7 +13,7 @@
 set -u
 export TMPDIR=/tmp
 if [ "${1:-}" = "--check" ]; then
-  R=${2:-r05}
+  R=${2:-r06}
   cd "$(dirname "$0")/.."
   HAVE=$(cat profiles/$R/kernel_source_sha256.txt 2>/dev/null || echo none)
   NOW=$(python tools/kernel_hash.py)
@@ -22,7 +22,7 @@ if [ "${1:-}" = "--check" ]; then
   fi
   echo "profiles/$R matches the working tree's device code ($NOW)"; exit 0
 fi
-R=${1:-r05}
+R=${1:-r06}
 PART=${2:-all}
 OUT=/root/repo/gpurun_out/$R
 mkdir -p $OUT

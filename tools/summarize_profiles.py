@@ -11,7 +11,7 @@ usage: summarize_profiles.py [round]"""
 import collections, csv, glob, json, os, shutil, subprocess, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-R = sys.argv[1] if len(sys.argv) > 1 else "r05"
+R = sys.argv[1] if len(sys.argv) > 1 else "r06"
 SRC, DST = os.path.join(ROOT, "gpurun_out", R), os.path.join(ROOT, "profiles", R)
 os.makedirs(DST, exist_ok=True)
 
