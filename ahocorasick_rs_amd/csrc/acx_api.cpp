@@ -1082,7 +1082,8 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     Workspace &w = x->ws;
     hipStream_t st = x->stream;
     // (the wide form of the post stage: K1b's hits only -- the hot pipeline behind it is theirs)
-    const bool wide = x->wide && c.pre;
+    static const bool force_wide = std::getenv("ACX_FORCE_WIDE") != nullptr; // tests: every K1b call in the wide form
+    const bool wide = (x->wide || force_wide) && c.pre;
     const uint32_t gmax = wide ? GROUP_MAX_WIDE : GROUP_MAX;
     int rc = ensure_tiles(a, x, c.tiles, gmax);
     if (rc) return rc;

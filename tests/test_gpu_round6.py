@@ -1,0 +1,83 @@
+"""GPU, round 6: the forms of the sparse path's post stage and of k_dense_main against the oracle.
+
+* narrow staged words (32-bit words, 128 threads, 8-byte reported occurrences) are what cfg2-shaped sets run by default --
+  ACX_MAIN_WIDE=1 puts the same inputs through the wide-word form;
+* the WIDE FORM (64 occurrences per bucket, 4 096 matches per group): forced on ordinary inputs (ACX_FORCE_WIDE=1: every
+  instantiation -- anchors, code points, narrow and wide words -- sees sparse AND dense inputs), and taken by a context by
+  itself when its groups mostly give up on the narrow stage (a match every 256 bytes), left again on a sparse input;
+* k_dense_main's compact form against its full form (ACX_NO_DENSE_COMPACT=1), and a call whose groups do not fit the compact
+  stage (more than 1 024 staged occurrences per group of four tiles) repeated in the full form.
+The environment switches are read once per process: subprocesses."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import gen
+from oracle_lib import KIND_DFA, Oracle
+
+pytestmark = pytest.mark.gpu
+capi = pytest.importorskip("ahocorasick_rs_amd.capi")
+HERE = os.path.dirname(os.path.abspath(__file__))
+from test_gpu_staged import SCRIPT  # noqa: E402  (all kinds + overlapping, short patterns, code points + anchors, a dense stretch, a batch)
+
+
+def cols(a):
+    return np.stack([a["pattern"], a["start"], a["end"]], 1) if len(a) else np.zeros((0, 3), np.uint64)
+
+
+@pytest.mark.parametrize("env", [{"ACX_FORCE_WIDE": "1"}, {"ACX_MAIN_WIDE": "1"}, {"ACX_FORCE_WIDE": "1", "ACX_MAIN_WIDE": "1"},
+                                 {"ACX_NO_DENSE_COMPACT": "1"}])
+def test_forms_of_the_post_stage_forced(env):
+    r = subprocess.run([sys.executable, "-c", SCRIPT], env={**os.environ, **env}, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def planted(n, step, pats, seed):
+    hay = gen.gen_textlike(n, 11, pats).copy()
+    rng = gen.SplitMix64(seed)
+    for k in range(0, n - 32, step):
+        p = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
+        hay[k:k + len(p)] = p
+    return hay.tobytes()
+
+
+def test_a_context_takes_the_wide_form_and_leaves_it_again():
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+    dense = planted(8 << 20, 256, pats, 3)   # ~20 occurrences per 4 KiB bucket: the narrow stage's buckets overflow
+    denser = planted(8 << 20, 128, pats, 4)  # ~36: the wide form's 64 slots hold them
+    sparse = gen.gen_textlike(8 << 20, 12, pats).tobytes()
+    for mk in (0, 1, 2):
+        o = Oracle(pats, mk, KIND_DFA)
+        a = capi.Automaton(pats, mk, capi.IMPL_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            a.path_stats(reset=True)
+            for h in (dense, denser, dense[5:]):
+                assert np.array_equal(cols(a.find(h, overlapping=ov)), o.find_raw(h, overlapping=ov)), (mk, ov)
+            st = a.path_stats()
+            assert st["wide_redone"] >= 1 and st["dense_tiles"] == st["dense_radix"] == 0, st
+            # a sparse input: still the wide form for this call, the narrow one from the next on -- never the dense path
+            for _ in range(2):
+                assert np.array_equal(cols(a.find(sparse, overlapping=ov)), o.find_raw(sparse, overlapping=ov))
+            st = a.path_stats()
+            assert st["sparse"] == 2 and st["wide_redone"] == 0 and st["hot_calls"] == 0, st
+        a.close()
+
+
+def test_the_compact_dense_main_hands_a_crowded_call_to_the_full_form():
+    # a pattern every 16 bytes: 256+ occurrences per tile, five staged tiles of a dense group hold more than the compact
+    # stage's 1 024 words -- the kernel is repeated in its full form; every 64 bytes: the compact form takes it
+    pats = gen.gen_patterns(3000, 5, 9, gen.AZ, 2)
+    for step in (16, 64):
+        hay = planted(6 << 20, step, pats, step)
+        for mk, ov in ((0, False), (0, True), (2, False)):
+            a = capi.Automaton(pats, mk, capi.IMPL_DFA)
+            want = Oracle(pats, mk, KIND_DFA).find_raw(hay, overlapping=ov)
+            for _ in range(2):  # (the second call: the context's hold on the dense path / on the full form)
+                got = cols(a.find(hay, overlapping=ov))
+                assert got.shape == want.shape and np.array_equal(got, want), (step, mk, ov)
+            st = a.path_stats()
+            assert st["dense_tiles"] >= 1, st
+            a.close()
