@@ -2207,6 +2207,9 @@ constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 #ifndef ACX_MAIN_THREADS_W32
 #define ACX_MAIN_THREADS_W32 128 // threads of the instantiation with narrow staged words (sixteen groups per CU)
 #endif
+#ifndef ACX_MAIN_THREADS_CP
+#define ACX_MAIN_THREADS_CP 128  // ... of the str API's (code points; round 6, same-box pairs: cfg5 0.5404 -> 0.5283 ms; cfg4's plain
+#endif                           // wide-word form loses 1.6 % with 128 threads and keeps 256)
 // How many groups a CU works on at once is what this latency-bound kernel lives on.  LDS (14.7 KiB) and VGPRs
 // (63) allow 8 workgroups of four waves per CU, but 256-thread workgroups are admitted up to
 // floor(800 / (ceil(sgpr / 16) * 16 + 16)) per CU (MI355X guide): the 106 SGPRs the compiler takes by itself
@@ -2288,7 +2291,7 @@ __device__ __forceinline__ void staged_span(uint32_t rank_bits, int key_mode, ui
 // sixteen groups fit a CU instead of eight -- all 4 096 groups of a 1 GiB haystack are resident at once.
 // SLOTS: occurrences a bucket stages -- SLOTS, or SLOTS_WIDE (the wide form: inputs with a match every 100 - 500 bytes).
 template <bool ANCH, bool CP, bool W32, uint32_t NT, uint32_t SLOTS>
-__global__ __launch_bounds__(NT, NT == 128 ? 8 : SLOTS > 32 ? 4 : 6) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
+__global__ __launch_bounds__(NT, NT == 128 ? (W32 ? 8 : 5) : SLOTS > 32 ? 4 : 6) ACX_MAIN_SGPR void k_tile_main(DevAutomaton A, Segments G, int key_mode,
                                                             int overlapping, TileSpace T, uint32_t lookback,
                                                             uint32_t lead, const uint8_t *__restrict__ stream,
                                                             uint64_t len, uint32_t *abort_flag, uint64_t seq,
@@ -2907,7 +2910,7 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
                        lead, d_hay, len, abort_flag, seq, seg_counts, seg_counts ? (G.n_hay ? G.n_hay : 1) : 0, hot_ok ? 1 : 0)
 #define ACX_TILE_MAIN(AN) {                                                                                           \
         if (wide) { if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS_WIDE); else if (w32) ACX_TILE_MAIN_W(AN, false, true, MAIN_THREADS, STAGE_SLOTS_WIDE); else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS_WIDE); } \
-        else if (cpw) ACX_TILE_MAIN_W(AN, true, false, MAIN_THREADS, STAGE_SLOTS);                                        \
+        else if (cpw) ACX_TILE_MAIN_W(AN, true, false, ACX_MAIN_THREADS_CP, STAGE_SLOTS);                                 \
         else if (w32) ACX_TILE_MAIN_W(AN, false, true, ACX_MAIN_THREADS_W32, STAGE_SLOTS_W32);                            \
         else ACX_TILE_MAIN_W(AN, false, false, MAIN_THREADS, STAGE_SLOTS); }
     if (A.max_shift) ACX_TILE_MAIN(true) else ACX_TILE_MAIN(false)
