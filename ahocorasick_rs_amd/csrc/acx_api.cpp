@@ -433,6 +433,7 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     bool hold_dense_input = false; // why: the INPUT was dense (the hold ends with the first call that is not) -- or the sparse
                                    // kernels gave up on it for another reason (counted down: one failed attempt in nine calls)
+    uint64_t hot_inline = 16;  // hot groups the output buffer of a sparse attempt has room for (HOT_INLINE .. HOT_INLINE_MAX)
     int dense_full = 0;        // > 0: calls left for which the tile-ordered dense path runs k_dense_main in its full form (a group
                                // did not fit the compact stage)
     bool wide = false;         // the sparse path's post stage runs in its WIDE form (device_types.hpp: GROUP_MAX_WIDE): the last
@@ -1007,7 +1008,10 @@ enum class Attempt { Done, GoDense, Again };
 // send the whole call to the dense path and keep the handle there for eight more calls).  *lost: the hot pipeline gave
 // up too (a bucket of more than DT_SLOTS occurrences, a chain longer than the context) -- the radix-sort form takes the call.
 constexpr uint64_t PIN_FINAL_MAX = 32ull << 20; // bytes of pinned result buffer a context keeps for host calls (acx_find up to ~8 MiB)
-constexpr uint64_t HOT_INLINE = 128; // hot groups whose capacity the output buffer has room for anyway (1 GiB: 3 % of the groups)
+// hot groups whose capacity the output buffer has room for anyway: 16 to start with, up to 128 for a context that has seen more
+// (Ctx::hot_inline; round 6 -- until then 128 for every call: ~100 MB per result from 32 MiB haystacks on, whatever the input);
+// beyond a context's figure: hot_totals, then a buffer of the exact size
+constexpr uint64_t HOT_INLINE = 16, HOT_INLINE_MAX = 128;
 int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uint32_t ovf_max, uint64_t *seg_counts,
             const uint64_t *cp_pre, bool counts_clear, bool *lost) {
     acx_automaton *a = c.a;
@@ -1099,7 +1103,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     T.cnt_iters = T.cnt_nw > 1 ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
     // (room for every group's capacity + what a few hot groups can report beyond it: run_hot)
     const uint64_t out_cap = (uint64_t)T.n_groups * gmax +
-                             (c.pre ? std::min<uint64_t>(T.n_groups, HOT_INLINE) * HOT_SUB * DT_GMAX : 0);
+                             (c.pre ? std::min<uint64_t>(T.n_groups, x->hot_inline) * HOT_SUB * DT_GMAX : 0);
     const bool pin = c.host_result && !c.segmented && out_cap * sizeof(acx_match_t) <= PIN_FINAL_MAX &&
                      !(c.overlapping && a->expand_ov);
     if (pin && w.pin_final_cap < out_cap) {
@@ -1251,7 +1255,10 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         bool lost = false;
         if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, hot_counts != nullptr, &lost)) != ACX_OK) return rc;
         if (lost) gave_up = 1;
-        else { a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf; }
+        else {
+            a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf;
+            if (n_hot > x->hot_inline) x->hot_inline = std::min<uint64_t>(HOT_INLINE_MAX, 2 * n_hot); // (the context's next calls)
+        }
     } else if (!gave_up) {
         a->path[0]++;
     }
@@ -2452,7 +2459,8 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                     const uint32_t want = (uint32_t)(w.h_line[1] >> K0_REST_HASH_SHIFT);
                     const uint64_t sq = c->small_seq;
                     const auto t0 = std::chrono::steady_clock::now();
-                    for (uint32_t spins = 0;; spins++) {
+                    bool synced = false; // the stream has been synchronised: what is read now is what the kernel wrote
+                    for (;;) {
                         uint32_t hx = 0;
                         for (uint64_t i = 0; i < n; i++) {
                             const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
@@ -2461,9 +2469,12 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                         }
                         if (n <= ACX_K0_LINE_MATCHES || hx == want) break;
                         cpu_relax();
+                        // (once the kernel is known to be over its writes have arrived: ONE more reading decides -- a hash that
+                        // still disagrees is an error, not a reason to synchronise the stream a million times)
+                        if (synced) { std::free(m); return fail(ACX_EDEVICE, "K0's matches did not arrive"); }
                         if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
-                            hipError_t e = hipStreamSynchronize(c->stream); // (the kernel is over: its writes have arrived)
-                            if (e != hipSuccess || spins > (1u << 20)) { std::free(m); return fail(ACX_EDEVICE, "K0's matches did not arrive"); }
+                            if (hipStreamSynchronize(c->stream) != hipSuccess) { std::free(m); return fail(ACX_EDEVICE, "K0's matches did not arrive"); }
+                            synced = true;
                         }
                     }
                 }

@@ -17,9 +17,14 @@
 //                        bytes, orders the occurrences, applies the match kind (Standard /
 //                        LeftmostFirst / LeftmostLongest, overlapping or not) exactly as the
 //                        reference iterators would; k_tile_write places and writes them
-//                        into the final (pattern, start, end) records
-//        dense inputs    (more occurrences than the slots hold) take the region path: K1b ->
-//                        k_walk_hits -> rocPRIM radix sort on the 64-bit key -> k_resolve
+//                        into the final (pattern, start, end) records.  Forms (round 6): narrow
+//                        staged words (32 bits, 128 threads, sixteen groups per CU) for sets
+//                        like the headline's, wide words otherwise; the WIDE FORM (64
+//                        occurrences per bucket) for inputs with a match every 100-500 bytes
+//        dense stretches the groups the sparse kernels cannot finish: the hot pipeline (k_hot_verify ->
+//                        k_dense_main -> k_tile_write<HOT>); inputs dense everywhere: K1b in region
+//                        mode -> k_dense_verify -> k_dense_main (compact or full) -> k_tile_write;
+//                        the path of last resort: k_walk_hits -> rocPRIM radix sort -> k_resolve
 //   K0   small haystacks: the whole call in one workgroup
 //   K3   UTF-8 byte offset -> code-point index (get_byte_to_code_point,
 //        src/lib.rs:73-88) by per-KiB lead-byte counts + prefix sum
@@ -2216,12 +2221,6 @@ constexpr uint32_t MAIN_THREADS = ACX_MAIN_THREADS;
 // admit 6, 80 admit 8 -- the few values that do not fit ride in VGPR lanes.
 #ifndef ACX_MAIN_SGPR_LIMIT
 #define ACX_MAIN_SGPR_LIMIT 80
-#endif
-// (at least 6 waves per SIMD: the instantiation with anchors AND code points would take 87 VGPRs -- 5 waves -- by itself)
-#ifdef ACX_NO_MAIN_BOUND
-#define ACX_MAIN_BOUNDS __launch_bounds__(MAIN_THREADS)
-#else
-#define ACX_MAIN_BOUNDS __launch_bounds__(MAIN_THREADS, 6)
 #endif
 #if ACX_MAIN_SGPR_LIMIT > 0
 #define ACX_MAIN_SGPR __attribute__((amdgpu_num_sgpr(ACX_MAIN_SGPR_LIMIT)))

@@ -64,11 +64,15 @@ def capi_comm_from_env(device: int, timeout_s: float = 120.0):
     import time
     from . import capi
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    # the name carries the launcher's pid (the ranks of one job on a node are children of one launcher), so the file
-    # of an earlier job with the same port is another file; rank 0 also removes what it finds before it creates the
-    # id and what it wrote once every rank holds the communicator
-    path = os.path.join(tempfile.gettempdir(), f"acx_comm_{os.environ.get('MASTER_PORT', '0')}_"
-                        f"{os.environ.get('TORCHELASTIC_RUN_ID', 'x')}_{os.getppid()}.id")
+    # the name is made of what EVERY rank of a job shares by construction -- the rendezvous address and port, the elastic
+    # agent's run id and restart count, or an explicit ACX_COMM_NONCE -- so ranks started by hand in separate shells, or each
+    # behind its own wrapper (numactl, bash -c), find the same file; only when none of those is set does the parent's pid
+    # stand in (the ranks of one launcher).  Rank 0 removes what it finds before it creates the id, and what it wrote once
+    # every rank holds the communicator.
+    shared = [os.environ.get(k) for k in ("ACX_COMM_NONCE", "MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT")]
+    tag = "_".join(v for v in shared if v) or f"ppid{os.getppid()}"
+    tag = "".join(ch if ch.isalnum() or ch in "._-" else "-" for ch in tag)
+    path = os.path.join(tempfile.gettempdir(), f"acx_comm_{tag}.id")
     if rank == 0:
         for stale in (path, path + ".tmp"):
             try:

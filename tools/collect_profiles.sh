@@ -70,6 +70,7 @@ fi
 if [ "$PART" = all ] || [ "$PART" = trace ]; then
 cd /tmp
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T -o bench -- python /root/repo/bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary > $OUT/trace_T.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_T_8gib -o bench -- python /root/repo/bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary --bytes 8589934592 > $OUT/trace_T_8gib.log 2>&1
 for cfg in cfg4 cfg5; do
   timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$cfg -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config $cfg > $OUT/trace_$cfg.log 2>&1
 done

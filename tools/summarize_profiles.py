@@ -32,6 +32,7 @@ for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SR
             shutil.copy(f, os.path.join(DST, os.path.basename(f)))
 P = "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-target-size --no-cold --no-secondary"
 for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary"),
+                 ("T_8gib", "python bench.py --steps 8 --warmup 3 --no-cpu-baseline --no-target-size --no-cold --no-secondary --bytes 8589934592"),
                  ("mixed", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-target-size --config mixed"),
                  ("cfg4", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg4"),
                  ("cfg5", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --config cfg5"),
