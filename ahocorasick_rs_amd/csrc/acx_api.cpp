@@ -1102,10 +1102,15 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     T.cnt_nw = c.pre ? c.scan_grid * 16 : pfac ? pgrid * 16 : 1;
     T.cnt_iters = T.cnt_nw > 1 ? (uint32_t)((c.tiles + T.cnt_nw - 1) / T.cnt_nw) : (uint32_t)c.tiles;
     // (room for every group's capacity + what a few hot groups can report beyond it: run_hot)
-    const uint64_t out_cap = (uint64_t)T.n_groups * gmax +
-                             (c.pre ? std::min<uint64_t>(T.n_groups, x->hot_inline) * HOT_SUB * DT_GMAX : 0);
-    const bool pin = c.host_result && !c.segmented && out_cap * sizeof(acx_match_t) <= PIN_FINAL_MAX &&
+    // (a host call's records go to the CONTEXT's pinned buffer, which is not regrown in the middle of a call: there the room
+    // for hot groups is the full figure while the whole fits PIN_FINAL_MAX; a device result's buffer is the caller's to hold:
+    // the context's own figure)
+    auto cap_for = [&](uint64_t hot_room) {
+        return (uint64_t)T.n_groups * gmax + (c.pre ? std::min<uint64_t>(T.n_groups, hot_room) * HOT_SUB * DT_GMAX : 0);
+    };
+    const bool pin = c.host_result && !c.segmented && cap_for(HOT_INLINE_MAX) * sizeof(acx_match_t) <= PIN_FINAL_MAX &&
                      !(c.overlapping && a->expand_ov);
+    const uint64_t out_cap = cap_for(pin ? HOT_INLINE_MAX : x->hot_inline);
     if (pin && w.pin_final_cap < out_cap) {
         HIPCHK_RC(hipStreamSynchronize(st));
         if (w.pin_final) (void)hipHostFree(w.pin_final);
