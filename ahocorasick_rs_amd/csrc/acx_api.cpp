@@ -357,7 +357,7 @@ private:
 
 // ---------------------------------------------------------------------------
 // pinned host scratch of a context, in 64-bit words (Workspace::h_pinned)
-constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PINNED_WORDS = 64;
+constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PINNED_WORDS = 64;
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -433,6 +433,9 @@ struct Ctx {
     int dense_hold = 0;        // > 0: the output was too dense for the sparse path; calls left in region mode
     bool hold_dense_input = false; // why: the INPUT was dense (the hold ends with the first call that is not) -- or the sparse
                                    // kernels gave up on it for another reason (counted down: one failed attempt in nine calls)
+    uint32_t spec_hot = 0;     // > 0: the last call had this many hot groups (few): the next one queues the hot pipeline ahead of
+                               // knowing that it needs it (kernels.hip: hot_groups_here), spec_ovf: that call's fullest overflow list
+    uint32_t spec_ovf = 0;
     uint64_t hot_inline = 16;  // hot groups the output buffer of a sparse attempt has room for (HOT_INLINE .. HOT_INLINE_MAX)
     int dense_full = 0;        // > 0: calls left for which the tile-ordered dense path runs k_dense_main in its full form (a group
                                // did not fit the compact stage)
@@ -1032,7 +1035,7 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     // groups -- unless the buckets are allocated by this very call)
     if (!counts_clear) HIPCHK_RC(hipMemsetAsync(w.dt.counts, 0, ((uint64_t)w.dt.n_tiles + 1) * 4, st));
     HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, n_hot, abort_flag, ovf_max,
-                              w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, st));
+                              w.dt, w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, 0, st));
     // the output's room: the groups' capacities bound the matches; with many hot groups the buffer is sized exactly
     // instead (one more round trip, next to that much hot work)
     const uint64_t bound = ((uint64_t)T.n_groups - n_hot) * T.gmax + (uint64_t)n_hot * HOT_SUB * DT_GMAX;
@@ -1068,7 +1071,7 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
     if ((uint64_t)n_hot * 4 > T.n_groups && T.n_groups >= 8) { x->dense_hold = 8; x->hold_dense_input = true; }
     const uint64_t pub = seq | (1ull << 63);
     HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, n_hot, c.lead, c.d_hay, c.out, w.summary,
-                        abort_flag, hot_abort, w.h_pinned + PIN_TOTALS, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, st));
+                        abort_flag, hot_abort, w.h_pinned + PIN_TOTALS, seq, pub, c.G, seg_counts, cp_pre, w.blocksub, 0, st));
     if (c.early_event && c.r->done) HIPCHK_RC(hipEventRecord(c.r->done, st)); // (again: behind the kernels queued since)
     int rc = wait_line(x, PIN_TOTALS, pub, w.t_line, "the write kernel did not publish its totals");
     if (rc) return rc;
@@ -1200,10 +1203,30 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     // (the hot pipeline's bucket counters, when a call of this context has allocated them: the write kernel clears them
     // when it announces hot groups)
     uint32_t *hot_counts = c.pre && w.dt.counts && c.tiles + 1 <= w.dt_cap ? w.dt.counts : nullptr;
+    // The hot pipeline queued ahead of the knowledge that the call needs it (round 6): the context's last call had a few hot
+    // groups and the buckets are allocated -- grids for spec_bound hot groups, their number read on the device (kernels.hip:
+    // hot_groups_here); more of them, or none: the kernels return at once.  (Not beyond the room the output buffer has for
+    // hot groups, nor where a call with that many would rather take the wide form.)
+    static const bool no_spec = std::getenv("ACX_NO_SPEC_HOT") != nullptr; // measurements
+    uint32_t spec_bound = 0;
+    if (hot_counts && x->spec_hot && !no_spec) {
+        uint64_t b = std::min<uint64_t>(2ull * x->spec_hot, 64);
+        b = std::min<uint64_t>(b, pin ? HOT_INLINE_MAX : x->hot_inline);
+        b = std::min<uint64_t>(b, T.n_groups >= 32 ? T.n_groups / 32 : T.n_groups);
+        if (b >= x->spec_hot && ensure_dense_tiles(x, c.tiles) == ACX_OK) spec_bound = (uint32_t)b;
+    }
     T.w8 = tile_words_narrow(view(a, c.overlapping), cp_pre != nullptr) ? 1u : 0u; // (what the groups' stretches hold: kernels.hpp)
     HIPCHK_RC(tile_post(view(a, c.overlapping), c.key_mode, c.overlapping, T, c.lead, c.d_hay, c.len, c.out, w.summary, abort_flag,
                         next_flag, w.h_pinned + PIN_TOTALS, seq, c.G, seg_counts, cp_pre, w.blocksub, before_write, c.pre, hot_counts,
                         (uint32_t)(c.tiles + 2), st));
+    const uint64_t pub_spec = seq | (1ull << 63);
+    if (spec_bound) {
+        uint32_t *hot_abort = (uint32_t *)(w.summary + 10);
+        HIPCHK_RC(hot_verify_main(view(a, c.overlapping), c.key_mode, c.overlapping, c.G, T, w.hot_list, 0, abort_flag, x->spec_ovf, w.dt,
+                                  w.TD, c.lead, c.d_hay, c.len, hot_abort, seq, spec_bound, st));
+        HIPCHK_RC(hot_write(view(a, c.overlapping), c.key_mode, T, w.TD, w.hot_list, 0, c.lead, c.d_hay, c.out, w.summary, abort_flag,
+                            hot_abort, w.h_pinned + PIN_SPEC_TOTALS, seq, pub_spec, c.G, seg_counts, cp_pre, w.blocksub, spec_bound, st));
+    }
     g_trace.mark(4);
     if (seg_counts) c.counts_zeroed = true; // (k_tile_main clears them, k_tile_write adds to them)
     // while the kernels run: the scan time of the previous call, and the event the result's
@@ -1237,6 +1260,17 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         }
         (void)hipGetLastError(); // (no room for it: the dense path)
     }
+    // what the context's next call queues ahead: the hot pipeline, when this one had a few hot groups
+    x->spec_hot = (!gave_up && n_hot && n_hot <= 64) ? (uint32_t)n_hot : 0u;
+    x->spec_ovf = (uint32_t)ovf_max;
+    bool spec_done = false;
+    if (spec_bound && !gave_up && n_hot && n_hot <= spec_bound) {
+        // the speculative pipeline is this call's: its pass 1 publishes the totals (a line of its own: pass 0's stays readable)
+        if ((rc = wait_line(x, PIN_SPEC_TOTALS, pub_spec, w.t_line, "the speculative hot pipeline did not publish its totals")) != ACX_OK) return rc;
+        if ((w.t_line[4] & 0xFF) != 0) { c.no_dense_tiles = true; gave_up = 1; }
+        else { a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf; }
+        spec_done = true;
+    }
     if (c.ovf_grown && gave_up != 2) a->path[6]++;
     // many groups gave up on the narrow stage although their tiles' slots held the hits (a match every 100 - 500 bytes: more
     // than 24 occurrences in a 4 KiB bucket, more than GROUP_MAX in a group): the context takes the WIDE form of the post stage
@@ -1256,7 +1290,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         *what = Attempt::Again;
         return ACX_OK;
     }
-    if (!gave_up && n_hot) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
+    if (!gave_up && n_hot && !spec_done) { // groups the sparse kernels could not finish: the hot pipeline, then the write kernel again
         bool lost = false;
         if ((rc = run_hot(c, abort_flag, seq, (uint32_t)n_hot, (uint32_t)ovf_max, seg_counts, cp_pre, hot_counts != nullptr, &lost)) != ACX_OK) return rc;
         if (lost) gave_up = 1;
@@ -1264,7 +1298,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
             a->path[1]++; a->path[2] += n_hot; a->path[3] += n_ovf;
             if (n_hot > x->hot_inline) x->hot_inline = std::min<uint64_t>(HOT_INLINE_MAX, 2 * n_hot); // (the context's next calls)
         }
-    } else if (!gave_up) {
+    } else if (!gave_up && !spec_done) {
         a->path[0]++;
     }
     if (gave_up != 0) { // the slots could not hold the output: dense path

@@ -2694,13 +2694,28 @@ struct PostOut {
     // memsets in the pipeline's way were 16 us of every call with a hot group (null: the host clears them)
     uint32_t *hot_counts;
     uint32_t hot_tiles;
+    const uint32_t *spec_ctl; // pass 1 of a speculative launch (hot_groups_here): the call's control block, else null
+    uint32_t spec_bound;
 };
+// Round 6 -- the hot pipeline queued AHEAD of the knowledge that it is needed (a context whose last call had hot groups): its
+// kernels are launched right behind k_tile_main / the write kernel's pass 0 with grids for `bound` hot groups and read the
+// number of hot groups from the call's control block themselves -- no host round trip between pass 0 and the pipeline, no
+// launch latency on the critical path (one hot 64 KiB region cost the call a round trip + four launches issued behind it:
+// +43 us on a 356 us step).  0 hot groups: every kernel returns at once (pass 0 has written everything); more than `bound`,
+// or a call that gave up: they return too, and the host runs the pipeline the old way.  ctl == null: n is the host's figure.
+__device__ __forceinline__ uint32_t hot_groups_here(const uint32_t *ctl, uint32_t bound, uint32_t n) {
+    if (!ctl) return n;
+    const uint32_t nh = ctl[CTL_HOT_COUNT];
+    return (nh > bound || ctl[CTL_ABORT] != 0 || ctl[CTL_OVF_LOST] != 0) ? 0u : nh;
+}
 // HOT instantiation: one workgroup per dense group (DT_GROUP tiles) of a hot group of the sparse path
 struct HotWrite {
     const uint32_t *list;  // hot groups (ids of the sparse path's groups)
     const uint64_t *trecs; // the dense groups' reported occurrences (DT_GMAX words each, k_dense_main)
     const uint32_t *btot;  // ... and their counts
     uint32_t n_dense;      // dense groups there are
+    const uint32_t *spec_ctl; // speculative launch (hot_groups_here): the call's control block, else null
+    uint32_t spec_bound;
 };
 // CPW: cp.blockpre != null (the instantiation without code points is the round-3 kernel); GMAX: records a group
 // of T.trecs holds (GROUP_MAX: the sparse path; DT_GMAX: the tile-ordered dense path)
@@ -2720,6 +2735,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     // (HOT: dense group `sub` of the hot group g)
     uint32_t g = blockIdx.x, gi = blockIdx.x, sub = 0;
     if constexpr (HOT) {
+        if (blockIdx.x / HOT_SUB >= hot_groups_here(W.spec_ctl, W.spec_bound, 0xFFFFFFFFu)) return;
         g = W.list[blockIdx.x / HOT_SUB];
         sub = blockIdx.x % HOT_SUB;
         gi = g * HOT_SUB + sub;
@@ -2727,6 +2743,7 @@ __global__ __launch_bounds__(WRITE_THREADS) void k_tile_write(uint32_t rank_bits
     // (the flags are stable by now: their writers completed)
     bool stop;
     uint32_t n_hot = 0, n_ovf = 0, why = 0; // why (the line's word 4): 1 the call gave up, 2 only the overflow list was too small
+    if (!HOT && O.pass == 1 && O.spec_ctl && hot_groups_here(O.spec_ctl, O.spec_bound, 0) == 0) return; // (nothing for this pass to do)
     if (HOT || O.pass == 1) {
         stop = *O.hot_abort != 0;
         why = stop ? 1 : 0;
@@ -2919,8 +2936,8 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
         hipError_t e = hipStreamWaitEvent(st, before_write, 0);
         if (e != hipSuccess) return e;
     }
-    const PostOut O{summary, (volatile uint64_t *)host_out, next_flag, seq, 0, seq, 0, nullptr, hot_counts, hot_tiles};
-    const HotWrite W0{nullptr, nullptr, nullptr, 0};
+    const PostOut O{summary, (volatile uint64_t *)host_out, next_flag, seq, 0, seq, 0, nullptr, hot_counts, hot_tiles, nullptr, 0};
+    const HotWrite W0{nullptr, nullptr, nullptr, 0, nullptr, 0};
     if (cpw)
         hipLaunchKernelGGL((k_tile_write<true, GROUP_MAX>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode, A.by_rank,
                            T, out, abort_flag, G, seg_counts, CodePointTables{d_hay, cp_blockpre, cp_sub, A.pchars}, O, W0);
@@ -3042,10 +3059,16 @@ template <bool ANCH>
 __global__ __launch_bounds__(256) void k_hot_verify(DevAutomaton A, Segments G, TileSpace T, const uint32_t *hot_list, uint32_t n_hot,
                                                     const uint32_t *ctl, uint32_t ovf_blocks, uint32_t lookback, DenseTiles D, int key_mode,
                                                     uint32_t lead, const uint8_t *__restrict__ stream, uint64_t len,
-                                                    uint32_t *abort_flag) {
+                                                    uint32_t *abort_flag, uint32_t spec_bound) {
     const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    if (blockIdx.x >= n_hot * HV_BLOCKS) { // the overflow lists: ovf_blocks workgroups each
-        const uint32_t q = blockIdx.x - n_hot * HV_BLOCKS, list = q / ovf_blocks, b0 = q % ovf_blocks;
+    // (a speculative launch -- spec_bound != 0 -- has its grid laid out for spec_bound hot groups and reads their number itself)
+    const uint32_t n_layout = spec_bound ? spec_bound : n_hot;
+    if (spec_bound) {
+        n_hot = hot_groups_here(ctl, spec_bound, 0);
+        if (n_hot == 0) return;
+    }
+    if (blockIdx.x >= n_layout * HV_BLOCKS) { // the overflow lists: ovf_blocks workgroups each
+        const uint32_t q = blockIdx.x - n_layout * HV_BLOCKS, list = q / ovf_blocks, b0 = q % ovf_blocks;
         const uint32_t cap = ctl[CTL_OVF_CAP];
         uint32_t n = (*(const uint32_t *const *)(ctl + CTL_OVF_COUNTS))[list * OVF_COUNT_STRIDE];
         n = n < cap ? n : cap;
@@ -3059,6 +3082,7 @@ __global__ __launch_bounds__(256) void k_hot_verify(DevAutomaton A, Segments G, 
         }
         return;
     }
+    if (blockIdx.x / HV_BLOCKS >= n_hot) return;
     const uint32_t g = hot_list[blockIdx.x / HV_BLOCKS];
     const uint32_t tile0 = g * GROUP_TILES;
     const uint32_t first = tile0 >= lookback ? tile0 - lookback : 0;
@@ -3154,6 +3178,8 @@ struct HotMain {
     const uint32_t *list; // hot groups, null: every dense group of the stream (the dense path proper)
     TileSpace S;          // the sparse path's groups
     uint64_t seq;         // the call's sequence number (its set of supergroup words)
+    const uint32_t *spec_ctl; // speculative launch (hot_groups_here): the call's control block, else null
+    uint32_t spec_bound;
 };
 template <uint32_t NT, bool COMPACT>
 __global__ __launch_bounds__(NT) void k_dense_main(uint32_t rank_bits, uint32_t max_len, int key_mode, int overlapping,
@@ -3164,6 +3190,7 @@ __global__ __launch_bounds__(NT) void k_dense_main(uint32_t rank_bits, uint32_t 
     using dt_scan_sum = typename DtLds<NT>::scan_sum;
     extern __shared__ __attribute__((aligned(16))) uint8_t dt_dyn[];
     const uint32_t t = threadIdx.x, wave = t >> 6, lane = t & 63;
+    if (hot.list && blockIdx.x / HOT_SUB >= hot_groups_here(hot.spec_ctl, hot.spec_bound, 0xFFFFFFFFu)) return;
     const uint32_t gs = hot.list ? hot.list[blockIdx.x / HOT_SUB] : 0u;
     const uint32_t g = hot.list ? gs * HOT_SUB + blockIdx.x % HOT_SUB : blockIdx.x;
     if (g >= T.n_groups) return; // (hot: the last group of the sparse path may reach beyond the stream's tiles)
@@ -3335,10 +3362,10 @@ hipError_t dense_tiles_main(const DevAutomaton &A, int key_mode, bool overlappin
     if (lookback > MAX_LOOKBACK) return hipErrorInvalidValue;
     if (compact)
         hipLaunchKernelGGL((k_dense_main<128, true>), dim3(T.n_groups), dim3(128), dense_main_lds_compact(), st, A.rank_bits, A.max_len, key_mode,
-                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
+                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0, nullptr, 0});
     else
         hipLaunchKernelGGL((k_dense_main<DT_THREADS, false>), dim3(T.n_groups), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len, key_mode,
-                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0});
+                           overlapping ? 1 : 0, D, T, lookback, lead, abort_flag, HotMain{nullptr, TileSpace{}, 0, nullptr, 0});
     hipLaunchKernelGGL(k_dense_totals, dim3(1), dim3(256), 0, st, T, summary);
     return hipGetLastError();
 }
@@ -3347,8 +3374,8 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
                              uint64_t *summary, const uint32_t *zero_flag, uint64_t *host_out, uint32_t lead, const Segments &G,
                              uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
     const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
-    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead, 0, 0, nullptr, nullptr, 0};
-    const HotWrite W{nullptr, nullptr, nullptr, 0};
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, 0, lead, 0, 0, nullptr, nullptr, 0, nullptr, 0};
+    const HotWrite W{nullptr, nullptr, nullptr, 0, nullptr, 0};
     if (cp_blockpre)
         hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true>), dim3(T.n_groups), dim3(WRITE_THREADS), 0, st, A.rank_bits, key_mode,
                            A.by_rank, T, out, zero_flag, G, seg_counts, cp, O, W);
@@ -3362,20 +3389,23 @@ hipError_t dense_tiles_write(const DevAutomaton &A, int key_mode, const TileSpac
 hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
                            const uint32_t *hot_list, uint32_t n_hot, const uint32_t *ctl, uint32_t ovf_max, const DenseTiles &D,
                            const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
-                           uint64_t seq, hipStream_t st) {
+                           uint64_t seq, uint32_t spec_bound, hipStream_t st) {
+    // spec_bound != 0: a speculative launch (hot_groups_here) -- grids for spec_bound hot groups, n_hot read on the device;
+    // ovf_max is then the caller's guess (the overflow lists' workgroups stride over their list: any number of them is right)
     const uint32_t lookback = tile_lookback(A.max_len);
-    if (lookback > MAX_LOOKBACK || n_hot == 0) return hipErrorInvalidValue;
+    const uint32_t n_grid = spec_bound ? spec_bound : n_hot;
+    if (lookback > MAX_LOOKBACK || n_grid == 0) return hipErrorInvalidValue;
     // workgroups per overflow list: by the fullest one (256 hits per step and workgroup: one step each up to 32 workgroups)
-    const uint32_t ovb = ovf_max ? std::min<uint32_t>((ovf_max + 255) / 256, 32u) : 0u;
-    const uint32_t grid = n_hot * HV_BLOCKS + OVF_LISTS * ovb;
+    const uint32_t ovb = ovf_max ? std::min<uint32_t>((ovf_max + 255) / 256, 32u) : (spec_bound ? 1u : 0u);
+    const uint32_t grid = n_grid * HV_BLOCKS + OVF_LISTS * ovb;
     if (A.max_shift)
         hipLaunchKernelGGL(k_hot_verify<true>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
-                           lead, d_hay, len, hot_abort);
+                           lead, d_hay, len, hot_abort, spec_bound);
     else
         hipLaunchKernelGGL(k_hot_verify<false>, dim3(grid), dim3(256), 0, st, A, G, S, hot_list, n_hot, ctl, ovb, lookback, D, key_mode,
-                           lead, d_hay, len, hot_abort);
-    hipLaunchKernelGGL((k_dense_main<DT_THREADS, false>), dim3(n_hot * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
-                       key_mode, overlapping ? 1 : 0, D, TD, lookback, lead, hot_abort, HotMain{hot_list, S, seq});
+                           lead, d_hay, len, hot_abort, spec_bound);
+    hipLaunchKernelGGL((k_dense_main<DT_THREADS, false>), dim3(n_grid * HOT_SUB), dim3(DT_THREADS), dense_main_lds(lookback), st, A.rank_bits, A.max_len,
+                       key_mode, overlapping ? 1 : 0, D, TD, lookback, lead, hot_abort, HotMain{hot_list, S, seq, spec_bound ? ctl : nullptr, spec_bound});
     return hipGetLastError();
 }
 
@@ -3403,11 +3433,15 @@ hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint
 hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, const TileSpace &TD, const uint32_t *hot_list,
                      uint32_t n_hot, uint32_t lead, const uint8_t *d_hay, acx_match_t *out, uint64_t *summary,
                      const uint32_t *abort_flag, const uint32_t *hot_abort, uint64_t *host_out, uint64_t seq, uint64_t pub,
-                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st) {
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, uint32_t spec_bound,
+                     hipStream_t st) {
+    // (spec_bound != 0: a speculative launch, abort_flag = the call's control block -- hot_groups_here)
     const CodePointTables cp{d_hay, cp_blockpre, cp_sub, A.pchars};
-    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, seq, lead, pub, 1, hot_abort, nullptr, 0};
-    const HotWrite W{hot_list, (const uint64_t *)TD.trecs, TD.btot, TD.n_groups};
-    const HotWrite W0{nullptr, nullptr, nullptr, 0};
+    const uint32_t *sc = spec_bound ? abort_flag : nullptr;
+    const PostOut O{summary, (volatile uint64_t *)host_out, nullptr, seq, lead, pub, 1, hot_abort, nullptr, 0, sc, spec_bound};
+    const HotWrite W{hot_list, (const uint64_t *)TD.trecs, TD.btot, TD.n_groups, sc, spec_bound};
+    const HotWrite W0{nullptr, nullptr, nullptr, 0, nullptr, 0};
+    if (spec_bound) n_hot = spec_bound;
     if (cp_blockpre) {
         hipLaunchKernelGGL((k_tile_write<true, DT_GMAX, true, true>), dim3(n_hot * HOT_SUB), dim3(WRITE_THREADS), 0, st, A.rank_bits,
                            key_mode, A.by_rank, S, out, abort_flag, G, seg_counts, cp, O, W);

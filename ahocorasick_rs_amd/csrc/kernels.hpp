@@ -151,12 +151,15 @@ hipError_t tile_post(const DevAutomaton &A, int key_mode, bool overlapping, cons
 hipError_t hot_verify_main(const DevAutomaton &A, int key_mode, bool overlapping, const Segments &G, const TileSpace &S,
                            const uint32_t *hot_list, uint32_t n_hot, const uint32_t *ctl, uint32_t ovf_max, const DenseTiles &D,
                            const TileSpace &TD, uint32_t lead, const uint8_t *d_hay, uint64_t len, uint32_t *hot_abort,
-                           uint64_t seq, hipStream_t st);
+                           uint64_t seq, uint32_t spec_bound, hipStream_t st);
 hipError_t hot_totals(const TileSpace &S, uint64_t seq, uint64_t *host_out, uint64_t pub, hipStream_t st);
 hipError_t hot_write(const DevAutomaton &A, int key_mode, const TileSpace &S, const TileSpace &TD, const uint32_t *hot_list,
                      uint32_t n_hot, uint32_t lead, const uint8_t *d_hay, acx_match_t *out, uint64_t *summary,
                      const uint32_t *abort_flag, const uint32_t *hot_abort, uint64_t *host_out, uint64_t seq, uint64_t pub,
-                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, hipStream_t st);
+                     const Segments &G, uint64_t *seg_counts, const uint64_t *cp_blockpre, const uint8_t *cp_sub, uint32_t spec_bound,
+                     hipStream_t st);
+// (spec_bound != 0, both: a SPECULATIVE launch, queued right behind tile_post before the host knows whether the call has hot
+// groups -- grids for spec_bound of them, their number read from the control block on the device: kernels.hip, hot_groups_here)
 // dense outputs, tile-ordered (kernels.hip): K1b's prefix hits (per-wave regions) -> occurrence words in the
 // bucket of their key tile (D.counts must be zero) -> per group of DT_GROUP tiles: sort + match kind in LDS, the
 // reported occurrences in T.trecs (DT_GMAX per group), T.btot, the supergroup words of set 0 (must be zero); summary[8]

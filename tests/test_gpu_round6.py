@@ -81,3 +81,36 @@ def test_the_compact_dense_main_hands_a_crowded_call_to_the_full_form():
             st = a.path_stats()
             assert st["dense_tiles"] >= 1, st
             a.close()
+
+
+def test_the_hot_pipeline_queued_ahead_of_the_knowledge_that_it_is_needed():
+    # a context whose last call had a few hot groups queues the hot pipeline right behind the tile kernels, its grids for a
+    # bound of hot groups, their number read on the device (kernels.hip: hot_groups_here).  The calls of one handle in turn:
+    # one hot region (the first: the old way; the next ones: speculative), more regions than the bound (the kernels return,
+    # the host runs the pipeline the old way), none at all (the speculative kernels return at once), one again
+    pats = gen.gen_patterns(10000, 5, 12, gen.AZ, 1)
+    n = 24 << 20  # 96 groups of 256 KiB
+
+    def with_regions(starts, seed):
+        hay = gen.gen_textlike(n, seed, pats).copy()
+        rng = gen.SplitMix64(seed)
+        for s0 in starts:
+            for k in range(s0, s0 + (48 << 10), 32):
+                p = np.frombuffer(pats[rng.next() % len(pats)], dtype=np.uint8)
+                hay[k:k + len(p)] = p
+        return hay.tobytes()
+
+    inputs = [with_regions([5 << 20], 21), with_regions([9 << 20], 22), with_regions([(9 << 20) + 100_000], 23),
+              with_regions([k << 20 for k in (1, 3, 6, 8, 11, 14, 17, 20)], 24), gen.gen_textlike(n, 25, pats).tobytes(),
+              gen.gen_textlike(n, 26, pats).tobytes(), with_regions([2 << 20], 27), with_regions([(2 << 20) + 70_000, 20 << 20], 28)]
+    for mk in (0, 1, 2):
+        o = Oracle(pats, mk, KIND_DFA)
+        a = capi.Automaton(pats, mk, capi.IMPL_DFA)
+        for ov in ([False, True] if mk == 0 else [False]):
+            a.path_stats(reset=True)
+            for i, h in enumerate(inputs):
+                got, want = cols(a.find(h, overlapping=ov)), o.find_raw(h, overlapping=ov)
+                assert got.shape == want.shape and np.array_equal(got, want), (mk, ov, i)
+            st = a.path_stats()
+            assert st["hot_calls"] == 6 and st["sparse"] == 2 and st["dense_tiles"] == st["dense_radix"] == 0, st
+        a.close()
