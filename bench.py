@@ -725,13 +725,17 @@ def secondary_runs(w, capi, gen, torch, dev, nbytes: int = GIB):
             overlay_planted(hay, w["patterns"], every, None, torch, dev)
             ms, n, kms = timed_steps(w["ac"], hay.data_ptr(), nbytes, torch, steps=6, warmup=3)
             dens[str(every)] = {"gbps": round(nbytes / ms / 1e6, 2), "ms_per_step": round(ms, 4), "scan_ms": kms, "matches": n}
-        dens["what"] = "the headline's text T + a pattern planted every N bytes everywhere: N -> GB/s (whole step, 1 GiB)"
+        dens["what"] = ("the headline's text T + a pattern planted every N bytes everywhere: N -> GB/s (whole step, 1 GiB); round 6: "
+                        "from one match per 256 bytes on the context takes the wide form of the post stage, from one per 64 bytes on "
+                        "the dense path")
+        g = [dens[str(e)]["gbps"] for e in DENSITIES]
+        dens["largest_step_between_neighbours"] = round(max(a / b for a, b in zip(g, g[1:])), 2)
         out["density"] = dens
         # (the handle as the headline left it: the dense inputs above hold a context on the dense path until it sees an input
-        # that is not dense -- one call)
+        # that is not dense -- one call -- and on the wide form of the post stage until a call of it sees a sparse input -- one more)
         w["ac"].generate(hay.data_ptr(), nbytes, 1, 11)
         torch.cuda.synchronize()
-        for _ in range(2):
+        for _ in range(3):
             r = w["ac"].find_device(hay.data_ptr(), nbytes)
             r.free()
         torch.cuda.synchronize()
