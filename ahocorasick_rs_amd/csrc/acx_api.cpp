@@ -1210,7 +1210,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
     static const bool no_spec = std::getenv("ACX_NO_SPEC_HOT") != nullptr; // measurements
     uint32_t spec_bound = 0;
     if (hot_counts && x->spec_hot && !no_spec) {
-        uint64_t b = std::min<uint64_t>(2ull * x->spec_hot, 64);
+        uint64_t b = std::min<uint64_t>(2ull * x->spec_hot, HOT_INLINE_MAX);
         b = std::min<uint64_t>(b, pin ? HOT_INLINE_MAX : x->hot_inline);
         b = std::min<uint64_t>(b, T.n_groups >= 32 ? T.n_groups / 32 : T.n_groups);
         if (b >= x->spec_hot && ensure_dense_tiles(x, c.tiles) == ACX_OK) spec_bound = (uint32_t)b;
@@ -1261,7 +1261,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         (void)hipGetLastError(); // (no room for it: the dense path)
     }
     // what the context's next call queues ahead: the hot pipeline, when this one had a few hot groups
-    x->spec_hot = (!gave_up && n_hot && n_hot <= 64) ? (uint32_t)n_hot : 0u;
+    x->spec_hot = (!gave_up && n_hot && n_hot <= HOT_INLINE_MAX) ? (uint32_t)n_hot : 0u;
     x->spec_ovf = (uint32_t)ovf_max;
     bool spec_done = false;
     if (spec_bound && !gave_up && n_hot && n_hot <= spec_bound) {
