@@ -26,7 +26,7 @@ MATCH_STANDARD, MATCH_LEFTMOST_FIRST, MATCH_LEFTMOST_LONGEST = 0, 1, 2
 IMPL_AUTO, IMPL_NONCONTIGUOUS_NFA, IMPL_CONTIGUOUS_NFA, IMPL_DFA = -1, 0, 1, 2
 KERNEL_AUTO, KERNEL_DFA_WALK, KERNEL_PREFILTER = 0, 1, 2
 KERNEL_NAMES = {1: "dfa_walk", 2: "prefilter"}
-ABI_VERSION = 8  # ACX_VERSION of include/acx.h this binding was written against
+ABI_VERSION = 9  # ACX_VERSION of include/acx.h this binding was written against
 
 MATCH_DTYPE = np.dtype([("pattern", "<u8"), ("start", "<u8"), ("end", "<u8")])
 
@@ -539,11 +539,11 @@ class Automaton:
         """True / 1: time every call's scan kernel; N > 1: every N-th call; False / 0: off."""
         _check(lib().acx_profile_enable(self._h, int(on)))
 
-    PATH_STATS = ("sparse", "hot_calls", "hot_groups", "overflow_hits", "dense_tiles", "dense_radix", "overflow_regrown", "k0", "byte_ranges", "wide_redone")
+    PATH_STATS = ("sparse", "hot_calls", "hot_groups", "overflow_hits", "dense_tiles", "dense_radix", "overflow_regrown", "k0", "byte_ranges", "wide_redone", "resident_launches")
 
     def path_stats(self, reset: bool = True) -> dict:
         """which way this handle's calls went (acx_path_stats): {sparse, hot_calls, hot_groups, overflow_hits,
-        dense_tiles, dense_radix, overflow_regrown, k0, byte_ranges, wide_redone}"""
+        dense_tiles, dense_radix, overflow_regrown, k0, byte_ranges, wide_redone, resident_launches}"""
         out = (ctypes.c_uint64 * len(self.PATH_STATS))()
         _check(lib().acx_path_stats(self._h, out, int(reset)))
         return dict(zip(self.PATH_STATS, [int(v) for v in out]))

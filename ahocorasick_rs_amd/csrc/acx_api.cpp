@@ -357,7 +357,7 @@ private:
 
 // ---------------------------------------------------------------------------
 // pinned host scratch of a context, in 64-bit words (Workspace::h_pinned)
-constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PINNED_WORDS = 64;
+constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PIN_RESIDENT = 48, PINNED_WORDS = 64;
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -378,12 +378,14 @@ struct Workspace {
                                       // (copied behind a stream synchronisation; [8], [9] = result of an unpolled K0), then the
                                       // POLLED lines, each written by one store and accepted on its check word (kernels.hpp):
                                       // [16 .. 23] K0's result, [24 .. 31] the sparse path's totals, [32 .. 39] the hot pipeline's
-                                      // early total (hot_totals)
+                                      // early total (hot_totals), [40 .. 47] the speculative hot pipeline's, [48] the epoch of
+                                      // the last resident K0 that has left (Resident)
     uint64_t t_line[8] = {};          // the sparse path's totals: the verified copy of the line (PIN_TOTALS / PIN_HOT_TOTALS)
     uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
     acx_match_t *pin_final = nullptr; // host entry point, mid-size calls: pinned host memory the write kernel's records go to
     uint64_t pin_final_cap = 0;       // (records)
-    uint8_t *pin_hay = nullptr;       // small calls: pinned copy of a host haystack (read by K0 in place)
+    uint64_t *mailbox = nullptr;      // small calls: coherent pinned memory -- the resident K0's command word (kernels.hpp), then
+    uint8_t *pin_hay = nullptr;       //   (K0_MAILBOX_HAY bytes behind it) the copy of a host haystack K0 reads in place
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
     uint64_t *blockcnt = nullptr, *blockpre = nullptr; // lead bytes per 1 KiB block / their prefix
     uint8_t *blocksub = nullptr;                        // lead bytes per 64 bytes of a block
@@ -414,9 +416,25 @@ struct Workspace {
     size_t chunk_bytes = 0;
 };
 
+// The resident K0 of a context (kernels.hip, k0_resident): one workgroup that stays on the device between the calls of a
+// loop over short haystacks and is fed through the workspace's mailbox, so that a call costs a poll on either side instead
+// of a launch.  At most one of them per context, and nothing else of the context runs beside it (streams may share a
+// hardware queue: whatever else the context launches first tells the kernel to leave -- stop_resident).  It leaves by
+// itself after idle_us without a call and life_us after its launch (ACX_RESIDENT_IDLE_US, ACX_RESIDENT_LIFE_US;
+// ACX_NO_RESIDENT=1: every small call is a launch, as until round 5).
+struct Resident {
+    hipStream_t stream = nullptr; // its own: created with the first launch
+    uint64_t epoch = 0;           // the number of the last launch; h_pinned[PIN_RESIDENT] == epoch: that kernel has left
+    bool live = false;            // a kernel has been launched and has not been seen to have left
+    int mode = -1, overlapping = 0; // what it was launched for (small_mode; the tables' view and the key follow from overlapping)
+    uint32_t switches = 0, calls = 0; // launches for another mode within the last calls: a loop that alternates between two
+    uint32_t off = 0;                 //   kinds of call pays a launch per call either way -- small calls left as plain launches
+};
+
 // everything one in-flight call needs
 struct Ctx {
     hipStream_t stream = nullptr, copy_stream = nullptr;
+    Resident res;
     // profiling: [0], [1] and [3], [4]: scan start / stop, two pairs used by the calls in turn (the time
     // of a call's scan is read while the NEXT call's kernels run, off the path between two calls);
     // [2]: end of the call
@@ -570,7 +588,7 @@ void free_ws(Workspace &w, int device) {
     (void)hipFree(w.hay); (void)hipFree(w.offsets);
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
     if (w.pin_final) (void)hipHostFree(w.pin_final);
-    if (w.pin_hay) (void)hipHostFree(w.pin_hay);
+    if (w.mailbox) (void)hipHostFree(w.mailbox);
     if (w.pin_out) (void)hipHostFree(w.pin_out);
     for (int i = 0; i < Workspace::RING; i++) {
         if (w.pin_chunk[i]) (void)hipHostFree(w.pin_chunk[i]);
@@ -579,8 +597,32 @@ void free_ws(Workspace &w, int device) {
     w = Workspace();
 }
 
+// the context's resident K0 is told to leave, and has left when this returns
+void stop_resident(Ctx *c) {
+    Resident &R = c->res;
+    if (!R.live) return;
+    R.live = false;
+    volatile uint64_t *status = c->ws.h_pinned + PIN_RESIDENT;
+    if (*status == R.epoch) return;
+    // (the word's call number is one the kernel is not waiting for: the quit flag is all it reads)
+    __atomic_store_n(c->ws.mailbox, k0_mailbox_word(0, 0, false, true), __ATOMIC_RELEASE);
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; *status != R.epoch; spins++) {
+        cpu_relax();
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(4)) {
+            (void)hipStreamSynchronize(R.stream);
+            break;
+        }
+    }
+}
+
 void destroy_ctx(Ctx *c, int device) {
     if (!c) return;
+    if (c->res.stream) {
+        stop_resident(c);
+        (void)hipStreamSynchronize(c->res.stream);
+        (void)hipStreamDestroy(c->res.stream);
+    }
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
     free_ws(c->ws, device);
@@ -612,7 +654,12 @@ struct Lease {
     acx_automaton *a;
     Ctx *c = nullptr;
     DeviceScope dev;
-    explicit Lease(acx_automaton *a_) : a(a_), dev(a_->device) {
+    // keep_resident: the call may go to the context's resident K0 (acx_find); every other call has the context to itself
+    explicit Lease(acx_automaton *a_, bool keep_resident = false) : a(a_), dev(a_->device) {
+        take();
+        if (c && !keep_resident) stop_resident(c);
+    }
+    void take() {
         std::unique_lock<std::mutex> lk(a->pool_mu);
         for (;;) {
             if (!a->idle.empty()) { c = a->idle.back(); a->idle.pop_back(); return; }
@@ -948,6 +995,100 @@ int wait_line(Ctx *c, uint32_t at, uint64_t seq, uint64_t line[8], const char *w
         }
     }
     line[0] = seq;
+    return ACX_OK;
+}
+
+// A small call of the host-memory entry point through the context's RESIDENT K0 (Resident above; kernels.hip k0_resident).
+// The haystack is in the mailbox already.  *taken = false: this call is a plain launch (run_small) -- residency is
+// switched off, or the loop alternates between kinds of call.  Otherwise as run_small with poll = true.
+bool resident_on() {
+    static const bool off = std::getenv("ACX_NO_RESIDENT") != nullptr;
+    return !off && small_polls();
+}
+uint64_t env_ticks(const char *name, uint64_t dflt_us) { // microseconds -> ticks of the device's 100 MHz clock
+    const char *e = std::getenv(name);
+    const uint64_t us = e && *e ? std::strtoull(e, nullptr, 10) : dflt_us;
+    return us * 100;
+}
+
+int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int codepoints, uint64_t *n_out, bool *done,
+                 bool *taken) {
+    *done = false;
+    *taken = false;
+    Resident &R = c->res;
+    if (!resident_on()) return ACX_OK;
+    if (R.off) { R.off--; stop_resident(c); return ACX_OK; }
+    int rc = ensure_common(c);
+    if (rc) return rc;
+    Workspace &w = c->ws;
+    const DevAutomaton &A = view(a, overlapping != 0);
+    const int mode = small_mode(A, (uint32_t)len, !(overlapping && a->expand_ov));
+    if (mode < 0) { stop_resident(c); return ACX_OK; }
+    static const uint64_t idle_ticks = env_ticks("ACX_RESIDENT_IDLE_US", 200), life_ticks = env_ticks("ACX_RESIDENT_LIFE_US", 1000);
+    volatile uint64_t *status = w.h_pinned + PIN_RESIDENT;
+    const int ov = overlapping ? 1 : 0;
+    if (R.live && (R.mode != mode || R.overlapping != ov)) {
+        // another kind of call than the kernel was launched for: that one leaves, the next one is launched below
+        stop_resident(c);
+        if (++R.switches >= 4) { R.switches = 0; R.calls = 0; R.off = 256; return ACX_OK; }
+    }
+    if (++R.calls >= 64) { R.calls = 0; R.switches = 0; }
+    const uint64_t seq = ++c->small_seq;
+    const int key_mode = overlapping ? 0 : a->host.match_kind;
+    auto launch = [&]() -> int { // (the mailbox holds the call: the kernel takes it as its first)
+        if (!R.stream) HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        R.epoch++;
+        R.mode = mode; R.overlapping = ov;
+        HIPCHK(launch_resident(d_view(a, overlapping != 0), mode, w.mailbox, key_mode, ov != 0, w.pin_out, w.h_pinned + PIN_K0,
+                               w.h_pinned + PIN_RESIDENT, R.epoch, seq - 1, idle_ticks, life_ticks, R.stream));
+        R.live = true;
+        std::lock_guard<std::mutex> lk(a->prof_mu);
+        a->path[10]++;
+        return ACX_OK;
+    };
+    // the haystack first, the word behind it (one aligned store: the kernel reads the haystack after it has seen the word)
+    __atomic_store_n(w.mailbox, k0_mailbox_word(seq, (uint32_t)len, codepoints != 0, false), __ATOMIC_RELEASE);
+    if (!R.live || *status == R.epoch) {
+        rc = launch();
+        if (rc) return rc;
+    }
+    // the result line, as run_small waits for it -- and the kernel's epoch: a kernel that has left (idle, end of its life)
+    // has published everything it took before it said so (one release store behind its last line): the line is read once
+    // more, and a call the kernel did not take is the first call of the next launch
+    volatile uint64_t *p = w.h_pinned + PIN_K0;
+    uint64_t line[K0_LINE_WORDS];
+    auto complete = [&]() -> bool {
+        if (p[0] != seq) return false;
+        std::atomic_thread_fence(std::memory_order_acquire);
+        for (uint32_t i = 1; i < 8; i++) line[i] = p[i];
+        return line[7] == (seq ^ k0_line_check(line + 1));
+    };
+    const auto t0 = std::chrono::steady_clock::now();
+    for (uint32_t spins = 0; !complete(); spins++) {
+        cpu_relax();
+        if ((spins & 15) == 15 && *status == R.epoch) {
+            std::atomic_thread_fence(std::memory_order_acquire);
+            if (complete()) break;
+            rc = launch();
+            if (rc) return rc;
+        }
+        if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+            stop_resident(c);
+            HIPCHK(hipStreamSynchronize(R.stream));
+            if (!complete()) return fail(ACX_EDEVICE, "the resident K0 did not publish its result");
+            break;
+        }
+    }
+    *taken = true;
+    for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i];
+    const uint64_t w1 = line[1]; // matches | too dense << 32 | hash of pin_out << 33
+    if (((w1 >> 32) & 1u) == 0) {
+        *n_out = w1 & 0xFFFFFFFFull;
+        *done = true;
+        std::lock_guard<std::mutex> lk(a->prof_mu);
+        a->profile.small_calls++;
+        a->path[7]++;
+    }
     return ACX_OK;
 }
 
@@ -2464,24 +2605,28 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     acx_result_t *r = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) // produces the error message, touches no device state
         return run_find(a, nullptr, nullptr, 0, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, true, true);
-    Lease lease(a);
+    const bool try_small = small_ok(a, len);
+    Lease lease(a, try_small);
     Ctx *c = lease.c;
     if (!c) return fail(ACX_EDEVICE, "could not create a stream for the call");
     int rc;
-    const bool try_small = small_ok(a, len);
     if (try_small) {
-        // small haystack: copy it into pinned memory, ONE launch (K0 reads and writes pinned host
-        // memory in place), one sync -- no H2D / D2H copies at all
+        // small haystack: copy it into pinned memory; the context's resident K0 takes it from there (a poll on either
+        // side), or ONE launch does (K0 reads and writes pinned host memory in place) -- no H2D / D2H copies at all
         Workspace &w = c->ws;
-        if (!w.pin_hay) {
-            HIPCHK(hipHostMalloc((void **)&w.pin_hay, SMALL_PF_MAX_LEN + 32, hipHostMallocDefault));
-            // (read by the host as soon as the kernel's sequence number shows up: system-coherent)
+        if (!w.mailbox) {
+            // (both read by the other side while a kernel runs: system-coherent)
+            HIPCHK(hipHostMalloc((void **)&w.mailbox, K0_MAILBOX_HAY + SMALL_PF_MAX_LEN + 32, hipHostMallocCoherent));
+            w.mailbox[0] = 0;
+            w.pin_hay = (uint8_t *)w.mailbox + K0_MAILBOX_HAY;
             HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocCoherent));
         }
         std::memcpy(w.pin_hay, hay, len);
         uint64_t n = 0;
-        bool done = false;
-        rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done, true);
+        bool done = false, taken = false;
+        rc = run_resident(a, c, len, overlapping, codepoints, &n, &done, &taken);
+        if (rc != ACX_OK) return rc;
+        if (!taken) rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done, true);
         if (rc != ACX_OK) return rc;
         if (done) {
             if (n) {
@@ -2540,6 +2685,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             return ACX_OK;
         }
     }
+    stop_resident(c); // (a small call that turned out dense: the pipeline has the context to itself)
     g_trace_find.begin();
     rc = stage_host(a, c, hay, len, nullptr, 0);
     g_trace_find.lap(0);

@@ -3529,10 +3529,12 @@ constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
 // pattern-info load per candidate -- instead of an anchored walk from every position, which is a chain of dependent table
 // gathers per position and what a call on a large automaton cost: 16 KiB took 38 us, and beyond 16 KiB the call went to
 // the three-kernel pipeline (64 KiB: 63 us).  A position costs one independent gather, whatever the automaton's size.
+// tables = false (the RESIDENT kernel's calls after its first): the automaton's LDS images (classes, LT's tables, DC's
+// patterns) are those of the call before.
 template <int MODE>
-__global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
-                                                 uint32_t len, int key_mode, int overlapping,
-                                                 int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq) {
+__device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode,
+                                        int overlapping, int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq,
+                                        bool tables) {
     constexpr bool LT = MODE == 1, DC = MODE == 2, PF = MODE == 3;
     constexpr uint32_t MAXLEN = PF ? SMALL_PF_MAX_LEN : SMALL_MAX_LEN; // bytes the haystack's LDS image holds
     __shared__ __attribute__((aligned(16))) uint8_t sh[MAXLEN + 32];
@@ -3556,7 +3558,7 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
     // one wave's shuffles instead of block scans, and an LT walk has its 16 class bytes in registers before it starts)
     const bool tiny = len <= 1024;
     if (t == 0) { nocc = 0; rest_hash = 0; }
-    if (t < 256) cls[t] = A.classes[t];
+    if (tables && t < 256) cls[t] = A.classes[t];
     if (PF && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all readable)
         for (uint32_t i = 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
         __syncthreads();
@@ -3564,14 +3566,14 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
         for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
     }
     if (PF && t < 32) sh[len + t] = 0; // (the bytes behind the haystack are read as part of the last windows)
-    if constexpr (LT) {
+    if (LT && tables) {
         const uint32_t ne = A.n_states << A.stride2;
         for (uint32_t i = t; i < ne; i += 1024) ltab[i] = A.table[i];
         for (uint32_t i = t; i < A.n_states; i += 1024) lown1[i] = A.own1[i];
         for (uint32_t i = t; i < (uint32_t)A.n_patterns; i += 1024) lrank[i] = A.rank[i];
         if (t < A.max_len + 2) llevel[t] = A.level_start[t];
     }
-    if constexpr (DC) {
+    if (DC && tables) {
         if (t < (uint32_t)A.n_patterns) {
             const uint32_t L = A.plen[t];
             uint64_t b0, b1;
@@ -3871,8 +3873,76 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
 #undef K0_SPAN
 }
 
-hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
-                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st, bool direct_ok) {
+template <int MODE>
+__global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *__restrict__ hay,
+                                                 uint32_t len, int key_mode, int overlapping,
+                                                 int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq) {
+    k0_call<MODE>(A, hay, len, key_mode, overlapping, codepoints, out, res, seq, true);
+}
+
+// The RESIDENT K0 (round 6): the same workgroup, launched once and fed through a MAILBOX in coherent pinned host memory --
+// word 0 = k0_mailbox_word(call number, length, code points / quit) (kernels.hpp), the haystack K0_MAILBOX_HAY bytes
+// behind it -- so that a call costs a poll on either side instead of a kernel launch (the reference's own benchmark loop
+// calls once per 75-byte haystack: /root/reference/benchmarks/test_comparison.py:113-124).  Thread 0 polls word 0 with
+// system-scope loads (one PCIe read each); the host writes the haystack first and the word last (one aligned 8-byte store),
+// the workgroup reads the haystack behind an acquire fence.  The result goes where a launched K0's goes (the line `res`
+// under the call's number; `out`).  The kernel leaves when told to (K0_MAILBOX_QUIT), after idle_ticks of the 100 MHz
+// clock without a call, or life_ticks after its launch whatever happens (other streams may share its hardware queue:
+// nobody waits for it longer than that) -- and says so in *status (= epoch, one release store behind everything it wrote):
+// the host launches the next one when a call finds the kernel gone; a call posted while the kernel was leaving is taken
+// by that launch (seq: the last call before this launch; the call the kernel takes carries seq + 1).
+// (one call of the resident kernel: a function of its own, the automaton's description read from HBM where it needs it --
+// inlined into the kernel's loop, the description's sixty fields stay in registers around the loop and the body spills)
+template <int MODE>
+__device__ __noinline__ void k0_resident_call(const DevAutomaton *A, const uint8_t *hay, uint32_t len, int key_mode,
+                                              int overlapping, int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq,
+                                              bool tables) {
+    k0_call<MODE>(*A, hay, len, key_mode, overlapping, codepoints, out, res, seq, tables);
+}
+
+template <int MODE>
+__global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const uint64_t *mailbox, int key_mode, int overlapping,
+                                                    acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch,
+                                                    uint64_t seq, uint64_t idle_ticks, uint64_t life_ticks) {
+    __shared__ uint64_t s_cmd;
+    const uint8_t *hay = (const uint8_t *)mailbox + K0_MAILBOX_HAY;
+    const uint64_t t_start = wall_clock64();
+    uint64_t t_last = t_start;
+    constexpr uint64_t LEAVE = ~0ull;
+    for (bool first = true;; first = false) {
+        if (threadIdx.x == 0) {
+            uint64_t w;
+            for (uint32_t polls = 0;; polls++) {
+                // (acquire: the haystack behind the word is read as the host wrote it)
+                w = __hip_atomic_load(mailbox, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                const uint64_t now = wall_clock64();
+                // (polls: a second bound, should the clock not be what it is taken for)
+                if ((w & K0_MAILBOX_QUIT) || now - t_start > life_ticks || now - t_last > idle_ticks || polls > (1u << 24)) {
+                    w = LEAVE;
+                    break;
+                }
+                if ((uint32_t)(w >> 32) == (uint32_t)(seq + 1)) break;
+            }
+            s_cmd = w;
+        }
+        __syncthreads();
+        const uint64_t w = s_cmd;
+        if (w == LEAVE) {
+            if (threadIdx.x == 0) __hip_atomic_store(status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            return;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // (system scope, every wave: nothing of the last haystack in its caches)
+        seq++;
+        k0_resident_call<MODE>(A, hay, (uint32_t)(w & K0_MAILBOX_LEN_MASK), key_mode, overlapping, (w & K0_MAILBOX_CP) ? 1 : 0,
+                               out, res, seq, first);
+        // the result line leaves the caches NOW: a launched K0's stores do at the end of the kernel, and this kernel has no
+        // end (measured, the first version: every call took the idle limit -- the line arrived when the kernel left)
+        if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        t_last = wall_clock64();
+    }
+}
+
+int small_mode(const DevAutomaton &A, uint32_t len, bool direct_ok) {
     // (ACX_K0_NO_LDS_TABLE: measurements)
     static const bool no_lt = std::getenv("ACX_K0_NO_LDS_TABLE") != nullptr;
     static const bool no_dc = std::getenv("ACX_K0_NO_DIRECT") != nullptr;
@@ -3883,12 +3953,31 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
     // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS,
     // from 1 KiB on (shorter: the walk's handful of gathers is as good)
     const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > 1024));
-    if (len > SMALL_MAX_LEN && !pf) return hipErrorInvalidValue;
+    if (len > SMALL_MAX_LEN && !pf) return -1;
+    return pf ? 3 : dc ? 2 : lt ? 1 : 0;
+}
+
+hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode, bool overlapping,
+                        bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st, bool direct_ok) {
+    const int mode = small_mode(A, len, direct_ok);
+    if (mode < 0) return hipErrorInvalidValue;
 #define ACX_K0(M)                                                                                                      \
     hipLaunchKernelGGL(k0_small<M>, dim3(1), dim3(1024), 0, st, A, hay, len, key_mode, overlapping ? 1 : 0,            \
                        codepoints ? 1 : 0, out, res, seq)
-    if (pf) ACX_K0(3); else if (dc) ACX_K0(2); else if (lt) ACX_K0(1); else ACX_K0(0);
+    if (mode == 3) ACX_K0(3); else if (mode == 2) ACX_K0(2); else if (mode == 1) ACX_K0(1); else ACX_K0(0);
 #undef ACX_K0
+    return hipGetLastError();
+}
+
+hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
+                           acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
+                           uint64_t idle_ticks, uint64_t life_ticks, hipStream_t st) {
+#define ACX_K0R(M)                                                                                                     \
+    hipLaunchKernelGGL(k0_resident<M>, dim3(1), dim3(1024), 0, st, A, mailbox, key_mode, overlapping ? 1 : 0, out, res, \
+                       status, epoch, seq, idle_ticks, life_ticks)
+    if (mode == 3) ACX_K0R(3); else if (mode == 2) ACX_K0R(2); else if (mode == 1) ACX_K0R(1); else if (mode == 0) ACX_K0R(0);
+    else return hipErrorInvalidValue;
+#undef ACX_K0R
     return hipGetLastError();
 }
 

@@ -107,6 +107,22 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
                         bool codepoints, acx_match_t *out, uint64_t *res, uint64_t seq, hipStream_t st, bool direct_ok = true);
 // (direct_ok = false: not MODE 2 -- it compares against the patterns themselves, every copy of a string, whatever view of the
 // tables A is: an overlapping search over a set with copies expects one occurrence per string, acx_api.cpp expand_copies)
+// how K0 finds the occurrences of a call of `len` bytes (kernels.hip: 0 the walk, 1 the tables in LDS, 2 direct comparison,
+// 3 the prefilter); -1: K0 does not take the call
+int small_mode(const DevAutomaton &A, uint32_t len, bool direct_ok);
+// The RESIDENT K0 (kernels.hip, k0_resident; A: the automaton's description in HBM): launched once per context in one `mode`
+// and one `overlapping`, fed through a
+// mailbox in coherent pinned host memory: word 0 below, the haystack K0_MAILBOX_HAY bytes behind it.  seq: the number of
+// the last call before the launch (the first call the kernel takes carries seq + 1 in its word); *status = epoch when the
+// kernel has left (told to, idle, or at the end of its life: ticks of the 100 MHz clock).
+constexpr uint64_t K0_MAILBOX_QUIT = 1ull << 31, K0_MAILBOX_CP = 1ull << 30, K0_MAILBOX_LEN_MASK = (1ull << 30) - 1;
+constexpr uint32_t K0_MAILBOX_HAY = 64;
+inline uint64_t k0_mailbox_word(uint64_t seq, uint32_t len, bool codepoints, bool quit) {
+    return (seq << 32) | (quit ? K0_MAILBOX_QUIT : 0) | (codepoints ? K0_MAILBOX_CP : 0) | len;
+}
+hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
+                           acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
+                           uint64_t idle_ticks, uint64_t life_ticks, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write

@@ -23,7 +23,8 @@
 extern "C" {
 #endif
 
-/* 8: acx_path_stats gained [9] (round 6: calls repeated with the wide form of the sparse path's post stage);
+/* 9: acx_path_stats gained [10] (round 6: launches of a context's resident K0);
+ * 8: acx_path_stats gained [9] (round 6: calls repeated with the wide form of the sparse path's post stage);
  * 7: acx_path_stats gained [8] (byte ranges of calls that were cut); K0's result line carries end - 1 and a hash of the
  *    matches beside it (round 5);
  * 6: acx_path_stats added (round 5);
@@ -32,7 +33,7 @@ extern "C" {
  * 3: acx_replicate / acx_find_batch_multi / acx_shard_range / acx_automaton_device added (round 3);
  * 2: acx_prefix_slot gained `salt`, acx_host_tables_t grew (round 2).  A binding built against another
  * header must refuse to load: compare acx_version() with the ACX_VERSION it was compiled with. */
-#define ACX_VERSION 8
+#define ACX_VERSION 9
 
 /* status codes */
 #define ACX_OK 0
@@ -315,9 +316,11 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
  * slots in all, [4] calls on the tile-ordered dense path, [5] calls on its radix-sort form, [6] calls that were redone
  * with a larger overflow list, [7] calls K0 answered, [8] byte ranges searched for calls that were cut (more than 2^32
  * occurrences in one pass: the pieces count in [0 .. 7] as well), [9] calls that were repeated with the WIDE form of the
- * sparse path's post stage (a match every 100 - 500 bytes: the context keeps that form while its inputs are like that).
+ * sparse path's post stage (a match every 100 - 500 bytes: the context keeps that form while its inputs are like that),
+ * [10] launches of a context's RESIDENT K0 (acx_find on short haystacks: one workgroup stays on the device between the
+ * calls of a loop and is fed through pinned host memory -- [7] counts the calls, [10] the launches they cost).
  * reset != 0 clears the counters. */
-#define ACX_PATH_STATS 10
+#define ACX_PATH_STATS 11
 int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset);
 
 /* ---- device memory helpers so that a host without torch can stage data ---- */
