@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <random>
 #include <new>
 #include <string>
 #include <thread>
@@ -427,6 +428,7 @@ struct Resident {
     uint64_t epoch = 0;           // the number of the last launch; h_pinned[PIN_RESIDENT] == epoch: that kernel has left
     bool live = false;            // a kernel has been launched and has not been seen to have left
     int mode = -1, overlapping = 0; // what it was launched for (small_mode; the tables' view and the key follow from overlapping)
+    uint64_t secret = 0;          // keys the check of the haystack bytes that travel with the poll (kernels.hpp, k0_hay_check)
     uint32_t switches = 0, calls = 0; // launches for another mode within the last calls: a loop that alternates between two
     uint32_t off = 0;                 //   kinds of call pays a launch per call either way -- small calls left as plain launches
 };
@@ -598,11 +600,21 @@ void free_ws(Workspace &w, int device) {
 }
 
 // the context's resident K0 is told to leave, and has left when this returns
+void trace_resident(Ctx *c) { // (ACX_RESIDENT_TRACE=1: what the kernel that has just left did -- kernels.hip, k0_resident)
+    static const bool on = std::getenv("ACX_RESIDENT_TRACE") != nullptr;
+    if (!on) return;
+    const uint64_t *s = c->ws.h_pinned + PIN_RESIDENT;
+    std::fprintf(stderr, "acx resident K0 epoch %llu: %llu calls, %llu with their bytes in the poll, %.2f us busy per call, %llu polls\n",
+                 (unsigned long long)s[0], (unsigned long long)s[1], (unsigned long long)s[2],
+                 s[1] ? (double)s[3] / 100.0 / (double)s[1] : 0.0, (unsigned long long)s[4]);
+}
+
 void stop_resident(Ctx *c) {
     Resident &R = c->res;
     if (!R.live) return;
     R.live = false;
     volatile uint64_t *status = c->ws.h_pinned + PIN_RESIDENT;
+    struct AtExit { Ctx *c; ~AtExit() { trace_resident(c); } } at_exit{c};
     if (*status == R.epoch) return;
     // (the word's call number is one the kernel is not waiting for: the quit flag is all it reads)
     __atomic_store_n(c->ws.mailbox, k0_mailbox_word(0, 0, false, true), __ATOMIC_RELEASE);
@@ -1036,22 +1048,30 @@ int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int co
     const uint64_t seq = ++c->small_seq;
     const int key_mode = overlapping ? 0 : a->host.match_kind;
     auto launch = [&]() -> int { // (the mailbox holds the call: the kernel takes it as its first)
-        if (!R.stream) HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+        if (!R.stream) {
+            HIPCHK(hipStreamCreateWithFlags(&R.stream, hipStreamNonBlocking));
+            std::random_device rd;
+            R.secret = ((uint64_t)rd() << 32) ^ rd() ^ (uint64_t)(uintptr_t)c;
+        }
         R.epoch++;
         R.mode = mode; R.overlapping = ov;
         HIPCHK(launch_resident(d_view(a, overlapping != 0), mode, w.mailbox, key_mode, ov != 0, w.pin_out, w.h_pinned + PIN_K0,
-                               w.h_pinned + PIN_RESIDENT, R.epoch, seq - 1, idle_ticks, life_ticks, R.stream));
+                               w.h_pinned + PIN_RESIDENT, R.epoch, seq - 1, idle_ticks, life_ticks, R.secret, R.stream));
         R.live = true;
         std::lock_guard<std::mutex> lk(a->prof_mu);
         a->path[10]++;
         return ACX_OK;
     };
-    // the haystack first, the word behind it (one aligned store: the kernel reads the haystack after it has seen the word)
-    __atomic_store_n(w.mailbox, k0_mailbox_word(seq, (uint32_t)len, codepoints != 0, false), __ATOMIC_RELEASE);
+    // the haystack first (acx_find), its check, the word behind them (one aligned store: the kernel takes the bytes that came
+    // with the word when the check agrees, and reads the haystack after it has seen the word otherwise)
     if (!R.live || *status == R.epoch) {
+        if (R.live) trace_resident(c);
+        w.mailbox[0] = 0; // (a word of the past -- a quit -- is not for the kernel launched now)
         rc = launch();
         if (rc) return rc;
     }
+    w.mailbox[1] = k0_hay_check(w.pin_hay, (uint32_t)len, seq, R.secret);
+    __atomic_store_n(w.mailbox, k0_mailbox_word(seq, (uint32_t)len, codepoints != 0, false), __ATOMIC_RELEASE);
     // the result line, as run_small waits for it -- and the kernel's epoch: a kernel that has left (idle, end of its life)
     // has published everything it took before it said so (one release store behind its last line): the line is read once
     // more, and a call the kernel did not take is the first call of the next launch
@@ -1069,6 +1089,7 @@ int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int co
         if ((spins & 15) == 15 && *status == R.epoch) {
             std::atomic_thread_fence(std::memory_order_acquire);
             if (complete()) break;
+            trace_resident(c);
             rc = launch();
             if (rc) return rc;
         }
@@ -2622,6 +2643,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocCoherent));
         }
         std::memcpy(w.pin_hay, hay, len);
+        std::memset(w.pin_hay + len, 0, (16 - (len & 15)) & 15); // (the resident kernel's check covers whole 16-byte pieces)
         uint64_t n = 0;
         bool done = false, taken = false;
         rc = run_resident(a, c, len, overlapping, codepoints, &n, &done, &taken);

@@ -3531,10 +3531,12 @@ constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
 // the three-kernel pipeline (64 KiB: 63 us).  A position costs one independent gather, whatever the automaton's size.
 // tables = false (the RESIDENT kernel's calls after its first): the automaton's LDS images (classes, LT's tables, DC's
 // patterns) are those of the call before.
+// npre != 0 (the resident kernel): the haystack's first npre bytes (a multiple of 16, or all of it) came with the poll --
+// thread 1 + j holds bytes [16 j, 16 j + 16) in `pre`.
 template <int MODE>
 __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *hay, uint32_t len, int key_mode,
                                         int overlapping, int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq,
-                                        bool tables) {
+                                        bool tables, uint4 pre = make_uint4(0, 0, 0, 0), uint32_t npre = 0) {
     constexpr bool LT = MODE == 1, DC = MODE == 2, PF = MODE == 3;
     constexpr uint32_t MAXLEN = PF ? SMALL_PF_MAX_LEN : SMALL_MAX_LEN; // bytes the haystack's LDS image holds
     __shared__ __attribute__((aligned(16))) uint8_t sh[MAXLEN + 32];
@@ -3559,11 +3561,12 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     const bool tiny = len <= 1024;
     if (t == 0) { nocc = 0; rest_hash = 0; }
     if (tables && t < 256) cls[t] = A.classes[t];
+    if (npre && t >= 1 && t < 64 && 16 * (t - 1) < npre) *(uint4 *)(sh + 16 * (t - 1)) = pre;
     if (PF && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all readable)
-        for (uint32_t i = 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
+        for (uint32_t i = npre + 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
         __syncthreads();
     } else {
-        for (uint32_t i = t; i < len; i += 1024) sh[i] = hay[i];
+        for (uint32_t i = npre + t; i < len; i += 1024) sh[i] = hay[i];
     }
     if (PF && t < 32) sh[len + t] = 0; // (the bytes behind the haystack are read as part of the last windows)
     if (LT && tables) {
@@ -3896,49 +3899,86 @@ __global__ __launch_bounds__(1024) void k0_small(DevAutomaton A, const uint8_t *
 template <int MODE>
 __device__ __noinline__ void k0_resident_call(const DevAutomaton *A, const uint8_t *hay, uint32_t len, int key_mode,
                                               int overlapping, int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq,
-                                              bool tables) {
-    k0_call<MODE>(*A, hay, len, key_mode, overlapping, codepoints, out, res, seq, tables);
+                                              bool tables, uint4 pre, uint32_t npre) {
+    k0_call<MODE>(*A, hay, len, key_mode, overlapping, codepoints, out, res, seq, tables, pre, npre);
 }
 
+// 16 bytes of host memory as they are NOW (system scope: no cache of the device answers)
+__device__ __forceinline__ uint4 load16_system(const void *p) {
+    uint4 v;
+    asm volatile("buffer_inv sc0 sc1\n\tglobal_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+
+// The poll: wave 0 reads the mailbox's first KiB in ONE instruction -- lane 0 the word and the check, lane 1 + j the
+// haystack's bytes [16 j, 16 j + 16) -- so that a haystack of up to K0_MAILBOX_INLINE bytes is there when the word is
+// (a dependent read of host memory is another PCIe round trip, ~2 us).  The lanes' reads are not ordered among
+// themselves: the bytes are taken when their hash (k0_hay_mix per 16 bytes, keyed with the call's number and the
+// context's secret, XORed) is the check the host wrote in front of the word, and read again behind the word otherwise.
 template <int MODE>
 __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const uint64_t *mailbox, int key_mode, int overlapping,
                                                     acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch,
-                                                    uint64_t seq, uint64_t idle_ticks, uint64_t life_ticks) {
+                                                    uint64_t seq, uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret) {
     __shared__ uint64_t s_cmd;
+    __shared__ uint32_t s_npre;
     const uint8_t *hay = (const uint8_t *)mailbox + K0_MAILBOX_HAY;
+    const uint32_t t = threadIdx.x;
     const uint64_t t_start = wall_clock64();
     uint64_t t_last = t_start;
     constexpr uint64_t LEAVE = ~0ull;
+    // what the kernel did, left beside the epoch when it leaves (status[1 .. 4]: calls, calls whose bytes came with the
+    // poll, ticks between a word seen and its result published, polls; ACX_RESIDENT_TRACE=1 prints them)
+    uint64_t n_calls = 0, n_inline = 0, busy = 0, n_polls = 0;
     for (bool first = true;; first = false) {
-        if (threadIdx.x == 0) {
+        uint4 pre = make_uint4(0, 0, 0, 0);
+        uint64_t t_seen = 0;
+        if (t < 64) {
             uint64_t w;
+            uint32_t npre = 0;
             for (uint32_t polls = 0;; polls++) {
-                // (acquire: the haystack behind the word is read as the host wrote it)
-                w = __hip_atomic_load(mailbox, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+                n_polls++;
+                pre = load16_system((const uint8_t *)mailbox + 16 * t);
+                w = ((uint64_t)__builtin_amdgcn_readfirstlane(pre.y) << 32) | __builtin_amdgcn_readfirstlane(pre.x);
                 const uint64_t now = wall_clock64();
                 // (polls: a second bound, should the clock not be what it is taken for)
                 if ((w & K0_MAILBOX_QUIT) || now - t_start > life_ticks || now - t_last > idle_ticks || polls > (1u << 24)) {
                     w = LEAVE;
                     break;
                 }
-                if ((uint32_t)(w >> 32) == (uint32_t)(seq + 1)) break;
+                if ((uint32_t)(w >> 32) != (uint32_t)(seq + 1)) continue;
+                const uint32_t len = (uint32_t)(w & K0_MAILBOX_LEN_MASK);
+                const uint32_t covered = len < K0_MAILBOX_INLINE ? (len + 15) & ~15u : K0_MAILBOX_INLINE;
+                const uint64_t want = ((uint64_t)__builtin_amdgcn_readfirstlane(pre.w) << 32) | __builtin_amdgcn_readfirstlane(pre.z);
+                uint64_t h = t >= 1 && 16 * (t - 1) < covered
+                                 ? k0_hay_mix(((uint64_t)pre.y << 32) | pre.x, ((uint64_t)pre.w << 32) | pre.z, t - 1, (seq + 1) ^ secret)
+                                 : 0;
+                for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
+                npre = h == want ? covered : 0;
+                t_seen = now;
+                break;
             }
-            s_cmd = w;
+            if (t == 0) { s_cmd = w; s_npre = npre; }
         }
         __syncthreads();
         const uint64_t w = s_cmd;
         if (w == LEAVE) {
-            if (threadIdx.x == 0) __hip_atomic_store(status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (t == 0) {
+                status[1] = n_calls; status[2] = n_inline; status[3] = busy; status[4] = n_polls;
+                __hip_atomic_store(status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             return;
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // (system scope, every wave: nothing of the last haystack in its caches)
         seq++;
         k0_resident_call<MODE>(A, hay, (uint32_t)(w & K0_MAILBOX_LEN_MASK), key_mode, overlapping, (w & K0_MAILBOX_CP) ? 1 : 0,
-                               out, res, seq, first);
+                               out, res, seq, first, pre, s_npre);
         // the result line leaves the caches NOW: a launched K0's stores do at the end of the kernel, and this kernel has no
         // end (measured, the first version: every call took the idle limit -- the line arrived when the kernel left)
-        if (threadIdx.x < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        if (t < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         t_last = wall_clock64();
+        n_calls++;
+        n_inline += s_npre ? 1 : 0;
+        busy += t_last - t_seen;
     }
 }
 
@@ -3971,10 +4011,10 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 
 hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
                            acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
-                           uint64_t idle_ticks, uint64_t life_ticks, hipStream_t st) {
+                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, hipStream_t st) {
 #define ACX_K0R(M)                                                                                                     \
     hipLaunchKernelGGL(k0_resident<M>, dim3(1), dim3(1024), 0, st, A, mailbox, key_mode, overlapping ? 1 : 0, out, res, \
-                       status, epoch, seq, idle_ticks, life_ticks)
+                       status, epoch, seq, idle_ticks, life_ticks, secret)
     if (mode == 3) ACX_K0R(3); else if (mode == 2) ACX_K0R(2); else if (mode == 1) ACX_K0R(1); else if (mode == 0) ACX_K0R(0);
     else return hipErrorInvalidValue;
 #undef ACX_K0R

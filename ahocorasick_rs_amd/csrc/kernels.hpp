@@ -111,18 +111,39 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 // 3 the prefilter); -1: K0 does not take the call
 int small_mode(const DevAutomaton &A, uint32_t len, bool direct_ok);
 // The RESIDENT K0 (kernels.hip, k0_resident; A: the automaton's description in HBM): launched once per context in one `mode`
-// and one `overlapping`, fed through a
-// mailbox in coherent pinned host memory: word 0 below, the haystack K0_MAILBOX_HAY bytes behind it.  seq: the number of
-// the last call before the launch (the first call the kernel takes carries seq + 1 in its word); *status = epoch when the
-// kernel has left (told to, idle, or at the end of its life: ticks of the 100 MHz clock).
+// and one `overlapping`, fed through a mailbox in coherent pinned host memory: [0] the word below, [1] the check of the
+// haystack's first bytes (k0_hay_check), the haystack K0_MAILBOX_HAY bytes behind the mailbox's start, zero-padded to
+// 16 bytes.  The host writes the haystack, the check, then the word (one aligned store).  seq: the number of the last call
+// before the launch (the first call the kernel takes carries seq + 1 in its word); *status = epoch when the kernel has
+// left (told to, idle, or at the end of its life: ticks of the 100 MHz clock).
 constexpr uint64_t K0_MAILBOX_QUIT = 1ull << 31, K0_MAILBOX_CP = 1ull << 30, K0_MAILBOX_LEN_MASK = (1ull << 30) - 1;
-constexpr uint32_t K0_MAILBOX_HAY = 64;
+constexpr uint32_t K0_MAILBOX_HAY = 16;
+constexpr uint32_t K0_MAILBOX_INLINE = 1008; // bytes of the haystack that travel with the poll (63 lanes x 16 bytes)
 inline uint64_t k0_mailbox_word(uint64_t seq, uint32_t len, bool codepoints, bool quit) {
     return (seq << 32) | (quit ? K0_MAILBOX_QUIT : 0) | (codepoints ? K0_MAILBOX_CP : 0) | len;
 }
+// the check: XOR over the 16-byte pieces j of the first min(len rounded up to 16, K0_MAILBOX_INLINE) bytes
+__host__ __device__ inline uint64_t k0_hay_mix(uint64_t lo, uint64_t hi, uint32_t j, uint64_t key) {
+    uint64_t x = (lo ^ key) * 0x9E3779B97F4A7C15ull;
+    x ^= x >> 31;
+    x = (x ^ hi ^ ((uint64_t)(j + 1) * 0xC2B2AE3D27D4EB4Full)) * 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
+    return x;
+}
+inline uint64_t k0_hay_check(const uint8_t *hay /* zero-padded to 16 bytes */, uint32_t len, uint64_t seq, uint64_t secret) {
+    const uint32_t covered = len < K0_MAILBOX_INLINE ? (len + 15) & ~15u : K0_MAILBOX_INLINE;
+    uint64_t h = 0;
+    for (uint32_t j = 0; 16 * j < covered; j++) {
+        uint64_t lo, hi;
+        __builtin_memcpy(&lo, hay + 16 * j, 8);
+        __builtin_memcpy(&hi, hay + 16 * j + 8, 8);
+        h ^= k0_hay_mix(lo, hi, j, seq ^ secret);
+    }
+    return h;
+}
 hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
                            acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
-                           uint64_t idle_ticks, uint64_t life_ticks, hipStream_t st);
+                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write
