@@ -428,6 +428,8 @@ struct Resident {
     uint64_t epoch = 0;           // the number of the last launch; h_pinned[PIN_RESIDENT] == epoch: that kernel has left
     bool live = false;            // a kernel has been launched and has not been seen to have left
     int mode = -1, overlapping = 0; // what it was launched for (small_mode; the tables' view and the key follow from overlapping)
+    uint32_t delay = 0;           // ticks the kernel waits behind a result before it polls (k0_resident: what the last kernel
+                                  // ended with -- h_pinned[PIN_RESIDENT + 13])
     uint64_t secret = 0;          // keys the check of the haystack bytes that travel with the poll (kernels.hpp, k0_hay_check)
     uint32_t switches = 0, calls = 0; // launches for another mode within the last calls: a loop that alternates between two
     uint32_t off = 0;                 //   kinds of call pays a launch per call either way -- small calls left as plain launches
@@ -600,6 +602,7 @@ void free_ws(Workspace &w, int device) {
 }
 
 // the context's resident K0 is told to leave, and has left when this returns
+void resident_left(Ctx *c); // (below: trace + the delay the kernel ended with)
 void trace_resident(Ctx *c) { // (ACX_RESIDENT_TRACE=1: what the kernel that has just left did -- kernels.hip, k0_resident)
     static const bool on = std::getenv("ACX_RESIDENT_TRACE") != nullptr;
     if (!on) return;
@@ -607,6 +610,15 @@ void trace_resident(Ctx *c) { // (ACX_RESIDENT_TRACE=1: what the kernel that has
     std::fprintf(stderr, "acx resident K0 epoch %llu: %llu calls, %llu with their bytes in the poll, %.2f us busy per call, %llu polls\n",
                  (unsigned long long)s[0], (unsigned long long)s[1], (unsigned long long)s[2],
                  s[1] ? (double)s[3] / 100.0 / (double)s[1] : 0.0, (unsigned long long)s[4]);
+    std::fprintf(stderr, "   delay %llu ticks, stages (us per call):", (unsigned long long)s[13]);
+    for (int i = 0; i < 8; i++) std::fprintf(stderr, " %.2f", s[1] ? (double)s[5 + i] / 100.0 / (double)s[1] : 0.0);
+    std::fprintf(stderr, "\n");
+}
+
+void resident_left(Ctx *c) {
+    trace_resident(c);
+    const uint64_t d = c->ws.h_pinned[PIN_RESIDENT + 13];
+    c->res.delay = d < 1000 ? (uint32_t)d : 0;
 }
 
 void stop_resident(Ctx *c) {
@@ -614,7 +626,7 @@ void stop_resident(Ctx *c) {
     if (!R.live) return;
     R.live = false;
     volatile uint64_t *status = c->ws.h_pinned + PIN_RESIDENT;
-    struct AtExit { Ctx *c; ~AtExit() { trace_resident(c); } } at_exit{c};
+    struct AtExit { Ctx *c; ~AtExit() { resident_left(c); } } at_exit{c};
     if (*status == R.epoch) return;
     // (the word's call number is one the kernel is not waiting for: the quit flag is all it reads)
     __atomic_store_n(c->ws.mailbox, k0_mailbox_word(0, 0, false, true), __ATOMIC_RELEASE);
@@ -1011,7 +1023,7 @@ int wait_line(Ctx *c, uint32_t at, uint64_t seq, uint64_t line[8], const char *w
 }
 
 // A small call of the host-memory entry point through the context's RESIDENT K0 (Resident above; kernels.hip k0_resident).
-// The haystack is in the mailbox already.  *taken = false: this call is a plain launch (run_small) -- residency is
+// *taken = false: this call is a plain launch (run_small) -- residency is
 // switched off, or the loop alternates between kinds of call.  Otherwise as run_small with poll = true.
 bool resident_on() {
     static const bool off = std::getenv("ACX_NO_RESIDENT") != nullptr;
@@ -1023,8 +1035,8 @@ uint64_t env_ticks(const char *name, uint64_t dflt_us) { // microseconds -> tick
     return us * 100;
 }
 
-int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int codepoints, uint64_t *n_out, bool *done,
-                 bool *taken) {
+int run_resident(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints, uint64_t *n_out,
+                 bool *done, bool *taken) {
     *done = false;
     *taken = false;
     Resident &R = c->res;
@@ -1056,7 +1068,7 @@ int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int co
         R.epoch++;
         R.mode = mode; R.overlapping = ov;
         HIPCHK(launch_resident(d_view(a, overlapping != 0), mode, w.mailbox, key_mode, ov != 0, w.pin_out, w.h_pinned + PIN_K0,
-                               w.h_pinned + PIN_RESIDENT, R.epoch, seq - 1, idle_ticks, life_ticks, R.secret, R.stream));
+                               w.h_pinned + PIN_RESIDENT, R.epoch, seq - 1, idle_ticks, life_ticks, R.secret, R.delay, R.stream));
         R.live = true;
         std::lock_guard<std::mutex> lk(a->prof_mu);
         a->path[10]++;
@@ -1065,13 +1077,17 @@ int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int co
     // the haystack first (acx_find), its check, the word behind them (one aligned store: the kernel takes the bytes that came
     // with the word when the check agrees, and reads the haystack after it has seen the word otherwise)
     if (!R.live || *status == R.epoch) {
-        if (R.live) trace_resident(c);
+        if (R.live) resident_left(c);
         w.mailbox[0] = 0; // (a word of the past -- a quit -- is not for the kernel launched now)
         rc = launch();
         if (rc) return rc;
     }
-    w.mailbox[1] = k0_hay_check(w.pin_hay, (uint32_t)len, seq, R.secret);
-    __atomic_store_n(w.mailbox, k0_mailbox_word(seq, (uint32_t)len, codepoints != 0, false), __ATOMIC_RELEASE);
+    // (nothing between the three writes: a poll that reads the mailbox while they are under way fails its check and reads again)
+    const uint64_t check = k0_hay_check(hay, (uint32_t)len, seq, R.secret), word = k0_mailbox_word(seq, (uint32_t)len, codepoints != 0, false);
+    std::memcpy(w.pin_hay, hay, len);
+    std::memset(w.pin_hay + len, 0, (16 - (len & 15)) & 15); // (the check covers whole 16-byte pieces)
+    w.mailbox[1] = check;
+    __atomic_store_n(w.mailbox, word, __ATOMIC_RELEASE);
     // the result line, as run_small waits for it -- and the kernel's epoch: a kernel that has left (idle, end of its life)
     // has published everything it took before it said so (one release store behind its last line): the line is read once
     // more, and a call the kernel did not take is the first call of the next launch
@@ -1089,7 +1105,7 @@ int run_resident(acx_automaton *a, Ctx *c, uint64_t len, int overlapping, int co
         if ((spins & 15) == 15 && *status == R.epoch) {
             std::atomic_thread_fence(std::memory_order_acquire);
             if (complete()) break;
-            trace_resident(c);
+            resident_left(c);
             rc = launch();
             if (rc) return rc;
         }
@@ -2642,13 +2658,14 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             w.pin_hay = (uint8_t *)w.mailbox + K0_MAILBOX_HAY;
             HIPCHK(hipHostMalloc((void **)&w.pin_out, SMALL_MAX_OCC * sizeof(acx_match_t), hipHostMallocCoherent));
         }
-        std::memcpy(w.pin_hay, hay, len);
-        std::memset(w.pin_hay + len, 0, (16 - (len & 15)) & 15); // (the resident kernel's check covers whole 16-byte pieces)
         uint64_t n = 0;
         bool done = false, taken = false;
-        rc = run_resident(a, c, len, overlapping, codepoints, &n, &done, &taken);
+        rc = run_resident(a, c, hay, len, overlapping, codepoints, &n, &done, &taken);
         if (rc != ACX_OK) return rc;
-        if (!taken) rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done, true);
+        if (!taken) {
+            std::memcpy(w.pin_hay, hay, len);
+            rc = run_small(a, c, w.pin_hay, len, overlapping, codepoints, w.pin_out, &n, &done, true);
+        }
         if (rc != ACX_OK) return rc;
         if (done) {
             if (n) {

@@ -3505,6 +3505,12 @@ __device__ __forceinline__ void k0_publish_line(uint64_t *line, uint32_t t, uint
     mid[0] = word1;
 #pragma unroll
     for (uint32_t i = 0; i < K0_LINE_MATCHES; i++) mid[1 + i] = i < npk ? pk[i] : 0;
+    // (the same in every lane: in scalar registers the check's twelve 64-bit multiplications are scalar instructions --
+    // as vector instructions they were most of the 0.55 us this function took, measured in the resident kernel)
+#pragma unroll
+    for (uint32_t i = 0; i < 6; i++)
+        mid[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mid[i] >> 32)) << 32) |
+                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mid[i]); // (readfirstlane returns an int: no sign extension)
     const uint64_t last = seq ^ k0_line_check(mid); // (the host accepts the line on word 0 AND this word: kernels.hpp)
     uint64_t w[2];
 #pragma unroll
@@ -3529,6 +3535,8 @@ constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
 // pattern-info load per candidate -- instead of an anchored walk from every position, which is a chain of dependent table
 // gathers per position and what a call on a large automaton cost: 16 KiB took 38 us, and beyond 16 KiB the call went to
 // the three-kernel pipeline (64 KiB: 63 us).  A position costs one independent gather, whatever the automaton's size.
+__shared__ uint64_t k0_ticks[8];
+#define K0_TICK(i) if (threadIdx.x == 0) k0_ticks[i] = wall_clock64();
 // tables = false (the RESIDENT kernel's calls after its first): the automaton's LDS images (classes, LT's tables, DC's
 // patterns) are those of the call before.
 // npre != 0 (the resident kernel): the haystack's first npre bytes (a multiple of 16, or all of it) came with the poll --
@@ -3556,6 +3564,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     const uint32_t t = threadIdx.x;
+    K0_TICK(0)
     // (haystacks of at most 1 KiB -- one position per thread, at most 64 slices of 16 bytes: the prefix sums below are
     // one wave's shuffles instead of block scans, and an LT walk has its 16 class bytes in registers before it starts)
     const bool tiny = len <= 1024;
@@ -3589,6 +3598,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
     }
     __syncthreads();
+    K0_TICK(1)
     if constexpr (DC) {
         const uint32_t np = (uint32_t)A.n_patterns, work = len * np;
         const uint64_t *sh64 = (const uint64_t *)sh;
@@ -3721,6 +3731,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
     }
     __syncthreads();
+    K0_TICK(2)
     const uint32_t n = nocc;
     if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
         if (seq) k0_publish_line(res, t, seq, 1ull << 32, nullptr, 0);
@@ -3735,6 +3746,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         order[r] = (uint16_t)i;
     }
     __syncthreads();
+    K0_TICK(3)
 #define K0_SPAN(I, S, E)                                                                          \
     {                                                                                             \
         const uint4 v_ = occ[order[(I)]];                                                         \
@@ -3816,6 +3828,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
         __syncthreads();
     }
+    K0_TICK(4)
     uint32_t dst = 0, total = 0;
     if (n <= 64) { // (mine != 0 only in wave 0)
         if (t < 64) {
@@ -3850,6 +3863,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     }
     if (n <= 64 ? t == 63 : t == 1023) s_total = total;
     __syncthreads();
+    K0_TICK(5)
     const uint32_t tot = s_total;
     if (seq) {
         const uint64_t *pk = (const uint64_t *)img;
@@ -3869,6 +3883,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             word1 |= (uint64_t)rest_hash << K0_REST_HASH_SHIFT;
         }
         k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+        K0_TICK(6)
     } else {
         for (uint32_t k = t; k < tot * 6; k += 1024) ((uint32_t *)out)[k] = img[k];
         if (t == 0) *(ulonglong2 *)res = make_ulonglong2(tot, 0); // res[0] = matches, res[1] = 0: one store
@@ -3903,22 +3918,38 @@ __device__ __noinline__ void k0_resident_call(const DevAutomaton *A, const uint8
     k0_call<MODE>(*A, hay, len, key_mode, overlapping, codepoints, out, res, seq, tables, pre, npre);
 }
 
+// a 64-bit value that is the same in every lane, into scalar registers (readfirstlane returns an int: the low half must not
+// be sign-extended over the high one)
+__device__ __forceinline__ uint64_t uniform64(uint32_t lo, uint32_t hi) {
+    return ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane(hi) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane(lo);
+}
 // 16 bytes of host memory as they are NOW (system scope: no cache of the device answers)
 __device__ __forceinline__ uint4 load16_system(const void *p) {
     uint4 v;
-    asm volatile("buffer_inv sc0 sc1\n\tglobal_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
     return v;
 }
 
-// The poll: wave 0 reads the mailbox's first KiB in ONE instruction -- lane 0 the word and the check, lane 1 + j the
+// The poll: wave 0 reads the mailbox's first lines in ONE instruction -- lane 0 the word and the check, lane 1 + j the
 // haystack's bytes [16 j, 16 j + 16) -- so that a haystack of up to K0_MAILBOX_INLINE bytes is there when the word is
-// (a dependent read of host memory is another PCIe round trip, ~2 us).  The lanes' reads are not ordered among
+// (a dependent read of host memory is another PCIe round trip, ~1.6 us).  The lanes' reads are not ordered among
 // themselves: the bytes are taken when their hash (k0_hay_mix per 16 bytes, keyed with the call's number and the
-// context's secret, XORed) is the check the host wrote in front of the word, and read again behind the word otherwise.
+// context's secret, XORed) is the check the host wrote in front of the word; otherwise the workgroup reads the haystack
+// behind an acquire fence, as a launched K0 reads it.
+// WHEN to poll: a poll that leaves as soon as the result is out arrives at the host's memory just before the host has
+// written the next call of a loop (the result takes as long to get there as the poll) -- measured: half of the polls
+// that saw the word had caught the haystack half-written, and the word was seen on the second poll, 2.3 us after it was
+// written.  The first poll after a result waits `delay` ticks: longer by K0_DELAY_UP after a call whose first poll was too
+// early (the word came with the second one, or with bytes that failed the check), shorter by one tick after a call
+// whose first poll was right -- it settles a little behind the host's usual answer.  (Four waves polling in their own
+// rhythms, the other way to have a poll arrive close behind the word: built, measured, 8.2 -> 11.5 us per call -- the
+// workgroup's barrier waits for every poll in flight, and the result's write-back queues behind them.)
+constexpr uint32_t K0_DELAY_UP = 25, K0_DELAY_MAX = 500;
 template <int MODE>
 __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const uint64_t *mailbox, int key_mode, int overlapping,
                                                     acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch,
-                                                    uint64_t seq, uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret) {
+                                                    uint64_t seq, uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret,
+                                                    uint32_t delay) {
     __shared__ uint64_t s_cmd;
     __shared__ uint32_t s_npre;
     const uint8_t *hay = (const uint8_t *)mailbox + K0_MAILBOX_HAY;
@@ -3927,18 +3958,24 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
     uint64_t t_last = t_start;
     constexpr uint64_t LEAVE = ~0ull;
     // what the kernel did, left beside the epoch when it leaves (status[1 .. 4]: calls, calls whose bytes came with the
-    // poll, ticks between a word seen and its result published, polls; ACX_RESIDENT_TRACE=1 prints them)
+    // poll, ticks between a word seen and its result published, polls; [13] the delay it ended with -- the next launch's
+    // first; ACX_RESIDENT_TRACE=1 prints them)
     uint64_t n_calls = 0, n_inline = 0, busy = 0, n_polls = 0;
+    uint64_t stage[8] = {};
+    // lanes that poll: the word's and as many as the last call's haystack took, in whole 64-byte lines (the fewer lines a
+    // poll reads, the less often it catches the host between two of them)
+    uint32_t width = 64;
     for (bool first = true;; first = false) {
         uint4 pre = make_uint4(0, 0, 0, 0);
         uint64_t t_seen = 0;
         if (t < 64) {
             uint64_t w;
             uint32_t npre = 0;
+            if (!first) while (wall_clock64() - t_last < delay) __builtin_amdgcn_s_sleep(1);
             for (uint32_t polls = 0;; polls++) {
                 n_polls++;
-                pre = load16_system((const uint8_t *)mailbox + 16 * t);
-                w = ((uint64_t)__builtin_amdgcn_readfirstlane(pre.y) << 32) | __builtin_amdgcn_readfirstlane(pre.x);
+                if (t < width) pre = load16_system((const uint8_t *)mailbox + 16 * t);
+                w = uniform64(pre.x, pre.y);
                 const uint64_t now = wall_clock64();
                 // (polls: a second bound, should the clock not be what it is taken for)
                 if ((w & K0_MAILBOX_QUIT) || now - t_start > life_ticks || now - t_last > idle_ticks || polls > (1u << 24)) {
@@ -3948,12 +3985,20 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
                 if ((uint32_t)(w >> 32) != (uint32_t)(seq + 1)) continue;
                 const uint32_t len = (uint32_t)(w & K0_MAILBOX_LEN_MASK);
                 const uint32_t covered = len < K0_MAILBOX_INLINE ? (len + 15) & ~15u : K0_MAILBOX_INLINE;
-                const uint64_t want = ((uint64_t)__builtin_amdgcn_readfirstlane(pre.w) << 32) | __builtin_amdgcn_readfirstlane(pre.z);
-                uint64_t h = t >= 1 && 16 * (t - 1) < covered
-                                 ? k0_hay_mix(((uint64_t)pre.y << 32) | pre.x, ((uint64_t)pre.w << 32) | pre.z, t - 1, (seq + 1) ^ secret)
-                                 : 0;
-                for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
-                npre = h == want ? covered : 0;
+                bool torn = false;
+                if (covered <= 16 * (width - 1)) {
+                    const uint64_t want = uniform64(pre.z, pre.w);
+                    uint64_t h = t >= 1 && 16 * (t - 1) < covered
+                                     ? k0_hay_mix(((uint64_t)pre.y << 32) | pre.x, ((uint64_t)pre.w << 32) | pre.z, t - 1, (seq + 1) ^ secret)
+                                     : 0;
+                    for (int o = 32; o > 0; o >>= 1) h ^= __shfl_xor(h, o);
+                    if (h == want) npre = covered; else torn = true;
+                }
+                width = min(64u, (1 + covered / 16 + 3) & ~3u);
+                if (!first) {
+                    if (polls == 1 || (polls == 0 && torn)) delay = min(delay + K0_DELAY_UP, K0_DELAY_MAX);
+                    else if (polls == 0 && delay) delay--;
+                }
                 t_seen = now;
                 break;
             }
@@ -3964,21 +4009,29 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
         if (w == LEAVE) {
             if (t == 0) {
                 status[1] = n_calls; status[2] = n_inline; status[3] = busy; status[4] = n_polls;
+                for (int i = 0; i < 8; i++) status[5 + i] = stage[i];
+                status[13] = delay;
                 __hip_atomic_store(status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, ""); // (system scope, every wave: nothing of the last haystack in its caches)
+        const uint32_t len = (uint32_t)(w & K0_MAILBOX_LEN_MASK), npre = s_npre;
+        // (bytes to read behind the word: system scope, every wave -- nothing of the last haystack in its caches)
+        if (npre < len) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
         seq++;
-        k0_resident_call<MODE>(A, hay, (uint32_t)(w & K0_MAILBOX_LEN_MASK), key_mode, overlapping, (w & K0_MAILBOX_CP) ? 1 : 0,
-                               out, res, seq, first, pre, s_npre);
+        k0_resident_call<MODE>(A, hay, len, key_mode, overlapping, (w & K0_MAILBOX_CP) ? 1 : 0, out, res, seq, first, pre, npre);
         // the result line leaves the caches NOW: a launched K0's stores do at the end of the kernel, and this kernel has no
         // end (measured, the first version: every call took the idle limit -- the line arrived when the kernel left)
         if (t < 64) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
         t_last = wall_clock64();
         n_calls++;
-        n_inline += s_npre ? 1 : 0;
+        n_inline += npre ? 1 : 0;
         busy += t_last - t_seen;
+        if (t == 0) {
+            stage[0] += k0_ticks[0] - t_seen;
+            for (int i = 1; i < 7; i++) stage[i] += k0_ticks[i] - k0_ticks[i - 1];
+            stage[7] += t_last - k0_ticks[6];
+        }
     }
 }
 
@@ -4011,10 +4064,10 @@ hipError_t launch_small(const DevAutomaton &A, const uint8_t *hay, uint32_t len,
 
 hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
                            acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
-                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, hipStream_t st) {
+                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, uint32_t delay, hipStream_t st) {
 #define ACX_K0R(M)                                                                                                     \
     hipLaunchKernelGGL(k0_resident<M>, dim3(1), dim3(1024), 0, st, A, mailbox, key_mode, overlapping ? 1 : 0, out, res, \
-                       status, epoch, seq, idle_ticks, life_ticks, secret)
+                       status, epoch, seq, idle_ticks, life_ticks, secret, delay)
     if (mode == 3) ACX_K0R(3); else if (mode == 2) ACX_K0R(2); else if (mode == 1) ACX_K0R(1); else if (mode == 0) ACX_K0R(0);
     else return hipErrorInvalidValue;
 #undef ACX_K0R

@@ -130,20 +130,19 @@ __host__ __device__ inline uint64_t k0_hay_mix(uint64_t lo, uint64_t hi, uint32_
     x ^= x >> 29; x *= 0x94D049BB133111EBull; x ^= x >> 32;
     return x;
 }
-inline uint64_t k0_hay_check(const uint8_t *hay /* zero-padded to 16 bytes */, uint32_t len, uint64_t seq, uint64_t secret) {
+inline uint64_t k0_hay_check(const uint8_t *hay, uint32_t len, uint64_t seq, uint64_t secret) { // (the last piece zero-padded)
     const uint32_t covered = len < K0_MAILBOX_INLINE ? (len + 15) & ~15u : K0_MAILBOX_INLINE;
     uint64_t h = 0;
     for (uint32_t j = 0; 16 * j < covered; j++) {
-        uint64_t lo, hi;
-        __builtin_memcpy(&lo, hay + 16 * j, 8);
-        __builtin_memcpy(&hi, hay + 16 * j + 8, 8);
-        h ^= k0_hay_mix(lo, hi, j, seq ^ secret);
+        uint64_t v[2] = {0, 0};
+        __builtin_memcpy(v, hay + 16 * j, 16 * j + 16 <= len ? 16 : len - 16 * j);
+        h ^= k0_hay_mix(v[0], v[1], j, seq ^ secret);
     }
     return h;
 }
 hipError_t launch_resident(const DevAutomaton *A, int mode, const uint64_t *mailbox, int key_mode, bool overlapping,
                            acx_match_t *out, uint64_t *res, uint64_t *status, uint64_t epoch, uint64_t seq,
-                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, hipStream_t st);
+                           uint64_t idle_ticks, uint64_t life_ticks, uint64_t secret, uint32_t delay, hipStream_t st);
 // sparse path: k_tile_main (verify the hits, order, match kind) -> k_tile_write
 // (final records in out[], capacity n_groups * GROUP_MAX).  The launch geometry depends on the
 // number of tiles only, so no host round trip is needed before them.  The first group of the write
