@@ -1110,9 +1110,18 @@ int run_resident(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int
             if (rc) return rc;
         }
         if ((spins & 1023) == 1023 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(8)) {
+            // no answer for 8 ms (a kernel that has not started yet -- its hardware queue may be another context's for a
+            // while --, a thread of the host that lost its core): the kernel is told to leave, and when the call is not
+            // among what it did, a plain launch answers it
+            const uint64_t st0 = *status, word0 = w.mailbox[0], l0 = p[0];
             stop_resident(c);
             HIPCHK(hipStreamSynchronize(R.stream));
-            if (!complete()) return fail(ACX_EDEVICE, "the resident K0 did not publish its result");
+            static const bool trace = std::getenv("ACX_RESIDENT_TRACE") != nullptr;
+            if (trace)
+                std::fprintf(stderr, "acx resident K0: call %llu unanswered for 8 ms (epoch %llu, status %llu, word %llx, line %llu): %s\n",
+                             (unsigned long long)seq, (unsigned long long)R.epoch, (unsigned long long)st0, (unsigned long long)word0,
+                             (unsigned long long)l0, complete() ? "answered by now" : "a launch takes it");
+            if (!complete()) { R.off = 64; return ACX_OK; }
             break;
         }
     }

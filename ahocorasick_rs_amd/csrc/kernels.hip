@@ -3560,7 +3560,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     // the records, assembled here and written as a flat run of dwords: `out` may be pinned HOST memory, where every
     // store instruction's every lane is a transaction of its own -- 4 matches written field by field were 12 partial
     // writes over PCIe (measured: the kernel took 12 us on 75-byte haystacks with 4 matches, ~6 without matches)
-    __shared__ uint32_t img[SMALL_MAX_OCC * 6];
+    __shared__ __attribute__((aligned(16))) uint32_t img[SMALL_MAX_OCC * 6];
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     const uint32_t t = threadIdx.x;
@@ -3571,9 +3571,10 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     if (t == 0) { nocc = 0; rest_hash = 0; }
     if (tables && t < 256) cls[t] = A.classes[t];
     if (npre && t >= 1 && t < 64 && 16 * (t - 1) < npre) *(uint4 *)(sh + 16 * (t - 1)) = pre;
-    if (PF && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all readable)
+    if ((PF || npre) && ((uintptr_t)hay & 15) == 0) { // (16 bytes per lane: the aligned block that holds the haystack's last byte is all
+        // readable -- the prefilter's callers' buffers and the mailbox are; the pieces of a wave are one request each)
         for (uint32_t i = npre + 16 * t; i < len; i += 16 * 1024) *(uint4 *)(sh + i) = *(const uint4 *)(hay + i);
-        __syncthreads();
+        if (PF) __syncthreads();
     } else {
         for (uint32_t i = npre + t; i < len; i += 1024) sh[i] = hay[i];
     }
@@ -3736,6 +3737,74 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
         if (seq) k0_publish_line(res, t, seq, 1ull << 32, nullptr, 0);
         else if (t == 0) { res[0] = 0; res[1] = 1; }
+        return;
+    }
+    // ---- a polled call on at most 1 KiB with at most 64 occurrences (the reference's benchmark loop): WAVE 0 finishes it
+    // alone, an occurrence per lane -- no barrier of the workgroup between here and the result (the general way below is
+    // five of them and four passes through LDS: 2.3 of a call's 4.2 us on the device, measured in the resident kernel)
+    if (seq && tiny && n <= 64) {
+        if (t >= 64) return;
+        const uint4 mine_occ = t < n ? occ[t] : make_uint4(~0u, ~0u, 0u, 0u);
+        // rank among the keys (unique), then every occurrence to the lane of its rank
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t jl = (uint32_t)__builtin_amdgcn_readlane((int)mine_occ.x, (int)j), jh = (uint32_t)__builtin_amdgcn_readlane((int)mine_occ.y, (int)j);
+            r += (jh < mine_occ.y || (jh == mine_occ.y && jl < mine_occ.x)) ? 1u : 0u;
+        }
+        const uint32_t to = (t < n ? r : 63u) << 2; // (lanes without an occurrence: n < 64, lane 63 is none of the n ranks' -- or is, and is overwritten)
+        uint4 v;
+        v.x = (uint32_t)__builtin_amdgcn_ds_permute((int)to, (int)mine_occ.x);
+        v.y = (uint32_t)__builtin_amdgcn_ds_permute((int)to, (int)mine_occ.y);
+        v.z = (uint32_t)__builtin_amdgcn_ds_permute((int)to, (int)mine_occ.z);
+        v.w = (uint32_t)__builtin_amdgcn_ds_permute((int)to, (int)mine_occ.w);
+        const uint32_t x = (uint32_t)(((((uint64_t)v.y << 32) | v.x)) >> A.rank_bits); // (an offset of at most 1 024)
+        uint32_t s = key_mode == 0 ? x - v.w : x, e = key_mode == 0 ? x : x + v.w;
+        if (t >= n) s = e = 0;
+        // match kind: one greedy pass over the sorted occurrences (what the sync points' chains below do piecewise)
+        uint64_t taken = 0;
+        if (overlapping) {
+            taken = n == 64 ? ~0ull : (1ull << n) - 1;
+        } else {
+            uint32_t pos = 0;
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t sj = (uint32_t)__builtin_amdgcn_readlane((int)s, (int)j), ej = (uint32_t)__builtin_amdgcn_readlane((int)e, (int)j);
+                if (sj >= pos) { taken |= 1ull << j; pos = ej; }
+            }
+        }
+        const bool mine1 = (taken >> t) & 1u;
+        const uint32_t dst = __popcll(taken & ((1ull << t) - 1)), tot = __popcll(taken);
+        if (codepoints) { // (src/lib.rs:73-88: lead bytes before the offset -- lane q counts slice q, the prefix by shuffles)
+            const uint32_t leads = t * 16 < len ? leads_in_first(*(const uint4 *)(sh + t * 16), len - t * 16 < 16 ? len - t * 16 : 16) : 0;
+            uint32_t incl = leads;
+            for (int o = 1; o < 64; o <<= 1) {
+                const uint32_t u = __shfl_up(incl, o);
+                if ((int)t >= o) incl += u;
+            }
+            const uint32_t excl = incl - leads, all = __shfl(incl, 63);
+            const uint32_t bs = __shfl(excl, (int)((s >> 4) & 63)), be = __shfl(excl, (int)((e >> 4) & 63));
+            const uint32_t cs = ((s >> 4) < 64 ? bs : all) + leads_in_first(*(const uint4 *)(sh + (s & ~15u)), s & 15u);
+            const uint32_t ce = ((e >> 4) < 64 ? be : all) + leads_in_first(*(const uint4 *)(sh + (e & ~15u)), e & 15u);
+            s = cs; e = ce;
+        }
+        uint64_t *pk = (uint64_t *)img;
+        if (mine1) pk[dst] = (uint64_t)v.z | ((uint64_t)s << 32) | ((uint64_t)(e - 1) << 48);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        uint64_t word1 = tot;
+        if (tot > K0_LINE_MATCHES) { // (uniform) out[] and the line are separate writes to host memory: k0_rest_mix
+            uint32_t hx = 0;
+            if (t < tot - K0_LINE_MATCHES) {
+                const uint64_t u = pk[K0_LINE_MATCHES + t];
+                ((uint64_t *)out)[t] = u;
+                hx = k0_rest_mix(u, t, seq);
+            }
+            for (int o = 32; o > 0; o >>= 1) hx ^= __shfl_xor(hx, o);
+            __threadfence_system();
+            word1 |= (uint64_t)hx << K0_REST_HASH_SHIFT;
+        }
+        K0_TICK(3) K0_TICK(4) K0_TICK(5)
+        k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+        K0_TICK(6)
         return;
     }
     // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
