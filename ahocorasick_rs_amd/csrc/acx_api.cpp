@@ -429,7 +429,7 @@ struct Resident {
     bool live = false;            // a kernel has been launched and has not been seen to have left
     int mode = -1, overlapping = 0; // what it was launched for (small_mode; the tables' view and the key follow from overlapping)
     uint32_t delay = 0;           // ticks the kernel waits behind a result before it polls (k0_resident: what the last kernel
-                                  // ended with -- h_pinned[PIN_RESIDENT + 13])
+                                  // ended with -- h_pinned[PIN_RESIDENT + 5])
     uint64_t secret = 0;          // keys the check of the haystack bytes that travel with the poll (kernels.hpp, k0_hay_check)
     uint32_t switches = 0, calls = 0; // launches for another mode within the last calls: a loop that alternates between two
     uint32_t off = 0;                 //   kinds of call pays a launch per call either way -- small calls left as plain launches
@@ -607,17 +607,14 @@ void trace_resident(Ctx *c) { // (ACX_RESIDENT_TRACE=1: what the kernel that has
     static const bool on = std::getenv("ACX_RESIDENT_TRACE") != nullptr;
     if (!on) return;
     const uint64_t *s = c->ws.h_pinned + PIN_RESIDENT;
-    std::fprintf(stderr, "acx resident K0 epoch %llu: %llu calls, %llu with their bytes in the poll, %.2f us busy per call, %llu polls\n",
+    std::fprintf(stderr, "acx resident K0 epoch %llu: %llu calls, %llu with their bytes in the poll, %.2f us busy per call, %llu polls, delay %llu ticks\n",
                  (unsigned long long)s[0], (unsigned long long)s[1], (unsigned long long)s[2],
-                 s[1] ? (double)s[3] / 100.0 / (double)s[1] : 0.0, (unsigned long long)s[4]);
-    std::fprintf(stderr, "   delay %llu ticks, stages (us per call):", (unsigned long long)s[13]);
-    for (int i = 0; i < 8; i++) std::fprintf(stderr, " %.2f", s[1] ? (double)s[5 + i] / 100.0 / (double)s[1] : 0.0);
-    std::fprintf(stderr, "\n");
+                 s[1] ? (double)s[3] / 100.0 / (double)s[1] : 0.0, (unsigned long long)s[4], (unsigned long long)s[5]);
 }
 
 void resident_left(Ctx *c) {
     trace_resident(c);
-    const uint64_t d = c->ws.h_pinned[PIN_RESIDENT + 13];
+    const uint64_t d = c->ws.h_pinned[PIN_RESIDENT + 5];
     c->res.delay = d < 1000 ? (uint32_t)d : 0;
 }
 
@@ -1047,7 +1044,8 @@ int run_resident(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int
     Workspace &w = c->ws;
     const DevAutomaton &A = view(a, overlapping != 0);
     const int mode = small_mode(A, (uint32_t)len, !(overlapping && a->expand_ov));
-    if (mode < 0) { stop_resident(c); return ACX_OK; }
+    // (beyond 16 KiB a launch is as good or better -- 60 000 bytes: 28 us launched, 39 through the mailbox, measured; 16 000: 30 and 17)
+    if (mode < 0 || len > SMALL_MAX_LEN) { stop_resident(c); return ACX_OK; }
     static const uint64_t idle_ticks = env_ticks("ACX_RESIDENT_IDLE_US", 200), life_ticks = env_ticks("ACX_RESIDENT_LIFE_US", 1000);
     volatile uint64_t *status = w.h_pinned + PIN_RESIDENT;
     const int ov = overlapping ? 1 : 0;

@@ -3535,8 +3535,6 @@ constexpr uint32_t K0_DC_PATTERNS = 64, K0_DC_WORK = 4096;
 // pattern-info load per candidate -- instead of an anchored walk from every position, which is a chain of dependent table
 // gathers per position and what a call on a large automaton cost: 16 KiB took 38 us, and beyond 16 KiB the call went to
 // the three-kernel pipeline (64 KiB: 63 us).  A position costs one independent gather, whatever the automaton's size.
-__shared__ uint64_t k0_ticks[8];
-#define K0_TICK(i) if (threadIdx.x == 0) k0_ticks[i] = wall_clock64();
 // tables = false (the RESIDENT kernel's calls after its first): the automaton's LDS images (classes, LT's tables, DC's
 // patterns) are those of the call before.
 // npre != 0 (the resident kernel): the haystack's first npre bytes (a multiple of 16, or all of it) came with the poll --
@@ -3564,7 +3562,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     using scan_t = rocprim::block_scan<uint32_t, 1024>;
     __shared__ typename scan_t::storage_type scan_tmp;
     const uint32_t t = threadIdx.x;
-    K0_TICK(0)
     // (haystacks of at most 1 KiB -- one position per thread, at most 64 slices of 16 bytes: the prefix sums below are
     // one wave's shuffles instead of block scans, and an LT walk has its 16 class bytes in registers before it starts)
     const bool tiny = len <= 1024;
@@ -3599,7 +3596,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
     }
     __syncthreads();
-    K0_TICK(1)
     if constexpr (DC) {
         const uint32_t np = (uint32_t)A.n_patterns, work = len * np;
         const uint64_t *sh64 = (const uint64_t *)sh;
@@ -3732,7 +3728,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
     }
     __syncthreads();
-    K0_TICK(2)
     const uint32_t n = nocc;
     if (n > SMALL_MAX_OCC) { // dense: the general pipeline takes the call
         if (seq) k0_publish_line(res, t, seq, 1ull << 32, nullptr, 0);
@@ -3802,9 +3797,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             __threadfence_system();
             word1 |= (uint64_t)hx << K0_REST_HASH_SHIFT;
         }
-        K0_TICK(3) K0_TICK(4) K0_TICK(5)
         k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
-        K0_TICK(6)
         return;
     }
     // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
@@ -3815,7 +3808,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         order[r] = (uint16_t)i;
     }
     __syncthreads();
-    K0_TICK(3)
 #define K0_SPAN(I, S, E)                                                                          \
     {                                                                                             \
         const uint4 v_ = occ[order[(I)]];                                                         \
@@ -3897,7 +3889,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         }
         __syncthreads();
     }
-    K0_TICK(4)
     uint32_t dst = 0, total = 0;
     if (n <= 64) { // (mine != 0 only in wave 0)
         if (t < 64) {
@@ -3932,7 +3923,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     }
     if (n <= 64 ? t == 63 : t == 1023) s_total = total;
     __syncthreads();
-    K0_TICK(5)
     const uint32_t tot = s_total;
     if (seq) {
         const uint64_t *pk = (const uint64_t *)img;
@@ -3952,7 +3942,6 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             word1 |= (uint64_t)rest_hash << K0_REST_HASH_SHIFT;
         }
         k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
-        K0_TICK(6)
     } else {
         for (uint32_t k = t; k < tot * 6; k += 1024) ((uint32_t *)out)[k] = img[k];
         if (t == 0) *(ulonglong2 *)res = make_ulonglong2(tot, 0); // res[0] = matches, res[1] = 0: one store
@@ -4027,10 +4016,9 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
     uint64_t t_last = t_start;
     constexpr uint64_t LEAVE = ~0ull;
     // what the kernel did, left beside the epoch when it leaves (status[1 .. 4]: calls, calls whose bytes came with the
-    // poll, ticks between a word seen and its result published, polls; [13] the delay it ended with -- the next launch's
+    // poll, ticks between a word seen and its result published, polls; [5] the delay it ended with -- the next launch's
     // first; ACX_RESIDENT_TRACE=1 prints them)
     uint64_t n_calls = 0, n_inline = 0, busy = 0, n_polls = 0;
-    uint64_t stage[8] = {};
     // lanes that poll: the word's and as many as the last call's haystack took, in whole 64-byte lines (the fewer lines a
     // poll reads, the less often it catches the host between two of them)
     uint32_t width = 64;
@@ -4078,8 +4066,7 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
         if (w == LEAVE) {
             if (t == 0) {
                 status[1] = n_calls; status[2] = n_inline; status[3] = busy; status[4] = n_polls;
-                for (int i = 0; i < 8; i++) status[5 + i] = stage[i];
-                status[13] = delay;
+                status[5] = delay;
                 __hip_atomic_store(status, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             return;
@@ -4096,11 +4083,6 @@ __global__ __launch_bounds__(1024) void k0_resident(const DevAutomaton *A, const
         n_calls++;
         n_inline += npre ? 1 : 0;
         busy += t_last - t_seen;
-        if (t == 0) {
-            stage[0] += k0_ticks[0] - t_seen;
-            for (int i = 1; i < 7; i++) stage[i] += k0_ticks[i] - k0_ticks[i - 1];
-            stage[7] += t_last - k0_ticks[6];
-        }
     }
 }
 
