@@ -3937,7 +3937,9 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             }
             for (int o = 32; o > 0; o >>= 1) hx ^= __shfl_xor(hx, o);
             if ((t & 63) == 0 && hx) atomicXor(&rest_hash, hx);
-            __threadfence_system();
+            // (the waves that wrote: a system-scope release is a write-back of the L2 per wave -- sixteen of them were most of
+            // what a sixth match cost: 16 KiB with ten matches 22.7 us, 8 KiB with five 13.3, measured)
+            if (t < tot - K0_LINE_MATCHES) __threadfence_system();
             __syncthreads();
             word1 |= (uint64_t)rest_hash << K0_REST_HASH_SHIFT;
         }
@@ -3973,7 +3975,13 @@ template <int MODE>
 __device__ __noinline__ void k0_resident_call(const DevAutomaton *A, const uint8_t *hay, uint32_t len, int key_mode,
                                               int overlapping, int codepoints, acx_match_t *out, uint64_t *res, uint64_t seq,
                                               bool tables, uint4 pre, uint32_t npre) {
-    k0_call<MODE>(*A, hay, len, key_mode, overlapping, codepoints, out, res, seq, tables, pre, npre);
+    // (a function's arguments arrive in vector registers: said to be uniform, the description's fields are scalar loads and
+    // what follows from them scalar registers and branches -- without this MODE 3 took 124 vector registers and spilled)
+    auto uni32 = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    auto uni64 = [&](uint64_t v) { return ((uint64_t)uni32((uint32_t)(v >> 32)) << 32) | uni32((uint32_t)v); };
+    k0_call<MODE>(*(const DevAutomaton *)uni64((uint64_t)A), (const uint8_t *)uni64((uint64_t)hay), uni32(len), (int)uni32((uint32_t)key_mode),
+                  (int)uni32((uint32_t)overlapping), (int)uni32((uint32_t)codepoints), (acx_match_t *)uni64((uint64_t)out),
+                  (uint64_t *)uni64((uint64_t)res), uni64(seq), uni32(tables ? 1u : 0u) != 0, pre, uni32(npre));
 }
 
 // a 64-bit value that is the same in every lane, into scalar registers (readfirstlane returns an int: the low half must not
@@ -4094,9 +4102,12 @@ int small_mode(const DevAutomaton &A, uint32_t len, bool direct_ok) {
                     A.n_patterns <= K0_LT_IDS && A.max_len < 256 && !no_lt;
     const bool dc = A.n_patterns <= K0_DC_PATTERNS && A.min_len >= 1 && A.max_len <= 16 && A.pat_blob && A.pat_off &&
                     (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc && direct_ok;
-    // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS,
-    // from 1 KiB on (shorter: the walk's handful of gathers is as good)
-    const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > 1024));
+    // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS
+    // from the first byte on since round 6 (until then from 1 KiB: "the walk's handful of gathers is as good" -- per launch
+    // it is, 13.4 us either way; in the resident kernel a haystack of 64 bytes with one match is 7.3 us against 8.9:
+    // the walk that finds the match is a chain of a dozen dependent gathers).  ACX_K0_PF_MIN: measurements
+    static const uint32_t pf_min = std::getenv("ACX_K0_PF_MIN") ? (uint32_t)std::atoi(std::getenv("ACX_K0_PF_MIN")) : 0u;
+    const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > pf_min));
     if (len > SMALL_MAX_LEN && !pf) return -1;
     return pf ? 3 : dc ? 2 : lt ? 1 : 0;
 }
