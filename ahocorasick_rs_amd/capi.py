@@ -539,11 +539,11 @@ class Automaton:
         """True / 1: time every call's scan kernel; N > 1: every N-th call; False / 0: off."""
         _check(lib().acx_profile_enable(self._h, int(on)))
 
-    PATH_STATS = ("sparse", "hot_calls", "hot_groups", "overflow_hits", "dense_tiles", "dense_radix", "overflow_regrown", "k0", "byte_ranges", "wide_redone", "resident_launches")
+    PATH_STATS = ("sparse", "hot_calls", "hot_groups", "overflow_hits", "dense_tiles", "dense_radix", "overflow_regrown", "k0", "byte_ranges", "wide_redone", "resident_launches", "in_place")
 
     def path_stats(self, reset: bool = True) -> dict:
         """which way this handle's calls went (acx_path_stats): {sparse, hot_calls, hot_groups, overflow_hits,
-        dense_tiles, dense_radix, overflow_regrown, k0, byte_ranges, wide_redone, resident_launches}"""
+        dense_tiles, dense_radix, overflow_regrown, k0, byte_ranges, wide_redone, resident_launches, in_place}"""
         out = (ctypes.c_uint64 * len(self.PATH_STATS))()
         _check(lib().acx_path_stats(self._h, out, int(reset)))
         return dict(zip(self.PATH_STATS, [int(v) for v in out]))

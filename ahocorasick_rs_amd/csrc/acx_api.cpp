@@ -385,6 +385,8 @@ struct Workspace {
     uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
     acx_match_t *pin_final = nullptr; // host entry point, mid-size calls: pinned host memory the write kernel's records go to
     uint64_t pin_final_cap = 0;       // (records)
+    uint8_t *pin_mid = nullptr;       // mid-size calls: pinned copy of a host haystack the scan reads in place
+    uint64_t pin_mid_cap = 0;
     uint64_t *mailbox = nullptr;      // small calls: coherent pinned memory -- the resident K0's command word (kernels.hpp), then
     uint8_t *pin_hay = nullptr;       //   (K0_MAILBOX_HAY bytes behind it) the copy of a host haystack K0 reads in place
     acx_match_t *pin_out = nullptr;   // small calls: pinned output of K0 (host entry point)
@@ -593,6 +595,7 @@ void free_ws(Workspace &w, int device) {
     if (w.h_pinned) (void)hipHostFree(w.h_pinned);
     if (w.pin_final) (void)hipHostFree(w.pin_final);
     if (w.mailbox) (void)hipHostFree(w.mailbox);
+    if (w.pin_mid) (void)hipHostFree(w.pin_mid);
     if (w.pin_out) (void)hipHostFree(w.pin_out);
     for (int i = 0; i < Workspace::RING; i++) {
         if (w.pin_chunk[i]) (void)hipHostFree(w.pin_chunk[i]);
@@ -2733,10 +2736,35 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     }
     stop_resident(c); // (a small call that turned out dense: the pipeline has the context to itself)
     g_trace_find.begin();
-    rc = stage_host(a, c, hay, len, nullptr, 0);
+    // Mid-size haystacks IN PLACE (round 6): copied into pinned host memory by this thread and read from there by the scan
+    // itself -- the runtime's copy of pageable memory is a staging copy of the same size PLUS a DMA the scan's launch waits
+    // for (1 MiB: 26 us in the copy call, 21 us in the launch behind it, the DMA's own time before the scan starts).
+    // Up to 1 MiB (same-box pairs, profiles/r06/exp_inplace_midsize_pairs.txt: 70 KB 45.2 -> 36.6 us, 128 KiB 49.9 -> 41.5,
+    // 512 KiB 69.8 -> 60.5, 1 MiB 103.1 -> 93.0; 2 MiB 112 -> 134: beyond, this thread's copy is what the call waits for).
+    // Only while the context's calls stay on the sparse path (a dense input is read several times: from HBM, then).
+    static const uint64_t inplace_max = std::getenv("ACX_INPLACE_MAX") ? std::strtoull(std::getenv("ACX_INPLACE_MAX"), nullptr, 10) : (1ull << 20);
+    const uint8_t *d_hay = nullptr;
+    if (len <= inplace_max && a->kernel == ACX_KERNEL_PREFILTER && a->sparse_ok && c->dense_hold == 0 && !c->wide && c->spec_hot == 0) {
+        Workspace &w = c->ws;
+        if (w.pin_mid_cap < len + 4096) {
+            if (w.pin_mid) (void)hipHostFree(w.pin_mid);
+            w.pin_mid = nullptr; w.pin_mid_cap = 0;
+            const uint64_t cap = std::max<uint64_t>(len + len / 4 + 4096, 1ull << 20);
+            HIPCHK(hipHostMalloc((void **)&w.pin_mid, cap, hipHostMallocDefault));
+            w.pin_mid_cap = cap;
+        }
+        std::memcpy(w.pin_mid, hay, len);
+        std::memset(w.pin_mid + len, 0, 64);
+        d_hay = w.pin_mid;
+        rc = ACX_OK;
+        a->path[11]++;
+    } else {
+        rc = stage_host(a, c, hay, len, nullptr, 0);
+        d_hay = c->ws.hay;
+    }
     g_trace_find.lap(0);
     if (rc == ACX_OK)
-        rc = run_find(a, c, c->ws.hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false, 0, true);
+        rc = run_find(a, c, d_hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false, 0, true);
     if (rc != ACX_OK) return rc;
     g_trace_find.lap(1);
     if (r->borrowed) {

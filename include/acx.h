@@ -23,7 +23,7 @@
 extern "C" {
 #endif
 
-/* 9: acx_path_stats gained [10] (round 6: launches of a context's resident K0);
+/* 9: acx_path_stats gained [10], [11] (round 6: launches of a context's resident K0; mid-size host haystacks read in place);
  * 8: acx_path_stats gained [9] (round 6: calls repeated with the wide form of the sparse path's post stage);
  * 7: acx_path_stats gained [8] (byte ranges of calls that were cut); K0's result line carries end - 1 and a hash of the
  *    matches beside it (round 5);
@@ -318,9 +318,10 @@ int acx_profile_read(acx_automaton_t *a, acx_profile_t *out, int reset);
  * occurrences in one pass: the pieces count in [0 .. 7] as well), [9] calls that were repeated with the WIDE form of the
  * sparse path's post stage (a match every 100 - 500 bytes: the context keeps that form while its inputs are like that),
  * [10] launches of a context's RESIDENT K0 (acx_find on short haystacks: one workgroup stays on the device between the
- * calls of a loop and is fed through pinned host memory -- [7] counts the calls, [10] the launches they cost).
- * reset != 0 clears the counters. */
-#define ACX_PATH_STATS 11
+ * calls of a loop and is fed through pinned host memory -- [7] counts the calls, [10] the launches they cost), [11] calls
+ * of acx_find whose haystack (beyond K0's sizes, up to 1 MiB) the scan read IN PLACE from pinned host memory instead of
+ * a copy in HBM.  reset != 0 clears the counters. */
+#define ACX_PATH_STATS 12
 int acx_path_stats(acx_automaton_t *a, uint64_t out[ACX_PATH_STATS], int reset);
 
 /* ---- device memory helpers so that a host without torch can stage data ---- */
