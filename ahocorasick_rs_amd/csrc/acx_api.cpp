@@ -358,7 +358,7 @@ private:
 
 // ---------------------------------------------------------------------------
 // pinned host scratch of a context, in 64-bit words (Workspace::h_pinned)
-constexpr uint32_t PIN_K0 = 16, PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PIN_RESIDENT = 48, PINNED_WORDS = 64;
+constexpr uint32_t PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PIN_RESIDENT = 48, PIN_K0 = 64, PINNED_WORDS = 96;
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -378,11 +378,11 @@ struct Workspace {
     uint64_t *h_pinned = nullptr;     // pinned host scratch (PINNED_WORDS x u64, 64-byte lines): [0 .. 15] the dense paths' totals
                                       // (copied behind a stream synchronisation; [8], [9] = result of an unpolled K0), then the
                                       // POLLED lines, each written by one store and accepted on its check word (kernels.hpp):
-                                      // [16 .. 23] K0's result, [24 .. 31] the sparse path's totals, [32 .. 39] the hot pipeline's
+                                      // [64 .. 95] K0's result (up to four lines), [24 .. 31] the sparse path's totals, [32 .. 39] the hot pipeline's
                                       // early total (hot_totals), [40 .. 47] the speculative hot pipeline's, [48] the epoch of
                                       // the last resident K0 that has left (Resident)
     uint64_t t_line[8] = {};          // the sparse path's totals: the verified copy of the line (PIN_TOTALS / PIN_HOT_TOTALS)
-    uint64_t h_line[8] = {};          // K0, polled: the verified copy of the call's result line (words 1 .. 6)
+    uint64_t h_lines[K0_RESULT_LINES][8] = {}; // K0, polled: the verified copies of the call's result lines (words 1 .. 6 of each)
     acx_match_t *pin_final = nullptr; // host entry point, mid-size calls: pinned host memory the write kernel's records go to
     uint64_t pin_final_cap = 0;       // (records)
     uint8_t *pin_mid = nullptr;       // mid-size calls: pinned copy of a host haystack the scan reads in place
@@ -917,6 +917,17 @@ bool small_polls() {
 }
 
 int wait_line(Ctx *c, uint32_t at, uint64_t seq, uint64_t line[8], const char *what); // (below)
+// the result lines behind the first that a polled K0 call with `n` matches wrote (kernels.hpp, K0_RESULT_LINES: the same
+// store instruction as the first): verified copies into the workspace
+int take_more_lines(Ctx *c, uint64_t seq, uint64_t n) {
+    for (uint32_t L = 1; L < k0_result_lines(n); L++) {
+        uint64_t line[K0_LINE_WORDS];
+        int rc = wait_line(c, PIN_K0 + 8 * L, seq, line, "K0's matches did not arrive");
+        if (rc) return rc;
+        for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) c->ws.h_lines[L][i] = line[i];
+    }
+    return ACX_OK;
+}
 
 int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int overlapping, int codepoints,
               acx_match_t *out, uint64_t *n_out, bool *done, bool poll = false) {
@@ -934,9 +945,10 @@ int run_small(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int ov
         uint64_t line[K0_LINE_WORDS];
         int rc = wait_line(c, PIN_K0, seq, line, "K0 did not publish its result");
         if (rc) return rc;
-        for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i]; // (what the caller unpacks the matches from)
+        for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_lines[0][i] = line[i]; // (what the caller unpacks the matches from)
         const uint64_t w1 = line[1]; // matches | too dense << 32 | hash of pin_out << 33
         if (((w1 >> 32) & 1u) == 0) {
+            if ((rc = take_more_lines(c, seq, w1 & 0xFFFFFFFFull)) != ACX_OK) return rc;
             *n_out = w1 & 0xFFFFFFFFull;
             *done = true;
             std::lock_guard<std::mutex> lk(a->prof_mu);
@@ -1127,9 +1139,10 @@ int run_resident(acx_automaton *a, Ctx *c, const uint8_t *hay, uint64_t len, int
         }
     }
     *taken = true;
-    for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_line[i] = line[i];
+    for (uint32_t i = 1; i < K0_LINE_WORDS - 1; i++) w.h_lines[0][i] = line[i];
     const uint64_t w1 = line[1]; // matches | too dense << 32 | hash of pin_out << 33
     if (((w1 >> 32) & 1u) == 0) {
+        if ((rc = take_more_lines(c, seq, w1 & 0xFFFFFFFFull)) != ACX_OK) return rc;
         *n_out = w1 & 0xFFFFFFFFull;
         *done = true;
         std::lock_guard<std::mutex> lk(a->prof_mu);
@@ -2683,24 +2696,27 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
                 if (!m) return fail(ACX_ENOMEM, "out of memory");
                 // (polled K0: the first matches ride in the result line, the others are in pin_out; all packed)
                 // (the line: the copy run_small checked, not the pinned words themselves)
-                const uint64_t *line = w.h_line + 2;
+                auto carried = [&](uint64_t i) -> uint64_t { // (i < K0_LINES_MATCHES: from the lines' verified copies)
+                    return i < ACX_K0_LINE_MATCHES ? w.h_lines[0][2 + i]
+                                                   : w.h_lines[1 + (i - ACX_K0_LINE_MATCHES) / K0_MORE_MATCHES][1 + (i - ACX_K0_LINE_MATCHES) % K0_MORE_MATCHES];
+                };
                 volatile const uint64_t *rest = (volatile const uint64_t *)w.pin_out;
                 if (!small_polls()) std::memcpy(m, w.pin_out, n * sizeof(acx_match_t));
                 else {
                     // pin_out and the line are separate writes of the device to host memory: the line carries a hash of what
                     // pin_out must hold (k0_rest_mix); what is read here is taken when it agrees, read again when not
-                    const uint32_t want = (uint32_t)(w.h_line[1] >> K0_REST_HASH_SHIFT);
+                    const uint32_t want = (uint32_t)(w.h_lines[0][1] >> K0_REST_HASH_SHIFT);
                     const uint64_t sq = c->small_seq;
                     const auto t0 = std::chrono::steady_clock::now();
                     bool synced = false; // the stream has been synchronised: what is read now is what the kernel wrote
                     for (;;) {
                         uint32_t hx = 0;
                         for (uint64_t i = 0; i < n; i++) {
-                            const uint64_t v = i < ACX_K0_LINE_MATCHES ? line[i] : rest[i - ACX_K0_LINE_MATCHES];
-                            if (i >= ACX_K0_LINE_MATCHES) hx ^= k0_rest_mix(v, (uint32_t)(i - ACX_K0_LINE_MATCHES), sq);
+                            const uint64_t v = i < K0_LINES_MATCHES ? carried(i) : rest[i - K0_LINES_MATCHES];
+                            if (i >= K0_LINES_MATCHES) hx ^= k0_rest_mix(v, (uint32_t)(i - K0_LINES_MATCHES), sq);
                             m[i].pattern = v & 0xFFFFFFFFull; m[i].start = (v >> 32) & 0xFFFF; m[i].end = (v >> 48) + 1;
                         }
-                        if (n <= ACX_K0_LINE_MATCHES || hx == want) break;
+                        if (n <= K0_LINES_MATCHES || hx == want) break;
                         cpu_relax();
                         // (once the kernel is known to be over its writes have arrived: ONE more reading decides -- a hash that
                         // still disagrees is an error, not a reason to synchronise the stream a million times)

@@ -3498,27 +3498,35 @@ constexpr uint32_t K0_LT_ENTRIES = 8192, K0_LT_IDS = 2048;
 // packed, to out[] first, behind a system-scope fence.
 constexpr uint32_t K0_LINE_MATCHES = ACX_K0_LINE_MATCHES;
 static_assert(K0_LINE_MATCHES + 3 == K0_LINE_WORDS, "seq, totals, matches, seq");
-__device__ __forceinline__ void k0_publish_line(uint64_t *line, uint32_t t, uint64_t seq, uint64_t word1, const uint64_t *pk,
-                                                uint32_t npk) {
-    if (t >= 4) return;
-    uint64_t mid[6]; // words 1 .. 6, the same in all four lanes
-    mid[0] = word1;
+// (tot: the call's matches, the first of them in pk[]; word1: the line's second word -- the count, flags, the hash of out[])
+__device__ __forceinline__ void k0_publish_line(uint64_t *res, uint32_t t, uint64_t seq, uint64_t word1, const uint64_t *pk,
+                                                uint32_t tot) {
+    const uint32_t inl = tot < K0_LINES_MATCHES ? tot : K0_LINES_MATCHES, nl = k0_result_lines(tot);
+    if (t >= 4 * nl) return;
+    uint64_t w[2] = {0, 0};
+    for (uint32_t L = 0; L < nl; L++) {
+        uint64_t mid[6]; // words 1 .. 6 of line L, the same in every lane
+        const uint32_t first = L ? K0_LINE_MATCHES + (L - 1) * K0_MORE_MATCHES : 0;
 #pragma unroll
-    for (uint32_t i = 0; i < K0_LINE_MATCHES; i++) mid[1 + i] = i < npk ? pk[i] : 0;
-    // (the same in every lane: in scalar registers the check's twelve 64-bit multiplications are scalar instructions --
-    // as vector instructions they were most of the 0.55 us this function took, measured in the resident kernel)
+        for (uint32_t i = 0; i < 6; i++) {
+            const uint32_t m = L ? first + i : i - 1; // (line 0: word 1 is word1, matches from word 2 on)
+            mid[i] = L == 0 && i == 0 ? word1 : m < inl ? pk[m] : 0;
+        }
+        // (the same in every lane: in scalar registers the check's twelve 64-bit multiplications are scalar instructions)
 #pragma unroll
-    for (uint32_t i = 0; i < 6; i++)
-        mid[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mid[i] >> 32)) << 32) |
-                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mid[i]); // (readfirstlane returns an int: no sign extension)
-    const uint64_t last = seq ^ k0_line_check(mid); // (the host accepts the line on word 0 AND this word: kernels.hpp)
-    uint64_t w[2];
+        for (uint32_t i = 0; i < 6; i++)
+            mid[i] = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(mid[i] >> 32)) << 32) |
+                     (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)mid[i]); // (readfirstlane returns an int: no sign extension)
+        const uint64_t last = seq ^ k0_line_check(mid); // (the host accepts the line on word 0 AND this word: kernels.hpp)
+        if ((t >> 2) == L) {
 #pragma unroll
-    for (uint32_t k = 0; k < 2; k++) {
-        const uint32_t i = 2 * t + k;
-        w[k] = i == 0 ? seq : i == 7 ? last : mid[i - 1 > 5 ? 5 : i - 1];
+            for (uint32_t k = 0; k < 2; k++) {
+                const uint32_t i = 2 * (t & 3) + k;
+                w[k] = i == 0 ? seq : i == 7 ? last : mid[i - 1 > 5 ? 5 : i - 1];
+            }
+        }
     }
-    ((ulonglong2 *)line)[t] = make_ulonglong2(w[0], w[1]);
+    ((ulonglong2 *)res)[t] = make_ulonglong2(w[0], w[1]);
 }
 // MODE 2, direct comparison (a handful of short patterns on a short haystack: at most K0_DC_PATTERNS patterns of at most
 // 16 bytes, haystack bytes x patterns <= K0_DC_WORK): one thread per (position, pattern) compares the pattern with the
@@ -3786,10 +3794,10 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         uint64_t word1 = tot;
-        if (tot > K0_LINE_MATCHES) { // (uniform) out[] and the line are separate writes to host memory: k0_rest_mix
+        if (tot > K0_LINES_MATCHES) { // (uniform) out[] and the lines are separate writes to host memory: k0_rest_mix
             uint32_t hx = 0;
-            if (t < tot - K0_LINE_MATCHES) {
-                const uint64_t u = pk[K0_LINE_MATCHES + t];
+            if (t < tot - K0_LINES_MATCHES) {
+                const uint64_t u = pk[K0_LINES_MATCHES + t];
                 ((uint64_t *)out)[t] = u;
                 hx = k0_rest_mix(u, t, seq);
             }
@@ -3797,7 +3805,7 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             __threadfence_system();
             word1 |= (uint64_t)hx << K0_REST_HASH_SHIFT;
         }
-        k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+        k0_publish_line(res, t, seq, word1, pk, tot);
         return;
     }
     // ---- rank sort (keys are unique: position + a tie-break that is unique per pattern)
@@ -3927,11 +3935,11 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
     if (seq) {
         const uint64_t *pk = (const uint64_t *)img;
         uint64_t word1 = tot;
-        if (tot > K0_LINE_MATCHES) { // (uniform)
+        if (tot > K0_LINES_MATCHES) { // (uniform)
             // out[] and the line are separate writes to host memory: the line says what out[] must hold (k0_rest_mix)
             uint32_t hx = 0;
-            for (uint32_t k = t; k < tot - K0_LINE_MATCHES; k += 1024) {
-                const uint64_t v = pk[K0_LINE_MATCHES + k];
+            for (uint32_t k = t; k < tot - K0_LINES_MATCHES; k += 1024) {
+                const uint64_t v = pk[K0_LINES_MATCHES + k];
                 ((uint64_t *)out)[k] = v;
                 hx ^= k0_rest_mix(v, k, seq);
             }
@@ -3939,11 +3947,11 @@ __device__ __forceinline__ void k0_call(const DevAutomaton &A, const uint8_t *ha
             if ((t & 63) == 0 && hx) atomicXor(&rest_hash, hx);
             // (the waves that wrote: a system-scope release is a write-back of the L2 per wave -- sixteen of them were most of
             // what a sixth match cost: 16 KiB with ten matches 22.7 us, 8 KiB with five 13.3, measured)
-            if (t < tot - K0_LINE_MATCHES) __threadfence_system();
+            if (t < tot - K0_LINES_MATCHES) __threadfence_system();
             __syncthreads();
             word1 |= (uint64_t)rest_hash << K0_REST_HASH_SHIFT;
         }
-        k0_publish_line(res, t, seq, word1, pk, tot < K0_LINE_MATCHES ? tot : K0_LINE_MATCHES);
+        k0_publish_line(res, t, seq, word1, pk, tot);
     } else {
         for (uint32_t k = t; k < tot * 6; k += 1024) ((uint32_t *)out)[k] = img[k];
         if (t == 0) *(ulonglong2 *)res = make_ulonglong2(tot, 0); // res[0] = matches, res[1] = 0: one store

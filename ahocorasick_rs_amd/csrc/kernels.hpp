@@ -81,6 +81,14 @@ bool small_prefilter_ok(const DevAutomaton &A);
 // seq == 0: out[] = acx_match_t records, res[0] / res[1] as above (device memory, read behind a stream synchronisation)
 #define ACX_K0_LINE_MATCHES 5
 constexpr uint32_t K0_LINE_WORDS = 8;
+// Round 6: up to K0_RESULT_LINES lines, one store instruction (sixteen lanes): the lines behind the first are [0] seq,
+// [1 .. 6] the next six matches, [7] seq ^ k0_line_check(words 1 .. 6) each -- 23 matches travel without a second write to
+// host memory and the release between the two (a sixth match cost a call ~7 us); out[] takes the matches beyond those.
+constexpr uint32_t K0_RESULT_LINES = 4, K0_MORE_MATCHES = 6, K0_LINES_MATCHES = ACX_K0_LINE_MATCHES + (K0_RESULT_LINES - 1) * K0_MORE_MATCHES;
+__host__ __device__ inline uint32_t k0_result_lines(uint64_t matches) { // lines that carry the first min(matches, K0_LINES_MATCHES) matches
+    const uint64_t m = matches < K0_LINES_MATCHES ? matches : K0_LINES_MATCHES;
+    return m <= ACX_K0_LINE_MATCHES ? 1u : 1u + (uint32_t)((m - ACX_K0_LINE_MATCHES + K0_MORE_MATCHES - 1) / K0_MORE_MATCHES);
+}
 // the line's last word = seq ^ k0_line_check(words 1 .. 6): the host takes the line when word 0 carries the call's number AND
 // the last word agrees with the six in the middle as it read them -- whatever order the line's four 16-byte pieces arrive in,
 // a line with a stale or half-written middle is not accepted (it is polled again)
