@@ -228,7 +228,14 @@ void acx_free_host(acx_host_automaton_t *h);
  * `hay` is borrowed for the call.  `*out` is library-owned (acx_free_matches).
  * Order and content are bit-exact with the reference iterator.
  * Large haystacks are staged through pinned chunks by several host threads, each chunk's DMA
- * under the next chunk's copy; large results are returned in pinned host memory. */
+ * under the next chunk's copy; large results are returned in pinned host memory.
+ * Short haystacks (<= 16 KiB; round 6): a loop of calls is answered by a RESIDENT workgroup per calling context that stays on
+ * the device between the calls and is fed through pinned host memory (a poll on either side instead of a kernel launch:
+ * ~5 us per call instead of ~12; the reference's benchmark loop, benchmarks/test_comparison.py:113-124).  It leaves
+ * 200 us after the last call and at most 1 ms after its launch (ACX_RESIDENT_IDLE_US / ACX_RESIDENT_LIFE_US), and at once
+ * when its context is used for anything else or the handle is freed: a device-wide synchronisation elsewhere in the
+ * process waits that long at most.  ACX_NO_RESIDENT=1: a launch per call.  Haystacks up to 1 MiB are copied into
+ * pinned host memory by the calling thread and read there by the scan (ACX_INPLACE_MAX, bytes; 0: never). */
 int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len,
              int overlapping, int codepoints, acx_match_t **out, uint64_t *n_out);
 void acx_free_matches(acx_match_t *m);
