@@ -710,9 +710,12 @@ int ensure_common(Ctx *c) {
     if (!w.summary) {
         HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline, [12], [13] the cut of a byte range
         HIPCHK(hipMalloc((void **)&w.ctl, 2 * CTL_WORDS * 4));
-        HIPCHK(hipMemset(w.ctl, 0, 2 * CTL_WORDS * 4));
+        // (every clearing of the workspace is queued on the CONTEXT'S stream: the stream does not wait for the null stream
+        // (hipStreamNonBlocking), and a hipMemset there has been seen to run behind this context's first scan when another
+        // thread kept the device busy -- round 6, tools/stress: a fresh handle's first batch lost its overflow hits)
+        HIPCHK(hipMemsetAsync(w.ctl, 0, 2 * CTL_WORDS * 4, c->stream));
         HIPCHK(hipMalloc((void **)&w.ovf_counts, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
-        HIPCHK(hipMemset(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
+        HIPCHK(hipMemsetAsync(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4, c->stream));
         HIPCHK(hipMalloc((void **)&w.block_counts, 8 * 16400)); // counts of <= 8192 regions + their exact bases
         HIPCHK(hipMalloc((void **)&w.region_off, 8 * 8193));
         HIPCHK(hipMalloc((void **)&w.hit_counts, 8 * 16 * 1024));
@@ -796,9 +799,9 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
         std::memcpy(blk + CTL_HOT_LIST, &list, 8);
         std::memcpy(blk + CTL_OVF_COUNTS, &counts, 8);
     }
-    HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(w.ctl, h, sizeof h, hipMemcpyHostToDevice)); // (the counters with them: clear)
-    HIPCHK(hipMemset(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4));
+    HIPCHK(hipMemcpyAsync(w.ctl, h, sizeof h, hipMemcpyHostToDevice, c->stream)); // (the counters with them: clear)
+    HIPCHK(hipMemsetAsync(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream)); // (h is this function's; and on the context's stream: see ensure_common)
     w.flags_dirty = false;
     return ACX_OK;
 }
@@ -828,7 +831,7 @@ int ensure_tiles(acx_automaton *a, Ctx *c, uint64_t tiles, uint32_t gmax) {
         grab((void **)&T.btot, cap_groups * 4);
         grab((void **)&T.sgw, 4 * cap_super * 8);
         grab((void **)&w.hot_list, cap_groups * 4);
-        if (rc == ACX_OK && hipMemset(T.sgw, 0, 4 * cap_super * 8) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMemset"); // both sets start clear
+        if (rc == ACX_OK && hipMemsetAsync(T.sgw, 0, 4 * cap_super * 8, c->stream) != hipSuccess) rc = hipfail(hipGetLastError(), "hipMemset"); // both sets start clear
         if (rc == ACX_OK) rc = set_overflow_room(c, (cap_tiles * OVF_PER_TILE + OVF_LISTS - 1) / OVF_LISTS);
         if (rc != ACX_OK) { free_tiles(w); return rc; }
         T.sg_cap = (uint32_t)cap_super;
@@ -855,7 +858,7 @@ int ensure_dense_tiles(Ctx *c, uint64_t tiles) {
         HIPCHK(hipMalloc((void **)&w.TD.trecs, cap_groups * DT_GMAX * 8));
         HIPCHK(hipMalloc((void **)&w.TD.btot, cap_groups * 4));
         HIPCHK(hipMalloc((void **)&w.TD.sgw, 4 * cap_super * 8));
-        HIPCHK(hipMemset(w.TD.sgw, 0, 4 * cap_super * 8));
+        HIPCHK(hipMemsetAsync(w.TD.sgw, 0, 4 * cap_super * 8, c->stream));
         w.TD.sg_cap = (uint32_t)cap_super;
         w.dt_cap = cap;
     }
