@@ -709,6 +709,7 @@ int ensure_common(Ctx *c) {
     Workspace &w = c->ws;
     if (!w.summary) {
         HIPCHK(hipMalloc((void **)&w.summary, 128)); // [0..4] totals, [8], [9] scratch, [10], [11] flags of the dense / hot pipeline, [12], [13] the cut of a byte range
+        HIPCHK(hipMemsetAsync(w.summary, 0, 128, c->stream)); // (its flags are cleared by the kernels that use them; recycled memory is not zero)
         HIPCHK(hipMalloc((void **)&w.ctl, 2 * CTL_WORDS * 4));
         // (every clearing of the workspace is queued on the CONTEXT'S stream: the stream does not wait for the null stream
         // (hipStreamNonBlocking), and a hipMemset there has been seen to run behind this context's first scan when another
