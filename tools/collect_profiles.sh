@@ -61,6 +61,8 @@ ACX_NO_BUCKET=1 timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-basel
 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node=1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 10 --warmup 3 --no-cpu-baseline --no-target-size > $OUT/bench_T_one_rank_rccl.json 2> $OUT/bench_T_one_rank_rccl.err
 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison.txt 2>&1
 ACX_SMALL_SYNC=1 timeout 600 python benchmarks/bench_comparison.py > $OUT/bench_comparison_stream_sync.txt 2>&1
+# round 6: without the resident K0 (a launch per small call) and without the in-place mid-size path, same box
+ACX_NO_RESIDENT=1 ACX_INPLACE_MAX=0 timeout 600 python benchmarks/bench_comparison.py < /dev/null > $OUT/exp_no_resident_no_inplace_bench_comparison.txt 2>&1
 # K0 without its prefilter mode (round 4's K0: the walks, 16 KiB at most), same box
 ACX_K0_NO_PREFILTER=1 timeout 300 python benchmarks/bench_comparison.py < /dev/null > $OUT/exp_k0_no_prefilter_bench_comparison.txt 2>&1
 for ds in short short_nomatch short_onematch long; do timeout 60 python tools/k0_probe.py $ds indexes 2000 < /dev/null; done > $OUT/k0_probe.txt 2>&1
@@ -80,6 +82,8 @@ timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_m
 for d in H1 H100; do
   timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$d -o bench -- python /root/repo/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist $d > $OUT/trace_$d.log 2>&1
 done
+# the resident K0 under the tracer: the reference's short loop (its kernels' lives are what the trace shows)
+timeout 120 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_k0_short -o bench -- python /root/repo/tools/k0_probe.py short indexes 5000 > $OUT/trace_k0_short.log 2>&1
 timeout 400 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_large -o bench -- python /root/repo/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cold --config large > $OUT/trace_large.log 2>&1
 cd /root/repo
 fi

@@ -22,7 +22,7 @@ def short(n):
 
 for f in sorted(glob.glob(os.path.join(SRC, "bench_*.json"))) + [os.path.join(SRC, x) for x in
                                                                   ("smoke.log", "bench_comparison.txt", "bench_comparison_stream_sync.txt", "ubench_stream.txt", "k0_probe.txt",
-                                                                   "exp_k0_no_prefilter_bench_comparison.txt", "pytest_gpu.log")]:
+                                                                   "exp_k0_no_prefilter_bench_comparison.txt", "exp_no_resident_no_inplace_bench_comparison.txt", "pytest_gpu.log")]:
     if os.path.exists(f) and os.path.getsize(f):
         if f.endswith(".json"):  # (only the JSON line: RCCL prints its banner to stdout)
             lines = [l for l in open(f) if l.startswith("{")]
@@ -40,6 +40,7 @@ for tag, cmd in (("T", "python bench.py --steps 10 --warmup 3 --no-cpu-baseline 
                  ("dense_D", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist D"),
                  ("H1", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist H1"),
                  ("H100", "python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-cold --no-secondary --no-target-size --dist H100"),
+                 ("k0_short", "python tools/k0_probe.py short indexes 5000"),
                  ("large", "python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-cold --config large")):
     src = os.path.join(SRC, f"trace_{tag}")
     if not os.path.exists(os.path.join(src, "bench_kernel_stats.csv")):
