@@ -4111,10 +4111,11 @@ int small_mode(const DevAutomaton &A, uint32_t len, bool direct_ok) {
     const bool dc = A.n_patterns <= K0_DC_PATTERNS && A.min_len >= 1 && A.max_len <= 16 && A.pat_blob && A.pat_off &&
                     (uint64_t)len * A.n_patterns <= K0_DC_WORK && !no_dc && direct_ok;
     // the prefilter (MODE 3): beyond SMALL_MAX_LEN the only way; below it for automata whose tables do not fit the LDS
-    // from the first byte on since round 6 (until then from 1 KiB: "the walk's handful of gathers is as good" -- per launch
-    // it is, 13.4 us either way; in the resident kernel a haystack of 64 bytes with one match is 7.3 us against 8.9:
-    // the walk that finds the match is a chain of a dozen dependent gathers).  ACX_K0_PF_MIN: measurements
-    static const uint32_t pf_min = std::getenv("ACX_K0_PF_MIN") ? (uint32_t)std::atoi(std::getenv("ACX_K0_PF_MIN")) : 0u;
+    // from 1 KiB on (shorter: the walk's handful of gathers is as good).  Measured again in round 6 with the resident kernel
+    // (ACX_K0_PF_MIN=0: from the first byte): a haystack WITH a match gains -- 64 bytes with one match 8.9 -> 7.4 us, the walk
+    // that finds it is a chain of a dozen dependent gathers --, one without loses: the reference's long dataset (1 haystack
+    // in 90 holds a match) 6.1-6.3 -> 6.6-6.9 us per call.  The reference's own loop decides: 1 KiB stays.
+    static const uint32_t pf_min = std::getenv("ACX_K0_PF_MIN") ? (uint32_t)std::atoi(std::getenv("ACX_K0_PF_MIN")) : 1024u;
     const bool pf = small_prefilter_ok(A) && (len > SMALL_MAX_LEN || (!dc && !lt && len > pf_min));
     if (len > SMALL_MAX_LEN && !pf) return -1;
     return pf ? 3 : dc ? 2 : lt ? 1 : 0;
