@@ -358,7 +358,7 @@ private:
 
 // ---------------------------------------------------------------------------
 // pinned host scratch of a context, in 64-bit words (Workspace::h_pinned)
-constexpr uint32_t PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PIN_RESIDENT = 48, PIN_READY = 62, PIN_K0 = 64, PINNED_WORDS = 96;
+constexpr uint32_t PIN_TOTALS = 24, PIN_HOT_TOTALS = 32, PIN_SPEC_TOTALS = 40, PIN_RESIDENT = 48, PIN_K0 = 64, PINNED_WORDS = 96;
 struct Workspace {
     uint64_t cap = 0; // occurrence capacity of the dense path (region mode + radix sort)
     uint64_t *keys[2] = {nullptr, nullptr};
@@ -799,8 +799,6 @@ int set_overflow_room(Ctx *c, uint64_t want) { // want: records per list
         std::memcpy(blk + CTL_OVF_RECS, &recs, 8);
         std::memcpy(blk + CTL_HOT_LIST, &list, 8);
         std::memcpy(blk + CTL_OVF_COUNTS, &counts, 8);
-        const uint64_t ready = (uint64_t)(uintptr_t)(w.h_pinned + PIN_READY);
-        std::memcpy(blk + CTL_READY, &ready, 8);
     }
     HIPCHK(hipMemcpyAsync(w.ctl, h, sizeof h, hipMemcpyHostToDevice, c->stream)); // (the counters with them: clear)
     HIPCHK(hipMemsetAsync(w.ovf_counts, 0, 2 * OVF_LISTS * OVF_COUNT_STRIDE * 4, c->stream));
@@ -1198,11 +1196,6 @@ struct FindCall {
     bool host_result = false;    // the caller reads the matches on the host right away (acx_find): the sparse path writes them
                                  // to the context's pinned buffer when its capacity fits (PIN_FINAL_MAX), no copy kernel-side
     acx_match_t *out = nullptr;  // sparse path: where the write kernels put the records (w.final, or w.pin_final)
-    // acx_find, mid-size haystacks read in place WHILE they are copied (K1b's READY form): d_hay is the context's pinned
-    // buffer, fill_src the caller's bytes; [0, fill_done) are there.  The first sparse attempt launches the scan, copies the
-    // rest chunk by chunk (the count in h_pinned[PIN_READY] behind every chunk), then launches the post kernels.
-    const uint8_t *fill_src = nullptr;
-    uint64_t fill_done = 0;
     uint64_t out_cap = 0;
     bool counts_zeroed = false; // batch: the per-haystack counts are zero or being accumulated into
     uint64_t exact_total = 0;
@@ -1295,23 +1288,6 @@ int run_hot(FindCall &c, uint32_t *abort_flag, uint64_t seq, uint32_t n_hot, uin
 }
 
 // ---- sparse output: hit slots + tile kernels; returns when the totals are known
-// (acx_find's READY form) the rest of the caller's haystack into the context's pinned buffer, the count of bytes that are
-// there published behind every chunk (K1b's waves wait for it per tile); the 64 bytes behind the haystack are zero
-// before the last count is out
-void finish_fill(FindCall &c) {
-    if (!c.fill_src || c.fill_done >= c.len) return;
-    uint8_t *dst = const_cast<uint8_t *>(c.d_hay);
-    uint64_t *ready = c.c->ws.h_pinned + PIN_READY;
-    constexpr uint64_t CHUNK = 64 << 10;
-    while (c.fill_done < c.len) {
-        const uint64_t n = std::min<uint64_t>(CHUNK, c.len - c.fill_done);
-        std::memcpy(dst + c.fill_done, c.fill_src + c.fill_done, n);
-        c.fill_done += n;
-        if (c.fill_done == c.len) std::memset(dst + c.len, 0, 64);
-        __atomic_store_n(ready, c.fill_done == c.len ? c.len + 64 : c.fill_done, __ATOMIC_RELEASE);
-    }
-}
-
 int attempt_sparse(FindCall &c, Attempt *what) {
     acx_automaton *a = c.a;
     Ctx *x = c.c;
@@ -1388,10 +1364,8 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         // is done -- the event it waits for rides on the scan's own dispatch, no packet in between)
         side_after = cp_sub && !c.segmented ? (prof ? scan_stop_ev(x) : x->fork_ev) : nullptr;
         g_trace.mark(2);
-        const bool ready_form = c.fill_src && c.fill_done < c.len; // (the first attempt of a call whose bytes are still coming)
         HIPCHK_RC(launch_prefilter(a->dev, K, c.d_hay, c.len, c.scan_grid, st, prof ? scan_start_ev(x) : nullptr,
-                                   prof ? scan_stop_ev(x) : side_after, cp_sub, ready_form));
-        if (ready_form) finish_fill(c); // (the scan is on its way: the copy runs beside it, the post kernels are launched behind)
+                                   prof ? scan_stop_ev(x) : side_after, cp_sub));
         g_trace.mark(3);
         c.leads_counted = cp_sub != nullptr;
     } else {
@@ -1820,9 +1794,7 @@ int run_pipeline(FindCall &c) {
     c.tiles = prefilter_tiles(c.d_hay, c.len);
     const bool no_sparse_env = std::getenv("ACX_NO_BUCKET") != nullptr; // tests / profiling: force the dense path (read per call)
     bool sparse = a->sparse_ok && x->dense_hold == 0 && !no_sparse_env && c.tiles < (1ull << 26);
-    if (!(sparse && c.pre && prefilter_ready_form(a->dev))) finish_fill(c); // (only K1b's READY form reads a haystack that is still coming)
     for (int attempt = 0;; attempt++) {
-        if (attempt) finish_fill(c);
         if (attempt == 6) return fail(ACX_EDEVICE, "occurrence buffer overflow persisted");
         Attempt what = Attempt::Done;
         if ((rc = sparse ? attempt_sparse(c, &what) : attempt_dense(c, &what)) != ACX_OK) return rc;
@@ -1895,7 +1867,7 @@ int run_batch_split(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len
                     int codepoints, acx_result **out, int depth);
 int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const Segments &G,
              int overlapping, int codepoints, acx_result **out, bool allow_small, bool wait, int depth = 0,
-             bool host_result = false, const uint8_t *fill_src = nullptr, uint64_t fill_done = 0) {
+             bool host_result = false) {
     *out = nullptr;
     if (overlapping && a->host.match_kind != ACX_MATCH_STANDARD) {
         static const char *names[3] = {"Standard", "LeftmostFirst", "LeftmostLongest"};
@@ -1914,7 +1886,6 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
     FindCall c{a, x, d_hay, len, G, overlapping != 0, codepoints != 0, segmented, r,
                overlapping ? 0 : a->host.match_kind};
     c.host_result = host_result;
-    c.fill_src = fill_src; c.fill_done = fill_done;
     auto body = [&]() -> int {
         if (segmented) {
             HIPCHK_RC(g_bufs.get((void **)&r->d_counts, std::max<uint64_t>(G.n_hay, 1) * 8, a->device));
@@ -1960,7 +1931,6 @@ int run_find(acx_automaton *a, Ctx *x, const uint8_t *d_hay, uint64_t len, const
     const char *cb = depth == 0 && !segmented ? std::getenv("ACX_CHUNK_BYTES") : nullptr;
     const uint64_t forced = cb ? std::strtoull(cb, nullptr, 10) : 0;
     int rc = forced && len > forced ? TOO_MANY_OCC : body();
-    finish_fill(c); // (whatever way the call went: the pinned copy is complete from here on)
     if (rc != ACX_OK) {
         (void)hipStreamSynchronize(st);
         acx_free_result(r);
@@ -2793,8 +2763,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     // 512 KiB 69.8 -> 60.5, 1 MiB 103.1 -> 93.0; 2 MiB 112 -> 134: beyond, this thread's copy is what the call waits for).
     // Only while the context's calls stay on the sparse path (a dense input is read several times: from HBM, then).
     static const uint64_t inplace_max = std::getenv("ACX_INPLACE_MAX") ? std::strtoull(std::getenv("ACX_INPLACE_MAX"), nullptr, 10) : (1ull << 20);
-    const uint8_t *d_hay = nullptr, *fill_src = nullptr;
-    uint64_t fill_done = 0;
+    const uint8_t *d_hay = nullptr;
     if (len <= inplace_max && a->kernel == ACX_KERNEL_PREFILTER && a->sparse_ok && c->dense_hold == 0 && !c->wide && c->spec_hot == 0) {
         Workspace &w = c->ws;
         if (w.pin_mid_cap < len + 4096) {
@@ -2804,18 +2773,10 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
             HIPCHK(hipHostMalloc((void **)&w.pin_mid, cap, hipHostMallocDefault));
             w.pin_mid_cap = cap;
         }
-        // K1b's READY form: the first chunk now, the rest WHILE the scan runs (run_find -> attempt_sparse -> finish_fill);
-        // otherwise -- a short copy, a set whose scan has no such form -- the whole copy now
-        static const bool no_ready = std::getenv("ACX_NO_READY_FORM") != nullptr;
-        const bool ready_form = !no_ready && len >= (256u << 10) && prefilter_ready_form(a->dev);
-        rc = ensure_common(c);
-        if (rc != ACX_OK) return rc;
-        fill_done = ready_form ? (64u << 10) : len;
-        std::memcpy(w.pin_mid, hay, fill_done);
-        if (!ready_form) std::memset(w.pin_mid + len, 0, 64);
-        __atomic_store_n(w.h_pinned + PIN_READY, ready_form ? fill_done : len + 64, __ATOMIC_RELEASE);
-        fill_src = ready_form ? hay : nullptr;
+        std::memcpy(w.pin_mid, hay, len);
+        std::memset(w.pin_mid + len, 0, 64);
         d_hay = w.pin_mid;
+        rc = ACX_OK;
         a->path[11]++;
     } else {
         rc = stage_host(a, c, hay, len, nullptr, 0);
@@ -2823,7 +2784,7 @@ int acx_find(acx_automaton_t *a, const uint8_t *hay, uint64_t len, int overlappi
     }
     g_trace_find.lap(0);
     if (rc == ACX_OK)
-        rc = run_find(a, c, d_hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false, 0, true, fill_src, fill_done);
+        rc = run_find(a, c, d_hay, len, Segments{nullptr, 1, 0}, overlapping, codepoints, &r, !try_small, false, 0, true);
     if (rc != ACX_OK) return rc;
     g_trace_find.lap(1);
     if (r->borrowed) {

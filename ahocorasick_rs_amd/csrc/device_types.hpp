@@ -145,10 +145,7 @@ __host__ __device__ inline uint64_t hcnt_index(uint64_t tile, uint32_t nw, uint3
 // One dense region no longer costs the whole call the dense path: the sparse kernels finish every other group, the
 // hot groups (+ their context tiles) go through the tile-ordered dense machinery, k_tile_write splices both by the
 // groups' counts (reference behaviour: the cost per byte does not depend on where the matches are, src/lib.rs:59).
-//   [CTL_READY]     (u64, round 6) a word of pinned host memory: the bytes of the haystack that ARE there -- K1b's READY form
-//                   (a host haystack read in place WHILE the host still copies it into pinned memory) waits for it per tile
-constexpr uint32_t CTL_ABORT = 0, CTL_OVF_LOST = 1, CTL_HOT_COUNT = 2, CTL_OVF_CAP = 4, CTL_OVF_RECS = 6, CTL_HOT_LIST = 8, CTL_OVF_COUNTS = 10,
-                   CTL_READY = 12;
+constexpr uint32_t CTL_ABORT = 0, CTL_OVF_LOST = 1, CTL_HOT_COUNT = 2, CTL_OVF_CAP = 4, CTL_OVF_RECS = 6, CTL_HOT_LIST = 8, CTL_OVF_COUNTS = 10;
 constexpr uint32_t OVF_LISTS = 256, OVF_COUNT_STRIDE = 16; // lists; u32 words from one list's counter to the next (64 bytes)
 constexpr uint32_t CTL_WORDS = 16;         // u32 words per block
 constexpr uint32_t HOT_BIT = 0x80000000u;  // TileSpace::btot[g]: the group is the hot pipeline's (low bits: its matches)

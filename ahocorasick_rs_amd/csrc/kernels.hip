@@ -855,13 +855,7 @@ struct K1bTables {
 // survivors travel through the same queue and pipeline with a flag (bit 15 of the offset) and are settled
 // against the exact codes (two 4-byte gathers: the 1-byte and the 2-byte pattern that may start there)
 // instead of the prefix table.
-// READY (round 6; hit-slot mode, BIGV == 0): the haystack is pinned host memory the HOST IS STILL FILLING -- mid-size calls of
-// acx_find copy the caller's bytes there chunk by chunk while this kernel already runs -- and [CTL_READY] of the control
-// block points at the count of bytes that are there (pinned, advanced by the host behind every chunk).  A wave waits for
-// the bytes of a tile (+ the windows' look-ahead) before it requests it; the count it has seen stays in a scalar register,
-// so a wave behind the host never asks.  200 ms without the bytes: the call is marked aborted (the host repeats it on the
-// complete copy).  The other instantiations are instruction-identical to the kernel without this parameter.
-template <int Q, bool SLOTS, bool CP, int BIGV, bool SH, bool READY = false>
+template <int Q, bool SLOTS, bool CP, int BIGV, bool SH>
 __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
                                                       const uint8_t *__restrict__ hay,
                                                       uint64_t len, uint64_t lead) {
@@ -1028,30 +1022,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
             nxtL = *(const uint2 *)(hay + (off_ < last_block ? off_ : last_block));              \
         }                                                                                        \
     }
-    [[maybe_unused]] uint64_t ready_seen = 0;
-    auto wait_ready = [&](uint64_t tile_) __attribute__((always_inline)) {
-        if constexpr (READY) {
-            uint64_t need = (tile_ + 1) * tile_bytes + 64;
-            if (need > total) need = total;
-            if (need > ready_seen) {
-                const uint64_t *rp = *(const uint64_t *const *)(GK.abort_flag + CTL_READY);
-                const uint64_t t0_ = wall_clock64();
-                for (;;) {
-                    const uint64_t v_ = __hip_atomic_load(rp, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
-                    ready_seen = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(v_ >> 32)) << 32) |
-                                 (uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)v_);
-                    if (ready_seen >= need) break;
-                    if (wall_clock64() - t0_ > 20000000ull) { // (200 ms of the 100 MHz clock: the host is not coming)
-                        if (lane == 0) GK.abort_flag[CTL_ABORT] = 1;
-                        ready_seen = ~0ull;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(16);
-                }
-            }
-        }
-    };
-    if (gw < ntiles) wait_ready(gw);
     K1B_ISSUE_TILE(gw)
 
     // ---- level-2 pipeline (one entry per lane per stage).  A *batch* is up to 64 survivors of one
@@ -1485,7 +1455,6 @@ __global__ __launch_bounds__(1024) void k1b_prefilter(K1bTables A, Sink GK,
         // of the next iteration and the three other waves of the SIMD cover its latency.  Measured
         // (round 1, T): issued before row 0: 310 us; after row 1: 299; after row 2: 293; here: 291;
         // no prefetch at all (loads at the top of the tile's own iteration): 308.
-        if (READY && tile + nw < ntiles) wait_ready(tile + nw);
         K1B_ISSUE_TILE(tile + nw)
         // ---- ballot-compact the survivors of the tile into Q1, one per lane per round
         // (one 64-bit mask per lane; the round is branch-free: the lowest set bit by two v_ffbl, lanes
@@ -1570,11 +1539,9 @@ uint64_t prefilter_tiles(const uint8_t *d_hay, uint64_t len) {
 }
 
 // K.hslots != null: sparse mode (hit slots + counts); else region mode (per-wave regions)
-bool prefilter_ready_form(const DevAutomaton &A) { return A.filter_q >= 3 && A.filter_big == 0; }
-
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
                             uint32_t grid, hipStream_t st, hipEvent_t ev_start, hipEvent_t ev_stop,
-                            uint8_t *cp_sub, bool ready) {
+                            uint8_t *cp_sub) {
     if (len == 0 || A.filter_q == 0) return hipSuccess;
     uint64_t lead = (uintptr_t)d_hay & 15;
     const uint8_t *base = d_hay - lead;
@@ -1592,21 +1559,6 @@ hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t 
     else ACX_K1B_LAUNCH(Q, false, false, B, H)
 #define ACX_K1B_SH(Q, B)                                                                                   \
     if (sh) { ACX_K1B(Q, B, true); } else { ACX_K1B(Q, B, false); }
-    if (ready) { // (the READY form: hit-slot mode, the plain level 1)
-        if (!K.hslots || !prefilter_ready_form(A)) return hipErrorInvalidValue;
-#define ACX_K1B_READY(Q, H)                                                                                \
-    if (cp_sub) hipExtLaunchKernelGGL((k1b_prefilter<Q, true, true, 0, H, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead); \
-    else hipExtLaunchKernelGGL((k1b_prefilter<Q, true, false, 0, H, true>), g, b, 0, st, ev_start, ev_stop, 0, T, K, base, len, lead)
-#define ACX_K1B_READY_SH(Q) if (sh) { ACX_K1B_READY(Q, true); } else { ACX_K1B_READY(Q, false); }
-        switch (A.filter_q) {
-        case 3: ACX_K1B_READY_SH(3) break;
-        case 4: ACX_K1B_READY_SH(4) break;
-        default: ACX_K1B_READY_SH(5) break;
-        }
-#undef ACX_K1B_READY_SH
-#undef ACX_K1B_READY
-        return hipGetLastError();
-    }
     switch (A.filter_q) {
     // (Q = 1, 2: only with ACX_NO_SHORT_SPLIT -- the split keeps such patterns out of these tables)
     case 1: ACX_K1B(1, 0, false); break;

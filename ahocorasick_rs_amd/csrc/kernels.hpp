@@ -45,10 +45,7 @@ uint32_t prefilter_hit_regions(uint32_t grid);
 // holds 256 * prefilter_tiles() bytes) -- block_totals() then replaces count_lead_bytes()
 hipError_t launch_prefilter(const DevAutomaton &A, const Sink &K, const uint8_t *d_hay, uint64_t len,
                             uint32_t grid, hipStream_t st, hipEvent_t ev_start = nullptr,
-                            hipEvent_t ev_stop = nullptr, uint8_t *cp_sub = nullptr, bool ready = false);
-// ready: K1b's READY form (kernels.hip) -- the haystack is pinned host memory the host is still filling; the control block's
-// [CTL_READY] points at the count of bytes that are there.  Exists for the sets prefilter_ready_form says.
-bool prefilter_ready_form(const DevAutomaton &A);
+                            hipEvent_t ev_stop = nullptr, uint8_t *cp_sub = nullptr);
 // sink bookkeeping (dense path): summary[0] = total kept, summary[1] = max count of a region
 hipError_t sink_summary(const uint64_t *block_counts, uint32_t grid, uint64_t region_cap,
                         const uint64_t *hit_counts, uint32_t hit_grid, uint64_t hit_cap,

@@ -82,27 +82,3 @@ def test_in_place_str_api_and_threads():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert not bad, bad[:3]
-
-
-@pytest.mark.parametrize("minlen", [3, 4, 5])
-def test_in_place_while_the_copy_runs_every_gram_length(minlen):
-    """From 256 KiB on the scan (K1b's READY form) starts on the first 64 KiB and waits per tile for the bytes the host is
-    still copying: sets whose shortest pattern has 3, 4 and 5+ bytes (the three level-1 gram lengths), with and without
-    1- and 2-byte patterns beside them (the side test's instantiations), bytes and code points."""
-    base = gen.gen_patterns(3000, minlen, 10, gen.AZ, 40 + minlen)
-    for extra in ([], [b"q", b"zx"]):
-        pats = base + extra
-        a = capi.Automaton(pats, 2)
-        o = Oracle(pats, 2, KIND_DFA)
-        for n in (262_144, 262_145, 999_999, 1 << 20):
-            hay = gen.gen_textlike(n, 5 + n, base[:2000]).tobytes()
-            want = o.find_raw(hay)
-            b2c = byte_to_code_point(hay)
-            for rep in range(3):
-                a.path_stats(reset=True)
-                got = cols(a.find(hay))
-                got_cp = cols(a.find(hay, codepoints=True))
-                assert got.shape == want.shape and np.array_equal(got, want), (minlen, len(extra), n, rep)
-                assert np.array_equal(got_cp[:, 0], want[:, 0]) and np.array_equal(got_cp[:, 1], b2c[want[:, 1]]), (minlen, n)
-            assert a.path_stats()["in_place"] >= 1
-        a.close()
