@@ -879,7 +879,7 @@ int ensure_blocks(Ctx *c, uint64_t nblocks_plus1) {
         HIPCHK(hipMalloc((void **)&w.blocksub, nblocks_plus1 * 64)); // one lead-byte count per 16 bytes
         w.block_cap = nblocks_plus1;
     }
-    size_t need = scan_temp_bytes(nblocks_plus1) + 256; // the scan temp storage must cover this size too
+    size_t need = std::max<size_t>(scan_temp_bytes(nblocks_plus1), 32768) + 256; // the scan temp storage must cover this size too (block_prefix: 32 KiB of partial sums)
     if (need > w.temp_bytes) {
         (void)hipFree(w.temp); w.temp = nullptr;
         HIPCHK(hipMalloc(&w.temp, need));
@@ -1398,8 +1398,7 @@ int attempt_sparse(FindCall &c, Attempt *what) {
         hipStream_t side = x->copy_stream;
         if (!side_after) { side_after = x->fork_ev; HIPCHK_RC(hipEventRecord(x->fork_ev, st)); }
         HIPCHK_RC(hipStreamWaitEvent(side, side_after, 0));
-        HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, side));
-        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, side));
+        HIPCHK_RC(block_prefix(w.blocksub, w.blockcnt, w.blockpre, nb1 - 1, w.temp, w.temp_bytes, side));
         HIPCHK_RC(hipEventRecord(x->join_ev, side));
         before_write = x->join_ev;
         cp_pre = w.blockpre;
@@ -1766,9 +1765,8 @@ int finish_matches(FindCall &c) {
         const uint64_t nb1 = (c.len + 1023) / 1024 + 1;
         int rc = ensure_blocks(x, c.leads_counted ? std::max<uint64_t>(nb1, 4 * c.tiles + 1) : nb1);
         if (rc) return rc;
-        if (c.leads_counted) HIPCHK_RC(block_totals(w.blocksub, w.blockcnt, nb1 - 1, st));
-        else HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, w.blocksub, st));
-        HIPCHK_RC(prefix_sum_u64(w.temp, w.temp_bytes, w.blockcnt, w.blockpre, nb1, st));
+        if (!c.leads_counted) HIPCHK_RC(count_lead_bytes(c.d_hay, c.len, w.blockcnt, w.blocksub, st));
+        HIPCHK_RC(block_prefix(c.leads_counted ? w.blocksub : nullptr, w.blockcnt, w.blockpre, nb1 - 1, w.temp, w.temp_bytes, st));
     }
     if (c.segmented) {
         int rc = zero_counts(c);

@@ -4212,6 +4212,84 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
                                    rocprim::plus<uint64_t>(), st);
 }
 
+// The code-point prefix of the 1 KiB blocks in TWO launches of this file's own kernels (round 6; until then k_block_totals +
+// the library's device-wide scan: three launches, 25 + 49 + 5 us beside k_tile_main on cfg5's 1 GiB): pre[blk] = lead bytes
+// in front of block blk, for blk = 0 .. nblocks (nblocks + 1 entries; cnt[nblocks] = 0).
+//   k_block_partials  a workgroup per BP_BLOCKS blocks: cnt[blk] = the sum of the block's 64 sub counts (sub != null:
+//                     K1b has counted the 16-byte stretches; else cnt is there already: k_count_leads), partial[wg] = the
+//                     workgroup's sum
+//   k_block_prefix    the same geometry: a workgroup sums the partials in front of it (at most BP_MAX_WGS of them: a
+//                     haystack of up to 4 GiB; beyond, block_prefix() takes the library's scan), scans its own counts
+constexpr uint32_t BP_BLOCKS = 1024, BP_MAX_WGS = 4096;
+__global__ __launch_bounds__(1024) void k_block_partials(const uint8_t *__restrict__ sub, uint64_t *cnt, uint64_t *partial,
+                                                         uint64_t nblocks) {
+    __shared__ uint32_t red[16];
+    const uint64_t blk = (uint64_t)blockIdx.x * BP_BLOCKS + threadIdx.x;
+    uint32_t acc = 0;
+    if (blk < nblocks) {
+        if (sub) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint4 v = *(const uint4 *)(sub + blk * 64 + 16 * k);
+                acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
+                acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+            }
+        } else {
+            acc = (uint32_t)cnt[blk];
+        }
+    }
+    if (blk <= nblocks && (sub || blk == nblocks)) cnt[blk] = acc;
+    uint32_t sum = acc; // (a block holds at most 1 024 lead bytes: a workgroup's sum fits 32 bits)
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t tot = 0;
+        for (int w = 0; w < 16; w++) tot += red[w];
+        partial[blockIdx.x] = tot;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_block_prefix(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ partial,
+                                                       uint64_t *pre, uint64_t n) {
+    using scan_t = rocprim::block_scan<uint64_t, 1024>;
+    __shared__ typename scan_t::storage_type scan_tmp;
+    __shared__ uint64_t red[16];
+    __shared__ uint64_t s_base;
+    uint64_t mine = 0;
+    for (uint32_t w = threadIdx.x; w < blockIdx.x; w += 1024) mine += partial[w];
+    for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint64_t b = 0;
+        for (int w = 0; w < 16; w++) b += red[w];
+        s_base = b;
+    }
+    __syncthreads();
+    const uint64_t blk = (uint64_t)blockIdx.x * BP_BLOCKS + threadIdx.x;
+    const uint64_t v = blk < n ? cnt[blk] : 0;
+    uint64_t excl = 0;
+    scan_t().exclusive_scan(v, excl, (uint64_t)0, scan_tmp);
+    if (blk < n) pre[blk] = s_base + excl;
+}
+
+hipError_t block_prefix(const uint8_t *sub, uint64_t *cnt, uint64_t *pre, uint64_t nblocks, void *temp, size_t temp_bytes,
+                        hipStream_t st) {
+    const uint64_t n = nblocks + 1, nwg = (n + BP_BLOCKS - 1) / BP_BLOCKS;
+    static const bool lib = std::getenv("ACX_BLOCK_PREFIX_LIBRARY") != nullptr; // (measurements: the round-5 way)
+    if (nwg > BP_MAX_WGS || temp_bytes < nwg * 8 || lib) {
+        if (sub) {
+            hipError_t e = block_totals(sub, cnt, nblocks, st);
+            if (e != hipSuccess) return e;
+        }
+        return prefix_sum_u64(temp, temp_bytes, cnt, pre, n, st);
+    }
+    hipLaunchKernelGGL(k_block_partials, dim3((uint32_t)nwg), dim3(1024), 0, st, sub, cnt, (uint64_t *)temp, nblocks);
+    hipLaunchKernelGGL(k_block_prefix, dim3((uint32_t)nwg), dim3(1024), 0, st, cnt, (const uint64_t *)temp, pre, n);
+    return hipGetLastError();
+}
+
 // one thread per match: the start from its 1 KiB block's prefix, the end from the start
 __global__ void k_to_code_points(const uint8_t *__restrict__ hay, const uint64_t *blockpre,
                                  const uint8_t *__restrict__ sub, acx_match_t *m, uint64_t n) {

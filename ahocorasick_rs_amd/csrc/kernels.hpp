@@ -245,6 +245,12 @@ hipError_t count_lead_bytes(const uint8_t *d_hay, uint64_t len, uint64_t *cnt, u
 hipError_t block_totals(const uint8_t *sub, uint64_t *cnt, uint64_t nblocks, hipStream_t st);
 hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uint64_t *out,
                           uint64_t n, hipStream_t st);
+// pre[0 .. nblocks] = the exclusive prefix of the blocks' lead-byte counts, in two launches of this file's own kernels
+// (haystacks up to 4 GiB; beyond: block_totals + the library's scan).  sub != null: the counts come from the 16-byte
+// stretches' counts (and are left in cnt); else cnt[0 .. nblocks) is there (count_lead_bytes).  temp: >= 32 KiB + what
+// prefix_sum_u64 wants.
+hipError_t block_prefix(const uint8_t *sub, uint64_t *cnt, uint64_t *pre, uint64_t nblocks, void *temp, size_t temp_bytes,
+                        hipStream_t st);
 hipError_t to_code_points(const uint8_t *d_hay, uint64_t len, const uint64_t *blockpre, const uint8_t *sub,
                           acx_match_t *m, uint64_t n, hipStream_t st);
 
