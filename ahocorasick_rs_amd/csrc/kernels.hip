@@ -4220,58 +4220,70 @@ hipError_t prefix_sum_u64(void *temp, size_t temp_bytes, const uint64_t *in, uin
 //                     workgroup's sum
 //   k_block_prefix    the same geometry: a workgroup sums the partials in front of it (at most BP_MAX_WGS of them: a
 //                     haystack of up to 4 GiB; beyond, block_prefix() takes the library's scan), scans its own counts
-constexpr uint32_t BP_BLOCKS = 1024, BP_MAX_WGS = 4096;
-__global__ __launch_bounds__(1024) void k_block_partials(const uint8_t *__restrict__ sub, uint64_t *cnt, uint64_t *partial,
-                                                         uint64_t nblocks) {
-    __shared__ uint32_t red[16];
-    const uint64_t blk = (uint64_t)blockIdx.x * BP_BLOCKS + threadIdx.x;
-    uint32_t acc = 0;
-    if (blk < nblocks) {
-        if (sub) {
+// (workgroups of 256 threads, four blocks per thread: beside k_tile_main's 128-thread groups a workgroup of 1 024 threads
+// waits for sixteen free wave slots on ONE compute unit -- the first version took 96 us for cfg5's 64 MiB of counts)
+constexpr uint32_t BP_BLOCKS = 1024, BP_THREADS = 256, BP_MAX_WGS = 4096;
+__global__ __launch_bounds__(BP_THREADS) void k_block_partials(const uint8_t *__restrict__ sub, uint64_t *cnt, uint64_t *partial,
+                                                               uint64_t nblocks) {
+    __shared__ uint32_t red[BP_THREADS / 64];
+    uint32_t sum = 0; // (a block holds at most 1 024 lead bytes: a workgroup's sum fits 32 bits)
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint4 v = *(const uint4 *)(sub + blk * 64 + 16 * k);
-                acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
-                acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+    for (uint32_t k = 0; k < BP_BLOCKS / BP_THREADS; k++) {
+        const uint64_t blk = (uint64_t)blockIdx.x * BP_BLOCKS + k * BP_THREADS + threadIdx.x;
+        uint32_t acc = 0;
+        if (blk < nblocks) {
+            if (sub) {
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint4 v = *(const uint4 *)(sub + blk * 64 + 16 * q);
+                    acc = __builtin_amdgcn_sad_u8(v.x, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.y, 0u, acc);
+                    acc = __builtin_amdgcn_sad_u8(v.z, 0u, acc); acc = __builtin_amdgcn_sad_u8(v.w, 0u, acc);
+                }
+            } else {
+                acc = (uint32_t)cnt[blk];
             }
-        } else {
-            acc = (uint32_t)cnt[blk];
         }
+        if (blk <= nblocks && (sub || blk == nblocks)) cnt[blk] = acc;
+        sum += acc;
     }
-    if (blk <= nblocks && (sub || blk == nblocks)) cnt[blk] = acc;
-    uint32_t sum = acc; // (a block holds at most 1 024 lead bytes: a workgroup's sum fits 32 bits)
     for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = sum;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t tot = 0;
-        for (int w = 0; w < 16; w++) tot += red[w];
+        for (uint32_t w = 0; w < BP_THREADS / 64; w++) tot += red[w];
         partial[blockIdx.x] = tot;
     }
 }
 
-__global__ __launch_bounds__(1024) void k_block_prefix(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ partial,
-                                                       uint64_t *pre, uint64_t n) {
-    using scan_t = rocprim::block_scan<uint64_t, 1024>;
+__global__ __launch_bounds__(BP_THREADS) void k_block_prefix(const uint64_t *__restrict__ cnt, const uint64_t *__restrict__ partial,
+                                                             uint64_t *pre, uint64_t n) {
+    using scan_t = rocprim::block_scan<uint64_t, BP_THREADS>;
     __shared__ typename scan_t::storage_type scan_tmp;
-    __shared__ uint64_t red[16];
+    __shared__ uint64_t red[BP_THREADS / 64];
     __shared__ uint64_t s_base;
     uint64_t mine = 0;
-    for (uint32_t w = threadIdx.x; w < blockIdx.x; w += 1024) mine += partial[w];
+    for (uint32_t w = threadIdx.x; w < blockIdx.x; w += BP_THREADS) mine += partial[w];
     for (int o = 32; o > 0; o >>= 1) mine += __shfl_xor(mine, o);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint64_t b = 0;
-        for (int w = 0; w < 16; w++) b += red[w];
+        for (uint32_t w = 0; w < BP_THREADS / 64; w++) b += red[w];
         s_base = b;
     }
     __syncthreads();
-    const uint64_t blk = (uint64_t)blockIdx.x * BP_BLOCKS + threadIdx.x;
-    const uint64_t v = blk < n ? cnt[blk] : 0;
+    // four consecutive blocks per thread
+    constexpr uint32_t PER = BP_BLOCKS / BP_THREADS;
+    const uint64_t b0 = (uint64_t)blockIdx.x * BP_BLOCKS + (uint64_t)threadIdx.x * PER;
+    uint64_t v[PER], sum = 0;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) { v[k] = b0 + k < n ? cnt[b0 + k] : 0; sum += v[k]; }
     uint64_t excl = 0;
-    scan_t().exclusive_scan(v, excl, (uint64_t)0, scan_tmp);
-    if (blk < n) pre[blk] = s_base + excl;
+    scan_t().exclusive_scan(sum, excl, (uint64_t)0, scan_tmp);
+    uint64_t run = s_base + excl;
+#pragma unroll
+    for (uint32_t k = 0; k < PER; k++) { if (b0 + k < n) pre[b0 + k] = run; run += v[k]; }
 }
 
 hipError_t block_prefix(const uint8_t *sub, uint64_t *cnt, uint64_t *pre, uint64_t nblocks, void *temp, size_t temp_bytes,
@@ -4285,8 +4297,8 @@ hipError_t block_prefix(const uint8_t *sub, uint64_t *cnt, uint64_t *pre, uint64
         }
         return prefix_sum_u64(temp, temp_bytes, cnt, pre, n, st);
     }
-    hipLaunchKernelGGL(k_block_partials, dim3((uint32_t)nwg), dim3(1024), 0, st, sub, cnt, (uint64_t *)temp, nblocks);
-    hipLaunchKernelGGL(k_block_prefix, dim3((uint32_t)nwg), dim3(1024), 0, st, cnt, (const uint64_t *)temp, pre, n);
+    hipLaunchKernelGGL(k_block_partials, dim3((uint32_t)nwg), dim3(BP_THREADS), 0, st, sub, cnt, (uint64_t *)temp, nblocks);
+    hipLaunchKernelGGL(k_block_prefix, dim3((uint32_t)nwg), dim3(BP_THREADS), 0, st, cnt, (const uint64_t *)temp, pre, n);
     return hipGetLastError();
 }
 
